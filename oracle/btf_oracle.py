@@ -1,0 +1,469 @@
+"""CPU oracle for the Bayesian Tensor Filtering Gibbs hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``functionalmf_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` use it, and only as the checker / the CPU number reported
+beside the GPU one.
+
+This is a numpy/scipy *restatement* (not a copy) of the algorithm of
+tansey/functionalmf for the path ``run_gibbs -> resample -> _resample_W /
+_resample_V / _resample_nu2`` (+ the hyper-parameter steps and the
+``fast_mvn`` precision sampler those call).  Every function cites the
+reference file:line whose arithmetic it follows.
+
+Parity status (see DESIGN.md "Oracle"):
+  * pinned by the real reference code run in the build container (fixtures in
+    tests/golden/, generator tests/golden/make_golden.py): trend-filter
+    penalty, W step (draw included), V-step precision/mean assembly, the mean
+    term Q^-1 mu, the RNG stream order, nu2/sigma2/Tau2/lam2 steps, run_gibbs
+    result layout, quirks Q1-Q4 of SURVEY.md section 8.
+  * NOT pinned ("parity unpinned"): the V-step *noise* term under CHOLMOD's own
+    fill-reducing ordering (scikit-sparse is absent from the image, version
+    unpinned in reference setup.py:51) and the Polya-Gamma draws (pypolyagamma
+    absent).  The build declares the factor ordering instead (``perm``
+    argument below: depth-major) and validates PG draws distributionally.
+
+The state is a plain dict so the oracle shares no class structure with the
+product code:  W (N,K)  V (M,T,K)  Tau2 (M,nD)  Tau2_a/b/c (M,nD)  lam2  lam2_a
+sigma2  nu2 (scalar or (N,M,T)).
+All random numbers come from the *global legacy* numpy generator, in the
+reference's order, unless a ``z`` array is injected.
+"""
+import numpy as np
+import scipy.linalg as sla
+
+# --------------------------------------------------------------------------
+# trend-filtering penalty            (reference functionalmf/utils.py:56-98)
+# --------------------------------------------------------------------------
+
+def first_difference(T):
+    """(T-1) x T first-difference operator, rows (-1, +1).  utils.py:93-98."""
+    D = np.zeros((T - 1, T))
+    idx = np.arange(T - 1)
+    D[idx, idx] = -1.0
+    D[idx, idx + 1] = 1.0
+    return D
+
+
+def difference_power(D, k):
+    """k-th order operator built by alternating D' and D.  utils.py:56-64."""
+    if k < 0:
+        raise ValueError("order must be >= 0")
+    out = D
+    for step in range(k):
+        out = D.T @ out if step % 2 == 0 else D @ out
+    return out
+
+
+def trend_penalty(T, order, anchor=0):
+    """Dense Delta = [e_anchor'; D^(0); ...; D^(order)].  utils.py:66-90."""
+    D = first_difference(T)
+    top = np.zeros((1, T))
+    top[0, anchor] = 1.0
+    blocks = [top] + [difference_power(D, k) for k in range(order + 1)]
+    return np.concatenate(blocks, axis=0)
+
+
+def depth_major_perm(K, T):
+    """perm[t*K + k] = k*T + t : new (depth-major) index -> reference (k-major)
+    index.  This is the factor ordering the build declares."""
+    t, k = np.meshgrid(np.arange(T), np.arange(K), indexing="ij")
+    return (k * T + t).reshape(-1)
+
+
+# --------------------------------------------------------------------------
+# sufficient statistics              (factor.py:323-330 and :368-375)
+# --------------------------------------------------------------------------
+
+def replicate_stats(Y):
+    """Observed-replicate count and NaN-mean over the last axis."""
+    if Y.ndim == 3:
+        Y = Y[..., None]
+    obs = ~np.isnan(Y)
+    cnt = obs.sum(axis=-1)
+    tot = np.where(obs, Y, 0.0).sum(axis=-1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ybar = tot / cnt
+    return cnt, ybar
+
+
+# --------------------------------------------------------------------------
+# precision-form Gaussian draw       (fast_mvn.py:10-74)
+# --------------------------------------------------------------------------
+
+class NotPositiveDefinite(Exception):
+    pass
+
+
+def mvn_from_precision(Q, mu_part=None, perm=None, z=None,
+                       force_psd=True, eps0=1e-6, attempts=4, info=None):
+    """x = Q^-1 mu_part + P' L^-T z  with  L L' = P Q P'.
+
+    fast_mvn.py:35-47 (sparse branch).  ``perm`` plays the role of CHOLMOD's
+    P(); None = identity.  z is drawn (global legacy RNG) only after a
+    factorisation succeeded (fast_mvn.py:38 then :41), so failed attempts use
+    no random numbers.  On failure eps0*10^a is added to the diagonal
+    cumulatively, at most ``attempts`` times (fast_mvn.py:62-68); where the
+    reference would then warn forever (:69-72) this raises instead.
+    """
+    Q = np.array(Q, dtype=float)
+    n = Q.shape[0]
+    p = np.arange(n) if perm is None else np.asarray(perm)
+    eps = eps0
+    tried = 0
+    while True:
+        Qp = Q[np.ix_(p, p)]
+        try:
+            L = np.linalg.cholesky(Qp)
+            break
+        except np.linalg.LinAlgError:
+            if force_psd and tried < attempts:
+                Q[np.diag_indices(n)] += eps
+                eps *= 10.0
+                tried += 1
+            else:
+                raise NotPositiveDefinite("precision not PD after %d shifts" % tried)
+    if info is not None:
+        info["attempts"] = tried
+    if z is None:
+        z = np.random.normal(size=n)
+    x = np.empty(n)
+    x[p] = sla.solve_triangular(L.T, z, lower=False)      # P' L^-T z
+    if mu_part is not None:
+        y = sla.cho_solve((L, True), np.asarray(mu_part)[p])
+        mean = np.empty(n)
+        mean[p] = y
+        x = x + mean
+    return x
+
+
+# --------------------------------------------------------------------------
+# W half-sweep                       (factor.py:313-362)
+# --------------------------------------------------------------------------
+
+def w_step(st, Y, z=None):
+    """Row-by-row conjugate draw of W.  Reproduces quirk Q1: the design/factor
+    cache is refreshed only for rows < K or when the data holds any NaN
+    (factor.py:320, :349).  ``z``: optional flat array of the sum_i min(i+1,K)
+    normals, consumed in row order; else the legacy global RNG is used.
+    """
+    W, V = st["W"], st["V"]
+    N, K = W.shape
+    any_nan = bool(np.isnan(Y).any())
+    cnt, ybar = replicate_stats(Y)
+    Vflat = V.reshape(-1, K)
+    nu2 = st["nu2"]
+    zpos = 0
+    Xt = Lt = None
+    for i in range(N):
+        d = min(i + 1, K)
+        yb = ybar[i].reshape(-1)
+        keep = ~np.isnan(yb)
+        if np.isscalar(nu2) or np.ndim(nu2) == 0:
+            c = cnt[i].reshape(-1)[keep] / nu2
+        else:
+            c = cnt[i].reshape(-1)[keep] / nu2[i].reshape(-1)[keep]
+        if i < K or any_nan:
+            Vd = Vflat[keep][:, :d]
+            Xt = (Vd * c[:, None]).T
+            Q = Xt @ Vd + np.eye(d) / st["sigma2"]
+            Lt = np.linalg.cholesky(Q).T
+        m = Xt @ yb[keep]
+        if z is None:
+            zi = np.random.normal(size=d)
+        else:
+            zi = z[zpos:zpos + d]
+            zpos += d
+        W[i, :d] = sla.cho_solve((Lt, False), m) + sla.solve_triangular(Lt, zi, lower=False)
+    return W
+
+
+# --------------------------------------------------------------------------
+# V half-sweep                       (factor.py:364-409)
+# --------------------------------------------------------------------------
+
+def prior_precision_1d(Delta, lam2, tau2_row):
+    """Delta' diag(1/(lam2*tau2)) Delta  (T x T).  factor.py:404-405."""
+    return Delta.T @ (Delta / (lam2 * tau2_row)[:, None])
+
+
+def v_step_system(st, Y, Delta, j, src):
+    """Precision (k-major, dense) and mean-part of column j with the likelihood
+    weights taken from column ``src`` (Q2: the reference re-uses the cached
+    design of the last column whose NaN pattern differed, factor.py:394-401)."""
+    W = st["W"]
+    N, K = W.shape
+    T = Delta.shape[1]
+    cnt, ybar = st["_cnt"], st["_ybar"]
+    nu2 = st["nu2"]
+    yb = ybar[:, j, :]                      # (N,T)
+    keep = ~np.isnan(yb)
+    if np.isscalar(nu2) or np.ndim(nu2) == 0:
+        c = cnt[:, src, :] / nu2
+    else:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            c = cnt[:, src, :] / nu2[:, src, :]
+    c = np.where(keep, c, 0.0)
+    y0 = np.where(keep, yb, 0.0)
+    # Q_lik[(k,t),(k',t)] = sum_i c_it W_ik W_ik'      (kron(W,I_T)' C kron(W,I_T))
+    G = np.einsum("it,ik,il->tkl", c, W, W)             # (T,K,K)
+    mu = np.einsum("it,ik->kt", c * y0, W).reshape(-1)   # k-major
+    Q = np.zeros((K * T, K * T))
+    tt = np.arange(T)
+    for k in range(K):
+        for l in range(K):
+            Q[k * T + tt, l * T + tt] = G[:, k, l]
+    P1 = prior_precision_1d(Delta, st["lam2"], st["Tau2"][j])
+    for k in range(K):
+        Q[k * T:(k + 1) * T, k * T:(k + 1) * T] += P1
+    return Q, mu
+
+
+def stale_column_sources(ybar):
+    """src[j] = column whose cached weights column j uses (quirk Q2)."""
+    M = ybar.shape[1]
+    src = np.zeros(M, dtype=np.int64)
+    pat = None
+    for j in range(M):
+        miss = np.isnan(ybar[:, j, :]).reshape(-1)
+        if j == 0 or np.any(pat != miss):
+            pat = miss
+            src[j] = j
+        else:
+            src[j] = src[j - 1]
+    return src
+
+
+def v_step(st, Y, Delta, perm="depth", z=None, compat="reference",
+           force_psd=True, eps0=1e-6, attempts=4, info=None):
+    """Column-by-column conjugate draw of V (factor.py:364-409 + fast_mvn).
+    perm: "depth" (declared ordering), "identity", or an explicit array.
+    z: optional (M, K*T) normals, row j used for column j, indexed in the
+    *permuted* order (as solve_Lt sees them, fast_mvn.py:44)."""
+    V = st["V"]
+    M, T, K = V.shape
+    st["_cnt"], st["_ybar"] = replicate_stats(Y)
+    if isinstance(perm, str):
+        p = depth_major_perm(K, T) if perm == "depth" else np.arange(K * T)
+    else:
+        p = np.asarray(perm)
+    src = stale_column_sources(st["_ybar"]) if compat == "reference" else np.arange(M)
+    tries = np.zeros(M, dtype=np.int64)
+    for j in range(M):
+        Q, mu = v_step_system(st, Y, Delta, j, int(src[j]))
+        inf = {}
+        x = mvn_from_precision(Q, mu_part=mu, perm=p,
+                               z=None if z is None else z[j],
+                               force_psd=force_psd, eps0=eps0, attempts=attempts, info=inf)
+        tries[j] = inf.get("attempts", 0)
+        V[j] = x.reshape(K, T).T
+    if info is not None:
+        info["attempts"] = tries
+        info["src"] = src
+    st.pop("_cnt"), st.pop("_ybar")
+    return V
+
+
+# --------------------------------------------------------------------------
+# variance / shrinkage steps   (genlasso.py:149-168, factor.py:130-153,411-416)
+# --------------------------------------------------------------------------
+
+def inv_gamma_precision_draw(means, obs, shape, rate):
+    """One Gamma(a + n/2, scale=1/(b + sse/2)) precision draw.  genlasso.py:149-168."""
+    miss = np.isnan(obs)
+    sse = np.nansum((means - obs) ** 2)
+    return np.random.gamma(shape + np.sum(~miss) / 2.0, 1.0 / (rate + sse / 2.0))
+
+
+def sse_and_count(st, Y):
+    """Residual sum of squares and number of observed values (the two numbers
+    the nu2 update needs).  factor.py:411-416."""
+    Mu = np.einsum("nk,mtk->nmt", st["W"], st["V"])
+    if Y.ndim == 4:
+        Mu = Mu[..., None]
+    r = Mu - Y
+    return float(np.nansum(r * r)), int(np.sum(~np.isnan(Y)))
+
+
+def nu2_step(st, Y, a=0.1, b=0.1):
+    sse, n = sse_and_count(st, Y)
+    st["nu2"] = 1.0 / np.random.gamma(a + n / 2.0, 1.0 / (b + sse / 2.0))
+    return st["nu2"]
+
+
+def free_w_entries(W):
+    """Lower-triangular head + dense tail of W as one vector.  factor.py:155-174."""
+    N, K = W.shape
+    h = min(N, K)
+    return np.concatenate([W[np.tril_indices(h)], W[h:].reshape(-1)])
+
+
+def sigma2_step(st, a=0.1, b=0.1):
+    w = free_w_entries(st["W"])
+    st["sigma2"] = 1.0 / inv_gamma_precision_draw(np.zeros_like(w), w, a, b)
+    return st["sigma2"]
+
+
+def tau2_step(st, Delta, stability=1e-6):
+    """Horseshoe+ chain per column, 4 vector gamma draws each.  factor.py:134-141."""
+    V = st["V"]
+    M, T, K = V.shape
+    lo, hi = stability, 1.0 / stability
+    for j in range(M):
+        d = Delta @ V[j]
+        rate = (d * d).sum(axis=1) / (2.0 * st["lam2"]) + 1.0 / np.clip(st["Tau2_c"][j], lo, hi)
+        st["Tau2"][j] = 1.0 / np.random.gamma((K + 1) / 2.0, 1.0 / np.clip(rate, lo, hi))
+        st["Tau2_c"][j] = 1.0 / np.random.gamma(1.0, 1.0 / np.clip(1.0 / st["Tau2"][j] + 1.0 / st["Tau2_b"][j], lo, hi))
+        st["Tau2_b"][j] = 1.0 / np.random.gamma(1.0, 1.0 / np.clip(1.0 / st["Tau2_c"][j] + 1.0 / st["Tau2_a"][j], lo, hi))
+        st["Tau2_a"][j] = 1.0 / np.random.gamma(1.0, 1.0 / np.clip(1.0 / st["Tau2_b"][j] + 1.0, lo, hi))
+
+
+def lam2_step(st, Delta, compat="reference"):
+    """Global shrinkage.  compat="reference" keeps quirk Q3 (factor.py:147-150:
+    the rate is overwritten each column, so only the last column counts);
+    "exact" accumulates 1/lam2_a + sum_j."""
+    V = st["V"]
+    M, T, K = V.shape
+    rate = 1.0 / st["lam2_a"]
+    for j in range(M):
+        d = Delta @ V[j]
+        term = ((d / np.sqrt(st["Tau2"][j])[:, None]) ** 2).sum() / 2.0
+        rate = term if compat == "reference" else rate + term
+    shape = Delta.shape[0] * M * K + 1
+    st["lam2"] = max(1e-5, 1.0 / np.random.gamma(shape / 2.0, 1.0 / rate))
+    st["lam2_a"] = 1.0 / np.random.gamma(1.0, 1.0 / (1.0 / st["lam2"] + 1.0))
+
+
+# --------------------------------------------------------------------------
+# construction draws                 (factor.py:53-110, 230-253; utils.py:115-124)
+# --------------------------------------------------------------------------
+
+def horseshoe_plus(size):
+    a = 1.0 / np.random.gamma(0.5, 1.0, size=size)
+    b = 1.0 / np.random.gamma(0.5, a)
+    c = 1.0 / np.random.gamma(0.5, b)
+    d = 1.0 / np.random.gamma(0.5, c)
+    return d, c, b, a
+
+
+def init_state(N, M, T, K=5, tf_order=2, sigma2_init=None, lam2_init=None,
+               nu2_init=None, sigma2_a=0.1, sigma2_b=0.1, nu2_a=0.1, nu2_b=0.1,
+               perm="depth", force_psd=True, eps0=1e-6, attempts=4):
+    """Initial state in the reference's construction order (factor.py:49-110,
+    then :292-304): sigma2, lam2(+a), Tau2(+a,b,c), W, V, then nu2."""
+    Delta = trend_penalty(T, tf_order)
+    st = {}
+    st["sigma2"] = sigma2_init if sigma2_init is not None else \
+        1.0 / np.random.gamma(sigma2_a, 1.0 / sigma2_b, size=1)
+    a = 1.0 / np.random.gamma(0.5, 1.0, size=1)
+    lam2 = 1.0 / np.random.gamma(0.5, a)
+    st["lam2"], st["lam2_a"] = np.clip(lam2, 0, 4), a
+    if lam2_init is not None:
+        st["lam2"] = lam2_init
+    t2, c, b, a = horseshoe_plus((M, Delta.shape[0]))
+    st["Tau2"], st["Tau2_c"], st["Tau2_b"], st["Tau2_a"] = np.clip(t2, 0, 9), c, b, a
+    W = np.random.normal(0, np.sqrt(st["sigma2"]), size=(N, K))
+    if N > 1:
+        W[np.triu_indices(K, k=1)] = 0
+    st["W"] = W
+    V = np.full((M, T, K), np.nan)
+    p = depth_major_perm(K, T) if perm == "depth" else np.arange(K * T)
+    for j in range(M):
+        P1 = prior_precision_1d(Delta, st["lam2"], st["Tau2"][j])
+        Q = np.kron(np.eye(K), P1)
+        V[j] = mvn_from_precision(Q, perm=p, force_psd=force_psd, eps0=eps0,
+                                  attempts=attempts).reshape(K, T).T
+    st["V"] = np.clip(V, -10, 10)
+    st["nu2"] = nu2_init if nu2_init is not None else \
+        1.0 / np.random.gamma(nu2_a, 1.0 / nu2_b, size=1)
+    return st, Delta
+
+
+# --------------------------------------------------------------------------
+# sweep + driver                     (factor.py:306-311, :112-128; genlasso.py:37-66)
+# --------------------------------------------------------------------------
+
+def gaussian_sweep(st, Y, Delta, perm="depth", compat="reference", flags=None):
+    f = dict(nu2=True, sigma2=True, Tau2=True, lam2=True, W=True, V=True)
+    if flags:
+        f.update(flags)
+    if f["nu2"]:
+        nu2_step(st, Y)
+    if f["sigma2"]:
+        sigma2_step(st)
+    if f["Tau2"]:
+        tau2_step(st, Delta)
+    if f["lam2"]:
+        lam2_step(st, Delta, compat=compat)
+    if f["W"]:
+        w_step(st, Y)
+    if f["V"]:
+        v_step(st, Y, Delta, perm=perm, compat=compat)
+
+
+def run_gibbs(st, Y, Delta, nburn, nthin, nsamples, perm="depth", compat="reference", flags=None):
+    """genlasso.py:37-66: result arrays [nsamples]+shape, scalars as [nsamples,1]."""
+    keys = ("W", "V", "sigma2", "lam2", "Tau2", "nu2")
+    out = None
+    for step in range(nburn + nthin * nsamples):
+        gaussian_sweep(st, Y, Delta, perm=perm, compat=compat, flags=flags)
+        if step >= nburn and (step - nburn) % nthin == 0:
+            s = (step - nburn) // nthin
+            if s == 0:
+                out = {k: np.zeros([nsamples] + ([1] if np.isscalar(st[k]) else list(np.shape(st[k]))))
+                       for k in keys}
+            for k in keys:
+                out[k][s] = st[k]
+    return out
+
+
+# --------------------------------------------------------------------------
+# Binomial / Polya-Gamma path        (factor.py:425-460)
+# --------------------------------------------------------------------------
+
+def binomial_kappa(Ysucc, Ntrials, nu2):
+    """kappa = (Y - N/2) * nu2 : the pseudo-observations handed to the Gaussian
+    steps (factor.py:437-445)."""
+    return (Ysucc - Ntrials / 2.0) * nu2
+
+
+def binomial_w_step(st, Ysucc, Ntrials, z=None):
+    return w_step(st, binomial_kappa(Ysucc, Ntrials, st["nu2"]), z=z)
+
+
+def binomial_v_step(st, Ysucc, Ntrials, Delta, **kw):
+    return v_step(st, binomial_kappa(Ysucc, Ntrials, st["nu2"]), Delta, **kw)
+
+
+def pg_mean(b, c):
+    """E[PG(b,c)] = b/(2c) tanh(c/2)  (b/4 at c=0)."""
+    b = np.asarray(b, float)
+    c = np.abs(np.asarray(c, float))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        m = np.where(c > 1e-8, b / (2 * c) * np.tanh(c / 2), b / 4.0 * (1 - c * c / 12.0))
+    return m
+
+
+def pg_var(b, c):
+    """Var[PG(b,c)] = b/(4c^3) (sinh c - c) sech^2(c/2)  (b/24 at c=0)."""
+    b = np.asarray(b, float)
+    c = np.abs(np.asarray(c, float))
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        v = np.where(c > 1e-3,
+                     b / (4 * c ** 3) * (np.sinh(c) - c) / np.cosh(c / 2) ** 2,
+                     b / 24.0 * (1 - c * c / 5.0))
+    return v
+
+
+def pg_draw_series(b, c, size, rng, nterms=256):
+    """Reference sampler straight from the definition (Polson, Scott & Windle
+    2013, eq. 2):  PG(b,c) = 1/(2 pi^2) sum_k g_k / ((k-1/2)^2 + c^2/(4 pi^2)),
+    g_k ~ Gamma(b,1).  Truncated at ``nterms`` with the tail replaced by its
+    mean.  Slow; used only to validate the device sampler's distribution."""
+    k = np.arange(1, nterms + 1)
+    den = (k - 0.5) ** 2 + (c * c) / (4 * np.pi ** 2)
+    g = rng.gamma(b, 1.0, size=(size, nterms))
+    x = (g / den).sum(axis=1)
+    kk = np.arange(nterms + 1, nterms + 200001)
+    tail = (b / ((kk - 0.5) ** 2 + (c * c) / (4 * np.pi ** 2))).sum()
+    return (x + tail) / (2 * np.pi ** 2)
