@@ -1,0 +1,163 @@
+"""ctypes binding of the C ABI in include/btf.h (libbtf_hip.so, built in-tree).
+
+There is no CPU fallback: if the shared library is missing or no GPU is
+visible, every compute entry point raises.  ``load()`` is lazy so that the pure
+host logic (and the symbol-export test) can be imported on a CPU-only box.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libbtf_hip.so")
+SOURCES = [os.path.join(CSRC, "btf_abi.hip")]
+HEADERS = [os.path.join(CSRC, "btf_kernels.h"), os.path.join(CSRC, "btf_device.h"),
+           os.path.join(ROOT, "include", "btf.h")]
+
+BTF_OK, BTF_EINVAL, BTF_EHIP, BTF_ENOTPD, BTF_ESTATE = 0, 1, 2, 3, 4
+COMPAT = {"reference": 0, "exact": 1}
+KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw"]
+
+# every symbol include/btf.h declares: (name, restype, argtypes)
+_c_dp = C.POINTER(C.c_double)
+_c_ip = C.POINTER(C.c_int32)
+_ctx = C.c_void_p
+SIGNATURES = {
+    "btf_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "btf_destroy": (None, [_ctx]),
+    "btf_last_error": (C.c_char_p, [_ctx]),
+    "btf_fail_index": (C.c_int, [_ctx]),
+    "btf_set_shard": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "btf_dev_W": (C.c_void_p, [_ctx]),
+    "btf_dev_V": (C.c_void_p, [_ctx]),
+    "btf_set_data_gaussian": (C.c_int, [_ctx, _c_dp, _c_dp, C.c_int]),
+    "btf_set_data_binomial": (C.c_int, [_ctx, _c_dp, _c_dp, _c_dp, _c_dp]),
+    "btf_set_stale_sources": (C.c_int, [_ctx, _c_ip, _c_ip]),
+    "btf_set_W": (C.c_int, [_ctx, _c_dp]),
+    "btf_get_W": (C.c_int, [_ctx, _c_dp]),
+    "btf_set_V": (C.c_int, [_ctx, _c_dp]),
+    "btf_get_V": (C.c_int, [_ctx, _c_dp]),
+    "btf_set_hyper": (C.c_int, [_ctx, _c_dp, C.c_double, C.c_double]),
+    "btf_set_nu2": (C.c_int, [_ctx, C.c_double]),
+    "btf_set_omega": (C.c_int, [_ctx, _c_dp, _c_dp]),
+    "btf_get_omega": (C.c_int, [_ctx, _c_dp]),
+    "btf_resample_W": (C.c_int, [_ctx, _c_dp, C.c_uint64, C.c_int]),
+    "btf_resample_V": (C.c_int, [_ctx, _c_dp, C.c_uint64, C.c_int, C.c_double, C.c_int]),
+    "btf_get_V_attempts": (C.c_int, [_ctx, _c_ip]),
+    "btf_sse": (C.c_int, [_ctx, _c_dp, _c_dp]),
+    "btf_pg_draw": (C.c_int, [_ctx, C.c_uint64]),
+    "btf_sync": (C.c_int, [_ctx]),
+    "btf_mvn_banded": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_uint64,
+                                 C.c_double, C.c_int, _c_dp, _c_ip]),
+    "btf_set_profiling": (C.c_int, [_ctx, C.c_int]),
+    "btf_kernel_times": (C.c_int, [_ctx, _c_dp, C.POINTER(C.c_int64)]),
+    "btf_set_tuning": (C.c_int, [_ctx, C.c_int, C.c_int]),
+}
+
+
+class BTFError(RuntimeError):
+    def __init__(self, code, msg, index=-1):
+        super().__init__("btf error %d: %s" % (code, msg))
+        self.code = code
+        self.index = index
+
+
+class NotPositiveDefiniteError(BTFError, np.linalg.LinAlgError):
+    """Raised where the reference raises LinAlgError (W step, factor.py:357) and
+    where it would loop forever after the jitter retries (fast_mvn.py:69-72)."""
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    deps = SOURCES + HEADERS
+    if not force and os.path.exists(LIB_PATH) and \
+            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load libbtf_hip.so and declare every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("functionalmf_amd: %s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+    # One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME).  If
+    # torch is (or will be) used in this process it has to be imported first so that
+    # our library binds to the runtime torch initialised.
+    if "torch" not in sys.modules and os.environ.get("BTF_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(_c_dp) if a is not None else None
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    """Thin RAII wrapper of btf_ctx."""
+
+    def __init__(self, nrows, ncols, ndepth, nembeds, tf_order, device=0, stream=None):
+        self.lib = load()
+        self.h = _ctx()
+        rc = self.lib.btf_create(C.byref(self.h), nrows, ncols, ndepth, nembeds, tf_order, device,
+                                 C.c_void_p(stream) if stream else None)
+        if rc != BTF_OK:
+            raise BTFError(rc, self.lib.btf_last_error(None).decode())
+        self.dims = (nrows, ncols, ndepth, nembeds, tf_order)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.btf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc == BTF_OK:
+            return
+        msg = self.lib.btf_last_error(self.h).decode()
+        if rc == BTF_ENOTPD:
+            raise NotPositiveDefiniteError(rc, msg, self.lib.btf_fail_index(self.h))
+        raise BTFError(rc, msg)
+
+    def call(self, name, *args):
+        self.check(getattr(self.lib, name)(self.h, *args))
+
+    def kernel_times(self):
+        ms = np.zeros(len(KERNEL_NAMES))
+        n = np.zeros(len(KERNEL_NAMES), dtype=np.int64)
+        self.check(self.lib.btf_kernel_times(self.h, dptr(ms), n.ctypes.data_as(C.POINTER(C.c_int64))))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(KERNEL_NAMES)}

@@ -1,0 +1,798 @@
+// C ABI (include/btf.h) over the HIP kernels: context, device buffers, launches.
+// gfx950 only.  No CPU fallback: every entry point either runs on the GPU or
+// returns an error.
+#include "../../include/btf.h"
+#include "btf_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace btf;
+
+namespace {
+
+constexpr int MAX_K = 10;
+constexpr int MAX_EVENTS = 8192;
+
+struct EvPair { hipEvent_t a, b; int kid; };
+
+}  // namespace
+
+struct btf_ctx {
+  int N = 0, M = 0, T = 0, K = 0, TF = 0, nD = 0, KK = 0;
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int row0 = 0, nl = 0, col0 = 0, ml = 0;
+  int ldw = 0, ldv = 0;      // padded leading dimensions of A_wT / A_v
+  int R = 1;
+  bool have_data = false, binomial = false, weighted = false;
+  double* A_wT = nullptr; double* C_wT = nullptr; double* A_v = nullptr; double* C_v = nullptr;
+  double* B_wT = nullptr; double* B_v = nullptr;   // binomial: trials (0 where missing)
+  double* W = nullptr; double* V = nullptr; double* WW = nullptr; double* VV = nullptr;
+  double* Tau2 = nullptr;
+  double lam2 = 1.0, sigma2 = 1.0, nu2 = 1.0;
+  bool have_W = false, have_V = false, have_hyper = false;
+  double* part = nullptr; size_t part_elems = 0;
+  double* gpart = nullptr;
+  double* zbuf = nullptr; size_t z_elems = 0;
+  double* bsum = nullptr; size_t bsum_elems = 0;
+  double* gband = nullptr; size_t gband_stride = 0;
+  int* status = nullptr;   // [0] flag [1] index
+  int* tries = nullptr;
+  int* st_ptr = nullptr; int* st_row = nullptr; double* st_coef = nullptr;
+  int32_t* src_row = nullptr; int32_t* src_col = nullptr;
+  double ssw = 0.0, nobs = 0.0;
+  int rpb_w = 0, rpb_v = 0;
+  unsigned long long sweep_w = 0, sweep_v = 0;
+  bool profiling = false;
+  std::vector<EvPair> ev_pool;
+  size_t ev_used = 0;
+  double ms_total[BTF_K_COUNT] = {0};
+  int64_t launches[BTF_K_COUNT] = {0};
+  std::string err;
+  int fail_index = -1;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(btf_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                  \
+  do {                                                                                     \
+    hipError_t e__ = (call);                                                               \
+    if (e__ != hipSuccess)                                                                 \
+      return fail(ctx, BTF_EHIP, std::string(#call) + ": " + hipGetErrorString(e__));      \
+  } while (0)
+
+template <typename T>
+int dev_alloc(btf_ctx* c, T** p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (n == 0) n = 1;
+  HIPCHK(c, hipMalloc((void**)p, n * sizeof(T)));
+  return BTF_OK;
+}
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct Prof {
+  btf_ctx* c; int kid; EvPair* ev = nullptr;
+  Prof(btf_ctx* c_, int kid_) : c(c_), kid(kid_) {
+    c->launches[kid]++;
+    if (c->profiling && c->ev_used < c->ev_pool.size()) {
+      ev = &c->ev_pool[c->ev_used++];
+      ev->kid = kid;
+      (void)hipEventRecord(ev->a, c->stream);
+    }
+  }
+  ~Prof() { if (ev) (void)hipEventRecord(ev->b, c->stream); }
+};
+
+// Delta' diag(lambda) Delta stencil: for every (t,d), d = 0..tf+1, the Delta rows r that
+// touch both t and t+d with the coefficient product Delta[r,t]*Delta[r,t+d].
+// Delta is rebuilt here from its definition (reference utils.py:56-98): anchor row
+// e_0, then D^(0..tf) with D the first-difference operator, alternating D' and D.
+void build_delta_dense(int T, int tf, std::vector<double>& Delta, int& nD) {
+  std::vector<std::vector<double>> rows;
+  {
+    std::vector<double> a(T, 0.0);
+    a[0] = 1.0;
+    rows.push_back(a);
+  }
+  // D : (T-1) x T
+  auto D = [&](int r, int c) -> double { return c == r ? -1.0 : (c == r + 1 ? 1.0 : 0.0); };
+  std::vector<std::vector<double>> cur(T - 1, std::vector<double>(T, 0.0));
+  for (int r = 0; r < T - 1; ++r) { cur[r][r] = -1.0; cur[r][r + 1] = 1.0; }
+  for (int k = 0; k <= tf; ++k) {
+    if (k > 0) {
+      std::vector<std::vector<double>> nxt;
+      if ((k - 1) % 2 == 0) {  // D' * cur : T x T
+        nxt.assign(T, std::vector<double>(T, 0.0));
+        for (int r = 0; r < T; ++r)
+          for (int q = 0; q < T - 1; ++q) {
+            double dq = D(q, r);
+            if (dq != 0.0)
+              for (int c = 0; c < T; ++c) nxt[r][c] += dq * cur[q][c];
+          }
+      } else {  // D * cur : (T-1) x T
+        nxt.assign(T - 1, std::vector<double>(T, 0.0));
+        for (int r = 0; r < T - 1; ++r)
+          for (int q = 0; q < T; ++q) {
+            double dq = D(r, q);
+            if (dq != 0.0)
+              for (int c = 0; c < T; ++c) nxt[r][c] += dq * cur[q][c];
+          }
+      }
+      cur.swap(nxt);
+    }
+    for (auto& r : cur) rows.push_back(r);
+  }
+  nD = (int)rows.size();
+  Delta.assign((size_t)nD * T, 0.0);
+  for (int r = 0; r < nD; ++r)
+    for (int c = 0; c < T; ++c) Delta[(size_t)r * T + c] = rows[r][c];
+}
+
+int build_stencil(btf_ctx* c) {
+  const int T = c->T, tf = c->TF, D1 = tf + 2;
+  std::vector<double> Delta;
+  int nD = 0;
+  build_delta_dense(T, tf, Delta, nD);
+  c->nD = nD;
+  std::vector<int> ptr(T * D1 + 1, 0), row;
+  std::vector<double> coef;
+  for (int t = 0; t < T; ++t)
+    for (int d = 0; d < D1; ++d) {
+      if (t + d < T)
+        for (int r = 0; r < nD; ++r) {
+          double p = Delta[(size_t)r * T + t] * Delta[(size_t)r * T + t + d];
+          if (p != 0.0) { row.push_back(r); coef.push_back(p); }
+        }
+      ptr[t * D1 + d + 1] = (int)row.size();
+    }
+  // sanity: nothing outside the band
+  for (int r = 0; r < nD; ++r) {
+    int lo = T, hi = -1;
+    for (int t = 0; t < T; ++t)
+      if (Delta[(size_t)r * T + t] != 0.0) { lo = std::min(lo, t); hi = std::max(hi, t); }
+    if (hi - lo > tf + 1) return fail(c, BTF_EINVAL, "penalty row wider than the band");
+  }
+  int rc;
+  if ((rc = dev_alloc(c, &c->st_ptr, ptr.size()))) return rc;
+  if ((rc = dev_alloc(c, &c->st_row, row.size()))) return rc;
+  if ((rc = dev_alloc(c, &c->st_coef, coef.size()))) return rc;
+  HIPCHK(c, hipMemcpy(c->st_ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->st_row, row.data(), row.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->st_coef, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice));
+  return BTF_OK;
+}
+
+// ---- templated launch tables -------------------------------------------------
+template <int K>
+void launch_accum(btf_ctx* c, bool weighted, const double* X, const double* Cx, const double* U,
+                  const double* UU, int Rdim, int ld, int rpb, int nch) {
+  dim3 grid(ld / ACC_TILE, nch);
+  if (weighted)
+    hipLaunchKernelGGL((accum_kernel<K, 1>), grid, dim3(ACC_THREADS), 0, c->stream, X, Cx, U, UU, c->part, Rdim, ld, rpb);
+  else
+    hipLaunchKernelGGL((accum_kernel<K, 0>), grid, dim3(ACC_THREADS), 0, c->stream, X, Cx, U, UU, c->part, Rdim, ld, rpb);
+}
+template <int K>
+void launch_gram(btf_ctx* c, const double* U, int Rdim) {
+  hipLaunchKernelGGL((gram_kernel<K>), dim3(GRAM_BLOCKS), dim3(GRAM_THREADS), 0, c->stream, U, Rdim, c->gpart);
+}
+template <int K>
+void launch_products(btf_ctx* c, const double* U, int Rdim, double* UU) {
+  hipLaunchKernelGGL((products_kernel<K>), dim3((Rdim + 255) / 256), dim3(256), 0, c->stream, U, Rdim, UU);
+}
+template <int K>
+void launch_wsolve(btf_ctx* c, const WSolveArgs& a) {
+  hipLaunchKernelGGL((w_solve_kernel<K>), dim3((a.nl + 127) / 128), dim3(128), 0, c->stream, a);
+}
+template <int K>
+hipError_t launch_vbanded(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)v_banded_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((v_banded_kernel<K>), dim3(a.ml), dim3(WAVE), lds_bytes, c->stream, a);
+  return hipSuccess;
+}
+template <int K>
+void launch_sse(btf_ctx* c, const double* A, const double* C, double Rc, int ncols, int ld, int rpb, int nrb) {
+  dim3 grid((ncols + SSE_THREADS - 1) / SSE_THREADS, nrb);
+  hipLaunchKernelGGL((sse_kernel<K>), grid, dim3(SSE_THREADS), 0, c->stream, A, C, Rc, c->W, c->V, c->N, ncols, ld,
+                     rpb, (size_t)c->col0 * c->T, c->bsum);
+}
+
+#define K_SWITCH(K, CALL)                                          \
+  switch (K) {                                                     \
+    case 1: { constexpr int KT = 1; CALL; } break;                 \
+    case 2: { constexpr int KT = 2; CALL; } break;                 \
+    case 3: { constexpr int KT = 3; CALL; } break;                 \
+    case 4: { constexpr int KT = 4; CALL; } break;                 \
+    case 5: { constexpr int KT = 5; CALL; } break;                 \
+    case 6: { constexpr int KT = 6; CALL; } break;                 \
+    case 7: { constexpr int KT = 7; CALL; } break;                 \
+    case 8: { constexpr int KT = 8; CALL; } break;                 \
+    case 9: { constexpr int KT = 9; CALL; } break;                 \
+    case 10: { constexpr int KT = 10; CALL; } break;               \
+    default: break;                                                \
+  }
+
+int check_status(btf_ctx* c) {
+  int st[2] = {0, -1};
+  HIPCHK(c, hipMemcpyAsync(st, c->status, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (st[0] != 0) {
+    c->fail_index = st[1];
+    int zero[2] = {0, -1};
+    HIPCHK(c, hipMemcpy(c->status, zero, sizeof(zero), hipMemcpyHostToDevice));
+    return fail(c, BTF_ENOTPD, "conditional precision not positive definite at index " + std::to_string(st[1]));
+  }
+  return BTF_OK;
+}
+
+int ensure_part(btf_ctx* c, size_t elems) {
+  if (elems > c->part_elems) {
+    int rc = dev_alloc(c, &c->part, elems);
+    if (rc) return rc;
+    c->part_elems = elems;
+  }
+  return BTF_OK;
+}
+
+int ensure_z(btf_ctx* c, size_t elems) {
+  if (elems > c->z_elems) {
+    int rc = dev_alloc(c, &c->zbuf, elems);
+    if (rc) return rc;
+    c->z_elems = elems;
+  }
+  return BTF_OK;
+}
+
+int pick_rpb(int Rdim, int tiles, int user) {
+  // rows per workgroup: a multiple of ACC_WAVES*ACC_UNR (=64) sized so that the
+  // grid has >= ~1024 workgroups when the problem allows, partials stay small
+  if (user > 0) return std::max(64, round_up(user, 64));
+  int want_chunks = std::max(1, 1024 / std::max(1, tiles));
+  int rpb = round_up((Rdim + want_chunks - 1) / want_chunks, 64);
+  return std::max(rpb, 128);
+}
+
+// upload a host slab and turn it into the padded device layouts
+int make_stats(btf_ctx* c, const double* hY, const double* hY2, int rows, int cols, int R, bool transposed,
+               double** A, double** C, double** B, int ld, size_t out_rows, bool want_sums) {
+  const size_t cells = (size_t)rows * cols;
+  double* dY = nullptr; double* dY2 = nullptr;
+  int rc;
+  if ((rc = dev_alloc(c, &dY, cells * R))) return rc;
+  HIPCHK(c, hipMemcpy(dY, hY, cells * R * sizeof(double), hipMemcpyHostToDevice));
+  if (hY2) {
+    if ((rc = dev_alloc(c, &dY2, cells))) return rc;
+    HIPCHK(c, hipMemcpy(dY2, hY2, cells * sizeof(double), hipMemcpyHostToDevice));
+  }
+  const size_t out_elems = out_rows * (size_t)ld;
+  if ((rc = dev_alloc(c, A, out_elems))) return rc;
+  HIPCHK(c, hipMemsetAsync(*A, 0, out_elems * sizeof(double), c->stream));
+  if ((rc = dev_alloc(c, C, out_elems))) return rc;
+  HIPCHK(c, hipMemsetAsync(*C, 0, out_elems * sizeof(double), c->stream));
+  int* dflag = c->status + 2;
+  const int blocks = (int)std::min<size_t>(4096, (cells + 255) / 256);
+  if (want_sums) {
+    if ((size_t)blocks * 2 > c->bsum_elems) {
+      if ((rc = dev_alloc(c, &c->bsum, (size_t)blocks * 2))) return rc;
+      c->bsum_elems = (size_t)blocks * 2;
+    }
+  }
+  StatsArgs a{dY, dY2, rows, cols, R, ld, transposed ? 1 : 0, *A, *C, want_sums ? c->bsum : nullptr, dflag};
+  {
+    Prof p(c, BTF_K_STATS);
+    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
+  }
+  HIPCHK(c, hipGetLastError());
+  if (B && hY2) {  // keep the trial counts for the PG draw: B = C at this point
+    if ((rc = dev_alloc(c, B, out_elems))) return rc;
+    HIPCHK(c, hipMemcpyAsync(*B, *C, out_elems * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (want_sums) {
+    std::vector<double> h((size_t)blocks * 2);
+    HIPCHK(c, hipMemcpy(h.data(), c->bsum, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    double ssw = 0.0, nobs = 0.0;
+    for (int b = 0; b < blocks; ++b) { ssw += h[2 * b]; nobs += h[2 * b + 1]; }
+    c->ssw = ssw;
+    c->nobs = nobs;
+  }
+  (void)hipFree(dY);
+  if (dY2) (void)hipFree(dY2);
+  return BTF_OK;
+}
+
+int upload_relayout(btf_ctx* c, const double* h, int rows, int cols, double* dst, int ld, bool transposed) {
+  const size_t cells = (size_t)rows * cols;
+  double* d = nullptr;
+  int rc;
+  if ((rc = dev_alloc(c, &d, cells))) return rc;
+  HIPCHK(c, hipMemcpy(d, h, cells * sizeof(double), hipMemcpyHostToDevice));
+  const int blocks = (int)std::min<size_t>(4096, (cells + 255) / 256);
+  hipLaunchKernelGGL(relayout_kernel, dim3(blocks), dim3(256), 0, c->stream, d, rows, cols, dst, ld, transposed ? 1 : 0, 1);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  return BTF_OK;
+}
+
+}  // namespace
+
+// =============================================================================
+extern "C" {
+
+int btf_create(btf_ctx** out, int nrows, int ncols, int ndepth, int nembeds, int tf_order, int device, void* stream) {
+  if (!out) return BTF_EINVAL;
+  *out = nullptr;
+  if (nrows < 1 || ncols < 1 || ndepth < 2 || nembeds < 1 || nembeds > MAX_K || tf_order < 0 || tf_order > 3)
+    return fail(nullptr, BTF_EINVAL, "unsupported dims (need 1<=nembeds<=10, 0<=tf_order<=3, ndepth>=2)");
+  if ((tf_order + 1) * nembeds > 63) return fail(nullptr, BTF_EINVAL, "half-bandwidth (tf_order+1)*nembeds must be <= 63");
+  btf_ctx* c = new btf_ctx();
+  c->N = nrows; c->M = ncols; c->T = ndepth; c->K = nembeds; c->TF = tf_order; c->KK = tri(nembeds);
+  c->dev = device;
+  c->row0 = 0; c->nl = nrows; c->col0 = 0; c->ml = ncols;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) { g_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete c; return BTF_EHIP; }
+  if (stream) { c->stream = (hipStream_t)stream; }
+  else {
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_err = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return BTF_EHIP; }
+    c->own_stream = true;
+  }
+  int rc = BTF_OK;
+  auto A = [&](int r) { if (rc == BTF_OK) rc = r; };
+  A(dev_alloc(c, &c->W, (size_t)(nrows + 64) * nembeds));        // +64: room for a padded all-gather
+  A(dev_alloc(c, &c->V, (size_t)(ncols + 64) * ndepth * nembeds));
+  A(dev_alloc(c, &c->WW, (size_t)nrows * c->KK));
+  A(dev_alloc(c, &c->VV, (size_t)ncols * ndepth * c->KK));
+  A(dev_alloc(c, &c->gpart, (size_t)GRAM_BLOCKS * c->KK));
+  A(dev_alloc(c, &c->status, 4));
+  if (rc == BTF_OK) {
+    int init[4] = {0, -1, 0, 0};
+    if (hipMemcpy(c->status, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) rc = BTF_EHIP;
+  }
+  if (rc == BTF_OK) rc = build_stencil(c);
+  A(dev_alloc(c, &c->Tau2, (size_t)ncols * c->nD));
+  A(dev_alloc(c, &c->tries, (size_t)ncols));
+  if (rc != BTF_OK) { std::string m = c->err; btf_destroy(c); g_err = m; return rc; }
+  *out = c;
+  return BTF_OK;
+}
+
+void btf_destroy(btf_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->dev);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->WW, c->VV, c->Tau2, c->part,
+                  c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
+                  c->src_row, c->src_col};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* btf_last_error(const btf_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+int btf_fail_index(const btf_ctx* c) { return c ? c->fail_index : -1; }
+
+int btf_set_shard(btf_ctx* c, int row0, int nrows_local, int col0, int ncols_local) {
+  if (!c) return BTF_EINVAL;
+  if (c->have_data) return fail(c, BTF_ESTATE, "btf_set_shard must precede btf_set_data_*");
+  if (row0 < 0 || nrows_local < 0 || row0 + nrows_local > c->N || col0 < 0 || ncols_local < 0 || col0 + ncols_local > c->M)
+    return fail(c, BTF_EINVAL, "shard out of range");
+  c->row0 = row0; c->nl = nrows_local; c->col0 = col0; c->ml = ncols_local;
+  return BTF_OK;
+}
+void* btf_dev_W(btf_ctx* c) { return c ? c->W : nullptr; }
+void* btf_dev_V(btf_ctx* c) { return c ? c->V : nullptr; }
+
+static int finish_data(btf_ctx* c) {
+  int flag = 0;
+  HIPCHK(c, hipMemcpy(&flag, c->status + 2, sizeof(int), hipMemcpyDeviceToHost));
+  c->weighted = c->binomial || flag != 0;
+  if (!c->weighted) {  // complete Gaussian data: counts are the constant R, drop them
+    (void)hipFree(c->C_wT); c->C_wT = nullptr;
+    (void)hipFree(c->C_v); c->C_v = nullptr;
+  }
+  c->have_data = true;
+  return BTF_OK;
+}
+
+int btf_set_data_gaussian(btf_ctx* c, const double* y_rows, const double* y_cols, int nreps) {
+  if (!c || !y_rows || !y_cols || nreps < 1) return fail(c, BTF_EINVAL, "bad data arguments");
+  HIPCHK(c, hipSetDevice(c->dev));
+  c->R = nreps; c->binomial = false;
+  const int MT = c->M * c->T;
+  c->ldw = round_up(std::max(c->nl, 1), ACC_TILE);
+  c->ldv = round_up(std::max(c->ml * c->T, 1), ACC_TILE);
+  int zero = 0;
+  HIPCHK(c, hipMemcpy(c->status + 2, &zero, sizeof(int), hipMemcpyHostToDevice));
+  int rc;
+  // row slab -> transposed layout A_wT[MT][ldw] (W half-sweep); carries the global sums
+  if ((rc = make_stats(c, y_rows, nullptr, c->nl, MT, nreps, true, &c->A_wT, &c->C_wT, nullptr, c->ldw, MT, true))) return rc;
+  // column slab -> A_v[N][ldv] (V half-sweep, SSE)
+  if ((rc = make_stats(c, y_cols, nullptr, c->N, c->ml * c->T, nreps, false, &c->A_v, &c->C_v, nullptr, c->ldv, c->N, false))) return rc;
+  return finish_data(c);
+}
+
+int btf_set_data_binomial(btf_ctx* c, const double* succ_rows, const double* trials_rows, const double* succ_cols,
+                          const double* trials_cols) {
+  if (!c || !succ_rows || !trials_rows || !succ_cols || !trials_cols) return fail(c, BTF_EINVAL, "bad data arguments");
+  HIPCHK(c, hipSetDevice(c->dev));
+  c->R = 1; c->binomial = true;
+  const int MT = c->M * c->T;
+  c->ldw = round_up(std::max(c->nl, 1), ACC_TILE);
+  c->ldv = round_up(std::max(c->ml * c->T, 1), ACC_TILE);
+  int zero = 0;
+  HIPCHK(c, hipMemcpy(c->status + 2, &zero, sizeof(int), hipMemcpyHostToDevice));
+  int rc;
+  if ((rc = make_stats(c, succ_rows, trials_rows, c->nl, MT, 1, true, &c->A_wT, &c->C_wT, &c->B_wT, c->ldw, MT, true))) return rc;
+  if ((rc = make_stats(c, succ_cols, trials_cols, c->N, c->ml * c->T, 1, false, &c->A_v, &c->C_v, &c->B_v, c->ldv, c->N, false))) return rc;
+  // until the first PG draw / set_omega the weights are zero
+  HIPCHK(c, hipMemset(c->C_wT, 0, (size_t)MT * c->ldw * sizeof(double)));
+  HIPCHK(c, hipMemset(c->C_v, 0, (size_t)c->N * c->ldv * sizeof(double)));
+  return finish_data(c);
+}
+
+int btf_set_stale_sources(btf_ctx* c, const int32_t* src_row, const int32_t* src_col) {
+  if (!c) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  int rc;
+  if (src_row) {
+    if ((rc = dev_alloc(c, &c->src_row, (size_t)c->N))) return rc;
+    HIPCHK(c, hipMemcpy(c->src_row, src_row, (size_t)c->N * sizeof(int32_t), hipMemcpyHostToDevice));
+  } else if (c->src_row) { (void)hipFree(c->src_row); c->src_row = nullptr; }
+  if (src_col) {
+    if ((rc = dev_alloc(c, &c->src_col, (size_t)c->M))) return rc;
+    HIPCHK(c, hipMemcpy(c->src_col, src_col, (size_t)c->M * sizeof(int32_t), hipMemcpyHostToDevice));
+  } else if (c->src_col) { (void)hipFree(c->src_col); c->src_col = nullptr; }
+  return BTF_OK;
+}
+
+int btf_set_W(btf_ctx* c, const double* W) {
+  if (!c || !W) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipMemcpyAsync(c->W, W, (size_t)c->N * c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_W = true;
+  return BTF_OK;
+}
+int btf_get_W(btf_ctx* c, double* W) {
+  if (!c || !W) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipMemcpyAsync(W, c->W, (size_t)c->N * c->K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  return check_status(c);
+}
+int btf_set_V(btf_ctx* c, const double* V) {
+  if (!c || !V) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipMemcpyAsync(c->V, V, (size_t)c->M * c->T * c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_V = true;
+  return BTF_OK;
+}
+int btf_get_V(btf_ctx* c, double* V) {
+  if (!c || !V) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipMemcpyAsync(V, c->V, (size_t)c->M * c->T * c->K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  return check_status(c);
+}
+int btf_set_hyper(btf_ctx* c, const double* Tau2, double lam2, double sigma2) {
+  if (!c) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (Tau2) {
+    HIPCHK(c, hipMemcpyAsync(c->Tau2, Tau2, (size_t)c->M * c->nD * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_hyper = true;
+  }
+  c->lam2 = lam2; c->sigma2 = sigma2;
+  return BTF_OK;
+}
+int btf_set_nu2(btf_ctx* c, double nu2) {
+  if (!c || !(nu2 > 0.0)) return fail(c, BTF_EINVAL, "nu2 must be positive");
+  c->nu2 = nu2;
+  return BTF_OK;
+}
+int btf_set_omega(btf_ctx* c, const double* omega_rows, const double* omega_cols) {
+  if (!c || !omega_rows || !omega_cols) return BTF_EINVAL;
+  if (!c->have_data || !c->binomial) return fail(c, BTF_ESTATE, "btf_set_omega needs binomial data");
+  HIPCHK(c, hipSetDevice(c->dev));
+  int rc;
+  const int MT = c->M * c->T;
+  HIPCHK(c, hipMemsetAsync(c->C_wT, 0, (size_t)MT * c->ldw * sizeof(double), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->C_v, 0, (size_t)c->N * c->ldv * sizeof(double), c->stream));
+  if ((rc = upload_relayout(c, omega_rows, c->nl, MT, c->C_wT, c->ldw, true))) return rc;
+  if ((rc = upload_relayout(c, omega_cols, c->N, c->ml * c->T, c->C_v, c->ldv, false))) return rc;
+  return BTF_OK;
+}
+int btf_get_omega(btf_ctx* c, double* omega_rows) {
+  if (!c || !omega_rows) return BTF_EINVAL;
+  if (!c->have_data || !c->C_wT) return fail(c, BTF_ESTATE, "no weights on this context");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const int MT = c->M * c->T;
+  std::vector<double> h((size_t)MT * c->ldw);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->C_wT, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < c->nl; ++i)
+    for (int jt = 0; jt < MT; ++jt) omega_rows[(size_t)i * MT + jt] = h[(size_t)jt * c->ldw + i];
+  return BTF_OK;
+}
+
+// ---------------------------------------------------------------------------- W
+int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
+  if (!c) return BTF_EINVAL;
+  if (!c->have_data || !c->have_V || !c->have_W) return fail(c, BTF_ESTATE, "set data, W and V first");
+  HIPCHK(c, hipSetDevice(c->dev));
+  (void)compat;
+  const int K = c->K, KK = c->KK, MT = c->M * c->T;
+  const bool wt = c->weighted;
+  const int NV = wt ? K + KK : K;
+  const int tiles = c->ldw / ACC_TILE;
+  const int rpb = pick_rpb(MT, tiles, c->rpb_w);
+  const int nch = (MT + rpb - 1) / rpb;
+  int rc;
+  if ((rc = ensure_part(c, (size_t)nch * NV * c->ldw))) return rc;
+  const double* dz = nullptr;
+  if (z) {
+    const size_t nz = (size_t)w_z_offset(c->N, K);
+    if ((rc = ensure_z(c, nz))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->zbuf, z, nz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    dz = c->zbuf;
+  }
+  if (c->nl > 0) {
+    if (wt) {
+      Prof p(c, BTF_K_PROD);
+      K_SWITCH(K, launch_products<KT>(c, c->V, MT, c->VV));
+    } else {
+      Prof p(c, BTF_K_GRAM);
+      K_SWITCH(K, launch_gram<KT>(c, c->V, MT));
+    }
+    {
+      Prof p(c, BTF_K_W_ACCUM);
+      K_SWITCH(K, launch_accum<KT>(c, wt, c->A_wT, c->C_wT, c->V, c->VV, MT, c->ldw, rpb, nch));
+    }
+    WSolveArgs a{};
+    a.part = c->part; a.nch = nch; a.ld = c->ldw; a.gpart = c->gpart; a.ngp = GRAM_BLOCKS; a.weighted = wt ? 1 : 0;
+    a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
+    a.sR = a.s * c->R;
+    a.inv_sigma2 = 1.0 / c->sigma2;
+    a.W = c->W; a.row0 = c->row0; a.nl = c->nl;
+    a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_w + 0x10000ULL;
+    a.status = c->status;
+    {
+      Prof p(c, BTF_K_W_SOLVE);
+      K_SWITCH(K, launch_wsolve<KT>(c, a));
+    }
+  }
+  c->sweep_w++;
+  HIPCHK(c, hipGetLastError());
+  return BTF_OK;
+}
+
+// ---------------------------------------------------------------------------- V
+int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, double eps0, int attempts) {
+  if (!c) return BTF_EINVAL;
+  if (!c->have_data || !c->have_V || !c->have_W || !c->have_hyper) return fail(c, BTF_ESTATE, "set data, W, V and hyper-parameters first");
+  if (attempts < 0) attempts = 0;
+  HIPCHK(c, hipSetDevice(c->dev));
+  (void)compat;
+  const int K = c->K, KK = c->KK, T = c->T, n = T * K;
+  const bool wt = c->weighted;
+  const int NV = wt ? K + KK : K;
+  const int tiles = c->ldv / ACC_TILE;
+  const int rpb = pick_rpb(c->N, tiles, c->rpb_v);
+  const int nch = (c->N + rpb - 1) / rpb;
+  int rc;
+  if ((rc = ensure_part(c, (size_t)nch * NV * c->ldv))) return rc;
+  const double* dz = nullptr;
+  if (z) {
+    const size_t nz = (size_t)c->M * n;
+    if ((rc = ensure_z(c, nz))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->zbuf, z, nz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    dz = c->zbuf;
+  }
+  if (c->ml > 0) {
+    if (wt) {
+      Prof p(c, BTF_K_PROD);
+      K_SWITCH(K, launch_products<KT>(c, c->W, c->N, c->WW));
+    } else {
+      Prof p(c, BTF_K_GRAM);
+      K_SWITCH(K, launch_gram<KT>(c, c->W, c->N));
+    }
+    {
+      Prof p(c, BTF_K_V_ACCUM);
+      K_SWITCH(K, launch_accum<KT>(c, wt, c->A_v, c->C_v, c->W, c->WW, c->N, c->ldv, rpb, nch));
+    }
+    const int bw = (c->TF + 1) * K, R1 = bw + 1, D1 = c->TF + 2;
+    size_t lds_fixed = (size_t)(3 * n + T * D1 + (wt ? T * KK : KK) + (bw * (bw + 1) / 2 + 3) / 4) * sizeof(double);
+    size_t lds_band = (size_t)n * R1 * sizeof(double);
+    size_t lds_bytes = lds_fixed + lds_band;
+    VBandArgs a{};
+    if (lds_bytes > 150 * 1024) {  // band lives in HBM scratch, only vectors on chip
+      if (lds_fixed > 150 * 1024) return fail(c, BTF_EINVAL, "ndepth*nembeds too large for the on-chip vectors");
+      if (!c->gband || c->gband_stride != (size_t)n * R1) {
+        if ((rc = dev_alloc(c, &c->gband, (size_t)c->ml * n * R1))) return rc;
+        c->gband_stride = (size_t)n * R1;
+      }
+      a.gband = c->gband; a.gband_stride = c->gband_stride;
+      lds_bytes = lds_fixed;
+    }
+    a.part = c->part; a.nch = nch; a.ld = c->ldv; a.gpart = c->gpart; a.ngp = GRAM_BLOCKS; a.weighted = wt ? 1 : 0;
+    a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
+    a.sR = a.s * c->R;
+    a.Tau2 = c->Tau2; a.lam2 = c->lam2; a.nD = c->nD;
+    a.st_ptr = c->st_ptr; a.st_row = c->st_row; a.st_coef = c->st_coef;
+    a.T = T; a.TF = c->TF; a.col0 = c->col0; a.ml = c->ml;
+    a.V = c->V; a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_v + 0x10001ULL;
+    a.eps0 = eps0; a.attempts = attempts; a.status = c->status; a.tries = c->tries;
+    hipError_t e = hipSuccess;
+    {
+      Prof p(c, BTF_K_V_BANDED);
+      K_SWITCH(K, e = launch_vbanded<KT>(c, a, lds_bytes));
+    }
+    HIPCHK(c, e);
+  }
+  c->sweep_v++;
+  HIPCHK(c, hipGetLastError());
+  return BTF_OK;
+}
+
+int btf_get_V_attempts(btf_ctx* c, int32_t* tries) {
+  if (!c || !tries) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipMemcpyAsync(tries, c->tries, (size_t)c->ml * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return BTF_OK;
+}
+
+// -------------------------------------------------------------------------- SSE
+int btf_sse(btf_ctx* c, double* sse, double* nobs) {
+  if (!c || !sse || !nobs) return BTF_EINVAL;
+  if (!c->have_data || c->binomial || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_sse needs Gaussian data, W and V");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const int ncols = c->ml * c->T;
+  const int gx = (ncols + SSE_THREADS - 1) / SSE_THREADS;
+  int nrb = std::max(1, std::min(c->N / 16, 2048 / std::max(1, gx)));
+  const int rpb = (c->N + nrb - 1) / nrb;
+  nrb = (c->N + rpb - 1) / rpb;
+  const size_t nb = (size_t)gx * nrb;
+  int rc;
+  if (nb > c->bsum_elems) {
+    if ((rc = dev_alloc(c, &c->bsum, nb))) return rc;
+    c->bsum_elems = nb;
+  }
+  if (ncols > 0) {
+    Prof p(c, BTF_K_SSE);
+    K_SWITCH(c->K, launch_sse<KT>(c, c->A_v, c->C_v, (double)c->R, ncols, c->ldv, rpb, nrb));
+  }
+  HIPCHK(c, hipGetLastError());
+  std::vector<double> h(nb);
+  if (ncols > 0) {
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->bsum, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  double s = 0.0;
+  for (size_t b = 0; b < (ncols > 0 ? nb : 0); ++b) s += h[b];
+  // NOTE: in a sharded run this is the column-slab share of the between-cell part; the
+  // within-cell part (ssw) and nobs were reduced over the ROW slab.  The host adds the
+  // two kinds over ranks (see functionalmf_amd/factor.py).
+  *sse = s + c->ssw;
+  *nobs = c->nobs;
+  return BTF_OK;
+}
+
+int btf_pg_draw(btf_ctx* c, uint64_t seed) {
+  (void)seed;
+  return fail(c, BTF_EINVAL, "btf_pg_draw: not built yet");
+}
+
+int btf_sync(btf_ctx* c) {
+  if (!c) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  return check_status(c);
+}
+
+// ---------------------------------------------------------------- stand-alone MVN
+int btf_mvn_banded(int device, int batch, int n, int bw, const double* band, const double* mu_part, const double* z,
+                   uint64_t seed, double eps0, int attempts, double* x_out, int32_t* tries_out) {
+  if (batch < 1 || n < 1 || bw < 0 || bw > 63 || !band || !x_out) return fail(nullptr, BTF_EINVAL, "bad mvn arguments");
+  btf_ctx* c = nullptr;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, BTF_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  const int R1 = bw + 1;
+  const size_t nb = (size_t)batch * n * R1, nv = (size_t)batch * n;
+  double *dband = nullptr, *dmu = nullptr, *dz = nullptr, *dx = nullptr, *dwork = nullptr;
+  int *dtries = nullptr, *dstatus = nullptr;
+  int rc = BTF_OK;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)dband, (void*)dmu, (void*)dz, (void*)dx, (void*)dwork, (void*)dtries, (void*)dstatus})
+      if (p) (void)hipFree(p);
+  };
+#define MV(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return fail(nullptr, BTF_EHIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+  MV(hipMalloc((void**)&dband, nb * sizeof(double)));
+  MV(hipMemcpy(dband, band, nb * sizeof(double), hipMemcpyHostToDevice));
+  if (mu_part) { MV(hipMalloc((void**)&dmu, nv * sizeof(double))); MV(hipMemcpy(dmu, mu_part, nv * sizeof(double), hipMemcpyHostToDevice)); }
+  if (z) { MV(hipMalloc((void**)&dz, nv * sizeof(double))); MV(hipMemcpy(dz, z, nv * sizeof(double), hipMemcpyHostToDevice)); }
+  MV(hipMalloc((void**)&dx, nv * sizeof(double)));
+  MV(hipMalloc((void**)&dwork, (nb + 2 * nv) * sizeof(double)));
+  MV(hipMalloc((void**)&dtries, batch * sizeof(int)));
+  MV(hipMalloc((void**)&dstatus, 2 * sizeof(int)));
+  MV(hipMemset(dstatus, 0, 2 * sizeof(int)));
+  MvnArgs a{dband, dmu, dz, dx, dwork, n, bw, seed, eps0, attempts < 0 ? 0 : attempts, dtries, dstatus};
+  const size_t lds = ((size_t)(bw * (bw + 1) / 2 + 3) / 4 + 1) * sizeof(double);
+  hipLaunchKernelGGL(mvn_banded_kernel, dim3(batch), dim3(WAVE), lds, 0, a);
+  MV(hipGetLastError());
+  MV(hipDeviceSynchronize());
+  int st[2];
+  MV(hipMemcpy(st, dstatus, sizeof(st), hipMemcpyDeviceToHost));
+  MV(hipMemcpy(x_out, dx, nv * sizeof(double), hipMemcpyDeviceToHost));
+  if (tries_out) MV(hipMemcpy(tries_out, dtries, batch * sizeof(int), hipMemcpyDeviceToHost));
+  cleanup();
+#undef MV
+  (void)c; (void)rc;
+  if (st[0]) return fail(nullptr, BTF_ENOTPD, "precision not positive definite in batch item " + std::to_string(st[1]));
+  return BTF_OK;
+}
+
+// ------------------------------------------------------------------ measurement
+int btf_set_profiling(btf_ctx* c, int on) {
+  if (!c) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (on && c->ev_pool.empty()) {
+    c->ev_pool.resize(MAX_EVENTS);
+    for (auto& e : c->ev_pool) {
+      HIPCHK(c, hipEventCreate(&e.a));
+      HIPCHK(c, hipEventCreate(&e.b));
+    }
+  }
+  c->profiling = on != 0;
+  return BTF_OK;
+}
+
+int btf_kernel_times(btf_ctx* c, double* ms_total, int64_t* launches) {
+  if (!c || !ms_total || !launches) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int64_t timed[BTF_K_COUNT] = {0};
+  for (size_t i = 0; i < c->ev_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) {
+      c->ms_total[c->ev_pool[i].kid] += ms;
+      timed[c->ev_pool[i].kid]++;
+    }
+  }
+  for (int k = 0; k < BTF_K_COUNT; ++k) {
+    ms_total[k] = c->ms_total[k];
+    launches[k] = c->profiling ? timed[k] : c->launches[k];
+    c->ms_total[k] = 0.0;
+    c->launches[k] = 0;
+  }
+  c->ev_used = 0;
+  return BTF_OK;
+}
+
+int btf_set_tuning(btf_ctx* c, int rows_per_block_w, int rows_per_block_v) {
+  if (!c) return BTF_EINVAL;
+  c->rpb_w = rows_per_block_w; c->rpb_v = rows_per_block_v;
+  return BTF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,630 @@
+// Hand-written CDNA4 kernels of the BTF Gibbs core (fp64 throughout).
+//
+// Data layout in HBM (DESIGN.md "Layout"):
+//   A_v  [N][ldv]   linear statistic, lanes run along (j,t)   -> V half-sweep, SSE
+//   A_wT [MT][ldw]  the same numbers transposed, lanes run along i -> W half-sweep
+//   C_v / C_wT      per-cell precision weights (replicate counts or PG omegas);
+//                   absent on the complete-data Gaussian path
+// Both half-sweeps are the same streaming contraction
+//   out[l][k] = sum_r X[r][l] * U[r][k]          (+ sum_r C[r][l] * U[r][k]U[r][k'])
+// with the reduction index r wave-uniform: U[r][:] is fetched with scalar loads
+// and used as the SGPR operand of v_fma_f64, every lane owns two adjacent outputs
+// l (one 16-byte global_load per row), and no cross-lane reduction is needed.
+#pragma once
+#include "btf_device.h"
+
+namespace btf {
+
+// ============================================================================
+// streaming accumulation  (BTF_K_W_ACCUM / BTF_K_V_ACCUM)
+// ============================================================================
+constexpr int ACC_WAVES = 8;            // waves per workgroup
+constexpr int ACC_THREADS = ACC_WAVES * WAVE;
+constexpr int ACC_TILE = 2 * WAVE;      // outputs per workgroup along the lane axis
+constexpr int ACC_UNR = 8;              // rows in flight per wave
+constexpr int ACC_RG = 4;               // values reduced per LDS round
+
+template <int K, int MODE>  // MODE 0: X only (complete data); 1: X, C and outer products
+__global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
+    const double* __restrict__ X, const double* __restrict__ Cx, const double* __restrict__ U,
+    const double* __restrict__ UU, double* __restrict__ part, int Rdim, int ld, int rows_per_block) {
+  constexpr int KK = tri(K);
+  constexpr int NV = MODE == 0 ? K : K + KK;
+  __shared__ double red[ACC_WAVES][ACC_RG][ACC_TILE];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x;
+  const int chunk = blockIdx.y;
+  const size_t col = (size_t)tile * ACC_TILE + 2 * lane;
+  const int r0 = chunk * rows_per_block;
+  const int r1 = min(r0 + rows_per_block, Rdim);
+
+  double acc[NV][2];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v][0] = acc[v][1] = 0.0;
+
+  for (int rb = r0 + wave; rb < r1; rb += ACC_WAVES * ACC_UNR) {
+    double2 x[ACC_UNR];
+    double2 c[MODE == 1 ? ACC_UNR : 1];
+#pragma unroll
+    for (int u = 0; u < ACC_UNR; ++u) {
+      const int r = rb + u * ACC_WAVES;  // wave-uniform
+      if (r < r1) {
+        x[u] = *reinterpret_cast<const double2*>(X + (size_t)r * ld + col);
+        if constexpr (MODE == 1) c[u] = *reinterpret_cast<const double2*>(Cx + (size_t)r * ld + col);
+      } else {
+        x[u] = make_double2(0.0, 0.0);
+        if constexpr (MODE == 1) c[u] = make_double2(0.0, 0.0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < ACC_UNR; ++u) {
+      const int r = min(rb + u * ACC_WAVES, r1 - 1);  // clamp: x/c are zero beyond r1
+      const double* __restrict__ up = U + (size_t)r * K;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const double uk = up[k];
+        acc[k][0] = fma(x[u].x, uk, acc[k][0]);
+        acc[k][1] = fma(x[u].y, uk, acc[k][1]);
+      }
+      if constexpr (MODE == 1) {
+        const double* __restrict__ uup = UU + (size_t)r * KK;
+#pragma unroll
+        for (int q = 0; q < KK; ++q) {
+          const double uq = uup[q];
+          acc[K + q][0] = fma(c[u].x, uq, acc[K + q][0]);
+          acc[K + q][1] = fma(c[u].y, uq, acc[K + q][1]);
+        }
+      }
+    }
+  }
+
+  // cross-wave reduction through LDS, ACC_RG values per round, fixed order
+  const int tv = threadIdx.x >> 7;   // value slot 0..3
+  const int tc = threadIdx.x & 127;  // column inside the tile
+#pragma unroll
+  for (int g = 0; g < NV; g += ACC_RG) {
+#pragma unroll
+    for (int v = 0; v < ACC_RG; ++v) {
+      if (g + v < NV)
+        *reinterpret_cast<double2*>(&red[wave][v][2 * lane]) = make_double2(acc[g + v][0], acc[g + v][1]);
+    }
+    __syncthreads();
+    if (g + tv < NV) {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < ACC_WAVES; ++w) s += red[w][tv][tc];
+      part[((size_t)chunk * NV + (g + tv)) * ld + (size_t)tile * ACC_TILE + tc] = s;
+    }
+    __syncthreads();
+  }
+}
+
+// ============================================================================
+// small helpers: Gram of the fixed factor, per-row outer products
+// ============================================================================
+constexpr int GRAM_BLOCKS = 64;
+constexpr int GRAM_THREADS = 256;
+
+template <int K>
+__global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const double* __restrict__ U, int Rdim,
+                                                            double* __restrict__ gpart) {
+  constexpr int KK = tri(K);
+  __shared__ double red[GRAM_THREADS / WAVE][KK];
+  double acc[KK];
+#pragma unroll
+  for (int q = 0; q < KK; ++q) acc[q] = 0.0;
+  for (int r = blockIdx.x * GRAM_THREADS + threadIdx.x; r < Rdim; r += GRAM_BLOCKS * GRAM_THREADS) {
+    double u[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) u[k] = U[(size_t)r * K + k];
+#pragma unroll
+    for (int a = 0; a < K; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) acc[lidx(a, b)] = fma(u[a], u[b], acc[lidx(a, b)]);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < KK; ++q) {
+    double s = wave_sum(acc[q]);
+    if (lane == 0) red[wave][q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < KK) {
+    double s = 0.0;
+    for (int w = 0; w < GRAM_THREADS / WAVE; ++w) s += red[w][threadIdx.x];
+    gpart[blockIdx.x * KK + threadIdx.x] = s;
+  }
+}
+
+template <int K>
+__global__ void products_kernel(const double* __restrict__ U, int Rdim, double* __restrict__ UU) {
+  constexpr int KK = tri(K);
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= Rdim) return;
+  double u[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) u[k] = U[(size_t)r * K + k];
+#pragma unroll
+  for (int a = 0; a < K; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) UU[(size_t)r * KK + lidx(a, b)] = u[a] * u[b];
+}
+
+// ============================================================================
+// W half-sweep: batched K x K Cholesky draw, one lane per row  (BTF_K_W_SOLVE)
+//   factor.py:349-362:  Q = X'CX + I/sigma2 ; Lt = chol(Q)' ;
+//                       W[i,:d] = cho_solve(Lt, m) + Lt^-1 z
+// ============================================================================
+struct WSolveArgs {
+  const double* part; int nch; int ld;
+  const double* gpart; int ngp;
+  int weighted;
+  double s;        // 1/nu2 (Gaussian) or 1 (Binomial)
+  double sR;       // s * nreps : scale of the shared Gram on the complete-data path
+  double inv_sigma2;
+  double* W; int row0; int nl;
+  const double* z; unsigned long long seed; unsigned long long stream;
+  int* status;     // [0] = failure flag, [1] = first failing row
+};
+
+template <int K>
+__global__ __launch_bounds__(128) void w_solve_kernel(WSolveArgs a) {
+  constexpr int KK = tri(K);
+  const int NV = a.weighted ? K + KK : K;
+  __shared__ double G[KK];
+  if (!a.weighted) {
+    if (threadIdx.x < KK) {
+      double s = 0.0;
+      for (int b = 0; b < a.ngp; ++b) s += a.gpart[b * KK + threadIdx.x];
+      G[threadIdx.x] = s * a.sR;
+    }
+    __syncthreads();
+  }
+  const int il = blockIdx.x * blockDim.x + threadIdx.x;
+  if (il >= a.nl) return;
+  const int i = a.row0 + il;
+  const int d = i + 1 < K ? i + 1 : K;
+
+  double m[K], Q[KK];
+#pragma unroll
+  for (int k = 0; k < K; ++k) m[k] = 0.0;
+#pragma unroll
+  for (int q = 0; q < KK; ++q) Q[q] = 0.0;
+  for (int c = 0; c < a.nch; ++c) {
+    const double* p = a.part + (size_t)c * NV * a.ld + il;
+#pragma unroll
+    for (int k = 0; k < K; ++k) m[k] += p[(size_t)k * a.ld];
+    if (a.weighted) {
+#pragma unroll
+      for (int q = 0; q < KK; ++q) Q[q] += p[(size_t)(K + q) * a.ld];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) m[k] *= a.s;
+#pragma unroll
+  for (int q = 0; q < KK; ++q) Q[q] = a.weighted ? Q[q] * a.s : G[q];
+#pragma unroll
+  for (int k = 0; k < K; ++k) Q[lidx(k, k)] += a.inv_sigma2;
+  // rows/cols >= d are frozen (W is lower triangular in its first K rows): identity there
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    if (r >= d) {
+      m[r] = 0.0;
+#pragma unroll
+      for (int c = 0; c <= r; ++c) Q[lidx(r, c)] = (r == c) ? 1.0 : 0.0;
+    }
+  }
+  // in-register Cholesky (lower, packed)
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    double p = Q[lidx(c, c)];
+#pragma unroll
+    for (int q = 0; q < c; ++q) p = fma(-Q[lidx(c, q)], Q[lidx(c, q)], p);
+    if (!(p > 0.0)) ok = false;
+    const double l = sqrt(p);
+    const double inv = 1.0 / l;
+    Q[lidx(c, c)] = l;
+#pragma unroll
+    for (int r = c + 1; r < K; ++r) {
+      double v = Q[lidx(r, c)];
+#pragma unroll
+      for (int q = 0; q < c; ++q) v = fma(-Q[lidx(r, q)], Q[lidx(c, q)], v);
+      Q[lidx(r, c)] = v * inv;
+    }
+  }
+  if (!ok) {
+    if (atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = i;
+    return;
+  }
+  // y = L^-1 m ; x = L^-T (y + z)
+  double y[K];
+  const long long zoff = w_z_offset(i, K);
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    double v = m[r];
+#pragma unroll
+    for (int c = 0; c < r; ++c) v = fma(-Q[lidx(r, c)], y[c], v);
+    y[r] = v / Q[lidx(r, r)];
+  }
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    if (r < d) {
+      const double zr = a.z ? a.z[zoff + r] : philox_normal(a.seed, a.stream, (unsigned long long)(zoff + r));
+      y[r] += zr;
+    }
+  }
+#pragma unroll
+  for (int r = K - 1; r >= 0; --r) {
+    double v = y[r];
+#pragma unroll
+    for (int c = r + 1; c < K; ++c) v = fma(-Q[lidx(c, r)], y[c], v);
+    y[r] = v / Q[lidx(r, r)];
+  }
+#pragma unroll
+  for (int r = 0; r < K; ++r)
+    if (r < d) a.W[(size_t)i * K + r] = y[r];
+}
+
+// ============================================================================
+// V half-sweep: block-banded Cholesky sampler, one wave per column (BTF_K_V_BANDED)
+//   the fast_mvn equivalent (fast_mvn.py:35-47 with the jitter loop :62-68)
+//   unknowns in depth-major order n = t*K + k, half-bandwidth bw = (tf+1)*K
+//   band storage (LDS or HBM scratch): Bc[n][a] = Q[n+a, n], a = 0..bw
+// ============================================================================
+struct VBandArgs {
+  // likelihood part
+  const double* part; int nch; int ld;   // accum partials [nch][NV][ld], column j at offset j*T
+  const double* gpart; int ngp;          // Gram partials (complete-data path)
+  int weighted;
+  double s, sR;
+  // prior part
+  const double* Tau2; double lam2; int nD;
+  const int* st_ptr; const int* st_row; const double* st_coef;  // Delta'.Delta stencil per (t,d)
+  int T, TF;
+  int col0, ml;
+  double* V;
+  const double* z; unsigned long long seed; unsigned long long stream;
+  double eps0; int attempts;
+  int* status;   // [0] flag, [1] failing column
+  int* tries;    // [ml]
+  double* gband; // HBM scratch for the band when it does not fit LDS, else nullptr
+  size_t gband_stride;
+};
+
+// generic banded factor + solves on a band at `Bc` (LDS or global), single wave.
+// returns false if a pivot is not positive.
+// pair table: entry q = (a << 8) | b enumerates 1 <= b <= a <= bw (filled once per kernel)
+__device__ inline void fill_pair_table(unsigned short* ptab, int bw) {
+  const int npairs = bw * (bw + 1) / 2;
+  for (int q = threadIdx.x; q < npairs; q += WAVE) {
+    int a = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5) + 1;
+    while ((a - 1) * a / 2 > q) --a;
+    while (a * (a + 1) / 2 <= q) ++a;
+    const int b = q - (a - 1) * a / 2 + 1;
+    ptab[q] = (unsigned short)((a << 8) | b);
+  }
+}
+
+__device__ inline bool banded_factor_forward(double* Bc, double* rhs, double* invd, const unsigned short* ptab,
+                                             int n, int bw) {
+  const int lane = threadIdx.x;
+  const int R1 = bw + 1;
+  const int npairs = bw * (bw + 1) / 2;
+  for (int nn = 0; nn < n; ++nn) {
+    const int len = min(bw, n - 1 - nn);
+    double* col = Bc + (size_t)nn * R1;
+    double v = (lane <= len) ? col[lane] : 0.0;
+    const double p = bcast_first(v);
+    if (!(p > 0.0)) return false;
+    const double l = sqrt(p);
+    const double inv = 1.0 / l;
+    double x = v * inv;
+    if (lane == 0) {
+      x = l;
+      invd[nn] = inv;
+    }
+    if (lane <= len) col[lane] = x;
+    // forward substitution folded in: y_nn = rhs[nn]/l ; rhs[nn+a] -= L[nn+a,nn] y_nn
+    const double yn = rhs[nn] * inv;
+    if (lane == 0) rhs[nn] = yn;
+    else if (lane <= len) rhs[nn + lane] -= x * yn;
+    // trailing update: A[nn+a, nn+b] -= L[nn+a,nn] L[nn+b,nn], 1 <= b <= a <= len
+    for (int q = lane; q < npairs; q += WAVE) {
+      const int ab = ptab[q];
+      const int a = ab >> 8, b = ab & 255;
+      if (a <= len) {
+        const double xa = col[a];
+        const double xb = col[b];
+        Bc[(size_t)(nn + b) * R1 + (a - b)] -= xa * xb;
+      }
+    }
+  }
+  return true;
+}
+
+__device__ inline void banded_backward(const double* Bc, double* rhs, const double* invd, int n, int bw) {
+  const int lane = threadIdx.x;
+  const int R1 = bw + 1;
+  for (int nn = n - 1; nn >= 0; --nn) {
+    const double xn = rhs[nn] * invd[nn];
+    if (lane == 0) rhs[nn] = xn;
+    else if (lane <= bw && lane <= nn) rhs[nn - lane] -= Bc[(size_t)(nn - lane) * R1 + lane] * xn;
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(WAVE) void v_banded_kernel(VBandArgs a) {
+  constexpr int KK = tri(K);
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int j = blockIdx.x;
+  const int jg = a.col0 + j;
+  const int T = a.T, n = T * K, D1 = a.TF + 2, bw = (a.TF + 1) * K, R1 = bw + 1;
+  const int NV = a.weighted ? K + KK : K;
+
+  // LDS carve-up
+  double* rhs = lds;                // n
+  double* m0 = rhs + n;             // n
+  double* invd = m0 + n;            // n
+  double* P = invd + n;             // T*D1 prior band  P[t][d] = (Delta' Lambda Delta)[t+d, t]
+  double* Ql = P + T * D1;          // weighted: T*KK ; else KK
+  double* Qe = Ql + (a.weighted ? T * KK : KK);
+  unsigned short* ptab = reinterpret_cast<unsigned short*>(Qe);   // bw(bw+1)/2 entries, padded to doubles
+  double* Bl = Qe + (bw * (bw + 1) / 2 + 3) / 4;
+  double* Bc = a.gband ? a.gband + (size_t)j * a.gband_stride : Bl;
+  fill_pair_table(ptab, bw);
+
+  // likelihood mean part and Gram blocks (fixed summation order over chunks)
+  for (int idx = lane; idx < n; idx += WAVE) {
+    const int t = idx / K, k = idx - t * K;
+    const double* p = a.part + (size_t)k * a.ld + (size_t)j * T + t;
+    double s = 0.0;
+    for (int c = 0; c < a.nch; ++c) s += p[(size_t)c * NV * a.ld];
+    m0[idx] = s * a.s;
+  }
+  if (a.weighted) {
+    for (int idx = lane; idx < T * KK; idx += WAVE) {
+      const int t = idx / KK, q = idx - t * KK;
+      const double* p = a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t;
+      double s = 0.0;
+      for (int c = 0; c < a.nch; ++c) s += p[(size_t)c * NV * a.ld];
+      Ql[idx] = s * a.s;
+    }
+  } else if (lane < KK) {
+    double s = 0.0;
+    for (int b = 0; b < a.ngp; ++b) s += a.gpart[b * KK + lane];
+    Ql[lane] = s * a.sR;
+  }
+  // prior band from the Delta stencil, rows ascending (the order of the sparse product)
+  for (int idx = lane; idx < T * D1; idx += WAVE) {
+    double s = 0.0;
+    for (int e = a.st_ptr[idx]; e < a.st_ptr[idx + 1]; ++e)
+      s += a.st_coef[e] / (a.lam2 * a.Tau2[(size_t)jg * a.nD + a.st_row[e]]);
+    P[idx] = s;
+  }
+  __syncthreads();
+
+  double shift = 0.0, eps = a.eps0;
+  int tried = 0;
+  bool ok = false;
+  while (true) {
+    // assemble the band
+    for (int idx = lane; idx < n * R1; idx += WAVE) {
+      const int nn = idx / R1, aa = idx - nn * R1;
+      const int t = nn / K, k = nn - t * K;
+      double v = 0.0;
+      if (aa < K - k) {
+        v = a.weighted ? Ql[t * KK + lidx(k + aa, k)] : Ql[lidx(k + aa, k)];
+        if (aa == 0) v += P[t * D1] + shift;
+      } else {
+        const int dd = aa / K;
+        if (dd * K == aa && dd < D1 && t + dd < T) v = P[t * D1 + dd];
+      }
+      Bc[idx] = v;
+    }
+    for (int idx = lane; idx < n; idx += WAVE) rhs[idx] = m0[idx];
+    __syncthreads();
+    ok = banded_factor_forward(Bc, rhs, invd, ptab, n, bw);
+    if (ok || tried >= a.attempts) break;
+    shift += eps;       // fast_mvn.py:64-68 : cumulative eps, eps *= 10
+    eps *= 10.0;
+    ++tried;
+    __syncthreads();
+  }
+  if (lane == 0) a.tries[j] = tried;
+  if (!ok) {
+    if (lane == 0 && atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = jg;
+    return;
+  }
+  // rhs holds y = L^-1 mu ; add z (depth-major index), back-substitute
+  for (int idx = lane; idx < n; idx += WAVE) {
+    const double zz = a.z ? a.z[(size_t)jg * n + idx]
+                          : philox_normal(a.seed, a.stream, (unsigned long long)jg * n + idx);
+    rhs[idx] += zz;
+  }
+  __syncthreads();
+  banded_backward(Bc, rhs, invd, n, bw);
+  __syncthreads();
+  for (int idx = lane; idx < n; idx += WAVE) a.V[(size_t)jg * n + idx] = rhs[idx];
+}
+
+// stand-alone banded sampler on a caller-supplied band (btf_mvn_banded)
+struct MvnArgs {
+  const double* band; const double* mu; const double* z; double* x; double* work;  // work: batch*(n*(bw+1)+2n)
+  int n, bw; unsigned long long seed; double eps0; int attempts; int* tries; int* status;
+};
+
+__global__ __launch_bounds__(WAVE) void mvn_banded_kernel(MvnArgs a) {
+  extern __shared__ double lds[];
+  unsigned short* ptab = reinterpret_cast<unsigned short*>(lds);
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const int n = a.n, bw = a.bw, R1 = bw + 1;
+  fill_pair_table(ptab, bw);
+  __syncthreads();
+  double* Bc = a.work + (size_t)b * ((size_t)n * R1 + 2 * n);
+  double* rhs = Bc + (size_t)n * R1;
+  double* invd = rhs + n;
+  const double* src = a.band + (size_t)b * n * R1;
+  double shift = 0.0, eps = a.eps0;
+  int tried = 0;
+  bool ok = false;
+  while (true) {
+    for (int idx = lane; idx < n * R1; idx += WAVE) Bc[idx] = src[idx] + ((idx % R1) == 0 ? shift : 0.0);
+    for (int idx = lane; idx < n; idx += WAVE) rhs[idx] = a.mu ? a.mu[(size_t)b * n + idx] : 0.0;
+    __syncthreads();
+    ok = banded_factor_forward(Bc, rhs, invd, ptab, n, bw);
+    if (ok || tried >= a.attempts) break;
+    shift += eps;
+    eps *= 10.0;
+    ++tried;
+    __syncthreads();
+  }
+  if (lane == 0) a.tries[b] = tried;
+  if (!ok) {
+    if (lane == 0 && atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = b;
+    return;
+  }
+  for (int idx = lane; idx < n; idx += WAVE)
+    rhs[idx] += a.z ? a.z[(size_t)b * n + idx] : philox_normal(a.seed, 7, (unsigned long long)b * n + idx);
+  __syncthreads();
+  banded_backward(Bc, rhs, invd, n, bw);
+  __syncthreads();
+  for (int idx = lane; idx < n; idx += WAVE) a.x[(size_t)b * n + idx] = rhs[idx];
+}
+
+// ============================================================================
+// one-time sufficient statistics  (BTF_K_STATS)
+//   replaces the per-half-sweep nanmean / count of factor.py:329-330, :374-375
+// ============================================================================
+// Y slab [rows][cols][R] -> out[(transposed ? col*ld + row : row*ld + col)]
+//   Gaussian : A = sum_r y (observed),  C = count            (A = S1, ybar = A/C)
+//   Binomial : A = succ - trials/2,     C = trials  (0 where missing)
+// block partial sums: ssw (within-cell sum of squares about the cell mean), nobs,
+// and a flag whether every cell has all R replicates.
+struct StatsArgs {
+  const double* Y; const double* Y2;  // Y2 = trials (binomial) or nullptr
+  int rows, cols, R; int ld; int transposed;
+  double* A; double* C;               // C may be nullptr (not kept)
+  double* bsum;                       // [gridDim][2] : ssw, nobs   (may be nullptr)
+  int* incomplete;                    // set to 1 if any cell has cnt != R (Gaussian) / is missing (binomial)
+};
+
+__global__ __launch_bounds__(256) void stats_kernel(StatsArgs a) {
+  __shared__ double red[4][2];
+  const size_t cells = (size_t)a.rows * a.cols;
+  double ssw = 0.0, nobs = 0.0;
+  bool inc = false;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < cells; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t row, col;
+    if (a.transposed) {  // consecutive lanes -> consecutive rows (coalesced writes)
+      col = idx / a.rows;
+      row = idx - col * a.rows;
+    } else {
+      row = idx / a.cols;
+      col = idx - row * a.cols;
+    }
+    const size_t cell = row * a.cols + col;
+    double A, C;
+    if (a.Y2 == nullptr) {
+      double s1 = 0.0;
+      int cnt = 0;
+      for (int r = 0; r < a.R; ++r) {
+        const double y = a.Y[cell * a.R + r];
+        if (y == y) { s1 += y; ++cnt; }
+      }
+      if (cnt > 0) {
+        const double mean = s1 / cnt;
+        for (int r = 0; r < a.R; ++r) {
+          const double y = a.Y[cell * a.R + r];
+          if (y == y) ssw = fma(y - mean, y - mean, ssw);
+        }
+      }
+      nobs += cnt;
+      inc |= (cnt != a.R);
+      A = s1;
+      C = (double)cnt;
+    } else {
+      const double y = a.Y[cell], nt = a.Y2[cell];
+      const bool miss = !(y == y) || !(nt == nt);
+      A = miss ? 0.0 : y - 0.5 * nt;
+      C = miss ? 0.0 : nt;
+      inc |= miss;
+      nobs += miss ? 0.0 : 1.0;
+    }
+    const size_t o = a.transposed ? col * a.ld + row : row * a.ld + col;
+    a.A[o] = A;
+    if (a.C) a.C[o] = C;
+  }
+  if (inc) *a.incomplete = 1;
+  if (a.bsum) {
+    ssw = wave_sum(ssw);
+    nobs = wave_sum(nobs);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = ssw; red[wave][1] = nobs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a.bsum[2 * blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+      a.bsum[2 * blockIdx.x + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    }
+  }
+}
+
+// plain / transposing copy of a host-layout slab [rows][cols] into a padded device layout
+__global__ void relayout_kernel(const double* src, int rows, int cols, double* dst, int ld, int transposed, int zero_nan) {
+  const size_t cells = (size_t)rows * cols;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < cells; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t row, col;
+    if (transposed) { col = idx / rows; row = idx - col * rows; }
+    else { row = idx / cols; col = idx - row * cols; }
+    double v = src[row * cols + col];
+    if (zero_nan && !(v == v)) v = 0.0;
+    dst[transposed ? col * ld + row : row * ld + col] = v;
+  }
+}
+
+// ============================================================================
+// residual sum of squares for the nu2 update  (BTF_K_SSE)
+//   sum_{cells} sum_r (y - mu)^2 = SSW + sum_cells (S1 - cnt*mu)^2 / cnt
+//   uses the V-layout slab: lanes along (j,t), W[i][:] wave-uniform
+// ============================================================================
+constexpr int SSE_THREADS = 256;
+
+template <int K>
+__global__ __launch_bounds__(SSE_THREADS) void sse_kernel(const double* __restrict__ A, const double* __restrict__ C,
+                                                          double Rconst, const double* __restrict__ W,
+                                                          const double* __restrict__ V, int N, int ncell_cols,
+                                                          int ld, int rows_per_block, size_t vcol0,
+                                                          double* __restrict__ bsum) {
+  __shared__ double red[SSE_THREADS / WAVE];
+  const int col = blockIdx.x * SSE_THREADS + threadIdx.x;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, N);
+  double acc = 0.0;
+  if (col < ncell_cols) {
+    double v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = V[(vcol0 + col) * K + k];
+    for (int i = r0; i < r1; ++i) {
+      const double* __restrict__ w = W + (size_t)i * K;
+      double mu = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) mu = fma(w[k], v[k], mu);
+      const double x = A[(size_t)i * ld + col];
+      const double c = C ? C[(size_t)i * ld + col] : Rconst;
+      const double e = x - c * mu;
+      if (c > 0.0) acc += e * e / c;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < SSE_THREADS / WAVE; ++w) s += red[w];
+    bsum[blockIdx.y * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+}  // namespace btf

@@ -1,0 +1,490 @@
+"""Bayesian Tensor Filtering models with the Gibbs hot path on MI355X.
+
+Counterpart of functionalmf/factor.py:23-460 (``BayesianTensorFiltering``,
+``GaussianBayesianTensorFiltering``, ``BinomialBayesianTensorFiltering``): same
+constructor keywords, public attributes (``W V Tau2 lam2 sigma2 nu2 Delta
+sample_*``), method names and ``run_gibbs`` result layout, so a script written
+for ``functionalmf.factor`` only changes its import.  The bodies of
+``_resample_W`` / ``_resample_V`` / ``_resample_nu2`` (and ``_init_V``) are
+calls into the C ABI of include/btf.h; the scalar / per-column hyper-parameter
+draws stay on the host because in ``rng="host"`` mode they must consume the
+legacy numpy stream in the reference's order.
+
+Extra keywords (all optional):
+  compat  "reference" (default) reproduces the reference's result-changing
+          quirks Q1-Q3 (stale cached likelihood weights, lam2 rate overwrite);
+          "exact" uses the textbook conditionals.
+  rng     "host" (default): every normal / gamma comes from the global legacy
+          numpy generator in the reference's order, so a seeded run reproduces
+          the reference chain; "device": the normals of the W and V draws come
+          from Philox4x32-10 on the GPU (nothing but scalars crosses PCIe).
+  device  HIP device ordinal;  stream: hipStream_t handle (int) or None.
+  shard   (rank, world) to update only this rank's block of rows / columns
+          (see functionalmf_amd/parallel.py); W and V stay replicated.
+"""
+import numpy as np
+
+from . import _native
+from .genlasso import _BayesianModel, ConjugateInverseGammaPrior
+from .utils import bayes_grid_penalty, sample_horseshoe_plus, sample_horseshoe
+from .parallel import ShardPlan, Exchange
+
+
+def stale_row_sources(nrows, nembeds, any_nan):
+    """Quirk Q1 (factor.py:320,349): without any NaN in the data the per-row design
+    cache is refreshed only for rows < K, so rows >= K reuse row K-1's weights."""
+    src = np.arange(nrows, dtype=np.int32)
+    if not any_nan and nrows > nembeds:
+        src[nembeds:] = nembeds - 1
+    return src
+
+
+def stale_col_sources(missing):
+    """Quirk Q2 (factor.py:394-400): column j reuses the cached design (hence the
+    weights) of the last column at which the NaN pattern of ybar[:, j, :] changed.
+    `missing`: bool (N, M, T), True where the cell has no observation."""
+    M = missing.shape[1]
+    src = np.zeros(M, dtype=np.int32)
+    for j in range(1, M):
+        same = np.array_equal(missing[:, j, :], missing[:, src[j - 1], :])
+        src[j] = src[j - 1] if same else j
+    return src
+
+
+class BayesianTensorFiltering(_BayesianModel):
+    def __init__(self, nrows, ncols, ndepth,
+                 nembeds=5, tf_order=2,
+                 sigma2_init=None, sigma2_true=None,
+                 sigma2_a=0.1, sigma2_b=0.1,
+                 lam2_init=None, lam2_true=None,
+                 Tau2_init=None, Tau2_true=None,
+                 W_init=None, V_init=None,
+                 W_true=None, V_true=None,
+                 stability=1e-6,
+                 force_psd=True,
+                 force_psd_eps=1e-6,
+                 force_psd_attempts=4,
+                 compat="reference", rng="host", device=0, stream=None, shard=None, device_seed=0,
+                 **kwargs):
+        super().__init__(**kwargs)
+        if compat not in _native.COMPAT:
+            raise ValueError("compat must be 'reference' or 'exact'")
+        if rng not in ("host", "device"):
+            raise ValueError("rng must be 'host' or 'device'")
+        self.nrows, self.ncols, self.ndepth, self.nembeds = nrows, ncols, ndepth, nembeds
+        self.tf_order = tf_order
+        self.stability = stability
+        self.linalg_opts = dict(force_psd=force_psd, force_psd_eps=force_psd_eps,
+                                force_psd_attempts=force_psd_attempts)
+        self.compat, self.rng, self.device = compat, rng, device
+        self._device_seed = int(device_seed)
+        self._draws = 0
+
+        # device context first: without the HIP library / a GPU nothing below can run
+        self._ctx = _native.Context(nrows, ncols, ndepth, nembeds, tf_order, device=device, stream=stream)
+        self._plan = ShardPlan(nrows, ncols, *(shard if shard is not None else (0, 1)))
+        self._exchange = Exchange(self._plan, self._ctx)
+        if self._plan.world > 1:
+            self._ctx.call("btf_set_shard", *self._plan.mine())
+        self._data_key = None
+        self._W_host_new = self._V_host_new = True      # host copy must be pushed before the next kernel
+        self._W_dev_new = self._V_dev_new = False       # device copy is newer than the host mirror
+        self._hyper_dirty = True
+
+        # trend-filtering prior (factor.py:50)
+        self.Delta = bayes_grid_penalty(ndepth, tf_order)
+
+        # construction draws in the reference's order (factor.py:53-110)
+        self.sigma2_a, self.sigma2_b = sigma2_a, sigma2_b
+        self.sigma2_model = ConjugateInverseGammaPrior(1, sigma2_a, sigma2_b)
+        self.sample_sigma2 = sigma2_true is None
+        if sigma2_true is not None:
+            self.sigma2 = sigma2_true
+        elif sigma2_init is not None:
+            self.sigma2 = sigma2_init
+        else:
+            self._init_sigma2()
+
+        self.sample_lam2 = lam2_true is None
+        if lam2_true is not None:
+            self.lam2 = lam2_true
+        else:
+            self._init_lam2()
+            if lam2_init is not None:
+                self.lam2 = lam2_init
+
+        self.sample_Tau2 = Tau2_true is None
+        if Tau2_true is not None:
+            self.Tau2 = np.array(Tau2_true, dtype=float)
+        elif Tau2_init is not None:
+            self.Tau2 = np.array(Tau2_init, dtype=float)
+        else:
+            self._init_Tau2()
+        assert self.Tau2.shape == (ncols, self.Delta.shape[0])
+
+        self.sample_W = W_true is None
+        if W_true is not None:
+            self._W = np.array(W_true, dtype=float)
+        elif W_init is not None:
+            self._W = np.array(W_init, dtype=float)
+        else:
+            self._init_W()
+        assert self._W.shape == (nrows, nembeds)
+
+        self.sample_V = V_true is None
+        if V_true is not None:
+            self._V = np.array(V_true, dtype=float)
+        elif V_init is not None:
+            self._V = np.array(V_init, dtype=float)
+        else:
+            self._init_V()
+        assert self._V.shape == (ncols, ndepth, nembeds)
+
+    # ---- host mirrors of the device-resident factors -----------------------------
+    # Reading .W / .V hands out the numpy mirror (refreshed from the GPU if a kernel
+    # wrote since); because callers may write into it in place (the reference's
+    # `model.W[:] = ...` idiom) the mirror is pushed back before the next kernel.
+    @property
+    def W(self):
+        self._pull_W()
+        self._W_host_new = True
+        return self._W
+
+    @W.setter
+    def W(self, value):
+        self._W = np.array(value, dtype=float)
+        self._W_host_new, self._W_dev_new = True, False
+
+    @property
+    def V(self):
+        self._pull_V()
+        self._V_host_new = True
+        return self._V
+
+    @V.setter
+    def V(self, value):
+        self._V = np.array(value, dtype=float)
+        self._V_host_new, self._V_dev_new = True, False
+
+    def _pull_W(self):
+        if self._W_dev_new:
+            self._ctx.call("btf_get_W", _native.dptr(self._W))
+            self._W_dev_new = False
+
+    def _pull_V(self):
+        if self._V_dev_new:
+            self._ctx.call("btf_get_V", _native.dptr(self._V))
+            self._V_dev_new = False
+
+    def _push_state(self):
+        if self._W_host_new:
+            self._W = _native.as_f64(self._W)
+            self._ctx.call("btf_set_W", _native.dptr(self._W))
+            self._W_host_new = False
+        if self._V_host_new:
+            self._V = _native.as_f64(self._V)
+            self._ctx.call("btf_set_V", _native.dptr(self._V))
+            self._V_host_new = False
+        tau = _native.as_f64(self.Tau2)
+        self._ctx.call("btf_set_hyper", _native.dptr(tau), float(self.lam2), float(self.sigma2))
+
+    def _next_seed(self):
+        self._draws += 1
+        return (self._device_seed * 0x9E3779B97F4A7C15 + self._draws) & 0xFFFFFFFFFFFFFFFF
+
+    # ---- data -------------------------------------------------------------------
+    def _bind_data(self, data):
+        """Upload the observations once and hoist their sufficient statistics (what
+        factor.py:329-330 / :374-375 recompute on every half-sweep)."""
+        arrays = data if isinstance(data, (tuple, list)) else (data,)
+        key = tuple((id(a), a.shape) for a in arrays)
+        if key == self._data_key:
+            return
+        self._upload(data)
+        self._data_ref = data          # keep alive so ids are not recycled
+        self._data_key = key
+
+    def set_data(self, data):
+        """Force a re-upload (e.g. after mutating the observation array in place)."""
+        self._data_key = None
+        self._bind_data(data)
+
+    def _upload(self, data):
+        raise NotImplementedError
+
+    # ---- construction draws ------------------------------------------------------
+    def _init_sigma2(self):
+        self.sigma2 = 1 / self.sigma2_model.draw_from_prior()
+
+    def _init_lam2(self):
+        self.lam2, self.lam2_a = sample_horseshoe()
+        self.lam2 = self.lam2.clip(0, 4)
+
+    def _init_Tau2(self):
+        self.Tau2, self.Tau2_c, self.Tau2_b, self.Tau2_a = \
+            sample_horseshoe_plus(size=(self.ncols, self.Delta.shape[0]))
+        self.Tau2 = self.Tau2.clip(0, 9)
+
+    def _init_W(self):
+        """N(0, sigma2) with the strict upper triangle of the first K rows zeroed
+        (factor.py:230-233)."""
+        self._W = np.random.normal(0, np.sqrt(self.sigma2), size=(self.nrows, self.nembeds))
+        if self.nrows > 1:
+            self._W[np.triu_indices(self.nembeds, k=1)] = 0
+
+    def prior_bands(self):
+        """(M, T, tf+2) band of Delta' diag(1/(lam2 Tau2_j)) Delta: [j,t,d] = entry (t+d,t)."""
+        D = self.Delta.toarray()
+        lam = 1.0 / (self.lam2 * self.Tau2)                     # (M, nD)
+        T, nb = self.ndepth, self.tf_order + 2
+        band = np.zeros((self.ncols, T, nb))
+        for d in range(nb):
+            S = D[:, :T - d] * D[:, d:]                         # (nD, T-d)
+            band[:, :T - d, d] = lam @ S
+        return band
+
+    def _init_V(self):
+        """Prior draw per column, V_j ~ N(0, (I_K (x) Delta'LambdaDelta)^-1), clipped to
+        +-10 (factor.py:235-242) - through the device banded sampler in depth-major order."""
+        from .fast_mvn import sample_banded_batch
+        K, T, M = self.nembeds, self.ndepth, self.ncols
+        bw = (self.tf_order + 1) * K
+        P = self.prior_bands()
+        band = np.zeros((M, T * K, bw + 1))
+        for d in range(self.tf_order + 2):
+            for k in range(K):
+                band[:, k::K, d * K][:, :T] = P[:, :, d]
+        z = np.random.normal(size=(M, K * T)) if self.rng == "host" else None
+        x, _ = sample_banded_batch(band, z=z, seed=self._next_seed(), device=self.device, **self.linalg_opts)
+        self._V = x.reshape(M, T, K).clip(-10, 10)
+        self._V_host_new, self._V_dev_new = True, False
+
+    # ---- one Gibbs sweep over the shared parameters (factor.py:112-128) -----------
+    def resample(self, data, **kwargs):
+        if self.sample_sigma2:
+            self._resample_sigma2()
+        if self.sample_Tau2:
+            self._resample_Tau2()
+        if self.sample_lam2:
+            self._resample_lam2()
+        if self.sample_W:
+            self._resample_W(data)
+        if self.sample_V:
+            self._resample_V(data)
+
+    def _pack_W(self, W):
+        """Free entries of W as one vector: lower triangle of the leading square block,
+        then the dense remainder (factor.py:155-174; the precision it also returns is
+        (1/sigma2) I and is not needed on this path)."""
+        h = min(self.nembeds, self.nrows)
+        return np.concatenate([W[np.tril_indices(h)], W[h:].reshape(-1)])
+
+    def _resample_sigma2(self):
+        self._pull_W()
+        w = self._pack_W(self._W)
+        self.sigma2 = 1 / self.sigma2_model.resample_from_stats(float(w @ w), w.size)
+
+    def _penalised_differences(self):
+        """sum_k (Delta V_j)[r,k]^2 for every column j and penalty row r: (M, nD)."""
+        self._pull_V()
+        d = np.einsum("rt,mtk->mrk", self.Delta.toarray(), self._V)
+        return (d * d).sum(axis=2)
+
+    def _resample_Tau2(self):
+        """Horseshoe+ local scales, one column after the other so that the legacy RNG
+        stream matches the reference (4 vector gamma draws per column, factor.py:134-141)."""
+        lo, hi = self.stability, 1 / self.stability
+        dsq = self._penalised_differences()
+        shape = (self.nembeds + 1) / 2
+        for j in range(self.ncols):
+            rate = dsq[j] / (2 * self.lam2) + 1 / self.Tau2_c[j].clip(lo, hi)
+            self.Tau2[j] = 1 / np.random.gamma(shape, 1 / rate.clip(lo, hi))
+            self.Tau2_c[j] = 1 / np.random.gamma(1, 1 / (1 / self.Tau2[j] + 1 / self.Tau2_b[j]).clip(lo, hi))
+            self.Tau2_b[j] = 1 / np.random.gamma(1, 1 / (1 / self.Tau2_c[j] + 1 / self.Tau2_a[j]).clip(lo, hi))
+            self.Tau2_a[j] = 1 / np.random.gamma(1, 1 / (1 / self.Tau2_b[j] + 1).clip(lo, hi))
+
+    def _resample_lam2(self):
+        """Global scale.  compat="reference": the rate keeps only the LAST column's term
+        (quirk Q3, factor.py:147-150); "exact": 1/lam2_a plus the sum over columns."""
+        terms = (self._penalised_differences() / self.Tau2).sum(axis=1) / 2
+        rate = terms[-1] if self.compat == "reference" else 1 / self.lam2_a + terms.sum()
+        shape = self.Delta.shape[0] * self.ncols * self.nembeds + 1
+        self.lam2 = max(1e-5, 1 / np.random.gamma(shape / 2, 1 / rate))
+        self.lam2_a = 1 / np.random.gamma(1, 1 / (1 / self.lam2 + 1))
+
+    def _inferred_variables(self, var_map):
+        self._pull_W()
+        self._pull_V()
+        var_map['W'] = np.copy(self._W)
+        var_map['V'] = np.copy(self._V)
+        var_map['sigma2'] = self.sigma2
+        var_map['lam2'] = self.lam2
+        var_map['Tau2'] = np.copy(self.Tau2)
+
+    def _set_hyperparameters(self, hyperparams):
+        self.lam2 = hyperparams['lam2']
+
+    # ---- the two half-sweeps (device) ----------------------------------------------
+    def _w_normals(self):
+        if self.rng != "host":
+            return None
+        K, N = self.nembeds, self.nrows
+        n = K * (K + 1) // 2 + (N - K) * K if N >= K else N * (N + 1) // 2
+        return np.random.normal(size=n)        # == the per-row draws of factor.py:361, concatenated
+
+    def _v_normals(self):
+        if self.rng != "host":
+            return None
+        return np.random.normal(size=(self.ncols, self.nembeds * self.ndepth))   # fast_mvn.py:41 per column
+
+    def _device_W_step(self):
+        self._push_state()
+        z = self._w_normals()
+        self._ctx.call("btf_resample_W", _native.dptr(z), self._next_seed(), _native.COMPAT[self.compat])
+        self._exchange.after_W()
+        self._W_dev_new = True
+
+    def _device_V_step(self):
+        self._push_state()
+        z = self._v_normals()
+        o = self.linalg_opts
+        self._ctx.call("btf_resample_V", _native.dptr(z), self._next_seed(), _native.COMPAT[self.compat],
+                       float(o["force_psd_eps"]), int(o["force_psd_attempts"]) if o["force_psd"] else 0)
+        self._exchange.after_V()
+        self._V_dev_new = True
+
+    def sync(self):
+        """Wait for the GPU; raises NotPositiveDefiniteError if a factorisation failed."""
+        self._ctx.call("btf_sync")
+
+    def _resample_W(self, data):
+        raise NotImplementedError
+
+    def _resample_V(self, data):
+        raise NotImplementedError
+
+
+class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
+    def __init__(self, nrows, ncols, ndepth,
+                 nu2_init=None, nu2_true=None,
+                 nu2_a=0.1, nu2_b=0.1, **kwargs):
+        super().__init__(nrows, ncols, ndepth, **kwargs)
+        self.nu2_a, self.nu2_b = nu2_a, nu2_b
+        self.nu2_model = ConjugateInverseGammaPrior(1, nu2_a, nu2_b)
+        self.sample_nu2 = nu2_true is None
+        if nu2_true is not None:
+            self.nu2 = nu2_true
+        elif nu2_init is not None:
+            self.nu2 = nu2_init
+        else:
+            self._init_nu2()
+
+    def _init_nu2(self):
+        self.nu2 = 1 / self.nu2_model.draw_from_prior()
+
+    def _upload(self, Y):
+        if Y.ndim not in (3, 4):
+            raise AssertionError('Observations must be 3- or 4-tensor.')
+        Y4 = Y[..., None] if Y.ndim == 3 else Y
+        if Y4.shape[:3] != (self.nrows, self.ncols, self.ndepth):
+            raise ValueError("data shape %r does not match the model" % (Y.shape,))
+        rows, cols = self._plan.slabs(Y4)
+        self._ctx.call("btf_set_data_gaussian", _native.dptr(rows), _native.dptr(cols), int(Y4.shape[3]))
+        miss = np.isnan(Y4)
+        self._ctx.call("btf_set_stale_sources",
+                       stale_row_sources(self.nrows, self.nembeds, bool(miss.any())).ctypes.data_as(_native._c_ip),
+                       stale_col_sources(miss.all(axis=3)).ctypes.data_as(_native._c_ip))
+
+    def resample(self, data):
+        if self.sample_nu2:
+            self._resample_nu2(data)
+        super().resample(data)
+
+    def _set_noise(self):
+        self._ctx.call("btf_set_nu2", float(np.asarray(self.nu2).reshape(-1)[0]))
+
+    def _resample_W(self, data):
+        self._bind_data(data)
+        self._set_noise()
+        self._device_W_step()
+
+    def _resample_V(self, data):
+        self._bind_data(data)
+        self._set_noise()
+        self._device_V_step()
+
+    def _resample_nu2(self, data):
+        """nu2 | rest: residual sum of squares reduced on the device (factor.py:411-416)."""
+        self._bind_data(data)
+        self._push_state()
+        import ctypes
+        sse, nobs = ctypes.c_double(), ctypes.c_double()
+        self._ctx.call("btf_sse", ctypes.byref(sse), ctypes.byref(nobs))
+        sse, nobs = self._exchange.sum_scalars(sse.value, nobs.value)
+        self.nu2 = 1 / self.nu2_model.resample_from_stats(sse, nobs)
+
+    def _inferred_variables(self, var_map):
+        super()._inferred_variables(var_map)
+        var_map['nu2'] = self.nu2
+
+
+class BinomialBayesianTensorFiltering(GaussianBayesianTensorFiltering):
+    """Logistic-Binomial likelihood through Polya-Gamma augmentation
+    (factor.py:425-460): omega ~ PG(N, w.v) on the device, then the weighted
+    Gaussian half-sweeps with pseudo-data kappa = Y - N/2."""
+
+    def __init__(self, nrows, ncols, ndepth, pg_seed=42, **kwargs):
+        super().__init__(nrows, ncols, ndepth, **kwargs)
+        self.pg_seed = pg_seed
+        self._pg_calls = 0
+        self._nu2 = np.zeros((nrows, ncols, ndepth))
+        self._omega_dev_new = False
+        self.sample_nu2 = True
+
+    # nu2 = 1/omega is materialised on the host only when somebody looks at it
+    @property
+    def nu2(self):
+        if getattr(self, "_omega_dev_new", False):
+            om = np.zeros((self._plan.nl, self.ncols, self.ndepth))
+            self._ctx.call("btf_get_omega", _native.dptr(om))
+            full = self._exchange.gather_rows_host(om)
+            with np.errstate(divide='ignore'):
+                self._nu2 = 1 / full
+            self._omega_dev_new = False
+        return self._nu2
+
+    @nu2.setter
+    def nu2(self, value):
+        self._nu2 = value
+        self._omega_dev_new = False
+        self._omega_host_new = True
+
+    def _upload(self, data):
+        Y, N = data
+        if Y.shape != (self.nrows, self.ncols, self.ndepth) or N.shape != Y.shape:
+            raise ValueError("binomial data must be a (Y, N) pair of (nrows, ncols, ndepth) arrays")
+        yr, yc = self._plan.slabs(Y[..., None])
+        nr, nc = self._plan.slabs(N[..., None])
+        self._ctx.call("btf_set_data_binomial", _native.dptr(yr), _native.dptr(nr), _native.dptr(yc), _native.dptr(nc))
+        miss = np.isnan(Y) | np.isnan(N)
+        self._ctx.call("btf_set_stale_sources",
+                       stale_row_sources(self.nrows, self.nembeds, bool(miss.any())).ctypes.data_as(_native._c_ip),
+                       stale_col_sources(miss).ctypes.data_as(_native._c_ip))
+        self._omega_host_new = True
+
+    def _set_noise(self):
+        if getattr(self, "_omega_host_new", False) and np.ndim(self._nu2) == 3:
+            with np.errstate(divide='ignore'):
+                om = np.where(np.isfinite(self._nu2) & (self._nu2 > 0), 1 / self._nu2, 0.0)
+            r, c = self._plan.slabs(om[..., None])
+            self._ctx.call("btf_set_omega", _native.dptr(r), _native.dptr(c))
+        self._omega_host_new = False
+
+    def _resample_nu2(self, data):
+        self._bind_data(data)
+        self._push_state()
+        self._pg_calls += 1
+        seed = (int(self.pg_seed) * 0x9E3779B97F4A7C15 + self._pg_calls) & 0xFFFFFFFFFFFFFFFF
+        self._ctx.call("btf_pg_draw", seed)
+        self._omega_dev_new = True
+        self._omega_host_new = False

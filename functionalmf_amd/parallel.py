@@ -1,0 +1,144 @@
+"""Row / column sharding of the two half-sweeps over the GPUs of one node.
+
+Given V the rows of W are conditionally independent (factor.py:333) and given W
+the columns of V are (factor.py:378), so rank p updates a contiguous block of
+rows in the W half-sweep and a contiguous block of columns in the V half-sweep,
+from two slabs of the sufficient statistics (its rows x everything, everything
+x its columns).  W and V are replicated; the only exchange per half-sweep is
+one all-gather of the freshly drawn block (RCCL over xGMI through
+torch.distributed's "nccl" backend on the device buffers of the context, or any
+other backend on host copies - used by the CPU tests with gloo).
+"""
+import numpy as np
+
+
+def _block(n, rank, world):
+    """Contiguous block [start, start+len) of an axis of length n; equal chunk
+    ceil(n/world) (the tail ranks may be short or empty) so that an in-place
+    all-gather with a fixed chunk size reassembles the axis."""
+    chunk = -(-n // world)
+    lo = min(rank * chunk, n)
+    hi = min(lo + chunk, n)
+    return lo, hi - lo, chunk
+
+
+class ShardPlan:
+    def __init__(self, nrows, ncols, rank=0, world=1):
+        if not (0 <= rank < world):
+            raise ValueError("rank %d outside world of %d" % (rank, world))
+        self.nrows, self.ncols, self.rank, self.world = nrows, ncols, rank, world
+        self.row0, self.nl, self.row_chunk = _block(nrows, rank, world)
+        self.col0, self.ml, self.col_chunk = _block(ncols, rank, world)
+
+    def mine(self):
+        return self.row0, self.nl, self.col0, self.ml
+
+    def slabs(self, Y4):
+        """Row slab Y[row0:row0+nl] and column slab Y[:, col0:col0+ml] as contiguous
+        float64 arrays (the same object twice when unsharded)."""
+        if self.world == 1:
+            a = np.ascontiguousarray(Y4, dtype=np.float64)
+            return a, a
+        rows = np.ascontiguousarray(Y4[self.row0:self.row0 + self.nl], dtype=np.float64)
+        cols = np.ascontiguousarray(Y4[:, self.col0:self.col0 + self.ml], dtype=np.float64)
+        return rows, cols
+
+    def assemble(self, blocks, axis_len):
+        """Concatenate per-rank blocks (each padded to the common chunk along axis 0)
+        back into the full axis."""
+        full = np.concatenate(blocks, axis=0)
+        return full[:axis_len]
+
+
+class _DevView:
+    """__cuda_array_interface__ holder so torch can wrap a raw device pointer."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class Exchange:
+    """The per-half-sweep exchange.  world == 1: no-ops."""
+
+    def __init__(self, plan, ctx=None, group=None):
+        self.plan, self.ctx, self.group = plan, ctx, group
+        self._Wt = self._Vt = None
+        if plan.world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("shard=(rank, world) needs an initialised torch.distributed process group")
+            if dist.get_world_size(group) != plan.world or dist.get_rank(group) != plan.rank:
+                raise RuntimeError("shard does not match the process group")
+
+    # -- device path (RCCL) ----------------------------------------------------------
+    def _views(self):
+        import torch
+        p, (N, M, T, K, _) = self.plan, self.ctx.dims
+        if self._Wt is None:
+            lib = self.ctx.lib
+            dev = torch.device("cuda", torch.cuda.current_device())
+            # the context over-allocates W / V by 64 rows / columns, so world*chunk fits
+            self._Wt = torch.as_tensor(_DevView(lib.btf_dev_W(self.ctx.h), (p.world * p.row_chunk * K,)), device=dev)
+            self._Vt = torch.as_tensor(_DevView(lib.btf_dev_V(self.ctx.h), (p.world * p.col_chunk * T * K,)), device=dev)
+        return self._Wt, self._Vt
+
+    def after_W(self):
+        if self.plan.world == 1:
+            return
+        import torch.distributed as dist
+        Wt, _ = self._views()
+        K = self.ctx.dims[3]
+        n = self.plan.row_chunk * K
+        dist.all_gather_into_tensor(Wt, Wt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group)
+
+    def after_V(self):
+        if self.plan.world == 1:
+            return
+        import torch.distributed as dist
+        _, Vt = self._views()
+        _, _, T, K, _ = self.ctx.dims
+        n = self.plan.col_chunk * T * K
+        dist.all_gather_into_tensor(Vt, Vt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group)
+
+    def sum_scalars(self, *vals):
+        if self.plan.world == 1:
+            return vals
+        import torch
+        import torch.distributed as dist
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, group=self.group)
+        return tuple(t.tolist())
+
+    # -- host path (any backend; CPU tests) --------------------------------------------
+    def gather_rows_host(self, block):
+        """All-gather a per-rank block of rows held in host memory; returns the full axis."""
+        p = self.plan
+        if p.world == 1:
+            return block
+        import torch
+        import torch.distributed as dist
+        pad = np.zeros((p.row_chunk,) + block.shape[1:])
+        pad[:block.shape[0]] = block
+        mine = torch.from_numpy(pad)
+        if dist.get_backend(self.group) == "nccl":
+            mine = mine.cuda()
+        out = [torch.empty_like(mine) for _ in range(p.world)]
+        dist.all_gather(out, mine, group=self.group)
+        return p.assemble([o.cpu().numpy() for o in out], p.nrows)
+
+    def gather_cols_host(self, block):
+        p = self.plan
+        if p.world == 1:
+            return block
+        import torch
+        import torch.distributed as dist
+        pad = np.zeros((p.col_chunk,) + block.shape[1:])
+        pad[:block.shape[0]] = block
+        mine = torch.from_numpy(pad)
+        if dist.get_backend(self.group) == "nccl":
+            mine = mine.cuda()
+        out = [torch.empty_like(mine) for _ in range(p.world)]
+        dist.all_gather(out, mine, group=self.group)
+        return p.assemble([o.cpu().numpy() for o in out], p.ncols)

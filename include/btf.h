@@ -1,0 +1,161 @@
+/* btf.h - C ABI of the MI355X-native Gibbs core for Bayesian Tensor Filtering.
+ *
+ * This is the drop-in boundary for the hot path of tansey/functionalmf
+ *   run_gibbs -> resample -> _resample_W / _resample_V / _resample_nu2
+ * (reference functionalmf/factor.py:306-460, functionalmf/fast_mvn.py:10-74).
+ * The reference has no FFI layer of its own: the boundary there is the Python
+ * method contract of the model object.  Each entry point below
+ * names the reference code whose *body* it replaces; the Python classes in
+ * functionalmf_amd/factor.py keep the reference's method names and call these
+ * through ctypes (see INTEGRATION.md for the binding a maintainer would add to
+ * functionalmf/factor.py itself).
+ *
+ * Conventions
+ *   - plain C types only; all arrays are float64, C-contiguous, caller-owned and
+ *     borrowed for the duration of the call;
+ *   - every function returns a BTF_* status; text via btf_last_error();
+ *   - one ctx = one Markov chain on one GPU; calls on a ctx must be serialised by
+ *     the caller; different ctxs may live on different threads / devices;
+ *   - "step" functions only enqueue work on the ctx's HIP stream; results are
+ *     visible after btf_sync() or any btf_get_* (which synchronise);
+ *   - NaN marks a missing observation (reference convention);
+ *   - dims: N=nrows, M=ncols, T=ndepth, R=nreps, K=nembeds, nD = rows of the
+ *     trend-filter penalty Delta (utils.py:66-90).
+ */
+#ifndef BTF_H_
+#define BTF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct btf_ctx btf_ctx;
+
+enum {
+  BTF_OK = 0,
+  BTF_EINVAL = 1, /* bad argument / unsupported shape                          */
+  BTF_EHIP = 2,   /* a HIP runtime call failed (text in btf_last_error)        */
+  BTF_ENOTPD = 3, /* a conditional precision was not positive definite (after
+                     the jitter retries for V; immediately for W, as
+                     np.linalg.cholesky raises at factor.py:357).  Where the
+                     reference would warn forever (fast_mvn.py:69-72) this
+                     returns instead.  btf_fail_index() names the row/column.  */
+  BTF_ESTATE = 4  /* call order: data / state not set yet                      */
+};
+
+enum { BTF_COMPAT_REFERENCE = 0, BTF_COMPAT_EXACT = 1 };
+
+/* kernel ids for btf_kernel_times() */
+enum {
+  BTF_K_STATS = 0,   /* one-time sufficient statistics                      */
+  BTF_K_W_ACCUM = 1, /* streaming Gram/mean accumulation, W half-sweep      */
+  BTF_K_W_SOLVE = 2, /* batched KxK Cholesky + draw per row                 */
+  BTF_K_V_ACCUM = 3, /* streaming Gram/mean accumulation, V half-sweep      */
+  BTF_K_V_BANDED = 4,/* block-banded Cholesky sampler per column (fast_mvn) */
+  BTF_K_GRAM = 5,    /* K x K Gram of the fixed factor (complete-data path) */
+  BTF_K_PROD = 6,    /* per-row outer products u u' (weighted path)         */
+  BTF_K_SSE = 7,     /* residual sum of squares for nu2                     */
+  BTF_K_PG = 8,      /* Polya-Gamma draws                                   */
+  BTF_K_COUNT = 9
+};
+
+/* ---- lifetime ------------------------------------------------------------
+ * Replaces the array allocations of BayesianTensorFiltering.__init__
+ * (factor.py:24-110) on the device side.  `stream` is a hipStream_t to run on
+ * (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a private one. */
+int btf_create(btf_ctx** out, int nrows, int ncols, int ndepth, int nembeds,
+               int tf_order, int device, void* stream);
+void btf_destroy(btf_ctx* ctx);
+const char* btf_last_error(const btf_ctx* ctx);
+int btf_fail_index(const btf_ctx* ctx);
+
+/* ---- sharding (multi-GPU) --------------------------------------
+ * This ctx updates rows [row0,row0+nrows_local) in the W half-sweep and columns
+ * [col0,col0+ncols_local) in the V half-sweep.  Must precede btf_set_data_*.
+ * Default: everything.  W and V are replicated: after each half-sweep the host
+ * all-gathers the updated block (device pointers via btf_dev_W / btf_dev_V). */
+int btf_set_shard(btf_ctx* ctx, int row0, int nrows_local, int col0, int ncols_local);
+void* btf_dev_W(btf_ctx* ctx); /* device double[N][K]    */
+void* btf_dev_V(btf_ctx* ctx); /* device double[M][T][K] */
+
+/* ---- data -----------------------------------------------------------------
+ * Hoists what factor.py:329-330 and :374-375 recompute every half-sweep
+ * (replicate counts and NaN-means) into one pass.  y_rows is the row slab
+ * Y[row0:row0+nrows_local] of shape (nrows_local,M,T,R); y_cols is the column
+ * slab Y[:,col0:col0+ncols_local] of shape (N,ncols_local,T,R).  Unsharded:
+ * pass the same pointer twice.                                               */
+int btf_set_data_gaussian(btf_ctx* ctx, const double* y_rows, const double* y_cols, int nreps);
+/* Binomial data tuple (Y, N) of factor.py:437-460; same slab convention, R=1. */
+int btf_set_data_binomial(btf_ctx* ctx, const double* succ_rows, const double* trials_rows,
+                          const double* succ_cols, const double* trials_cols);
+/* Quirks Q1/Q2: which row / column the cached likelihood weights
+ * come from in compat=REFERENCE.  src_row[N], src_col[M] (global indices);
+ * NULL = identity.  Only consulted by the weighted kernels.                   */
+int btf_set_stale_sources(btf_ctx* ctx, const int32_t* src_row, const int32_t* src_col);
+
+/* ---- state ---------------------------------------------------------------- */
+int btf_set_W(btf_ctx* ctx, const double* W);            /* (N,K)      */
+int btf_get_W(btf_ctx* ctx, double* W);
+int btf_set_V(btf_ctx* ctx, const double* V);            /* (M,T,K)    */
+int btf_get_V(btf_ctx* ctx, double* V);
+int btf_set_hyper(btf_ctx* ctx, const double* Tau2 /* (M,nD) */, double lam2, double sigma2);
+int btf_set_nu2(btf_ctx* ctx, double nu2);               /* Gaussian scalar noise variance */
+int btf_set_omega(btf_ctx* ctx, const double* omega_rows, const double* omega_cols); /* Binomial: PG draws, slabs as data */
+int btf_get_omega(btf_ctx* ctx, double* omega_rows);     /* (nrows_local,M,T) */
+
+/* ---- half-sweeps ----------------------------------------------------------
+ * btf_resample_W replaces the body of GaussianBTF._resample_W (factor.py:313-362)
+ * [and BinomialBTF._resample_W :437-440]: for every local row i, d=min(i+1,K):
+ *   Q_i = sum_{j,t} c_ijt v_jt v_jt' + I/sigma2,  m_i = sum c_ijt ybar_ijt v_jt,
+ *   W[i,:d] = Q_i^-1 m_i + L_i^-T z_i.
+ * z: host array of the sum_i min(i+1,K) standard normals of ALL rows in row
+ * order (the legacy-RNG stream of factor.py:361), or NULL to draw them on the
+ * device (Philox4x32-10 keyed by `seed`).                                     */
+int btf_resample_W(btf_ctx* ctx, const double* z, uint64_t seed, int compat);
+/* btf_resample_V replaces GaussianBTF._resample_V (factor.py:364-409) including
+ * its call into sample_mvn_from_precision (fast_mvn.py:35-47, :62-68): for every
+ * local column j the (K*T)x(K*T) precision  kron(W,I)'C kron(W,I) + I_K (x)
+ * Delta' diag(1/(lam2 Tau2_j)) Delta  is formed in depth-major order (t,k), factored
+ * as a block-banded Cholesky, and  V[j] = Q^-1 mu + P' L^-T z  is drawn.
+ * z: host (M, K*T) normals, row j for column j, indexed in the factor's
+ * (depth-major) order, or NULL for device Philox.  eps0/attempts: the
+ * force_psd jitter schedule (eps0*10^a added cumulatively, <= attempts).      */
+int btf_resample_V(btf_ctx* ctx, const double* z, uint64_t seed, int compat,
+                   double eps0, int attempts);
+int btf_get_V_attempts(btf_ctx* ctx, int32_t* tries /* (ncols_local) */);
+
+/* Residual sum of squares and observation count over the LOCAL rows: the two
+ * numbers GaussianBTF._resample_nu2 (factor.py:411-416, genlasso.py:157-160)
+ * reduces the whole tensor for.  Synchronises.                                */
+int btf_sse(btf_ctx* ctx, double* sse, double* nobs);
+/* omega_ijt ~ PG(Ntrials_ijt, w_i . v_jt) on the device: replaces the
+ * pypolyagamma call at factor.py:459 (own RNG: Philox keyed by seed).         */
+int btf_pg_draw(btf_ctx* ctx, uint64_t seed);
+
+int btf_sync(btf_ctx* ctx); /* waits; returns BTF_ENOTPD if a step failed since the last sync */
+
+/* ---- structured-Gaussian sampler (the fast_mvn equivalent, stand-alone) ----
+ * Batched draw  x_b = Q_b^-1 mu_b + L_b^-T z_b,  L_b L_b' = Q_b (+ jitter), for
+ * symmetric banded precisions given as lower band by columns:
+ * band[b][c][a] = Q_b[c+a, c], a = 0..bw.  mu_part and/or z may be NULL (zero /
+ * device Philox).  Replaces sample_mvn_from_precision(Q, mu_part=..., sparse=True)
+ * (fast_mvn.py:10-74) for banded Q in the given ordering.                     */
+int btf_mvn_banded(int device, int batch, int n, int bw, const double* band,
+                   const double* mu_part, const double* z, uint64_t seed,
+                   double eps0, int attempts, double* x_out, int32_t* tries_out);
+
+/* ---- measurement ----------------------------------------------------------
+ * With profiling on, every kernel launch is bracketed by hipEvents on the ctx
+ * stream; btf_kernel_times drains them: total milliseconds and launch count per
+ * BTF_K_* id (arrays of BTF_K_COUNT).                                         */
+int btf_set_profiling(btf_ctx* ctx, int on);
+int btf_kernel_times(btf_ctx* ctx, double* ms_total, int64_t* launches);
+/* Launch geometry of the streaming kernels (tuning knob; 0 = default).        */
+int btf_set_tuning(btf_ctx* ctx, int rows_per_block_w, int rows_per_block_v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTF_H_ */
