@@ -45,7 +45,8 @@ struct btf_ctx {
   int* status = nullptr;   // [0] flag [1] index
   int* tries = nullptr;
   int* st_ptr = nullptr; int* st_row = nullptr; double* st_coef = nullptr;
-  int32_t* src_row = nullptr; int32_t* src_col = nullptr;
+  int* srcmap_w = nullptr; int* srcmap_v = nullptr;   // per-output source index of the cached weights
+  bool stale_w = false, stale_v = false;
   double ssw = 0.0, nobs = 0.0;
   int rpb_w = 0, rpb_v = 0;
   unsigned long long sweep_w = 0, sweep_v = 0;
@@ -179,13 +180,25 @@ int build_stencil(btf_ctx* c) {
 
 // ---- templated launch tables -------------------------------------------------
 template <int K>
-void launch_accum(btf_ctx* c, bool weighted, const double* X, const double* Cx, const double* U,
-                  const double* UU, int Rdim, int ld, int rpb, int nch) {
+void launch_accum(btf_ctx* c, int mode, const double* X, const double* Cx, const double* U,
+                  const double* UU, const int* srcmap, int Rdim, int ld, int rpb, int nch) {
   dim3 grid(ld / ACC_TILE, nch);
-  if (weighted)
-    hipLaunchKernelGGL((accum_kernel<K, 1>), grid, dim3(ACC_THREADS), 0, c->stream, X, Cx, U, UU, c->part, Rdim, ld, rpb);
+  if (mode == 2)
+    hipLaunchKernelGGL((accum_kernel<K, 2>), grid, dim3(ACC_THREADS), 0, c->stream, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
+  else if (mode == 1)
+    hipLaunchKernelGGL((accum_kernel<K, 1>), grid, dim3(ACC_THREADS), 0, c->stream, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
   else
-    hipLaunchKernelGGL((accum_kernel<K, 0>), grid, dim3(ACC_THREADS), 0, c->stream, X, Cx, U, UU, c->part, Rdim, ld, rpb);
+    hipLaunchKernelGGL((accum_kernel<K, 0>), grid, dim3(ACC_THREADS), 0, c->stream, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
+}
+template <int K>
+void launch_pg(btf_ctx* c, const double* B, double* out, const double* Lf, const double* Uf, int nl, int ld, int Rdim,
+               unsigned long long base, unsigned long long stride_r, unsigned long long stride_l, unsigned long long seed) {
+  const int gx = (nl + PG_THREADS - 1) / PG_THREADS;
+  int nrb = std::max(1, std::min(Rdim, 4096 / std::max(1, gx)));
+  const int rpb = (Rdim + nrb - 1) / nrb;
+  nrb = (Rdim + rpb - 1) / rpb;
+  hipLaunchKernelGGL((pg_kernel<K>), dim3(gx, nrb), dim3(PG_THREADS), 0, c->stream, B, out, Lf, Uf, nl, ld, Rdim, rpb,
+                     base, stride_r, stride_l, seed);
 }
 template <int K>
 void launch_gram(btf_ctx* c, const double* U, int Rdim) {
@@ -383,7 +396,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->WW, c->VV, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->src_row, c->src_col};
+                  c->srcmap_w, c->srcmap_v};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -454,16 +467,32 @@ int btf_set_data_binomial(btf_ctx* c, const double* succ_rows, const double* tri
 
 int btf_set_stale_sources(btf_ctx* c, const int32_t* src_row, const int32_t* src_col) {
   if (!c) return BTF_EINVAL;
+  if (!c->have_data) return fail(c, BTF_ESTATE, "btf_set_stale_sources follows btf_set_data_*");
   HIPCHK(c, hipSetDevice(c->dev));
   int rc;
-  if (src_row) {
-    if ((rc = dev_alloc(c, &c->src_row, (size_t)c->N))) return rc;
-    HIPCHK(c, hipMemcpy(c->src_row, src_row, (size_t)c->N * sizeof(int32_t), hipMemcpyHostToDevice));
-  } else if (c->src_row) { (void)hipFree(c->src_row); c->src_row = nullptr; }
-  if (src_col) {
-    if ((rc = dev_alloc(c, &c->src_col, (size_t)c->M))) return rc;
-    HIPCHK(c, hipMemcpy(c->src_col, src_col, (size_t)c->M * sizeof(int32_t), hipMemcpyHostToDevice));
-  } else if (c->src_col) { (void)hipFree(c->src_col); c->src_col = nullptr; }
+  std::vector<int> mw(c->ldw), mv(c->ldv);
+  for (int l = 0; l < c->ldw; ++l) mw[l] = l;
+  for (int l = 0; l < c->ldv; ++l) mv[l] = l;
+  c->stale_w = c->stale_v = false;
+  if (!c->weighted) src_row = src_col = nullptr;   // constant weights: staleness cannot change anything
+  if (src_row)
+    for (int il = 0; il < c->nl; ++il) {
+      const int s = src_row[c->row0 + il] - c->row0;
+      if (s < 0 || s >= c->nl) return fail(c, BTF_EINVAL, "stale weight source row outside this shard (use compat=exact when sharding)");
+      mw[il] = s;
+      c->stale_w |= (s != il);
+    }
+  if (src_col)
+    for (int jl = 0; jl < c->ml; ++jl) {
+      const int s = src_col[c->col0 + jl] - c->col0;
+      if (s < 0 || s >= c->ml) return fail(c, BTF_EINVAL, "stale weight source column outside this shard (use compat=exact when sharding)");
+      for (int t = 0; t < c->T; ++t) mv[jl * c->T + t] = s * c->T + t;
+      c->stale_v |= (s != jl);
+    }
+  if ((rc = dev_alloc(c, &c->srcmap_w, mw.size()))) return rc;
+  if ((rc = dev_alloc(c, &c->srcmap_v, mv.size()))) return rc;
+  HIPCHK(c, hipMemcpy(c->srcmap_w, mw.data(), mw.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->srcmap_v, mv.data(), mv.size() * sizeof(int), hipMemcpyHostToDevice));
   return BTF_OK;
 }
 
@@ -521,6 +550,10 @@ int btf_set_omega(btf_ctx* c, const double* omega_rows, const double* omega_cols
   HIPCHK(c, hipMemsetAsync(c->C_v, 0, (size_t)c->N * c->ldv * sizeof(double), c->stream));
   if ((rc = upload_relayout(c, omega_rows, c->nl, MT, c->C_wT, c->ldw, true))) return rc;
   if ((rc = upload_relayout(c, omega_cols, c->N, c->ml * c->T, c->C_v, c->ldv, false))) return rc;
+  // cells without an observation (trials stored as 0) carry no weight
+  hipLaunchKernelGGL(mask_kernel, dim3(1024), dim3(256), 0, c->stream, c->C_wT, c->B_wT, (size_t)MT * c->ldw);
+  hipLaunchKernelGGL(mask_kernel, dim3(1024), dim3(256), 0, c->stream, c->C_v, c->B_v, (size_t)c->N * c->ldv);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return BTF_OK;
 }
 int btf_get_omega(btf_ctx* c, double* omega_rows) {
@@ -541,9 +574,9 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
   if (!c) return BTF_EINVAL;
   if (!c->have_data || !c->have_V || !c->have_W) return fail(c, BTF_ESTATE, "set data, W and V first");
   HIPCHK(c, hipSetDevice(c->dev));
-  (void)compat;
   const int K = c->K, KK = c->KK, MT = c->M * c->T;
   const bool wt = c->weighted;
+  const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_w && c->srcmap_w ? 2 : 1);
   const int NV = wt ? K + KK : K;
   const int tiles = c->ldw / ACC_TILE;
   const int rpb = pick_rpb(MT, tiles, c->rpb_w);
@@ -567,7 +600,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     }
     {
       Prof p(c, BTF_K_W_ACCUM);
-      K_SWITCH(K, launch_accum<KT>(c, wt, c->A_wT, c->C_wT, c->V, c->VV, MT, c->ldw, rpb, nch));
+      K_SWITCH(K, launch_accum<KT>(c, mode, c->A_wT, c->C_wT, c->V, c->VV, c->srcmap_w, MT, c->ldw, rpb, nch));
     }
     WSolveArgs a{};
     a.part = c->part; a.nch = nch; a.ld = c->ldw; a.gpart = c->gpart; a.ngp = GRAM_BLOCKS; a.weighted = wt ? 1 : 0;
@@ -593,9 +626,9 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
   if (!c->have_data || !c->have_V || !c->have_W || !c->have_hyper) return fail(c, BTF_ESTATE, "set data, W, V and hyper-parameters first");
   if (attempts < 0) attempts = 0;
   HIPCHK(c, hipSetDevice(c->dev));
-  (void)compat;
   const int K = c->K, KK = c->KK, T = c->T, n = T * K;
   const bool wt = c->weighted;
+  const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_v && c->srcmap_v ? 2 : 1);
   const int NV = wt ? K + KK : K;
   const int tiles = c->ldv / ACC_TILE;
   const int rpb = pick_rpb(c->N, tiles, c->rpb_v);
@@ -619,7 +652,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     }
     {
       Prof p(c, BTF_K_V_ACCUM);
-      K_SWITCH(K, launch_accum<KT>(c, wt, c->A_v, c->C_v, c->W, c->WW, c->N, c->ldv, rpb, nch));
+      K_SWITCH(K, launch_accum<KT>(c, mode, c->A_v, c->C_v, c->W, c->WW, c->srcmap_v, c->N, c->ldv, rpb, nch));
     }
     const int bw = (c->TF + 1) * K, R1 = bw + 1, D1 = c->TF + 2;
     size_t lds_fixed = (size_t)(3 * n + T * D1 + (wt ? T * KK : KK) + (bw * (bw + 1) / 2 + 3) / 4) * sizeof(double);
@@ -700,8 +733,44 @@ int btf_sse(btf_ctx* c, double* sse, double* nobs) {
 }
 
 int btf_pg_draw(btf_ctx* c, uint64_t seed) {
-  (void)seed;
-  return fail(c, BTF_EINVAL, "btf_pg_draw: not built yet");
+  if (!c) return BTF_EINVAL;
+  if (!c->have_data || !c->binomial || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_pg_draw needs binomial data, W and V");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const unsigned long long MT = (unsigned long long)c->M * c->T;
+  // every cell is drawn once per layout from the same (seed, cell) stream: identical values
+  if (c->nl > 0) {  // W layout [jt][i_local]: lanes = rows of W, reduction axis = (j,t)
+    Prof p(c, BTF_K_PG);
+    K_SWITCH(c->K, launch_pg<KT>(c, c->B_wT, c->C_wT, c->W + (size_t)c->row0 * c->K, c->V, c->nl, c->ldw, (int)MT,
+                                 (unsigned long long)c->row0 * MT, 1ULL, MT, seed));
+  }
+  if (c->ml > 0) {  // V layout [i][jt_local]
+    Prof p(c, BTF_K_PG);
+    K_SWITCH(c->K, launch_pg<KT>(c, c->B_v, c->C_v, c->V + (size_t)c->col0 * c->T * c->K, c->W, c->ml * c->T, c->ldv,
+                                 c->N, (unsigned long long)c->col0 * c->T, MT, 1ULL, seed));
+  }
+  HIPCHK(c, hipGetLastError());
+  return BTF_OK;
+}
+
+int btf_pg_batch(int device, int64_t n, const double* b, const double* psi, uint64_t seed, double* out) {
+  if (n < 1 || !b || !psi || !out) return fail(nullptr, BTF_EINVAL, "bad pg_batch arguments");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, BTF_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  double *db = nullptr, *dp = nullptr, *dout = nullptr;
+  auto cleanup = [&]() { for (void* p : {(void*)db, (void*)dp, (void*)dout}) if (p) (void)hipFree(p); };
+#define PB(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return fail(nullptr, BTF_EHIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+  PB(hipMalloc((void**)&db, n * sizeof(double)));
+  PB(hipMalloc((void**)&dp, n * sizeof(double)));
+  PB(hipMalloc((void**)&dout, n * sizeof(double)));
+  PB(hipMemcpy(db, b, n * sizeof(double), hipMemcpyHostToDevice));
+  PB(hipMemcpy(dp, psi, n * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(pg_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, db, dp, dout, (long long)n, seed);
+  PB(hipGetLastError());
+  PB(hipDeviceSynchronize());
+  PB(hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
+  cleanup();
+#undef PB
+  return BTF_OK;
 }
 
 int btf_sync(btf_ctx* c) {

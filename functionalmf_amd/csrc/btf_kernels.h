@@ -24,10 +24,16 @@ constexpr int ACC_TILE = 2 * WAVE;      // outputs per workgroup along the lane 
 constexpr int ACC_UNR = 8;              // rows in flight per wave
 constexpr int ACC_RG = 4;               // values reduced per LDS round
 
-template <int K, int MODE>  // MODE 0: X only (complete data); 1: X, C and outer products
+// MODE 0: X only (complete data)
+// MODE 1: X, C and the outer products UU
+// MODE 2: as 1, but the precision weight of output l is read from output srcmap[l] of the
+//         same row and the linear statistic is rescaled by C_src/C_own - the reference's
+//         stale cached weights (factor.py:349 and :394-401)
+template <int K, int MODE>
 __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
     const double* __restrict__ X, const double* __restrict__ Cx, const double* __restrict__ U,
-    const double* __restrict__ UU, double* __restrict__ part, int Rdim, int ld, int rows_per_block) {
+    const double* __restrict__ UU, const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
+    int rows_per_block) {
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   __shared__ double red[ACC_WAVES][ACC_RG][ACC_TILE];
@@ -43,19 +49,30 @@ __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
   double acc[NV][2];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v][0] = acc[v][1] = 0.0;
+  int s0 = 0, s1 = 0;
+  if constexpr (MODE == 2) {
+    s0 = srcmap[col];
+    s1 = srcmap[col + 1];
+  }
 
   for (int rb = r0 + wave; rb < r1; rb += ACC_WAVES * ACC_UNR) {
     double2 x[ACC_UNR];
-    double2 c[MODE == 1 ? ACC_UNR : 1];
+    double2 c[MODE >= 1 ? ACC_UNR : 1];
 #pragma unroll
     for (int u = 0; u < ACC_UNR; ++u) {
       const int r = rb + u * ACC_WAVES;  // wave-uniform
       if (r < r1) {
         x[u] = *reinterpret_cast<const double2*>(X + (size_t)r * ld + col);
-        if constexpr (MODE == 1) c[u] = *reinterpret_cast<const double2*>(Cx + (size_t)r * ld + col);
+        if constexpr (MODE >= 1) c[u] = *reinterpret_cast<const double2*>(Cx + (size_t)r * ld + col);
+        if constexpr (MODE == 2) {
+          const double cs0 = Cx[(size_t)r * ld + s0], cs1 = Cx[(size_t)r * ld + s1];
+          if (s0 != (int)col) x[u].x = c[u].x != 0.0 ? x[u].x * cs0 / c[u].x : 0.0;
+          if (s1 != (int)col + 1) x[u].y = c[u].y != 0.0 ? x[u].y * cs1 / c[u].y : 0.0;
+          c[u] = make_double2(cs0, cs1);
+        }
       } else {
         x[u] = make_double2(0.0, 0.0);
-        if constexpr (MODE == 1) c[u] = make_double2(0.0, 0.0);
+        if constexpr (MODE >= 1) c[u] = make_double2(0.0, 0.0);
       }
     }
 #pragma unroll
@@ -68,7 +85,7 @@ __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
         acc[k][0] = fma(x[u].x, uk, acc[k][0]);
         acc[k][1] = fma(x[u].y, uk, acc[k][1]);
       }
-      if constexpr (MODE == 1) {
+      if constexpr (MODE >= 1) {
         const double* __restrict__ uup = UU + (size_t)r * KK;
 #pragma unroll
         for (int q = 0; q < KK; ++q) {
@@ -585,6 +602,11 @@ __global__ void relayout_kernel(const double* src, int rows, int cols, double* d
   }
 }
 
+__global__ void mask_kernel(double* C, const double* B, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if (!(B[i] > 0.0)) C[i] = 0.0;
+}
+
 // ============================================================================
 // residual sum of squares for the nu2 update  (BTF_K_SSE)
 //   sum_{cells} sum_r (y - mu)^2 = SSW + sum_cells (S1 - cnt*mu)^2 / cnt
@@ -625,6 +647,196 @@ __global__ __launch_bounds__(SSE_THREADS) void sse_kernel(const double* __restri
     for (int w = 0; w < SSE_THREADS / WAVE; ++w) s += red[w];
     bsum[blockIdx.y * gridDim.x + blockIdx.x] = s;
   }
+}
+
+// ============================================================================
+// Polya-Gamma draws  (BTF_K_PG)   omega ~ PG(b, psi),  psi = w_i . v_jt
+//   replaces the pypolyagamma call of factor.py:459.  Integer b: sum of b exact
+//   PG(1,psi) draws by Devroye's alternating-series method (Polson, Scott &
+//   Windle 2013, sec. 4); fractional remainder by the truncated sum-of-gammas
+//   representation; b >= PG_NORMAL_B by moment-matched normal.
+//   RNG: Philox keyed by (seed, global cell index) - the draw of a cell does not
+//   depend on layout, launch geometry or sharding.
+// ============================================================================
+constexpr double PG_T = 0.64;
+constexpr double PG_PI = 3.141592653589793238462643383279502884;
+constexpr int PG_NORMAL_B = 200;
+
+struct CellRng {
+  uint64_t seed, cell, ctr;
+  uint32_t buf[4];
+  int have;
+  __device__ CellRng(uint64_t s, uint64_t c) : seed(s), cell(c), ctr(0), have(0) {}
+  __device__ double uniform() {
+    if (have == 0) { Philox::gen(seed, cell, ctr++, buf); have = 2; }
+    --have;
+    return u01(buf[2 * have], buf[2 * have + 1]);
+  }
+  __device__ double expo() { return -log(uniform()); }
+  __device__ double normal() {
+    const double u1 = uniform(), u2 = uniform();
+    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+  }
+};
+
+__device__ inline double log_ncdf(double x) {
+  if (x > -10.0) return log(0.5 * erfc(-x * 0.70710678118654752440));
+  const double x2 = x * x;  // Mills-ratio asymptotics for the far lower tail
+  return -0.5 * x2 - log(-x) - 0.91893853320467274178 + log1p(-1.0 / x2 + 3.0 / (x2 * x2));
+}
+
+__device__ inline double pg_a(int n, double x) {
+  const double Kc = (n + 0.5) * PG_PI;
+  if (x > PG_T) return Kc * exp(-0.5 * Kc * Kc * x);
+  return exp(-1.5 * (log(0.5 * PG_PI) + log(x)) + log(Kc) - 2.0 * (n + 0.5) * (n + 0.5) / x);
+}
+
+// probability of the exponential (right) piece of the proposal
+__device__ inline double pg_mass_texpon(double z) {
+  const double fz = 0.125 * PG_PI * PG_PI + 0.5 * z * z;
+  const double rt = 1.0 / sqrt(PG_T);
+  const double b = rt * (PG_T * z - 1.0), a = -rt * (PG_T * z + 1.0);
+  const double x0 = log(fz) + fz * PG_T;
+  const double xb = x0 - z + log_ncdf(b), xa = x0 + z + log_ncdf(a);
+  const double qdivp = 4.0 / PG_PI * (exp(xb) + exp(xa));
+  return 1.0 / (1.0 + qdivp);
+}
+
+// inverse-Gaussian(1/z, 1) truncated to (0, PG_T)
+__device__ inline double pg_rtigauss(double z, CellRng& g) {
+  double X = PG_T + 1.0;
+  if (1.0 / z > PG_T) {  // mu > t
+    double alpha = 0.0;
+    while (g.uniform() > alpha) {
+      double E1 = g.expo(), E2 = g.expo();
+      while (E1 * E1 > 2.0 * E2 / PG_T) { E1 = g.expo(); E2 = g.expo(); }
+      X = 1.0 + E1 * PG_T;
+      X = PG_T / (X * X);
+      alpha = exp(-0.5 * z * z * X);
+    }
+  } else {
+    const double mu = 1.0 / z;
+    while (X > PG_T) {
+      double Y = g.normal();
+      Y *= Y;
+      const double half_mu = 0.5 * mu, mu_Y = mu * Y;
+      X = mu + half_mu * mu_Y - half_mu * sqrt(4.0 * mu_Y + mu_Y * mu_Y);
+      if (g.uniform() > mu / (mu + X)) X = mu * mu / X;
+    }
+  }
+  return X;
+}
+
+__device__ inline double pg_one(double z /* = |psi|/2 */, double p_exp, CellRng& g) {
+  const double fz = 0.125 * PG_PI * PG_PI + 0.5 * z * z;
+  while (true) {
+    const double X = (g.uniform() < p_exp) ? PG_T + g.expo() / fz : pg_rtigauss(z, g);
+    double S = pg_a(0, X);
+    const double Y = g.uniform() * S;
+    int n = 0;
+    bool go = true;
+    while (go) {
+      ++n;
+      if (n & 1) {
+        S -= pg_a(n, X);
+        if (Y <= S) return 0.25 * X;
+      } else {
+        S += pg_a(n, X);
+        if (Y > S) go = false;
+      }
+      if (n > 1000) return 0.25 * X;  // unreachable in exact arithmetic; bounds the loop
+    }
+  }
+}
+
+__device__ inline double pg_mean_dev(double b, double c) {
+  const double a = fabs(c);
+  return a > 1e-6 ? b / (2.0 * a) * tanh(0.5 * a) : b * 0.25 * (1.0 - a * a / 12.0);
+}
+__device__ inline double pg_var_dev(double b, double c) {
+  const double a = fabs(c);
+  if (a < 1e-3) return b / 24.0 * (1.0 - a * a / 5.0);
+  const double ch = cosh(0.5 * a);
+  return a > 40.0 ? b / (2.0 * a * a * a) * (1.0 - 2.0 * a * exp(-a))
+                  : b / (4.0 * a * a * a) * (sinh(a) - a) / (ch * ch);
+}
+
+// Gamma(shape,1), Marsaglia & Tsang (2000); shape < 1 by the U^(1/shape) boost
+__device__ inline double gamma_mt(double shape, CellRng& g) {
+  double boost = 1.0;
+  if (shape < 1.0) { boost = pow(g.uniform(), 1.0 / shape); shape += 1.0; }
+  const double d = shape - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
+  while (true) {
+    double x, v;
+    do { x = g.normal(); v = 1.0 + cc * x; } while (v <= 0.0);
+    v = v * v * v;
+    const double u = g.uniform();
+    if (u < 1.0 - 0.0331 * x * x * x * x) return boost * d * v;
+    if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return boost * d * v;
+  }
+}
+
+__device__ inline double pg_draw(double b, double psi, CellRng& g) {
+  if (!(b > 0.0)) return 0.0;
+  if (b >= PG_NORMAL_B) {
+    const double m = pg_mean_dev(b, psi), sd = sqrt(pg_var_dev(b, psi));
+    double x;
+    do { x = m + sd * g.normal(); } while (x <= 0.0);
+    return x;
+  }
+  const double z = 0.5 * fabs(psi);
+  const int nb = (int)floor(b);
+  const double frac = b - nb;
+  double sum = 0.0;
+  if (nb > 0) {
+    const double p_exp = pg_mass_texpon(z);
+    for (int i = 0; i < nb; ++i) sum += pg_one(z, p_exp, g);
+  }
+  if (frac > 1e-12) {  // PG(frac, psi) = 1/(2 pi^2) sum_k g_k / ((k-1/2)^2 + psi^2/(4 pi^2))
+    constexpr int NT = 128;
+    const double c2 = psi * psi / (4.0 * PG_PI * PG_PI);
+    double s = 0.0;
+    for (int k = 1; k <= NT; ++k) s += gamma_mt(frac, g) / ((k - 0.5) * (k - 0.5) + c2);
+    // tail mean: frac * sum_{k>NT} 1/((k-1/2)^2 + c2) ~ frac * atan-type integral
+    const double sc = sqrt(c2);
+    const double tail = sc > 1e-8 ? (0.5 * PG_PI - atan((double)NT / sc)) / sc : 1.0 / NT;
+    sum += (s + frac * tail) / (2.0 * PG_PI * PG_PI);
+  }
+  return sum;
+}
+
+constexpr int PG_THREADS = 256;
+
+// out[r][l] = PG(B[r][l], L[l0+l] . U[r]);  global cell id = base + r*stride_r + l*stride_l
+template <int K>
+__global__ __launch_bounds__(PG_THREADS) void pg_kernel(const double* __restrict__ B, double* __restrict__ out,
+                                                        const double* __restrict__ Lf, const double* __restrict__ Uf,
+                                                        int nl, int ld, int Rdim, int rows_per_block,
+                                                        unsigned long long base, unsigned long long stride_r,
+                                                        unsigned long long stride_l, unsigned long long seed) {
+  const int l = blockIdx.x * PG_THREADS + threadIdx.x;
+  if (l >= nl) return;
+  double f[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) f[k] = Lf[(size_t)l * K + k];
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, Rdim);
+  for (int r = r0; r < r1; ++r) {
+    const double* __restrict__ u = Uf + (size_t)r * K;
+    double psi = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) psi = fma(f[k], u[k], psi);
+    const double b = B[(size_t)r * ld + l];
+    CellRng g(seed, base + (unsigned long long)r * stride_r + (unsigned long long)l * stride_l);
+    out[(size_t)r * ld + l] = pg_draw(b, psi, g);
+  }
+}
+
+// stand-alone batch of PG draws (validation entry point)
+__global__ void pg_batch_kernel(const double* b, const double* psi, double* out, long long n, unsigned long long seed) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  CellRng g(seed, (unsigned long long)i);
+  out[i] = pg_draw(b[i], psi[i], g);
 }
 
 }  // namespace btf

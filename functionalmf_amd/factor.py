@@ -30,6 +30,12 @@ from .utils import bayes_grid_penalty, sample_horseshoe_plus, sample_horseshoe
 from .parallel import ShardPlan, Exchange
 
 
+def _scalar(x):
+    """Python float from a float, 0-d or 1-element array (the reference's prior draws
+    are shape-(1,) arrays until the first resample replaces them)."""
+    return float(np.asarray(x, dtype=float).reshape(-1)[0])
+
+
 def stale_row_sources(nrows, nembeds, any_nan):
     """Quirk Q1 (factor.py:320,349): without any NaN in the data the per-row design
     cache is refreshed only for rows < K, so rows >= K reuse row K-1's weights."""
@@ -89,7 +95,7 @@ class BayesianTensorFiltering(_BayesianModel):
         self._data_key = None
         self._W_host_new = self._V_host_new = True      # host copy must be pushed before the next kernel
         self._W_dev_new = self._V_dev_new = False       # device copy is newer than the host mirror
-        self._hyper_dirty = True
+        self._tau_dirty = True
 
         # trend-filtering prior (factor.py:50)
         self.Delta = bayes_grid_penalty(ndepth, tf_order)
@@ -166,6 +172,17 @@ class BayesianTensorFiltering(_BayesianModel):
         self._V = np.array(value, dtype=float)
         self._V_host_new, self._V_dev_new = True, False
 
+    # Tau2 is handed out the same way: any access may be followed by an in-place write
+    @property
+    def Tau2(self):
+        self._tau_dirty = True
+        return self._Tau2
+
+    @Tau2.setter
+    def Tau2(self, value):
+        self._Tau2 = value
+        self._tau_dirty = True
+
     def _pull_W(self):
         if self._W_dev_new:
             self._ctx.call("btf_get_W", _native.dptr(self._W))
@@ -185,8 +202,12 @@ class BayesianTensorFiltering(_BayesianModel):
             self._V = _native.as_f64(self._V)
             self._ctx.call("btf_set_V", _native.dptr(self._V))
             self._V_host_new = False
-        tau = _native.as_f64(self.Tau2)
-        self._ctx.call("btf_set_hyper", _native.dptr(tau), float(self.lam2), float(self.sigma2))
+        if self._tau_dirty:
+            self._Tau2 = _native.as_f64(self._Tau2)
+            self._ctx.call("btf_set_hyper", _native.dptr(self._Tau2), _scalar(self.lam2), _scalar(self.sigma2))
+            self._tau_dirty = False
+        else:
+            self._ctx.call("btf_set_hyper", None, _scalar(self.lam2), _scalar(self.sigma2))
 
     def _next_seed(self):
         self._draws += 1
@@ -401,7 +422,7 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
         super().resample(data)
 
     def _set_noise(self):
-        self._ctx.call("btf_set_nu2", float(np.asarray(self.nu2).reshape(-1)[0]))
+        self._ctx.call("btf_set_nu2", _scalar(self.nu2))
 
     def _resample_W(self, data):
         self._bind_data(data)

@@ -92,7 +92,8 @@ int btf_set_data_binomial(btf_ctx* ctx, const double* succ_rows, const double* t
                           const double* succ_cols, const double* trials_cols);
 /* Quirks Q1/Q2: which row / column the cached likelihood weights
  * come from in compat=REFERENCE.  src_row[N], src_col[M] (global indices);
- * NULL = identity.  Only consulted by the weighted kernels.                   */
+ * NULL = identity.  Only consulted by the weighted kernels.  Call after
+ * btf_set_data_*; a source outside this ctx's shard is BTF_EINVAL.             */
 int btf_set_stale_sources(btf_ctx* ctx, const int32_t* src_row, const int32_t* src_col);
 
 /* ---- state ---------------------------------------------------------------- */
@@ -133,6 +134,10 @@ int btf_sse(btf_ctx* ctx, double* sse, double* nobs);
 /* omega_ijt ~ PG(Ntrials_ijt, w_i . v_jt) on the device: replaces the
  * pypolyagamma call at factor.py:459 (own RNG: Philox keyed by seed).         */
 int btf_pg_draw(btf_ctx* ctx, uint64_t seed);
+
+/* Stand-alone batch of PG(b_i, psi_i) draws from the same device sampler (used to
+ * validate its distribution; element i uses the Philox stream (seed, i)).      */
+int btf_pg_batch(int device, int64_t n, const double* b, const double* psi, uint64_t seed, double* out);
 
 int btf_sync(btf_ctx* ctx); /* waits; returns BTF_ENOTPD if a step failed since the last sync */
 

@@ -171,7 +171,7 @@ def test_device_rng_moments():
     model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=1, sigma2_init=2.0, lam2_init=0.1,
                                             nu2_init=3.0, V_init=V, W_init=W0, rng="device", device_seed=9)
     model._resample_W(Y)
-    W = model.W[K:]
+    W = model.W[K:].copy()
     Vf = V.reshape(-1, K)
     Q = R / 3.0 * Vf.T @ Vf + np.eye(K) / 2.0
     mean = np.linalg.solve(Q, R / 3.0 * Vf.T @ Y[0].mean(-1).reshape(-1))
@@ -181,3 +181,141 @@ def test_device_rng_moments():
     # and a second call draws different numbers
     model._resample_W(Y)
     assert np.abs(model.W[K:] - W).max() > 1e-3
+
+
+# ------------------------------------------------------------------ Binomial / PG
+def binomial_model(g, **kw):
+    from functionalmf_amd.factor import BinomialBayesianTensorFiltering
+    N, M, T, R, K, tf = [int(x) for x in g["dims"]]
+    st = state_from(g, "s0_")
+    model = BinomialBayesianTensorFiltering(
+        N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+        W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], **kw)
+    model.nu2 = st["nu2"]            # = 1/omega, as the reference holds it (factor.py:460)
+    return model
+
+
+@pytest.mark.parametrize("tag", ["nan", "full"])
+def test_binomial_half_sweeps_given_omega(golden, tag):
+    """Q1 (tag=full: no NaN => rows >= K reuse row K-1's omega) and Q2 (every column
+    reuses the omega of the last pattern change) are reproduced."""
+    g = golden("g4_binomial_%s.npz" % tag)
+    data = (g["Ysucc"], g["Ntrials"])
+    model = binomial_model(g)
+    np.random.seed(500)
+    model._resample_W(data)
+    assert relerr(model.W, g["W_after"]) < W_TOL
+    np.random.seed(501)
+    model._resample_V(data)
+    assert relerr(model.V, g["V_after_depth"]) < V_TOL
+
+
+def test_binomial_exact_mode_differs_from_reference_quirk(golden):
+    g = golden("g4_binomial_full.npz")
+    data = (g["Ysucc"], g["Ntrials"])
+    model = binomial_model(g, compat="exact")
+    np.random.seed(500)
+    model._resample_W(data)
+    from oracle import btf_oracle as orc
+    st = state_from(g, "s0_")
+    # textbook conditional: every row uses its own omega = force the refresh branch
+    Yk = orc.binomial_kappa(g["Ysucc"], g["Ntrials"], st["nu2"])
+    W = st["W"].copy()
+    N, K = W.shape
+    Vf = st["V"].reshape(-1, K)
+    zpos = 0
+    for i in range(N):
+        d = min(i + 1, K)
+        c = 1.0 / st["nu2"][i].reshape(-1)
+        Q = (Vf[:, :d] * c[:, None]).T @ Vf[:, :d] + np.eye(d) / st["sigma2"]
+        m = (Vf[:, :d] * c[:, None]).T @ Yk[i].reshape(-1)
+        L = np.linalg.cholesky(Q)
+        W[i, :d] = np.linalg.solve(Q, m) + np.linalg.solve(L.T, g["z_W"][zpos:zpos + d])
+        zpos += d
+    assert relerr(model.W, W) < 1e-10
+    assert relerr(model.W, g["W_after"]) > 1e-3
+
+
+def pg_batch(b, psi, seed):
+    import ctypes as C
+    from functionalmf_amd import _native
+    lib = _native.load()
+    b = _native.as_f64(b)
+    psi = _native.as_f64(psi)
+    out = np.empty_like(b)
+    rc = lib.btf_pg_batch(0, b.size, _native.dptr(b), _native.dptr(psi), C.c_uint64(seed), _native.dptr(out))
+    assert rc == 0, lib.btf_last_error(None)
+    return out
+
+
+@pytest.mark.parametrize("b", [1, 2, 4, 10, 100.5, 300])
+@pytest.mark.parametrize("c", [0.0, 0.5, 2.0, 8.0, 60.0])
+def test_pg_moments(b, c):
+    from oracle import btf_oracle as orc
+    n = 400000
+    x = pg_batch(np.full(n, float(b)), np.full(n, c), seed=1234 + int(10 * c) + int(b))
+    m, v = float(orc.pg_mean(b, c)), float(orc.pg_var(b, c))
+    assert np.all(x > 0)
+    assert abs(x.mean() - m) < 5 * np.sqrt(v / n), (x.mean(), m)
+    assert abs(x.var() - v) / v < 0.03, (x.var(), v)
+
+
+@pytest.mark.parametrize("b,c", [(1, 0.0), (1, 3.0), (4, 1.0), (2.5, 2.0)])
+def test_pg_distribution_ks(b, c):
+    """Two-sample KS against the definition-based series sampler of the oracle."""
+    from scipy.stats import ks_2samp
+    from oracle import btf_oracle as orc
+    x = pg_batch(np.full(20000, float(b)), np.full(20000, c), seed=77)
+    y = orc.pg_draw_series(b, c, 20000, np.random.default_rng(3))
+    assert ks_2samp(x, y).pvalue > 1e-3
+
+
+def test_pg_draw_fills_both_layouts_identically_and_masks_missing(golden):
+    g = golden("g4_binomial_nan.npz")
+    data = (g["Ysucc"], g["Ntrials"])
+    model = binomial_model(g)
+    model._resample_nu2(data)
+    nu2 = model.nu2
+    miss = np.isnan(g["Ysucc"])
+    assert np.all(np.isinf(nu2[miss])) and np.all(np.isfinite(nu2[~miss])) and np.all(nu2[~miss] > 0)
+    # mean of omega against E[PG(6, psi)]
+    from oracle import btf_oracle as orc
+    psi = np.einsum("nk,mtk->nmt", model.W, model.V)
+    om = 1 / nu2[~miss]
+    mref = orc.pg_mean(6.0, psi[~miss])
+    vref = orc.pg_var(6.0, psi[~miss])
+    zscore = (om - mref).sum() / np.sqrt(vref.sum())
+    assert abs(zscore) < 5
+    # the V-layout copy holds the same draws: a V step in exact mode must match the oracle given omega
+    st = dict(W=model.W.copy(), V=model.V.copy(), Tau2=model.Tau2.copy(), lam2=float(model.lam2),
+              sigma2=float(model.sigma2), nu2=nu2.copy())
+    model2_V0 = model.V.copy()
+    np.random.seed(9)
+    z = np.random.normal(size=(model.ncols, model.nembeds * model.ndepth))
+    np.random.seed(9)
+    model.compat = "exact"
+    model._resample_V(data)
+    Delta = orc.trend_penalty(model.ndepth, 2)
+    with np.errstate(invalid="ignore"):
+        Vref = orc.binomial_v_step(st, g["Ysucc"], g["Ntrials"], Delta, z=z, compat="exact")
+    assert relerr(model.V, Vref) < V_TOL
+
+
+def test_binomial_chain_recovers_probabilities():
+    """End-to-end statistical check of the PG path (device PG + weighted half-sweeps)."""
+    from functionalmf_amd.factor import BinomialBayesianTensorFiltering
+    rs = np.random.RandomState(3)
+    N, M, T, K = 24, 10, 12, 2
+    Wt = rs.normal(size=(N, K))
+    Vt = 0.4 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    P = 1 / (1 + np.exp(-np.einsum("nk,mtk->nmt", Wt, Vt)))
+    Nt = np.full((N, M, T), 30.0)
+    Ys = rs.binomial(30, P).astype(float)
+    np.random.seed(4)
+    model = BinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=1, sigma2_init=1.0, lam2_init=0.1,
+                                            compat="exact")
+    res = model.run_gibbs((Ys, Nt), nburn=150, nthin=2, nsamples=100, verbose=False)
+    Mu = np.einsum("znk,zmtk->znmt", res["W"], res["V"])
+    Phat = (1 / (1 + np.exp(-Mu))).mean(0)
+    assert np.corrcoef(Phat.reshape(-1), P.reshape(-1))[0, 1] > 0.97
+    assert np.abs(Phat - P).mean() < 0.06
