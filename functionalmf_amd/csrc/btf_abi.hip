@@ -210,7 +210,7 @@ void launch_products(btf_ctx* c, const double* U, int Rdim, double* UU) {
 }
 template <int K>
 void launch_wsolve(btf_ctx* c, const WSolveArgs& a) {
-  hipLaunchKernelGGL((w_solve_kernel<K>), dim3((a.nl + 127) / 128), dim3(128), 0, c->stream, a);
+  hipLaunchKernelGGL((w_solve_kernel<K>), dim3((a.nl + WS_ROWS - 1) / WS_ROWS), dim3(WS_ROWS * ws_split(K)), 0, c->stream, a);
 }
 template <int K>
 hipError_t launch_vbanded(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {

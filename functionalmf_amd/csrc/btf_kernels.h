@@ -186,42 +186,67 @@ struct WSolveArgs {
   int* status;     // [0] = failure flag, [1] = first failing row
 };
 
+constexpr int WS_ROWS = 64;   // rows per workgroup (one per lane)
+// waves per workgroup: the chunk partials are summed WS_SPLIT-way in parallel (LDS-bounded)
+__host__ __device__ constexpr int ws_split(int K) { return K <= 6 ? 8 : (K <= 8 ? 4 : 2); }
+
 template <int K>
-__global__ __launch_bounds__(128) void w_solve_kernel(WSolveArgs a) {
+__global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveArgs a) {
   constexpr int KK = tri(K);
+  constexpr int WS_SPLIT = ws_split(K);
+  constexpr int NVMAX = K + KK;
   const int NV = a.weighted ? K + KK : K;
   __shared__ double G[KK];
+  __shared__ double red[WS_SPLIT][NVMAX][WS_ROWS];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   if (!a.weighted) {
     if (threadIdx.x < KK) {
       double s = 0.0;
       for (int b = 0; b < a.ngp; ++b) s += a.gpart[b * KK + threadIdx.x];
       G[threadIdx.x] = s * a.sR;
     }
-    __syncthreads();
   }
-  const int il = blockIdx.x * blockDim.x + threadIdx.x;
-  if (il >= a.nl) return;
+  const int il = blockIdx.x * WS_ROWS + lane;
+  // stage 1: wave `grp` sums chunks grp, grp+WS_SPLIT, ... (fixed order => deterministic)
+  {
+    double part[NVMAX];
+#pragma unroll
+    for (int v = 0; v < NVMAX; ++v) part[v] = 0.0;
+    if (il < a.nl) {
+      for (int c = grp; c < a.nch; c += WS_SPLIT) {
+        const double* p = a.part + (size_t)c * NV * a.ld + il;
+#pragma unroll
+        for (int v = 0; v < NVMAX; ++v)
+          if (v < NV) part[v] += p[(size_t)v * a.ld];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < NVMAX; ++v) red[grp][v][lane] = part[v];
+  }
+  __syncthreads();
+  if (grp != 0 || il >= a.nl) return;
+  double m[K], Q[KK];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < WS_SPLIT; ++w) s += red[w][k][lane];
+    m[k] = s * a.s;
+  }
+#pragma unroll
+  for (int q = 0; q < KK; ++q) {
+    if (a.weighted) {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < WS_SPLIT; ++w) s += red[w][K + q][lane];
+      Q[q] = s * a.s;
+    } else {
+      Q[q] = G[q];
+    }
+  }
   const int i = a.row0 + il;
   const int d = i + 1 < K ? i + 1 : K;
 
-  double m[K], Q[KK];
-#pragma unroll
-  for (int k = 0; k < K; ++k) m[k] = 0.0;
-#pragma unroll
-  for (int q = 0; q < KK; ++q) Q[q] = 0.0;
-  for (int c = 0; c < a.nch; ++c) {
-    const double* p = a.part + (size_t)c * NV * a.ld + il;
-#pragma unroll
-    for (int k = 0; k < K; ++k) m[k] += p[(size_t)k * a.ld];
-    if (a.weighted) {
-#pragma unroll
-      for (int q = 0; q < KK; ++q) Q[q] += p[(size_t)(K + q) * a.ld];
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < K; ++k) m[k] *= a.s;
-#pragma unroll
-  for (int q = 0; q < KK; ++q) Q[q] = a.weighted ? Q[q] * a.s : G[q];
 #pragma unroll
   for (int k = 0; k < K; ++k) Q[lidx(k, k)] += a.inv_sigma2;
   // rows/cols >= d are frozen (W is lower triangular in its first K rows): identity there

@@ -141,8 +141,9 @@ def mvn_from_precision(Q, mu_part=None, perm=None, z=None,
 # W half-sweep                       (factor.py:313-362)
 # --------------------------------------------------------------------------
 
-def w_step(st, Y, z=None):
-    """Row-by-row conjugate draw of W.  Reproduces quirk Q1: the design/factor
+def w_step(st, Y, z=None, row0=0):
+    """Row-by-row conjugate draw of W.  (row0: global index of the first row when
+    st["W"] / Y hold only a block of rows - used by the sharding tests.)  Reproduces quirk Q1: the design/factor
     cache is refreshed only for rows < K or when the data holds any NaN
     (factor.py:320, :349).  ``z``: optional flat array of the sum_i min(i+1,K)
     normals, consumed in row order; else the legacy global RNG is used.
@@ -155,15 +156,17 @@ def w_step(st, Y, z=None):
     nu2 = st["nu2"]
     zpos = 0
     Xt = Lt = None
+    if z is not None and row0:
+        zpos = row0 * (row0 + 1) // 2 if row0 < K else K * (K + 1) // 2 + (row0 - K) * K
     for i in range(N):
-        d = min(i + 1, K)
+        d = min(row0 + i + 1, K)
         yb = ybar[i].reshape(-1)
         keep = ~np.isnan(yb)
         if np.isscalar(nu2) or np.ndim(nu2) == 0:
             c = cnt[i].reshape(-1)[keep] / nu2
         else:
             c = cnt[i].reshape(-1)[keep] / nu2[i].reshape(-1)[keep]
-        if i < K or any_nan:
+        if row0 + i < K or any_nan or Xt is None:
             Vd = Vflat[keep][:, :d]
             Xt = (Vd * c[:, None]).T
             Q = Xt @ Vd + np.eye(d) / st["sigma2"]
@@ -235,7 +238,7 @@ def stale_column_sources(ybar):
 
 
 def v_step(st, Y, Delta, perm="depth", z=None, compat="reference",
-           force_psd=True, eps0=1e-6, attempts=4, info=None):
+           force_psd=True, eps0=1e-6, attempts=4, info=None, cols=None):
     """Column-by-column conjugate draw of V (factor.py:364-409 + fast_mvn).
     perm: "depth" (declared ordering), "identity", or an explicit array.
     z: optional (M, K*T) normals, row j used for column j, indexed in the
@@ -249,7 +252,7 @@ def v_step(st, Y, Delta, perm="depth", z=None, compat="reference",
         p = np.asarray(perm)
     src = stale_column_sources(st["_ybar"]) if compat == "reference" else np.arange(M)
     tries = np.zeros(M, dtype=np.int64)
-    for j in range(M):
+    for j in (range(M) if cols is None else cols):
         Q, mu = v_step_system(st, Y, Delta, j, int(src[j]))
         inf = {}
         x = mvn_from_precision(Q, mu_part=mu, perm=p,
