@@ -16,8 +16,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libbtf_hip.so")
 SOURCES = [os.path.join(CSRC, "btf_abi.hip")]
-HEADERS = [os.path.join(CSRC, "btf_kernels.h"), os.path.join(CSRC, "btf_device.h"),
-           os.path.join(ROOT, "include", "btf.h")]
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+    [os.path.join(ROOT, "include", "btf.h")]
 
 BTF_OK, BTF_EINVAL, BTF_EHIP, BTF_ENOTPD, BTF_ESTATE = 0, 1, 2, 3, 4
 COMPAT = {"reference": 0, "exact": 1}

@@ -3,6 +3,8 @@
 // returns an error.
 #include "../../include/btf.h"
 #include "btf_kernels.h"
+#include "btf_banded_fast.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -49,6 +51,9 @@ struct btf_ctx {
   bool stale_w = false, stale_v = false;
   double ssw = 0.0, nobs = 0.0;
   int rpb_w = 0, rpb_v = 0;
+  bool force_generic_banded = false;
+  long long* dbg = nullptr;
+  double* pband = nullptr; bool pband_dirty = true;
   unsigned long long sweep_w = 0, sweep_v = 0;
   bool profiling = false;
   std::vector<EvPair> ev_pool;
@@ -86,6 +91,9 @@ int dev_alloc(btf_ctx* c, T** p, size_t n) {
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// One kernel launch, counted per BTF_K_* id.  With profiling on the launch goes through
+// hipExtLaunchKernelGGL so that the two events bracket exactly this dispatch (its start
+// and completion timestamps), not the gaps around it.
 struct Prof {
   btf_ctx* c; int kid; EvPair* ev = nullptr;
   Prof(btf_ctx* c_, int kid_) : c(c_), kid(kid_) {
@@ -93,10 +101,13 @@ struct Prof {
     if (c->profiling && c->ev_used < c->ev_pool.size()) {
       ev = &c->ev_pool[c->ev_used++];
       ev->kid = kid;
-      (void)hipEventRecord(ev->a, c->stream);
     }
   }
-  ~Prof() { if (ev) (void)hipEventRecord(ev->b, c->stream); }
+  template <typename F, typename... Args>
+  void launch(F kernel, dim3 grid, dim3 block, size_t lds, Args... args) {
+    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, c->stream, ev->a, ev->b, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, c->stream, args...);
+  }
 };
 
 // Delta' diag(lambda) Delta stencil: for every (t,d), d = 0..tf+1, the Delta rows r that
@@ -180,37 +191,38 @@ int build_stencil(btf_ctx* c) {
 
 // ---- templated launch tables -------------------------------------------------
 template <int K>
-void launch_accum(btf_ctx* c, int mode, const double* X, const double* Cx, const double* U,
+void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const double* U,
                   const double* UU, const int* srcmap, int Rdim, int ld, int rpb, int nch) {
-  dim3 grid(ld / ACC_TILE, nch);
-  if (mode == 2)
-    hipLaunchKernelGGL((accum_kernel<K, 2>), grid, dim3(ACC_THREADS), 0, c->stream, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
-  else if (mode == 1)
-    hipLaunchKernelGGL((accum_kernel<K, 1>), grid, dim3(ACC_THREADS), 0, c->stream, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
-  else
-    hipLaunchKernelGGL((accum_kernel<K, 0>), grid, dim3(ACC_THREADS), 0, c->stream, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
+  Prof p(c, kid);
+  dim3 grid(ld / ACC_TILE, nch), block(ACC_THREADS);
+  if (mode == 2) p.launch(accum_kernel<K, 2>, grid, block, 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
+  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, block, 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
+  else p.launch(accum_kernel<K, 0>, grid, block, 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
 }
 template <int K>
 void launch_pg(btf_ctx* c, const double* B, double* out, const double* Lf, const double* Uf, int nl, int ld, int Rdim,
                unsigned long long base, unsigned long long stride_r, unsigned long long stride_l, unsigned long long seed) {
+  Prof p(c, BTF_K_PG);
   const int gx = (nl + PG_THREADS - 1) / PG_THREADS;
   int nrb = std::max(1, std::min(Rdim, 4096 / std::max(1, gx)));
   const int rpb = (Rdim + nrb - 1) / nrb;
   nrb = (Rdim + rpb - 1) / rpb;
-  hipLaunchKernelGGL((pg_kernel<K>), dim3(gx, nrb), dim3(PG_THREADS), 0, c->stream, B, out, Lf, Uf, nl, ld, Rdim, rpb,
-                     base, stride_r, stride_l, seed);
+  p.launch(pg_kernel<K>, dim3(gx, nrb), dim3(PG_THREADS), 0, B, out, Lf, Uf, nl, ld, Rdim, rpb, base, stride_r, stride_l, seed);
 }
 template <int K>
 void launch_gram(btf_ctx* c, const double* U, int Rdim) {
-  hipLaunchKernelGGL((gram_kernel<K>), dim3(GRAM_BLOCKS), dim3(GRAM_THREADS), 0, c->stream, U, Rdim, c->gpart);
+  Prof p(c, BTF_K_GRAM);
+  p.launch(gram_kernel<K>, dim3(GRAM_BLOCKS), dim3(GRAM_THREADS), 0, U, Rdim, c->gpart);
 }
 template <int K>
 void launch_products(btf_ctx* c, const double* U, int Rdim, double* UU) {
-  hipLaunchKernelGGL((products_kernel<K>), dim3((Rdim + 255) / 256), dim3(256), 0, c->stream, U, Rdim, UU);
+  Prof p(c, BTF_K_PROD);
+  p.launch(products_kernel<K>, dim3((Rdim + 255) / 256), dim3(256), 0, U, Rdim, UU);
 }
 template <int K>
 void launch_wsolve(btf_ctx* c, const WSolveArgs& a) {
-  hipLaunchKernelGGL((w_solve_kernel<K>), dim3((a.nl + WS_ROWS - 1) / WS_ROWS), dim3(WS_ROWS * ws_split(K)), 0, c->stream, a);
+  Prof p(c, BTF_K_W_SOLVE);
+  p.launch(w_solve_kernel<K>, dim3((a.nl + WS_ROWS - 1) / WS_ROWS), dim3(WS_ROWS * ws_split(K)), 0, a);
 }
 template <int K>
 hipError_t launch_vbanded(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
@@ -220,14 +232,51 @@ hipError_t launch_vbanded(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((v_banded_kernel<K>), dim3(a.ml), dim3(WAVE), lds_bytes, c->stream, a);
+  Prof p(c, BTF_K_V_BANDED);
+  p.launch(v_banded_kernel<K>, dim3(a.ml), dim3(WAVE), lds_bytes, a);
+  return hipSuccess;
+}
+template <int NPL, bool ROW16>
+hipError_t launch_vbanded_fast(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)v_banded_fast_kernel<NPL, ROW16>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  Prof p(c, BTF_K_V_BANDED);
+  p.launch(v_banded_fast_kernel<NPL, ROW16>, dim3(a.ml), dim3(VB_THREADS), lds_bytes, a, c->K);
+  return hipSuccess;
+}
+hipError_t dispatch_vbanded_fast(btf_ctx* c, const VBandArgs& a, int bw, size_t lds_bytes, bool* handled) {
+  const int npairs = bw * (bw - 1) / 2;
+  const int npl = std::max(1, (npairs + WAVE - 1) / WAVE);
+  *handled = true;
+  if (bw <= 15) {
+    if (npl == 1) return launch_vbanded_fast<1, true>(c, a, lds_bytes);
+    if (npl == 2) return launch_vbanded_fast<2, true>(c, a, lds_bytes);
+  } else {
+    switch (npl) {
+      case 2: return launch_vbanded_fast<2, false>(c, a, lds_bytes);
+      case 3: return launch_vbanded_fast<3, false>(c, a, lds_bytes);
+      case 4: return launch_vbanded_fast<4, false>(c, a, lds_bytes);
+      case 5: return launch_vbanded_fast<5, false>(c, a, lds_bytes);
+      case 6: return launch_vbanded_fast<6, false>(c, a, lds_bytes);
+      case 7: return launch_vbanded_fast<7, false>(c, a, lds_bytes);
+      case 8: return launch_vbanded_fast<8, false>(c, a, lds_bytes);
+      default: break;
+    }
+  }
+  *handled = false;
   return hipSuccess;
 }
 template <int K>
 void launch_sse(btf_ctx* c, const double* A, const double* C, double Rc, int ncols, int ld, int rpb, int nrb) {
+  Prof p(c, BTF_K_SSE);
   dim3 grid((ncols + SSE_THREADS - 1) / SSE_THREADS, nrb);
-  hipLaunchKernelGGL((sse_kernel<K>), grid, dim3(SSE_THREADS), 0, c->stream, A, C, Rc, c->W, c->V, c->N, ncols, ld,
-                     rpb, (size_t)c->col0 * c->T, c->bsum);
+  p.launch(sse_kernel<K>, grid, dim3(SSE_THREADS), 0, A, C, Rc, (const double*)c->W, (const double*)c->V, c->N, ncols, ld, rpb,
+           (size_t)c->col0 * c->T, c->bsum);
 }
 
 #define K_SWITCH(K, CALL)                                          \
@@ -280,7 +329,7 @@ int pick_rpb(int Rdim, int tiles, int user) {
   // rows per workgroup: a multiple of ACC_WAVES*ACC_UNR (=64) sized so that the
   // grid has >= ~1024 workgroups when the problem allows, partials stay small
   if (user > 0) return std::max(64, round_up(user, 64));
-  int want_chunks = std::max(1, 1024 / std::max(1, tiles));
+  int want_chunks = std::max(1, (tiles >= 32 ? 512 : 256) / std::max(1, tiles));
   int rpb = round_up((Rdim + want_chunks - 1) / want_chunks, 64);
   return std::max(rpb, 128);
 }
@@ -313,7 +362,7 @@ int make_stats(btf_ctx* c, const double* hY, const double* hY2, int rows, int co
   StatsArgs a{dY, dY2, rows, cols, R, ld, transposed ? 1 : 0, *A, *C, want_sums ? c->bsum : nullptr, dflag};
   {
     Prof p(c, BTF_K_STATS);
-    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
+    p.launch(stats_kernel, dim3(blocks), dim3(256), 0, a);
   }
   HIPCHK(c, hipGetLastError());
   if (B && hY2) {  // keep the trial counts for the PG draw: B = C at this point
@@ -396,7 +445,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->WW, c->VV, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -531,7 +580,9 @@ int btf_set_hyper(btf_ctx* c, const double* Tau2, double lam2, double sigma2) {
     HIPCHK(c, hipMemcpyAsync(c->Tau2, Tau2, (size_t)c->M * c->nD * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_hyper = true;
+    c->pband_dirty = true;
   }
+  if (lam2 != c->lam2) c->pband_dirty = true;
   c->lam2 = lam2; c->sigma2 = sigma2;
   return BTF_OK;
 }
@@ -591,17 +642,9 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     dz = c->zbuf;
   }
   if (c->nl > 0) {
-    if (wt) {
-      Prof p(c, BTF_K_PROD);
-      K_SWITCH(K, launch_products<KT>(c, c->V, MT, c->VV));
-    } else {
-      Prof p(c, BTF_K_GRAM);
-      K_SWITCH(K, launch_gram<KT>(c, c->V, MT));
-    }
-    {
-      Prof p(c, BTF_K_W_ACCUM);
-      K_SWITCH(K, launch_accum<KT>(c, mode, c->A_wT, c->C_wT, c->V, c->VV, c->srcmap_w, MT, c->ldw, rpb, nch));
-    }
+    if (wt) { K_SWITCH(K, launch_products<KT>(c, c->V, MT, c->VV)); }
+    else { K_SWITCH(K, launch_gram<KT>(c, c->V, MT)); }
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->V, c->VV, c->srcmap_w, MT, c->ldw, rpb, nch));
     WSolveArgs a{};
     a.part = c->part; a.nch = nch; a.ld = c->ldw; a.gpart = c->gpart; a.ngp = GRAM_BLOCKS; a.weighted = wt ? 1 : 0;
     a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
@@ -610,10 +653,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     a.W = c->W; a.row0 = c->row0; a.nl = c->nl;
     a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_w + 0x10000ULL;
     a.status = c->status;
-    {
-      Prof p(c, BTF_K_W_SOLVE);
-      K_SWITCH(K, launch_wsolve<KT>(c, a));
-    }
+    K_SWITCH(K, launch_wsolve<KT>(c, a));
   }
   c->sweep_w++;
   HIPCHK(c, hipGetLastError());
@@ -643,17 +683,9 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     dz = c->zbuf;
   }
   if (c->ml > 0) {
-    if (wt) {
-      Prof p(c, BTF_K_PROD);
-      K_SWITCH(K, launch_products<KT>(c, c->W, c->N, c->WW));
-    } else {
-      Prof p(c, BTF_K_GRAM);
-      K_SWITCH(K, launch_gram<KT>(c, c->W, c->N));
-    }
-    {
-      Prof p(c, BTF_K_V_ACCUM);
-      K_SWITCH(K, launch_accum<KT>(c, mode, c->A_v, c->C_v, c->W, c->WW, c->srcmap_v, c->N, c->ldv, rpb, nch));
-    }
+    if (wt) { K_SWITCH(K, launch_products<KT>(c, c->W, c->N, c->WW)); }
+    else { K_SWITCH(K, launch_gram<KT>(c, c->W, c->N)); }
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->W, c->WW, c->srcmap_v, c->N, c->ldv, rpb, nch));
     const int bw = (c->TF + 1) * K, R1 = bw + 1, D1 = c->TF + 2;
     size_t lds_fixed = (size_t)(3 * n + T * D1 + (wt ? T * KK : KK) + (bw * (bw + 1) / 2 + 3) / 4) * sizeof(double);
     size_t lds_band = (size_t)n * R1 * sizeof(double);
@@ -675,12 +707,25 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     a.st_ptr = c->st_ptr; a.st_row = c->st_row; a.st_coef = c->st_coef;
     a.T = T; a.TF = c->TF; a.col0 = c->col0; a.ml = c->ml;
     a.V = c->V; a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_v + 0x10001ULL;
-    a.eps0 = eps0; a.attempts = attempts; a.status = c->status; a.tries = c->tries;
+    a.eps0 = eps0; a.attempts = attempts; a.status = c->status; a.tries = c->tries; a.dbg = c->dbg;
     hipError_t e = hipSuccess;
-    {
-      Prof p(c, BTF_K_V_BANDED);
-      K_SWITCH(K, e = launch_vbanded<KT>(c, a, lds_bytes));
+    bool handled = false;
+    const size_t fast_bytes = vb_fast_lds_bytes(T, K, c->TF, wt ? 1 : 0);
+    const bool fast = !c->force_generic_banded && bw >= 3 && fast_bytes <= 158 * 1024;
+    if (fast) {
+      const int TD1 = T * D1;
+      if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; c->pband_dirty = true; }
+      if (c->pband_dirty) {
+        Prof p(c, BTF_K_PROD);
+        p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
+                 (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband);
+        c->pband_dirty = false;
+      }
+      a.pband = c->pband;
     }
+    if (fast) e = dispatch_vbanded_fast(c, a, bw, fast_bytes, &handled);
+    HIPCHK(c, e);
+    if (!handled) { K_SWITCH(K, e = launch_vbanded<KT>(c, a, lds_bytes)); }
     HIPCHK(c, e);
   }
   c->sweep_v++;
@@ -712,10 +757,7 @@ int btf_sse(btf_ctx* c, double* sse, double* nobs) {
     if ((rc = dev_alloc(c, &c->bsum, nb))) return rc;
     c->bsum_elems = nb;
   }
-  if (ncols > 0) {
-    Prof p(c, BTF_K_SSE);
-    K_SWITCH(c->K, launch_sse<KT>(c, c->A_v, c->C_v, (double)c->R, ncols, c->ldv, rpb, nrb));
-  }
+  if (ncols > 0) { K_SWITCH(c->K, launch_sse<KT>(c, c->A_v, c->C_v, (double)c->R, ncols, c->ldv, rpb, nrb)); }
   HIPCHK(c, hipGetLastError());
   std::vector<double> h(nb);
   if (ncols > 0) {
@@ -739,12 +781,10 @@ int btf_pg_draw(btf_ctx* c, uint64_t seed) {
   const unsigned long long MT = (unsigned long long)c->M * c->T;
   // every cell is drawn once per layout from the same (seed, cell) stream: identical values
   if (c->nl > 0) {  // W layout [jt][i_local]: lanes = rows of W, reduction axis = (j,t)
-    Prof p(c, BTF_K_PG);
     K_SWITCH(c->K, launch_pg<KT>(c, c->B_wT, c->C_wT, c->W + (size_t)c->row0 * c->K, c->V, c->nl, c->ldw, (int)MT,
                                  (unsigned long long)c->row0 * MT, 1ULL, MT, seed));
   }
   if (c->ml > 0) {  // V layout [i][jt_local]
-    Prof p(c, BTF_K_PG);
     K_SWITCH(c->K, launch_pg<KT>(c, c->B_v, c->C_v, c->V + (size_t)c->col0 * c->T * c->K, c->W, c->ml * c->T, c->ldv,
                                  c->N, (unsigned long long)c->col0 * c->T, MT, 1ULL, seed));
   }
@@ -858,9 +898,26 @@ int btf_kernel_times(btf_ctx* c, double* ms_total, int64_t* launches) {
   return BTF_OK;
 }
 
+// diagnostic (not in btf.h): phase stamps of the fast banded kernel, [ncols_local][6] shader clocks
+extern "C" int btf_debug_stamps(btf_ctx* c, long long* out) {
+  if (!c) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (!c->dbg) {
+    int rc = dev_alloc(c, &c->dbg, (size_t)c->M * 6);
+    if (rc) return rc;
+    HIPCHK(c, hipMemset(c->dbg, 0, (size_t)c->M * 6 * sizeof(long long)));
+    return BTF_OK;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, c->dbg, (size_t)c->ml * 6 * sizeof(long long), hipMemcpyDeviceToHost));
+  return BTF_OK;
+}
+
 int btf_set_tuning(btf_ctx* c, int rows_per_block_w, int rows_per_block_v) {
   if (!c) return BTF_EINVAL;
-  c->rpb_w = rows_per_block_w; c->rpb_v = rows_per_block_v;
+  // negative rows_per_block_v selects the generic (any-size) banded kernel: test hook
+  c->force_generic_banded = rows_per_block_v < 0;
+  c->rpb_w = rows_per_block_w; c->rpb_v = rows_per_block_v < 0 ? 0 : rows_per_block_v;
   return BTF_OK;
 }
 

@@ -1,0 +1,379 @@
+// Fast path of the V half-sweep sampler (BTF_K_V_BANDED): band resident in LDS,
+// one workgroup of 4 waves per column.
+//
+//   * LDL' instead of LL': the sequential pivot chain carries one v_rcp_f64 (+2 Newton
+//     steps) instead of a square root and a division; the square roots are taken
+//     afterwards, in parallel, where the noise term needs them
+//     (x = L^-T (D^-1 L^-1 mu + D^-1/2 z): the same vector as Q^-1 mu + L~^-T z with
+//     the Cholesky factor L~ = L D^1/2 of fast_mvn.py:38-47).
+//   * the NEXT pivot column never leaves registers: lane l of wave 0 keeps A[n+1+l, n+1];
+//     its rank-1 correction needs only a one-lane shift and one readlane, so the
+//     dependent chain per pivot is readlane -> rcp -> mul -> fma.  All other trailing
+//     updates are read-modify-writes on the LDS band, off the chain.
+//   * the band and rhs are zero-padded by bw+1 columns: no tail special-casing.
+//   * waves 1..3 assemble, then draw the Philox normals while wave 0 factors.
+//   * back-substitution keeps the bw+1 live unknowns in registers (lane = column mod
+//     (bw+1)); factor entries and fresh right-hand sides are prefetched two steps ahead.
+#pragma once
+#include "btf_kernels.h"
+
+namespace btf {
+
+constexpr int VB_THREADS = 256;
+
+__device__ __forceinline__ double rcp_nr(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(e, r, r);
+  e = fma(-d, r, 1.0);
+  return fma(e, r, r);
+}
+
+// lane l <- lane l+1 (lanes past the end read 0)
+template <bool ROW16>
+__device__ __forceinline__ double shift_down1(double v) {
+  if constexpr (ROW16) {  // DPP row_shl:1 inside a 16-lane row, out-of-row reads give 0
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x101, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x101, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+  } else {
+    const int lane = threadIdx.x & 63;
+    double r = __shfl_down(v, 1, WAVE);
+    return lane == 63 ? 0.0 : r;
+  }
+}
+
+// Everything below addresses LDS as `lds[int offset]` (offsets in doubles from the
+// dynamic-LDS base): pointer selects make hipcc fall back to flat_load/flat_store,
+// and exec-masked regions make it drain lgkmcnt(0); so the two sequential loops are
+// written branch-free - idle lanes are steered to private dummy words instead of being
+// masked off - and every load of a step is issued before its first store.
+struct VbLayout {     // offsets (doubles) inside the dynamic LDS block
+  int band;           // npad*R1 + 64   band, [c][a] = A[c+a,c]; zero padded
+  int rhs;            // FP + npad + 64 right-hand side, FP zeros in front
+  int m0, zs, invd;   // npad each
+  int P, Ql, flag, vsc, dummy;
+  int total;
+  int FP, npad, R1;
+};
+__host__ __device__ inline VbLayout vb_layout(int T, int K, int TF, int weighted) {
+  VbLayout L;
+  const int n = T * K, bw = (TF + 1) * K, D1 = TF + 2, KK = tri(K);
+  L.R1 = bw + 1;
+  L.npad = n + bw + 2;
+  L.FP = bw + 4;
+  int o = 0;
+  L.band = o; o += L.npad * L.R1 + 64;
+  L.rhs = o + L.FP; o += L.FP + L.npad + 64;
+  L.m0 = o; o += L.npad;
+  L.zs = o; o += L.npad;
+  L.invd = o; o += L.npad;
+  L.P = o; o += T * D1;
+  L.Ql = o; o += weighted ? T * KK : KK;
+  L.flag = o; o += 8;
+  L.vsc = o; o += 64;
+  L.dummy = o; o += 64 * 9 + 8;
+  L.total = o;
+  return L;
+}
+__host__ __device__ inline size_t vb_fast_lds_bytes(int T, int K, int TF, int weighted) {
+  return (size_t)vb_layout(T, K, TF, weighted).total * sizeof(double);
+}
+
+// lane l <- lane l+2 (lanes past the end read 0)
+template <bool ROW16>
+__device__ __forceinline__ double shift_down2(double v) {
+  if constexpr (ROW16) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x102, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x102, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+  } else {
+    const int lane = threadIdx.x & 63;
+    double r = __shfl_down(v, 2, WAVE);
+    return lane >= 62 ? 0.0 : r;
+  }
+}
+
+// LDS access by BYTE offset from the dynamic-LDS base (one ds_read/ds_write, no shift)
+__device__ __forceinline__ double ldsr(const double* lds, int boff) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds) + boff);
+}
+__device__ __forceinline__ void ldsw(double* lds, int boff, double x) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + boff) = x;
+}
+
+// LDL' of the band with the forward substitution of rhs folded in.  Wave 0 only.
+// On return: band = unit-lower factor columns, invd[c] = 1/D_c, rhs = L^-1 rhs.
+//
+// The next TWO pivot columns live in registers (v: column nn, w: column nn+1, lane l =
+// row offset l); their rank-1 corrections need a lane shift and a readlane only, so the
+// dependent chain per pivot is readfirstlane -> rcp -> mul -> readlane -> fma.  The other
+// trailing pairs (a,b), 3 <= b <= a <= bw, are read-modify-writes on the LDS band whose
+// loads are issued at the END of the previous step (software pipelining): their operands
+// are the UNSCALED pivot column (A[n+a,n] A[n+b,n] / D_n), parked in a scratch row as
+// soon as it is known, so no LDS load is consumed in the step that issues it.
+// A lone wave issues roughly one instruction per 4-8 cycles, so the loop is written for
+// instruction count: byte offsets, and lanes outside the band are steered to private
+// dummy / zero words through their (precomputed) addresses and strides instead of
+// being masked with selects.
+template <int NPL, bool ROW16>
+__device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, int bw) {
+  const int lane = threadIdx.x & 63;
+  const int R1 = L.R1, R1B = L.R1 * 8;
+  const int npairs = (bw - 1) * (bw - 2) / 2;       // pairs with b >= 3
+  int to[NPL], ao[NPL], bo[NPL], tinc[NPL];          // byte offsets
+#pragma unroll
+  for (int s = 0; s < NPL; ++s) {
+    const int q = lane + WAVE * s;
+    if (q < npairs) {   // q = (a-3)(a-2)/2 + (b-3)
+      int a = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5) + 3;
+      while ((a - 3) * (a - 2) / 2 > q) --a;
+      while ((a - 2) * (a - 1) / 2 <= q) ++a;
+      const int b = q - (a - 3) * (a - 2) / 2 + 3;
+      to[s] = 8 * (L.band + b * R1 + (a - b));
+      ao[s] = 8 * (L.vsc + a);
+      bo[s] = 8 * (L.vsc + b);
+      tinc[s] = R1B;
+    } else {                       // idle slot: read-modify-write of a private dummy word
+      to[s] = 8 * (L.dummy + 64 * (1 + s) + lane);
+      ao[s] = bo[s] = 8 * (L.vsc + 63);  // entry 63 of the scratch row is always 0 (bw <= 62)
+      tinc[s] = 0;
+    }
+  }
+  const bool in_col = lane <= bw;
+  const bool in_sub = in_col && lane >= 1;
+  const int dmy = 8 * (L.dummy + lane);
+  const int zero = 8 * (L.dummy + 64 * 9);                   // a word that is never written
+  double v = in_col ? lds[L.band + lane] : 0.0;             // column 0
+  double w = in_col ? lds[L.band + R1 + lane] : 0.0;        // column 1 (uncorrected)
+  // per-lane addresses with per-lane strides: lanes outside the band stay on dummy / zero words
+  int co = in_col ? 8 * (L.band + lane) : dmy;               // store of L[nn+lane, nn]
+  const int coinc = in_col ? R1B : 0;
+  int wo = in_col ? 8 * (L.band + 2 * R1 + lane) : zero;     // load of column nn+2
+  int ro = in_sub ? 8 * (L.rhs + lane) : dmy;                // rhs[nn+lane] read-modify-write
+  const int roinc = in_sub ? 8 : 0;
+  int io = lane == 0 ? 8 * L.invd : dmy;                     // invd[nn] (lane 0)
+  const int ioinc = lane == 0 ? 8 : 0;
+  const int vo = 8 * (L.vsc + lane);
+  // prologue of the software pipeline: operands / targets of step 0
+  ldsw(lds, vo, v);
+  double t[NPL], xa[NPL], xb[NPL];
+#pragma unroll
+  for (int s = 0; s < NPL; ++s) {
+    t[s] = ldsr(lds, to[s]);
+    xa[s] = ldsr(lds, ao[s]);
+    xb[s] = ldsr(lds, bo[s]);
+  }
+  double rt = ldsr(lds, ro);
+  double wn = ldsr(lds, wo);
+  double u = lds[L.rhs];                                     // rhs[0]
+  __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): enter the loop with nothing pending
+  for (int nn = 0; nn < n; ++nn) {
+    const double p = bcast_first(v);
+    if (!(p > 0.0)) return false;
+    // ---- dependent chain
+    const double inv = rcp_nr(p);
+    const double y = v * inv;                                // L[nn+lane, nn]  (lane 0: 1)
+    const double y1 = bcast_lane(y, 1);
+    const double y2 = bcast_lane(y, 2);
+    const double vnext = fma(-shift_down1<ROW16>(v), y1, w);   // column nn+1, final
+    const double wnext = fma(-shift_down2<ROW16>(v), y2, wn);  // column nn+2 after this step
+    const double rnew = fma(-y, u, rt);                      // rhs[nn+lane] - L[nn+lane,nn] u
+    // ---- trailing updates  A[nn+a, nn+b] -= A[nn+a,nn] A[nn+b,nn] / D   (b >= 3)
+#pragma unroll
+    for (int s = 0; s < NPL; ++s) {
+      ldsw(lds, to[s], fma(-(xa[s] * inv), xb[s], t[s]));
+      to[s] += tinc[s];
+    }
+    ldsw(lds, co, y);
+    ldsw(lds, ro, rnew);
+    ldsw(lds, io, inv);
+    co += coinc;
+    ro += roinc;
+    io += ioinc;
+    wo += coinc;
+    v = vnext;                                               // lanes outside the band: 0 by construction
+    w = wnext;
+    u = bcast_lane(rnew, 1);                                 // rhs[nn+1], final after this step
+    // ---- issue the loads of step nn+1 (after the stores above: in-order LDS sees them)
+    ldsw(lds, vo, v);
+#pragma unroll
+    for (int s = 0; s < NPL; ++s) {
+      t[s] = ldsr(lds, to[s]);
+      xa[s] = ldsr(lds, ao[s]);
+      xb[s] = ldsr(lds, bo[s]);
+    }
+    rt = ldsr(lds, ro);
+    wn = ldsr(lds, wo);
+  }
+  return true;
+}
+
+// x = L^-T w for the unit-lower band factor; w = rhs in/out.  Wave 0 only; bw >= 3.
+// Lane = column mod (bw+1) keeps the live unknowns in registers; the factor entry and the
+// fresh right-hand side of step r are fetched three steps ahead into registers that are
+// renamed (not copied) by the 3-way unrolled loop; branch-free (see above).
+__device__ inline void banded_unit_backward(double* lds, const VbLayout L, int n, int bw) {
+  const int lane = threadIdx.x & 63;
+  const int R1 = L.R1, Rw = bw + 1;
+  const bool act = lane < Rw;
+  const int dmy = 8 * (L.dummy + lane);
+  // lane owns the column p == lane (mod Rw) of the sliding window (r-Rw, r]
+  int pcur = act ? (n - 1) - ((n - 1 - lane) % Rw + Rw) % Rw : -(1 << 20);
+  double wv = (act && pcur >= 0) ? lds[L.rhs + pcur] : 0.0;
+  int own = __builtin_amdgcn_readfirstlane((n - 1) % Rw);
+  // byte offset of L[r, p] = band[p*R1 + (r-p)] :  8*(band + p*(R1-1) + r)
+  auto lload = [&](int r) -> double {   // L[r, column this lane owns at step r]; branch-free
+    const int pe = (pcur >= r + 1) ? pcur - Rw : pcur;
+    const bool valid = pe >= 0 && r > pe;
+    const double x = ldsr(lds, valid ? 8 * (L.band + pe * (R1 - 1) + r) : dmy);
+    return valid ? x : 0.0;
+  };
+  auto wload = [&](int r) -> double { return lds[L.rhs + r - Rw]; };   // front-padded with zeros
+  auto step = [&](int r, double& Lc, double& Wc) {
+    const double xr = bcast_lane(wv, own);
+    const bool retire = lane == own;
+    wv = retire ? Wc : fma(-Lc, xr, wv);
+    ldsw(lds, retire ? 8 * (L.rhs + r) : dmy, xr);
+    pcur -= retire ? Rw : 0;
+    own = own == 0 ? Rw - 1 : own - 1;
+    Lc = lload(r - 3);
+    Wc = wload(r - 3);
+  };
+  double L0 = lload(n - 1), L1 = lload(n - 2), L2 = lload(n - 3);
+  double W0 = wload(n - 1), W1 = wload(n - 2), W2 = wload(n - 3);
+  int r = n - 1;
+  for (; r >= 2; r -= 3) {
+    step(r, L0, W0);
+    step(r - 1, L1, W1);
+    step(r - 2, L2, W2);
+  }
+  if (r >= 0) step(r, L0, W0);
+  if (r >= 1) step(r - 1, L1, W1);
+}
+
+template <int NPL, bool ROW16>
+__global__ __launch_bounds__(VB_THREADS) void v_banded_fast_kernel(VBandArgs a, int K) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = blockIdx.x, jg = a.col0 + j;
+  const int KK = tri(K), T = a.T, n = T * K, D1 = a.TF + 2, bw = (a.TF + 1) * K, R1 = bw + 1;
+  const int NV = a.weighted ? K + KK : K;
+
+  const VbLayout L = vb_layout(T, K, a.TF, a.weighted);
+  double* Bc = lds + L.band;
+  double* rhs = lds + L.rhs;
+  double* m0 = lds + L.m0;
+  double* zs = lds + L.zs;
+  double* invd = lds + L.invd;
+  double* P = lds + L.P;
+  double* Ql = lds + L.Ql;
+  double* flag = lds + L.flag;
+  long long stamp[6];
+  stamp[0] = __builtin_amdgcn_s_memtime();
+
+  // ---- likelihood mean part / Gram blocks / prior band (all threads) ----------------
+  auto chunk_sum = [&](const double* p) -> double {      // fixed order; loads issued 4 at a time
+    double s = 0.0;
+    const size_t st = (size_t)NV * a.ld;
+    int c = 0;
+    for (; c + 4 <= a.nch; c += 4) {
+      const double x0 = p[(size_t)c * st], x1 = p[(size_t)(c + 1) * st], x2 = p[(size_t)(c + 2) * st], x3 = p[(size_t)(c + 3) * st];
+      s += x0; s += x1; s += x2; s += x3;
+    }
+    for (; c < a.nch; ++c) s += p[(size_t)c * st];
+    return s;
+  };
+  for (int idx = tid; idx < n; idx += VB_THREADS) {
+    const int t = idx / K, k = idx - t * K;
+    m0[idx] = chunk_sum(a.part + (size_t)k * a.ld + (size_t)j * T + t) * a.s;
+  }
+  if (a.weighted) {
+    for (int idx = tid; idx < T * KK; idx += VB_THREADS) {
+      const int t = idx / KK, q = idx - t * KK;
+      Ql[idx] = chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t) * a.s;
+    }
+  } else {
+    reduce_gram(a.gpart, a.ngp, KK, a.sR, Bc, Ql);   // Bc is free scratch until the assembly
+  }
+  for (int idx = tid; idx < T * D1; idx += VB_THREADS) P[idx] = a.pband[(size_t)j * T * D1 + idx];
+  const int npad = L.npad;
+  for (int idx = n + tid; idx < npad; idx += VB_THREADS) m0[idx] = 0.0;
+  // zero pads: band tail (+64), rhs front pad and tail, scratch row, dummy words
+  for (int idx = tid; idx < 64; idx += VB_THREADS) {
+    Bc[npad * R1 + idx] = 0.0;
+    rhs[npad + idx] = 0.0;
+    lds[L.vsc + idx] = 0.0;
+  }
+  for (int idx = tid; idx < L.FP; idx += VB_THREADS) rhs[idx - L.FP] = 0.0;
+  for (int idx = tid; idx < 64 * 9 + 8; idx += VB_THREADS) lds[L.dummy + idx] = 0.0;
+  __syncthreads();
+  stamp[1] = __builtin_amdgcn_s_memtime();
+
+  double shift = 0.0, eps = a.eps0;
+  int tried = 0;
+  bool ok = false;
+  while (true) {
+    for (int nn = tid; nn < npad; nn += VB_THREADS) {      // one band column per thread, no divisions inside
+      double* colw = Bc + (size_t)nn * R1;
+      if (nn >= n) {
+        for (int aa = 0; aa < R1; ++aa) colw[aa] = 0.0;
+        continue;
+      }
+      const int t = nn / K, k = nn - t * K;
+      const double* q = a.weighted ? Ql + t * KK : Ql;
+      int dd = 0, rem = 0;                                   // aa = dd*K + rem
+      for (int aa = 0; aa < R1; ++aa) {
+        double v = 0.0;
+        if (aa < K - k) {
+          v = q[lidx(k + aa, k)];
+          if (aa == 0) v += P[t * D1] + shift;
+        } else if (rem == 0 && dd < D1 && t + dd < T) {
+          v = P[t * D1 + dd];
+        }
+        colw[aa] = v;
+        if (++rem == K) { rem = 0; ++dd; }
+      }
+    }
+    for (int idx = tid; idx < npad; idx += VB_THREADS) rhs[idx] = m0[idx];
+    __syncthreads();
+    stamp[2] = __builtin_amdgcn_s_memtime();
+    if (wave == 0) {
+      const bool good = banded_ldl_forward<NPL, ROW16>(lds, L, n, bw);
+      if (tid == 0) flag[0] = good ? 1.0 : 0.0;
+    } else if (tried == 0) {
+      // the normals of this column, depth-major index (drawn once, whatever the retries)
+      for (int idx = tid - WAVE; idx < n; idx += VB_THREADS - WAVE)
+        zs[idx] = a.z ? a.z[(size_t)jg * n + idx] : philox_normal(a.seed, a.stream, (unsigned long long)jg * n + idx);
+    }
+    __syncthreads();
+    ok = flag[0] != 0.0;
+    if (ok || tried >= a.attempts) break;
+    shift += eps;   // fast_mvn.py:64-68: cumulative eps, eps *= 10
+    eps *= 10.0;
+    ++tried;
+    __syncthreads();
+  }
+  if (tid == 0) a.tries[j] = tried;
+  if (!ok) {
+    if (tid == 0 && atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = jg;
+    return;
+  }
+  stamp[3] = __builtin_amdgcn_s_memtime();
+  // w = D^-1 u + D^-1/2 z
+  for (int idx = tid; idx < n; idx += VB_THREADS) {
+    const double iv = invd[idx];
+    rhs[idx] = fma(rhs[idx], iv, zs[idx] * sqrt(iv));
+  }
+  __syncthreads();
+  stamp[4] = __builtin_amdgcn_s_memtime();
+  if (wave == 0) banded_unit_backward(lds, L, n, bw);
+  __syncthreads();
+  stamp[5] = __builtin_amdgcn_s_memtime();
+  for (int idx = tid; idx < n; idx += VB_THREADS) a.V[(size_t)jg * n + idx] = rhs[idx];
+  if (a.dbg && tid == 0)
+    for (int i = 0; i < 6; ++i) a.dbg[(size_t)j * 6 + i] = stamp[i];
+}
+
+}  // namespace btf

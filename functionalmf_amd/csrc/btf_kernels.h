@@ -121,7 +121,7 @@ __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
 // ============================================================================
 // small helpers: Gram of the fixed factor, per-row outer products
 // ============================================================================
-constexpr int GRAM_BLOCKS = 64;
+constexpr int GRAM_BLOCKS = 16;
 constexpr int GRAM_THREADS = 256;
 
 template <int K>
@@ -153,6 +153,21 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const double* __rest
     for (int w = 0; w < GRAM_THREADS / WAVE; ++w) s += red[w][threadIdx.x];
     gpart[blockIdx.x * KK + threadIdx.x] = s;
   }
+}
+
+// Sum the GRAM_BLOCKS partial Grams into G[KK] (LDS) with one global-load latency:
+// every thread fetches at most a few partial entries, then KK threads add them up in a
+// fixed order.  `stage` is LDS scratch of ngp*KK doubles.  Ends with a barrier.
+__device__ inline void reduce_gram(const double* __restrict__ gpart, int ngp, int KK, double scale,
+                                   double* stage, double* G) {
+  for (int i = threadIdx.x; i < ngp * KK; i += blockDim.x) stage[i] = gpart[i];
+  __syncthreads();
+  if ((int)threadIdx.x < KK) {
+    double s = 0.0;
+    for (int b = 0; b < ngp; ++b) s += stage[b * KK + threadIdx.x];
+    G[threadIdx.x] = s * scale;
+  }
+  __syncthreads();
 }
 
 template <int K>
@@ -198,15 +213,18 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
   const int NV = a.weighted ? K + KK : K;
   __shared__ double G[KK];
   __shared__ double red[WS_SPLIT][NVMAX][WS_ROWS];
+  __shared__ double zsh[K][WS_ROWS];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  if (!a.weighted) {
-    if (threadIdx.x < KK) {
-      double s = 0.0;
-      for (int b = 0; b < a.ngp; ++b) s += a.gpart[b * KK + threadIdx.x];
-      G[threadIdx.x] = s * a.sR;
-    }
-  }
+  if (!a.weighted) reduce_gram(a.gpart, a.ngp, KK, a.sR, &red[0][0][0], G);
   const int il = blockIdx.x * WS_ROWS + lane;
+  // the normals of row i (device RNG): component k by wave k % WS_SPLIT, in parallel with stage 1
+  if (il < a.nl) {
+    const int i = a.row0 + il;
+    const long long zoff = w_z_offset(i, K);
+    const int d = i + 1 < K ? i + 1 : K;
+    for (int k = grp; k < K; k += WS_SPLIT)
+      zsh[k][lane] = k < d ? (a.z ? a.z[zoff + k] : philox_normal(a.seed, a.stream, (unsigned long long)(zoff + k))) : 0.0;
+  }
   // stage 1: wave `grp` sums chunks grp, grp+WS_SPLIT, ... (fixed order => deterministic)
   {
     double part[NVMAX];
@@ -283,7 +301,6 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
   }
   // y = L^-1 m ; x = L^-T (y + z)
   double y[K];
-  const long long zoff = w_z_offset(i, K);
 #pragma unroll
   for (int r = 0; r < K; ++r) {
     double v = m[r];
@@ -292,12 +309,8 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
     y[r] = v / Q[lidx(r, r)];
   }
 #pragma unroll
-  for (int r = 0; r < K; ++r) {
-    if (r < d) {
-      const double zr = a.z ? a.z[zoff + r] : philox_normal(a.seed, a.stream, (unsigned long long)(zoff + r));
-      y[r] += zr;
-    }
-  }
+  for (int r = 0; r < K; ++r)
+    if (r < d) y[r] += zsh[r][lane];
 #pragma unroll
   for (int r = K - 1; r >= 0; --r) {
     double v = y[r];
@@ -334,7 +347,25 @@ struct VBandArgs {
   int* tries;    // [ml]
   double* gband; // HBM scratch for the band when it does not fit LDS, else nullptr
   size_t gband_stride;
+  long long* dbg; // diagnostic phase stamps [ml][6] (nullptr in normal runs)
+  const double* pband; // [ml][T][TF+2] prior band Delta' diag(1/(lam2 Tau2_j)) Delta, entry (t+d,t) (fast kernel)
 };
+
+// Prior band of every local column at once (depends on the hyper-parameters only, so it is
+// recomputed when they change, not per half-sweep): one thread per (column, t, d), Delta
+// rows ascending as in the sparse product of factor.py:404-405.
+__global__ void prior_band_kernel(const double* __restrict__ Tau2, double lam2, int nD,
+                                  const int* __restrict__ st_ptr, const int* __restrict__ st_row,
+                                  const double* __restrict__ st_coef, int TD1, int col0, int ml,
+                                  double* __restrict__ pband) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ml * TD1) return;
+  const int j = idx / TD1, e0 = idx - j * TD1;
+  const double* tau = Tau2 + (size_t)(col0 + j) * nD;
+  double s = 0.0;
+  for (int e = st_ptr[e0]; e < st_ptr[e0 + 1]; ++e) s += st_coef[e] / (lam2 * tau[st_row[e]]);
+  pband[idx] = s;
+}
 
 // generic banded factor + solves on a band at `Bc` (LDS or global), single wave.
 // returns false if a pivot is not positive.
@@ -435,10 +466,8 @@ __global__ __launch_bounds__(WAVE) void v_banded_kernel(VBandArgs a) {
       for (int c = 0; c < a.nch; ++c) s += p[(size_t)c * NV * a.ld];
       Ql[idx] = s * a.s;
     }
-  } else if (lane < KK) {
-    double s = 0.0;
-    for (int b = 0; b < a.ngp; ++b) s += a.gpart[b * KK + lane];
-    Ql[lane] = s * a.sR;
+  } else {
+    reduce_gram(a.gpart, a.ngp, KK, a.sR, Bc, Ql);   // Bc is free scratch until the assembly
   }
   // prior band from the Delta stencil, rows ascending (the order of the sparse product)
   for (int idx = lane; idx < T * D1; idx += WAVE) {

@@ -1,0 +1,29 @@
+"""Diagnostic: where does the fast banded kernel spend its cycles (phase stamps)."""
+import ctypes as C
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+from bench import synth_rows, synth_V
+
+N, M, T, R, K = 512, 256, 64, 4, 5
+Vt = synth_V(1, M, T, K)
+Y, _ = synth_rows(1, range(N), M, T, R, K, Vt)
+np.random.seed(1)
+m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, nu2_init=1.0, rng="device")
+for _ in range(2):
+    m.resample(Y)
+lib = m._ctx.lib
+lib.btf_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+out = np.zeros((M, 6), dtype=np.int64)
+lib.btf_debug_stamps(m._ctx.h, out.ctypes.data_as(C.POINTER(C.c_longlong)))   # arm
+for _ in range(3):
+    m._resample_W(Y); m._resample_V(Y)
+m.sync()
+lib.btf_debug_stamps(m._ctx.h, out.ctypes.data_as(C.POINTER(C.c_longlong)))
+d = np.diff(out, axis=1)
+names = ["setup(m0,gram,P)", "assemble", "factor(+z gen)", "w init", "backward"]
+print("median cycles per phase (shader clock):")
+for i, nme in enumerate(names):
+    print("  %-18s %8.0f   (min %d max %d)" % (nme, np.median(d[:, i]), d[:, i].min(), d[:, i].max()))
+print("  total %.0f cycles; start spread %.0f" % (np.median(out[:, 5] - out[:, 0]), out[:, 0].max() - out[:, 0].min()))
