@@ -175,6 +175,7 @@ def main():
     alg_bytes = 8.0 * cells_local
     achieved = alg_bytes / (acc_us * 1e-6) / 1e9 if acc_us > 0 else 0.0
     kernels_us = {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in kt.items() if v[1] > 0}
+    traffic = pmc_traffic("accum_kernel") if (world == 1 and args.config == "c3") else None
 
     out = {
         "metric": "Gibbs sweeps/sec (full W+V update) at (512,256,64) K=5; % HBM roofline",
@@ -196,7 +197,7 @@ def main():
                    "parallelism": "rows(W)/cols(V) x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "accum_kernel (w_accum + v_accum launches)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(acc_us, 2)},
         "kernels_us": kernels_us,
     }
@@ -209,6 +210,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the streaming kernel from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_summary.json: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+    MI355X_MICROARCH.md applied); None if no profile of this workload is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        vals = [v["hbm_bytes_per_launch_corrected"] for k, v in d.items() if kernel_substr in k]
+        return round(max(vals), 1) if vals else None
+    except Exception:
+        return None
 
 
 class _SlabData:
