@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--strong", action="store_true", help="fixed global tensor instead of weak scaling")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--rpb", type=int, nargs=2, default=[0, 0], help="rows per workgroup (W, V) tuning override")
+    ap.add_argument("--variant", default="complete", choices=["complete", "heldout", "missing5", "binomial"],
+                    help="complete: headline; heldout: Y[:3,:3]=NaN; missing5: 5%% curves + 5%% single replicates NaN; "
+                         "binomial: 4 trials per cell, device Polya-Gamma draw included in the step (config C4)")
     ap.add_argument("--burn", type=int, default=3, help="full Gibbs sweeps before timing (leave the initial state)")
     args = ap.parse_args()
 
@@ -85,7 +88,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering, BinomialBayesianTensorFiltering
     from functionalmf_amd.parallel import ShardPlan
 
     cfg = dict(CONFIGS[args.config])
@@ -111,12 +114,28 @@ def main():
         Y = None
     t_data = time.time() - t0
 
+    if args.variant != "complete":
+        if world > 1:
+            sys.exit("--variant other than complete is single-GPU only in this round")
+        rs = np.random.RandomState(7)
+        if args.variant == "heldout":
+            Y[:3, :3] = np.nan
+        elif args.variant == "missing5":
+            Y[rs.rand(N, M) < 0.05] = np.nan
+            Y[rs.rand(N, M, T, R) < 0.05] = np.nan
+        else:
+            Mu = np.einsum("nk,mtk->nmt", synth_rows(1, range(N), M, T, 1, K, Vt, noise=0.0)[1], Vt)
+            Ntr = np.full((N, M, T), 4.0)
+            Y = (rs.binomial(4, 1 / (1 + np.exp(-Mu))).astype(float), Ntr)
     np.random.seed(1)
     stream = torch.cuda.current_stream().cuda_stream
-    model = GaussianBayesianTensorFiltering(
-        N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, nu2_init=1.0,
-        rng="device", compat="reference" if world == 1 else "exact", device=local_rank, stream=stream,
-        shard=(rank, world) if world > 1 else None, device_seed=1)
+    common = dict(nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, rng="device",
+                  compat="reference" if world == 1 else "exact", device=local_rank, stream=stream,
+                  shard=(rank, world) if world > 1 else None, device_seed=1)
+    if args.variant == "binomial":
+        model = BinomialBayesianTensorFiltering(N, M, T, **common)
+    else:
+        model = GaussianBayesianTensorFiltering(N, M, T, nu2_init=1.0, **common)
     if args.rpb != [0, 0]:
         model._ctx.call("btf_set_tuning", args.rpb[0], args.rpb[1])
     if world == 1:
@@ -129,9 +148,15 @@ def main():
         model.resample(data)
     model.sync()
 
-    def step():
-        model._resample_W(data)
-        model._resample_V(data)
+    if args.variant == "binomial":
+        def step():                       # C4: full Binomial sweep of the device part: PG draw + W + V
+            model._resample_nu2(data)
+            model._resample_W(data)
+            model._resample_V(data)
+    else:
+        def step():
+            model._resample_W(data)
+            model._resample_V(data)
 
     def fence():
         if world > 1:
@@ -172,7 +197,7 @@ def main():
     acc_ms = kt["w_accum"][0] + kt["v_accum"][0]
     acc_n = kt["w_accum"][1] + kt["v_accum"][1]
     acc_us = 1e3 * acc_ms / max(acc_n, 1)
-    alg_bytes = 8.0 * cells_local
+    alg_bytes = (8.0 if args.variant == "complete" else 16.0) * cells_local
     achieved = alg_bytes / (acc_us * 1e-6) / 1e9 if acc_us > 0 else 0.0
     kernels_us = {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in kt.items() if v[1] > 0}
     traffic = pmc_traffic("accum_kernel") if (world == 1 and args.config == "c3") else None
@@ -190,8 +215,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "gaussian_btf %s (%d,%d,%d,%d) nembeds=%d tf_order=2 complete data, W+V update, rng=device%s"
-                               % (args.config, N, M, T, R, K,
+        "config": {"workload": "%s_btf %s (%d,%d,%d,%d) nembeds=%d tf_order=2 %s data, W+V update, rng=device%s"
+                               % ("binomial" if args.variant == "binomial" else "gaussian", args.config, N, M, T, R, K, args.variant,
                                   "; %d-way row/column shards, RCCL all-gather of W and V" % world if world > 1 else ""),
                    "global_sweeps_per_s": round(sweeps_per_s, 2), "units_per_sweep": units,
                    "parallelism": "rows(W)/cols(V) x%d" % world},
@@ -202,7 +227,7 @@ def main():
         "kernels_us": kernels_us,
     }
 
-    if world == 1 and not args.no_cpu:
+    if world == 1 and not args.no_cpu and args.variant != "binomial":
         out["cpu_baseline"] = cpu_baseline(Y, model, cfg)
 
     if rank == 0:

@@ -182,7 +182,8 @@ __device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, 
     // ---- trailing updates  A[nn+a, nn+b] -= A[nn+a,nn] A[nn+b,nn] / D   (b >= 3)
 #pragma unroll
     for (int s = 0; s < NPL; ++s) {
-      ldsw(lds, to[s], fma(-(xa[s] * inv), xb[s], t[s]));
+      const double prod = xa[s] * xb[s];                     // independent of the rcp chain
+      ldsw(lds, to[s], fma(-prod, inv, t[s]));
       to[s] += tinc[s];
     }
     ldsw(lds, co, y);
@@ -210,38 +211,45 @@ __device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, 
 }
 
 // x = L^-T w for the unit-lower band factor; w = rhs in/out.  Wave 0 only; bw >= 3.
-// Lane = column mod (bw+1) keeps the live unknowns in registers; the factor entry and the
-// fresh right-hand side of step r are fetched three steps ahead into registers that are
-// renamed (not copied) by the 3-way unrolled loop; branch-free (see above).
+// Lane = column mod (bw+1) keeps the live unknowns in registers.  The factor entry
+// L[r, p(lane)] and the fresh right-hand side of step r are fetched three steps ahead into
+// registers renamed (not copied) by the 3-way unrolled loop; the per-lane load address
+// just walks down the band column (-8 bytes per step) and jumps to the lane's next column
+// when the look-ahead stream passes a retirement, so a step is ~25 instructions.
 __device__ inline void banded_unit_backward(double* lds, const VbLayout L, int n, int bw) {
   const int lane = threadIdx.x & 63;
   const int R1 = L.R1, Rw = bw + 1;
   const bool act = lane < Rw;
   const int dmy = 8 * (L.dummy + lane);
   // lane owns the column p == lane (mod Rw) of the sliding window (r-Rw, r]
-  int pcur = act ? (n - 1) - ((n - 1 - lane) % Rw + Rw) % Rw : -(1 << 20);
-  double wv = (act && pcur >= 0) ? lds[L.rhs + pcur] : 0.0;
-  int own = __builtin_amdgcn_readfirstlane((n - 1) % Rw);
-  // byte offset of L[r, p] = band[p*R1 + (r-p)] :  8*(band + p*(R1-1) + r)
-  auto lload = [&](int r) -> double {   // L[r, column this lane owns at step r]; branch-free
-    const int pe = (pcur >= r + 1) ? pcur - Rw : pcur;
-    const bool valid = pe >= 0 && r > pe;
-    const double x = ldsr(lds, valid ? 8 * (L.band + pe * (R1 - 1) + r) : dmy);
-    return valid ? x : 0.0;
+  const int p0 = (n - 1) - ((n - 1 - lane) % Rw + Rw) % Rw;   // first (largest) column of this lane
+  double wv = (act && p0 >= 0) ? lds[L.rhs + p0] : 0.0;
+  int own = __builtin_amdgcn_readfirstlane((n - 1) % Rw);       // lane that retires at step r
+  // look-ahead stream (target step r-3 .. ): byte address of L[rt, p] = 8*(band + p*(R1-1) + rt)
+  const int jump = 8 * Rw * (R1 - 1);
+  int la = act ? 8 * (L.band + p0 * (R1 - 1) + (n - 1)) : dmy;
+  const int lstep = act ? 8 : 0, ljump = act ? jump : 0;
+  int lown = own;                                               // lane retiring at the look-ahead target
+  int wa = 8 * (L.rhs + n - 1 - Rw);                            // &w[rt - Rw]  (front-padded with zeros)
+  auto fetch = [&](double& Lc, double& Wc) {                    // issue the loads for the next target
+    Lc = ldsr(lds, la);      // at rt == p (the retirement itself) this is the diagonal: unused
+    Wc = ldsr(lds, wa);
+    la -= lstep + (lane == lown ? ljump : 0);
+    wa -= 8;
+    lown = lown == 0 ? Rw - 1 : lown - 1;
   };
-  auto wload = [&](int r) -> double { return lds[L.rhs + r - Rw]; };   // front-padded with zeros
   auto step = [&](int r, double& Lc, double& Wc) {
     const double xr = bcast_lane(wv, own);
     const bool retire = lane == own;
     wv = retire ? Wc : fma(-Lc, xr, wv);
     ldsw(lds, retire ? 8 * (L.rhs + r) : dmy, xr);
-    pcur -= retire ? Rw : 0;
     own = own == 0 ? Rw - 1 : own - 1;
-    Lc = lload(r - 3);
-    Wc = wload(r - 3);
+    fetch(Lc, Wc);
   };
-  double L0 = lload(n - 1), L1 = lload(n - 2), L2 = lload(n - 3);
-  double W0 = wload(n - 1), W1 = wload(n - 2), W2 = wload(n - 3);
+  double L0, L1, L2, W0, W1, W2;
+  fetch(L0, W0);
+  fetch(L1, W1);
+  fetch(L2, W2);
   int r = n - 1;
   for (; r >= 2; r -= 3) {
     step(r, L0, W0);

@@ -323,3 +323,43 @@ def test_binomial_chain_recovers_probabilities():
     Phat = (1 / (1 + np.exp(-Mu))).mean(0)
     assert np.corrcoef(Phat.reshape(-1), P.reshape(-1))[0, 1] > 0.97
     assert np.abs(Phat - P).mean() < 0.06
+
+
+def test_device_buffers_are_visible_to_torch_distributed(tmp_path):
+    """The RCCL exchange wraps the ctx's W / V device buffers as torch tensors and gathers in
+    place.  On a 1-GPU box: 1-rank nccl group, check aliasing both ways and the collective."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        N, M, T, K = 12, 5, 8, 3
+        np.random.seed(0)
+        model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=1, sigma2_init=1.0, lam2_init=0.1,
+                                                nu2_init=1.0, shard=(0, 1),
+                                                stream=torch.cuda.current_stream().cuda_stream)
+        W0 = model.W.copy()
+        model._push_state()
+        Wt, Vt = model._exchange._views()
+        assert Wt.is_cuda and Wt.dtype == torch.float64
+        assert np.array_equal(Wt[:N * K].cpu().numpy().reshape(N, K), W0)          # same memory, read
+        Wt[:N * K] += 1.0                                                            # ... and write
+        torch.cuda.synchronize()
+        model._W_dev_new = True
+        assert np.array_equal(model.W, W0 + 1.0)
+        n = model._plan.row_chunk * K
+        dist.all_gather_into_tensor(Wt[:n], Wt[0:n])                                 # in-place form used by after_W
+        torch.cuda.synchronize()
+        model._W_dev_new = True
+        assert np.array_equal(model.W, W0 + 1.0)
+        s, c = model._exchange.sum_scalars(1.5, 2.0)
+        assert (s, c) == (1.5, 2.0)
+    finally:
+        if created:
+            dist.destroy_process_group()
