@@ -54,6 +54,9 @@ struct btf_ctx {
   bool force_generic_banded = false;
   long long* dbg = nullptr;
   double* pband = nullptr; bool pband_dirty = true;
+  double* gpart_w = nullptr; int ngp_w = 0;   // W'W partials written by w_solve (valid until W changes otherwise)
+  double* gpart_v = nullptr; int ngp_v = 0;   // V'V partials written by the fast banded sampler
+  bool fuse_gram = true;
   unsigned long long sweep_w = 0, sweep_v = 0;
   bool profiling = false;
   std::vector<EvPair> ev_pool;
@@ -445,7 +448,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->WW, c->VV, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -551,6 +554,7 @@ int btf_set_W(btf_ctx* c, const double* W) {
   HIPCHK(c, hipMemcpyAsync(c->W, W, (size_t)c->N * c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_W = true;
+  c->ngp_w = 0;
   return BTF_OK;
 }
 int btf_get_W(btf_ctx* c, double* W) {
@@ -565,6 +569,7 @@ int btf_set_V(btf_ctx* c, const double* V) {
   HIPCHK(c, hipMemcpyAsync(c->V, V, (size_t)c->M * c->T * c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_V = true;
+  c->ngp_v = 0;
   return BTF_OK;
 }
 int btf_get_V(btf_ctx* c, double* V) {
@@ -642,11 +647,19 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     dz = c->zbuf;
   }
   if (c->nl > 0) {
+    const bool whole = c->nl == c->N && c->ml == c->M;      // fused Grams cover all rows/columns only when unsharded
+    const bool use_gv = !wt && whole && c->fuse_gram && c->ngp_v > 0;
     if (wt) { K_SWITCH(K, launch_products<KT>(c, c->V, MT, c->VV)); }
-    else { K_SWITCH(K, launch_gram<KT>(c, c->V, MT)); }
+    else if (!use_gv) { K_SWITCH(K, launch_gram<KT>(c, c->V, MT)); }
     K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->V, c->VV, c->srcmap_w, MT, c->ldw, rpb, nch));
     WSolveArgs a{};
-    a.part = c->part; a.nch = nch; a.ld = c->ldw; a.gpart = c->gpart; a.ngp = GRAM_BLOCKS; a.weighted = wt ? 1 : 0;
+    a.part = c->part; a.nch = nch; a.ld = c->ldw; a.weighted = wt ? 1 : 0;
+    a.gpart = use_gv ? c->gpart_v : c->gpart; a.ngp = use_gv ? c->ngp_v : GRAM_BLOCKS;
+    const int wblocks = (c->nl + WS_ROWS - 1) / WS_ROWS;
+    if (whole && c->fuse_gram) {
+      if (!c->gpart_w) { if ((rc = dev_alloc(c, &c->gpart_w, (size_t)((c->N + WS_ROWS - 1) / WS_ROWS) * KK))) return rc; }
+      a.gout = c->gpart_w;
+    }
     a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
     a.sR = a.s * c->R;
     a.inv_sigma2 = 1.0 / c->sigma2;
@@ -654,6 +667,8 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_w + 0x10000ULL;
     a.status = c->status;
     K_SWITCH(K, launch_wsolve<KT>(c, a));
+    c->ngp_w = a.gout ? wblocks : 0;
+    c->ngp_v = 0;   // V'V partials are consumed once; any other W/V change must recompute
   }
   c->sweep_w++;
   HIPCHK(c, hipGetLastError());
@@ -683,8 +698,10 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     dz = c->zbuf;
   }
   if (c->ml > 0) {
+    const bool whole = c->nl == c->N && c->ml == c->M;
+    const bool use_gw = !wt && whole && c->fuse_gram && c->ngp_w > 0;
     if (wt) { K_SWITCH(K, launch_products<KT>(c, c->W, c->N, c->WW)); }
-    else { K_SWITCH(K, launch_gram<KT>(c, c->W, c->N)); }
+    else if (!use_gw) { K_SWITCH(K, launch_gram<KT>(c, c->W, c->N)); }
     K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->W, c->WW, c->srcmap_v, c->N, c->ldv, rpb, nch));
     const int bw = (c->TF + 1) * K, R1 = bw + 1, D1 = c->TF + 2;
     size_t lds_fixed = (size_t)(3 * n + T * D1 + (wt ? T * KK : KK) + (bw * (bw + 1) / 2 + 3) / 4) * sizeof(double);
@@ -700,7 +717,8 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       a.gband = c->gband; a.gband_stride = c->gband_stride;
       lds_bytes = lds_fixed;
     }
-    a.part = c->part; a.nch = nch; a.ld = c->ldv; a.gpart = c->gpart; a.ngp = GRAM_BLOCKS; a.weighted = wt ? 1 : 0;
+    a.part = c->part; a.nch = nch; a.ld = c->ldv; a.weighted = wt ? 1 : 0;
+    a.gpart = use_gw ? c->gpart_w : c->gpart; a.ngp = use_gw ? c->ngp_w : GRAM_BLOCKS;
     a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
     a.sR = a.s * c->R;
     a.Tau2 = c->Tau2; a.lam2 = c->lam2; a.nD = c->nD;
@@ -723,6 +741,15 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       }
       a.pband = c->pband;
     }
+    // V'V partials for the next W half-sweep (one KK block per column; bounded by the consumer's LDS stage)
+    const bool emit_gv = fast && whole && c->fuse_gram && !wt &&
+                         (size_t)c->ml * KK + 16 * KK <= (size_t)ws_split(K) * (K + KK) * WS_ROWS;   // w_solve's LDS stage
+    if (emit_gv) {
+      if (!c->gpart_v) { if ((rc = dev_alloc(c, &c->gpart_v, (size_t)c->M * KK))) return rc; }
+      a.gout = c->gpart_v;
+    }
+    c->ngp_v = emit_gv ? c->ml : 0;
+    c->ngp_w = 0;
     if (fast) e = dispatch_vbanded_fast(c, a, bw, fast_bytes, &handled);
     HIPCHK(c, e);
     if (!handled) { K_SWITCH(K, e = launch_vbanded<KT>(c, a, lds_bytes)); }

@@ -380,6 +380,24 @@ __global__ __launch_bounds__(VB_THREADS) void v_banded_fast_kernel(VBandArgs a, 
   __syncthreads();
   stamp[5] = __builtin_amdgcn_s_memtime();
   for (int idx = tid; idx < n; idx += VB_THREADS) a.V[(size_t)jg * n + idx] = rhs[idx];
+  if (a.gout) {   // this column's share of V'V (rows (j,t), t = 0..T-1): two fixed-order levels
+    __syncthreads();
+    const int ng = VB_THREADS / KK, g = tid / KK, q = tid - g * KK;
+    int p = 0;
+    while ((p + 1) * (p + 2) / 2 <= q) ++p;
+    const int pq = q - p * (p + 1) / 2;
+    if (g < ng) {
+      double s = 0.0;
+      for (int t = g; t < T; t += ng) s = fma(rhs[t * K + p], rhs[t * K + pq], s);
+      Bc[g * KK + q] = s;                  // the band is dead by now: scratch
+    }
+    __syncthreads();
+    if (tid < KK) {
+      double s = 0.0;
+      for (int b = 0; b < ng; ++b) s += Bc[b * KK + tid];
+      a.gout[(size_t)j * KK + tid] = s;
+    }
+  }
   if (a.dbg && tid == 0)
     for (int i = 0; i < 6; ++i) a.dbg[(size_t)j * 6 + i] = stamp[i];
 }

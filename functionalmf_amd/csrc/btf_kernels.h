@@ -160,11 +160,24 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const double* __rest
 // fixed order.  `stage` is LDS scratch of ngp*KK doubles.  Ends with a barrier.
 __device__ inline void reduce_gram(const double* __restrict__ gpart, int ngp, int KK, double scale,
                                    double* stage, double* G) {
-  for (int i = threadIdx.x; i < ngp * KK; i += blockDim.x) stage[i] = gpart[i];
+  const int nthr = blockDim.x;
+  for (int i = threadIdx.x; i < ngp * KK; i += nthr) stage[i] = gpart[i];
+  __syncthreads();
+  // two levels, fixed order: `lanes` threads per Gram entry each add a strided share, then one adds those
+  int lanes = nthr / KK;
+  if (lanes > 16) lanes = 16;
+  if (lanes < 1) lanes = 1;
+  double* lvl = stage + ngp * KK;          // lanes*KK doubles of scratch after the staged partials
+  const int q = threadIdx.x % KK, l = threadIdx.x / KK;
+  if (l < lanes) {
+    double s = 0.0;
+    for (int b = l; b < ngp; b += lanes) s += stage[b * KK + q];
+    lvl[l * KK + q] = s;
+  }
   __syncthreads();
   if ((int)threadIdx.x < KK) {
     double s = 0.0;
-    for (int b = 0; b < ngp; ++b) s += stage[b * KK + threadIdx.x];
+    for (int b = 0; b < lanes; ++b) s += lvl[b * KK + threadIdx.x];
     G[threadIdx.x] = s * scale;
   }
   __syncthreads();
@@ -199,6 +212,7 @@ struct WSolveArgs {
   double* W; int row0; int nl;
   const double* z; unsigned long long seed; unsigned long long stream;
   int* status;     // [0] = failure flag, [1] = first failing row
+  double* gout;    // [gridDim.x][KK] Gram partial of the rows this workgroup wrote (W'W for the V half-sweep)
 };
 
 constexpr int WS_ROWS = 64;   // rows per workgroup (one per lane)
@@ -242,7 +256,10 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
     for (int v = 0; v < NVMAX; ++v) red[grp][v][lane] = part[v];
   }
   __syncthreads();
-  if (grp != 0 || il >= a.nl) return;
+  if (grp != 0) return;                      // wave 0 finishes: one lane per row
+  const bool live = il < a.nl;
+  const int i = a.row0 + (live ? il : 0);
+  const int d = i + 1 < K ? i + 1 : K;
   double m[K], Q[KK];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -262,9 +279,6 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
       Q[q] = G[q];
     }
   }
-  const int i = a.row0 + il;
-  const int d = i + 1 < K ? i + 1 : K;
-
 #pragma unroll
   for (int k = 0; k < K; ++k) Q[lidx(k, k)] += a.inv_sigma2;
   // rows/cols >= d are frozen (W is lower triangular in its first K rows): identity there
@@ -295,10 +309,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
       Q[lidx(r, c)] = v * inv;
     }
   }
-  if (!ok) {
-    if (atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = i;
-    return;
-  }
+  if (live && !ok && atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = i;
   // y = L^-1 m ; x = L^-T (y + z)
   double y[K];
 #pragma unroll
@@ -318,9 +329,29 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
     for (int c = r + 1; c < K; ++c) v = fma(-Q[lidx(c, r)], y[c], v);
     y[r] = v / Q[lidx(r, r)];
   }
+  // the row as it now stands (entries >= d keep their stored value), written back and
+  // folded into this workgroup's share of W'W for the next V half-sweep
+  double wrow[K];
 #pragma unroll
-  for (int r = 0; r < K; ++r)
-    if (r < d) a.W[(size_t)i * K + r] = y[r];
+  for (int r = 0; r < K; ++r) {
+    const bool fresh = live && ok && r < d;
+    if (fresh) a.W[(size_t)i * K + r] = y[r];
+    wrow[r] = fresh ? y[r] : 0.0;
+  }
+  if (live && (d < K || !ok)) {   // only the first K rows keep stored entries (their frozen upper triangle)
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+      if (!(ok && r < d)) wrow[r] = a.W[(size_t)i * K + r];
+  }
+  if (a.gout) {
+#pragma unroll
+    for (int p = 0; p < K; ++p)
+#pragma unroll
+      for (int q = 0; q <= p; ++q) {
+        const double s = wave_sum(wrow[p] * wrow[q]);
+        if (lane == 0) a.gout[(size_t)blockIdx.x * KK + lidx(p, q)] = s;
+      }
+  }
 }
 
 // ============================================================================
@@ -348,6 +379,7 @@ struct VBandArgs {
   double* gband; // HBM scratch for the band when it does not fit LDS, else nullptr
   size_t gband_stride;
   long long* dbg; // diagnostic phase stamps [ml][6] (nullptr in normal runs)
+  double* gout;   // [ml][KK] V_j'V_j of the freshly drawn column (V'V partials for the next W half-sweep) or nullptr
   const double* pband; // [ml][T][TF+2] prior band Delta' diag(1/(lam2 Tau2_j)) Delta, entry (t+d,t) (fast kernel)
 };
 

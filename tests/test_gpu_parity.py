@@ -363,3 +363,26 @@ def test_device_buffers_are_visible_to_torch_distributed(tmp_path):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_fused_gram_path_complete_data(golden):
+    """Complete data: the K x K Gram of the fixed factor is produced by the preceding solve
+    kernel (W'W by w_solve, V'V by the banded sampler) instead of a separate launch.  Run
+    W -> V -> W back to back and check each against the reference / oracle."""
+    from oracle import btf_oracle as orc
+    g = golden("g2_c2_complete.npz")
+    model, st = gaussian_model(g, "s0_")
+    np.random.seed(300)
+    model._resample_W(g["Y"])                 # V'V from the stand-alone kernel (first call)
+    np.random.seed(301)
+    model._resample_V(g["Y"])                 # W'W fused into w_solve
+    assert relerr(model._W if not model._W_dev_new else model.W, g["W_after"]) < W_TOL
+    assert relerr(model.V, g["V_after_depth"]) < V_TOL
+    ost = dict(st, W=g["W_after"].copy(), V=model.V.copy())
+    model._V_host_new = False                 # keep the device copy (and its fused V'V) authoritative
+    np.random.seed(302)
+    z = np.random.normal(size=g["z_W"].size)
+    np.random.seed(302)
+    model._resample_W(g["Y"])                 # V'V fused into the banded sampler
+    orc.w_step(ost, g["Y"], z=z)
+    assert relerr(model.W, ost["W"]) < W_TOL
