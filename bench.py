@@ -128,7 +128,7 @@ def main():
             Ntr = np.full((N, M, T), 4.0)
             Y = (rs.binomial(4, 1 / (1 + np.exp(-Mu))).astype(float), Ntr)
     np.random.seed(1)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = torch.cuda.current_stream().cuda_stream or None     # null stream -> the ctx's own / a dedicated torch stream
     common = dict(nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, rng="device",
                   compat="reference" if world == 1 else "exact", device=local_rank, stream=stream,
                   shard=(rank, world) if world > 1 else None, device_seed=1)

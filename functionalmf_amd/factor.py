@@ -86,6 +86,14 @@ class BayesianTensorFiltering(_BayesianModel):
         self._device_seed = int(device_seed)
         self._draws = 0
 
+        # Sharded runs exchange W / V through torch.distributed: kernels and collectives must
+        # share one (non-null) stream so that the all-gather is ordered after the draw and the
+        # next half-sweep after the all-gather.
+        if shard is not None and shard[1] > 1 and not stream:
+            import torch
+            self._torch_stream = torch.cuda.Stream(device=device)
+            torch.cuda.set_stream(self._torch_stream)
+            stream = self._torch_stream.cuda_stream
         # device context first: without the HIP library / a GPU nothing below can run
         self._ctx = _native.Context(nrows, ncols, ndepth, nembeds, tf_order, device=device, stream=stream)
         self._plan = ShardPlan(nrows, ncols, *(shard if shard is not None else (0, 1)))

@@ -1,0 +1,111 @@
+"""Parity against the oracle over the supported shape space: every nembeds 1..10 (register-
+chain kernel with DPP shifts for half-bandwidth <= 15, with shuffles above, generic kernel
+for tiny bandwidths), tf_order 0..3, 3-D data, fewer rows than embeddings, missing data,
+odd sizes that exercise the padding.  Needs an MI355X."""
+import numpy as np
+import pytest
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(N, M, T, R, K, tf, missing, seed):
+    rs = np.random.RandomState(seed)
+    Wt = rs.normal(size=(N, K))
+    Vt = 0.3 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    Y = np.einsum("nk,mtk->nmt", Wt, Vt)[..., None] + rs.normal(0, 0.7, size=(N, M, T, R))
+    if missing:
+        Y[rs.rand(N, M, T, R) < 0.2] = np.nan
+        Y[0, min(1, M - 1)] = np.nan
+    if R == 1 and seed % 2:
+        Y = Y[..., 0]                       # 3-D input: one replicate implied (factor.py:323-324)
+    nD = {0: T, 1: 2 * T, 2: 3 * T - 1, 3: 4 * T - 1}[tf]
+    st = dict(W=rs.normal(size=(N, K)), V=0.2 * rs.normal(size=(M, T, K)),
+              Tau2=np.exp(rs.normal(size=(M, nD))), lam2=0.3, sigma2=0.8, nu2=0.6)
+    if N > 1:
+        st["W"][np.triu_indices(N, 1, K)] = 0
+    return Y, st
+
+
+CASES = [
+    # N,  M,  T, R, K, tf, missing
+    (9, 4, 7, 2, 1, 2, False),
+    (9, 4, 7, 2, 1, 0, True),       # half-bandwidth 1: generic kernel
+    (11, 5, 9, 1, 2, 0, False),     # half-bandwidth 2: generic kernel
+    (11, 5, 9, 1, 2, 2, True),
+    (13, 3, 8, 3, 3, 1, False),
+    (70, 3, 6, 2, 4, 2, True),      # > 64 rows: two w_solve workgroups
+    (16, 6, 10, 2, 5, 2, False),    # bw 15: DPP path, headline shape
+    (16, 6, 10, 2, 5, 3, False),    # bw 20: shuffle path
+    (12, 4, 8, 2, 6, 2, True),      # bw 18
+    (12, 3, 9, 1, 7, 1, False),
+    (20, 3, 8, 2, 8, 2, False),     # bw 24 (config C5's embedding size)
+    (14, 2, 7, 2, 9, 2, True),      # bw 27
+    (14, 2, 6, 2, 10, 2, False),    # bw 30
+    (3, 4, 8, 2, 5, 2, False),      # fewer rows than embeddings
+    (1, 3, 6, 2, 2, 1, False),      # a single row
+    (130, 67, 5, 1, 3, 2, True),    # odd sizes across the 128-wide tiles
+]
+
+
+@pytest.mark.parametrize("N,M,T,R,K,tf,missing", CASES)
+def test_half_sweeps_match_oracle(N, M, T, R, K, tf, missing):
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    from oracle import btf_oracle as orc
+    Y, st = make_case(N, M, T, R, K, tf, missing, seed=N * 131 + K * 7 + tf)
+    model = GaussianBayesianTensorFiltering(
+        N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
+        W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"])
+    assert model.Delta.shape[0] == st["Tau2"].shape[1]
+    Delta = orc.trend_penalty(T, tf)
+    nzw = sum(min(i + 1, K) for i in range(N))
+    np.random.seed(5)
+    zw = np.random.normal(size=nzw)
+    zv = np.random.normal(size=(M, K * T))
+    ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    np.random.seed(5)
+    model._resample_W(Y)
+    model._resample_V(Y)
+    orc.w_step(ost, Y, z=zw)
+    assert relerr(model.W, ost["W"]) < 1e-10
+    orc.v_step(ost, Y, Delta, z=zv)
+    assert relerr(model.V, ost["V"]) < 1e-8
+    # nu2 statistics on the new state
+    np.random.seed(6)
+    model._resample_nu2(Y)
+    sse, n = orc.sse_and_count(ost, Y)
+    np.random.seed(6)
+    ref = 1.0 / np.random.gamma(0.1 + n / 2.0, 1.0 / (0.1 + sse / 2.0))
+    assert abs(model.nu2 - ref) / ref < 1e-10
+
+
+def test_all_missing_column_and_row_are_prior_draws():
+    """A column without any observation is a pure prior draw; a row without any is N(0, sigma2)."""
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    from oracle import btf_oracle as orc
+    Y, st = make_case(10, 5, 8, 2, 3, 2, False, seed=3)
+    Y[:, 2] = np.nan
+    Y[7] = np.nan
+    model = GaussianBayesianTensorFiltering(10, 5, 8, nembeds=3, tf_order=2, sigma2_init=0.8, lam2_init=0.3,
+                                            nu2_init=0.6, W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"])
+    np.random.seed(1)
+    zw = np.random.normal(size=sum(min(i + 1, 3) for i in range(10)))
+    zv = np.random.normal(size=(5, 24))
+    np.random.seed(1)
+    model._resample_W(Y)
+    model._resample_V(Y)
+    ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    orc.w_step(ost, Y, z=zw)
+    orc.v_step(ost, Y, orc.trend_penalty(8, 2), z=zv)
+    assert relerr(model.W, ost["W"]) < 1e-10 and relerr(model.V, ost["V"]) < 1e-8
+    off = sum(min(i + 1, 3) for i in range(7))
+    assert np.allclose(model.W[7], np.sqrt(0.8) * zw[off:off + 3], rtol=1e-12)
+
+
+def test_rejects_unsupported_shapes():
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    from functionalmf_amd._native import BTFError
+    with pytest.raises(BTFError):
+        GaussianBayesianTensorFiltering(8, 4, 6, nembeds=11, tf_order=2)
+    with pytest.raises(BTFError):
+        GaussianBayesianTensorFiltering(8, 4, 6, nembeds=3, tf_order=4)
