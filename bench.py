@@ -85,8 +85,11 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    exercise = os.environ.get("BTF_EXERCISE_EXCHANGE", "0") == "1"
+    if world > 1 or exercise:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from functionalmf_amd.factor import GaussianBayesianTensorFiltering, BinomialBayesianTensorFiltering
     from functionalmf_amd.parallel import ShardPlan
@@ -159,7 +162,7 @@ def main():
             model._resample_V(data)
 
     def fence():
-        if world > 1:
+        if world > 1 or exercise:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -232,7 +235,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or exercise:
         dist.barrier()
         dist.destroy_process_group()
 

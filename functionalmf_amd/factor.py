@@ -89,7 +89,9 @@ class BayesianTensorFiltering(_BayesianModel):
         # Sharded runs exchange W / V through torch.distributed: kernels and collectives must
         # share one (non-null) stream so that the all-gather is ordered after the draw and the
         # next half-sweep after the all-gather.
-        if shard is not None and shard[1] > 1 and not stream:
+        import os
+        sharded = (shard is not None and shard[1] > 1) or os.environ.get("BTF_EXERCISE_EXCHANGE", "0") == "1"
+        if sharded and not stream:
             import torch
             self._torch_stream = torch.cuda.Stream(device=device)
             torch.cuda.set_stream(self._torch_stream)

@@ -64,7 +64,11 @@ class Exchange:
     def __init__(self, plan, ctx=None, group=None):
         self.plan, self.ctx, self.group = plan, ctx, group
         self._Wt = self._Vt = None
-        if plan.world > 1:
+        # BTF_EXERCISE_EXCHANGE=1: issue the collectives even in a 1-rank group (lets a 1-GPU box
+        # run the exact RCCL call sequence of the sharded path)
+        import os
+        self.active = plan.world > 1 or os.environ.get("BTF_EXERCISE_EXCHANGE", "0") == "1"
+        if self.active:
             import torch.distributed as dist
             if not dist.is_initialized():
                 raise RuntimeError("shard=(rank, world) needs an initialised torch.distributed process group")
@@ -84,7 +88,7 @@ class Exchange:
         return self._Wt, self._Vt
 
     def after_W(self):
-        if self.plan.world == 1:
+        if not self.active:
             return
         import torch.distributed as dist
         Wt, _ = self._views()
@@ -93,7 +97,7 @@ class Exchange:
         dist.all_gather_into_tensor(Wt, Wt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group)
 
     def after_V(self):
-        if self.plan.world == 1:
+        if not self.active:
             return
         import torch.distributed as dist
         _, Vt = self._views()
@@ -102,7 +106,7 @@ class Exchange:
         dist.all_gather_into_tensor(Vt, Vt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group)
 
     def sum_scalars(self, *vals):
-        if self.plan.world == 1:
+        if not self.active:
             return vals
         import torch
         import torch.distributed as dist
