@@ -4,6 +4,7 @@
 #include "../../include/btf.h"
 #include "btf_kernels.h"
 #include "btf_banded_fast.h"
+#include "btf_banded_pipe.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -52,6 +53,7 @@ struct btf_ctx {
   double ssw = 0.0, nobs = 0.0;
   int rpb_w = 0, rpb_v = 0;
   bool force_generic_banded = false;
+  int banded_variant = 1;   // 1: single-wave LDS kernel (default), 0: wave-specialised pipeline (experimental, slower)
   long long* dbg = nullptr;
   double* pband = nullptr; bool pband_dirty = true;
   double* gpart_w = nullptr; int ngp_w = 0;   // W'W partials written by w_solve (valid until W changes otherwise)
@@ -268,6 +270,42 @@ hipError_t dispatch_vbanded_fast(btf_ctx* c, const VBandArgs& a, int bw, size_t 
       case 6: return launch_vbanded_fast<6, false>(c, a, lds_bytes);
       case 7: return launch_vbanded_fast<7, false>(c, a, lds_bytes);
       case 8: return launch_vbanded_fast<8, false>(c, a, lds_bytes);
+      default: break;
+    }
+  }
+  *handled = false;
+  return hipSuccess;
+}
+template <int NPLH, bool ROW16>
+hipError_t launch_vbanded_pipe(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)v_banded_pipe_kernel<NPLH, ROW16>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  Prof p(c, BTF_K_V_BANDED);
+  p.launch(v_banded_pipe_kernel<NPLH, ROW16>, dim3(a.ml), dim3(VP_THREADS), lds_bytes, a, c->K);
+  return hipSuccess;
+}
+// pairs per helper lane: the larger parity class of the diagonal-offset split
+int pipe_nplh(int bw) {
+  int cnt[2] = {0, 0};
+  for (int d = 0; d <= bw - 3; ++d) cnt[d & 1] += bw - d - 2;
+  return std::max(1, (std::max(cnt[0], cnt[1]) + WAVE - 1) / WAVE);
+}
+hipError_t dispatch_vbanded_pipe(btf_ctx* c, const VBandArgs& a, int bw, size_t lds_bytes, bool* handled) {
+  const int nplh = pipe_nplh(bw);
+  *handled = true;
+  if (bw <= 15) {
+    if (nplh == 1) return launch_vbanded_pipe<1, true>(c, a, lds_bytes);
+  } else {
+    switch (nplh) {
+      case 1: return launch_vbanded_pipe<1, false>(c, a, lds_bytes);
+      case 2: return launch_vbanded_pipe<2, false>(c, a, lds_bytes);
+      case 3: return launch_vbanded_pipe<3, false>(c, a, lds_bytes);
+      case 4: return launch_vbanded_pipe<4, false>(c, a, lds_bytes);
       default: break;
     }
   }
@@ -750,7 +788,10 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     }
     c->ngp_v = emit_gv ? c->ml : 0;
     c->ngp_w = 0;
-    if (fast) e = dispatch_vbanded_fast(c, a, bw, fast_bytes, &handled);
+    const size_t pipe_bytes = vp_lds_bytes(T, K, c->TF, wt ? 1 : 0);
+    if (fast && c->banded_variant == 0 && pipe_bytes <= 158 * 1024) e = dispatch_vbanded_pipe(c, a, bw, pipe_bytes, &handled);
+    HIPCHK(c, e);
+    if (fast && !handled) e = dispatch_vbanded_fast(c, a, bw, fast_bytes, &handled);
     HIPCHK(c, e);
     if (!handled) { K_SWITCH(K, e = launch_vbanded<KT>(c, a, lds_bytes)); }
     HIPCHK(c, e);
@@ -942,8 +983,10 @@ extern "C" int btf_debug_stamps(btf_ctx* c, long long* out) {
 
 int btf_set_tuning(btf_ctx* c, int rows_per_block_w, int rows_per_block_v) {
   if (!c) return BTF_EINVAL;
-  // negative rows_per_block_v selects the generic (any-size) banded kernel: test hook
-  c->force_generic_banded = rows_per_block_v < 0;
+  // test hooks: rows_per_block_v == -1 selects the generic (any-size) banded kernel,
+  // -3 the wave-specialised pipeline, anything else the default
+  c->force_generic_banded = rows_per_block_v == -1;
+  c->banded_variant = rows_per_block_v == -3 ? 0 : 1;
   c->rpb_w = rows_per_block_w; c->rpb_v = rows_per_block_v < 0 ? 0 : rows_per_block_v;
   return BTF_OK;
 }

@@ -11,6 +11,8 @@ Vt = synth_V(1, M, T, K)
 Y, _ = synth_rows(1, range(N), M, T, R, K, Vt)
 np.random.seed(1)
 m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, nu2_init=1.0, rng="device")
+import os
+m._ctx.call("btf_set_tuning", 0, int(os.environ.get("BTF_VARIANT", "0")))
 for _ in range(2):
     m.resample(Y)
 lib = m._ctx.lib
@@ -22,6 +24,8 @@ for _ in range(3):
 m.sync()
 lib.btf_debug_stamps(m._ctx.h, out.ctypes.data_as(C.POINTER(C.c_longlong)))
 d = np.diff(out, axis=1)
+import os
+print("variant", os.environ.get("BTF_VARIANT", "0"))
 names = ["setup(m0,gram,P)", "assemble", "factor(+z gen)", "w init", "backward"]
 print("median cycles per phase (shader clock):")
 for i, nme in enumerate(names):

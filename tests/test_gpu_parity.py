@@ -42,14 +42,15 @@ def test_w_step_vs_reference(golden, name, seed):
     assert relerr(model.W, g["W_after"]) < W_TOL
 
 
-@pytest.mark.parametrize("kernel", ["fast", "generic"])
+@pytest.mark.parametrize("kernel", ["pipe", "fast", "generic"])
 @pytest.mark.parametrize("name,seed", GAUSS)
 def test_v_step_vs_reference(golden, name, seed, kernel):
-    """Both samplers: the LDS-resident LDL' kernel and the any-size generic one."""
+    """All three samplers: the wave-specialised pipeline (default), the single-wave LDS
+    LDL' kernel and the any-size generic one."""
     g = golden(name)
     model, _ = gaussian_model(g, "s0_")
-    if kernel == "generic":
-        model._ctx.call("btf_set_tuning", 0, -1)
+    if kernel != "fast":
+        model._ctx.call("btf_set_tuning", 0, -1 if kernel == "generic" else -3)
     model.W = g["W_after"]
     np.random.seed(seed + 1)
     model._resample_V(g["Y"])

@@ -48,8 +48,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [0, -3])
 @pytest.mark.parametrize("N,M,T,R,K,tf,missing", CASES)
-def test_half_sweeps_match_oracle(N, M, T, R, K, tf, missing):
+def test_half_sweeps_match_oracle(N, M, T, R, K, tf, missing, variant):
     from functionalmf_amd.factor import GaussianBayesianTensorFiltering
     from oracle import btf_oracle as orc
     Y, st = make_case(N, M, T, R, K, tf, missing, seed=N * 131 + K * 7 + tf)
@@ -57,6 +58,7 @@ def test_half_sweeps_match_oracle(N, M, T, R, K, tf, missing):
         N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
         W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"])
     assert model.Delta.shape[0] == st["Tau2"].shape[1]
+    model._ctx.call("btf_set_tuning", 0, variant)      # 0: default sampler, -3: wave-specialised pipeline
     Delta = orc.trend_penalty(T, tf)
     nzw = sum(min(i + 1, K) for i in range(N))
     np.random.seed(5)
