@@ -5,6 +5,7 @@
 #include "btf_kernels.h"
 #include "btf_banded_fast.h"
 #include "btf_banded_pipe.h"
+#include "btf_banded_twist.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -53,7 +54,7 @@ struct btf_ctx {
   double ssw = 0.0, nobs = 0.0;
   int rpb_w = 0, rpb_v = 0;
   bool force_generic_banded = false;
-  int banded_variant = 1;   // 1: single-wave LDS kernel (default), 0: wave-specialised pipeline (experimental, slower)
+  int banded_variant = 2;   // 2: twisted two-chain kernel (default), 1: single chain, 0: wave-specialised pipeline (experimental)
   long long* dbg = nullptr;
   double* pband = nullptr; bool pband_dirty = true;
   double* gpart_w = nullptr; int ngp_w = 0;   // W'W partials written by w_solve (valid until W changes otherwise)
@@ -289,7 +290,55 @@ hipError_t launch_vbanded_pipe(btf_ctx* c, const VBandArgs& a, size_t lds_bytes)
   p.launch(v_banded_pipe_kernel<NPLH, ROW16>, dim3(a.ml), dim3(VP_THREADS), lds_bytes, a, c->K);
   return hipSuccess;
 }
+bool pipe_nplh_ok(int bw);
+template <int NPL, bool ROW16>
+hipError_t launch_vbanded_twist(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)v_banded_twist_kernel<NPL, ROW16>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  Prof p(c, BTF_K_V_BANDED);
+  p.launch(v_banded_twist_kernel<NPL, ROW16>, dim3(a.ml), dim3(VT_THREADS), lds_bytes, a, c->K);
+  return hipSuccess;
+}
+hipError_t dispatch_vbanded_twist(btf_ctx* c, const VBandArgs& a, int bw, size_t lds_bytes, bool* handled) {
+  const int npairs = (bw - 1) * (bw - 2) / 2;
+  const int npl = std::max(1, (npairs + WAVE - 1) / WAVE);
+  *handled = true;
+  if (bw <= 15) {
+    if (npl == 1) return launch_vbanded_twist<1, true>(c, a, lds_bytes);
+    if (npl == 2) return launch_vbanded_twist<2, true>(c, a, lds_bytes);
+  } else {
+    switch (npl) {
+      case 2: return launch_vbanded_twist<2, false>(c, a, lds_bytes);
+      case 3: return launch_vbanded_twist<3, false>(c, a, lds_bytes);
+      case 4: return launch_vbanded_twist<4, false>(c, a, lds_bytes);
+      case 5: return launch_vbanded_twist<5, false>(c, a, lds_bytes);
+      case 6: return launch_vbanded_twist<6, false>(c, a, lds_bytes);
+      case 7: return launch_vbanded_twist<7, false>(c, a, lds_bytes);
+      case 8: return launch_vbanded_twist<8, false>(c, a, lds_bytes);
+      default: break;
+    }
+  }
+  *handled = false;
+  return hipSuccess;
+}
+// which sampler a V half-sweep of this context will use: 2 twisted, 1 single chain (LDS), 0 pipeline, -1 generic
+int banded_choice(const btf_ctx* c) {
+  const int bw = (c->TF + 1) * c->K;
+  const bool wt = c->weighted;
+  if (c->force_generic_banded || bw < 3) return -1;
+  if (c->banded_variant == 2 && twist_ok(c->T, c->K, c->TF) && tw_lds_bytes(c->T, c->K, c->TF, wt) <= 160 * 1024) return 2;
+  if (c->banded_variant == 0 && vp_lds_bytes(c->T, c->K, c->TF, wt) <= 158 * 1024 && pipe_nplh_ok(bw)) return 0;
+  if (vb_fast_lds_bytes(c->T, c->K, c->TF, wt) <= 158 * 1024) return 1;
+  return -1;
+}
 // pairs per helper lane: the larger parity class of the diagonal-offset split
+int pipe_nplh(int bw);
+bool pipe_nplh_ok(int bw) { return pipe_nplh(bw) <= 4 && (bw > 15 || pipe_nplh(bw) == 1); }
 int pipe_nplh(int bw) {
   int cnt[2] = {0, 0};
   for (int d = 0; d <= bw - 3; ++d) cnt[d & 1] += bw - d - 2;
@@ -766,8 +815,8 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     a.eps0 = eps0; a.attempts = attempts; a.status = c->status; a.tries = c->tries; a.dbg = c->dbg;
     hipError_t e = hipSuccess;
     bool handled = false;
-    const size_t fast_bytes = vb_fast_lds_bytes(T, K, c->TF, wt ? 1 : 0);
-    const bool fast = !c->force_generic_banded && bw >= 3 && fast_bytes <= 158 * 1024;
+    const int choice = banded_choice(c);
+    const bool fast = choice >= 0;
     if (fast) {
       const int TD1 = T * D1;
       if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; c->pband_dirty = true; }
@@ -788,16 +837,30 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     }
     c->ngp_v = emit_gv ? c->ml : 0;
     c->ngp_w = 0;
-    const size_t pipe_bytes = vp_lds_bytes(T, K, c->TF, wt ? 1 : 0);
-    if (fast && c->banded_variant == 0 && pipe_bytes <= 158 * 1024) e = dispatch_vbanded_pipe(c, a, bw, pipe_bytes, &handled);
+    if (choice == 2) e = dispatch_vbanded_twist(c, a, bw, tw_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
     HIPCHK(c, e);
-    if (fast && !handled) e = dispatch_vbanded_fast(c, a, bw, fast_bytes, &handled);
+    if (choice == 0) e = dispatch_vbanded_pipe(c, a, bw, vp_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
     HIPCHK(c, e);
+    if (fast && !handled) e = dispatch_vbanded_fast(c, a, bw, vb_fast_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
+    HIPCHK(c, e);
+    if (!handled) { a.gout = nullptr; c->ngp_v = 0; }
     if (!handled) { K_SWITCH(K, e = launch_vbanded<KT>(c, a, lds_bytes)); }
     HIPCHK(c, e);
   }
   c->sweep_v++;
   HIPCHK(c, hipGetLastError());
+  return BTF_OK;
+}
+
+int btf_get_V_order(btf_ctx* c, int32_t* order) {
+  if (!c || !order) return BTF_EINVAL;
+  const int n = c->T * c->K;
+  if (banded_choice(c) == 2) {
+    const TwLayout W = tw_layout(c->T, c->K, c->TF, 0);
+    for (int i = 0; i < n; ++i) order[i] = twist_order(i, n, W.nl, W.nr);
+  } else {
+    for (int i = 0; i < n; ++i) order[i] = i;
+  }
   return BTF_OK;
 }
 
@@ -983,10 +1046,10 @@ extern "C" int btf_debug_stamps(btf_ctx* c, long long* out) {
 
 int btf_set_tuning(btf_ctx* c, int rows_per_block_w, int rows_per_block_v) {
   if (!c) return BTF_EINVAL;
-  // test hooks: rows_per_block_v == -1 selects the generic (any-size) banded kernel,
-  // -3 the wave-specialised pipeline, anything else the default
+  // sampler selection hooks: rows_per_block_v == -1 generic (any-size) kernel, -2 single-chain LDS
+  // kernel, -3 wave-specialised pipeline; anything else the default (twisted where it applies)
   c->force_generic_banded = rows_per_block_v == -1;
-  c->banded_variant = rows_per_block_v == -3 ? 0 : 1;
+  c->banded_variant = rows_per_block_v == -3 ? 0 : (rows_per_block_v == -2 ? 1 : 2);
   c->rpb_w = rows_per_block_w; c->rpb_v = rows_per_block_v < 0 ? 0 : rows_per_block_v;
   return BTF_OK;
 }

@@ -116,10 +116,14 @@ __device__ __forceinline__ void ldsw(double* lds, int boff, double x) {
 // instruction count: byte offsets, and lanes outside the band are steered to private
 // dummy / zero words through their (precomputed) addresses and strides instead of
 // being masked with selects.
+// n_elim < n: eliminate only the first n_elim unknowns; the band columns >= n_elim then hold
+// the Schur complement of the rest (the two register-resident columns are flushed) and
+// rhs[>= n_elim] the correspondingly reduced right-hand side (twisted factorisation).
 template <int NPL, bool ROW16>
-__device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, int bw) {
+__device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, int bw, int n_elim = -1) {
   const int lane = threadIdx.x & 63;
   const int R1 = L.R1, R1B = L.R1 * 8;
+  if (n_elim < 0) n_elim = n;
   const int npairs = (bw - 1) * (bw - 2) / 2;       // pairs with b >= 3
   int to[NPL], ao[NPL], bo[NPL], tinc[NPL];          // byte offsets
 #pragma unroll
@@ -168,7 +172,7 @@ __device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, 
   double wn = ldsr(lds, wo);
   double u = lds[L.rhs];                                     // rhs[0]
   __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): enter the loop with nothing pending
-  for (int nn = 0; nn < n; ++nn) {
+  for (int nn = 0; nn < n_elim; ++nn) {
     const double p = bcast_first(v);
     if (!(p > 0.0)) return false;
     // ---- dependent chain
@@ -206,6 +210,10 @@ __device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, 
     }
     rt = ldsr(lds, ro);
     wn = ldsr(lds, wo);
+  }
+  if (n_elim < n && in_col) {          // flush the two register-resident columns of the Schur complement
+    lds[L.band + n_elim * R1 + lane] = v;
+    lds[L.band + (n_elim + 1) * R1 + lane] = w;
   }
   return true;
 }

@@ -1,0 +1,291 @@
+// Twisted ("burn at both ends") V half-sweep sampler - the default (BTF_K_V_BANDED).
+//
+// The pivot chain of the banded LDL' is sequential, and a lone wave needs ~430 cycles per
+// pivot (btf_banded_fast.h).  The precision of a column couples depth t only with t +- (tf+1),
+// so a separator of S = tf+1 consecutive depths [ts, ts+S) splits the unknowns into two
+// blocks that do not touch: wave 0 eliminates depths 0..ts-1 downwards, wave 1 eliminates
+// depths T-1..ts+S upwards (the same kernel on the mirrored indices), concurrently and with
+// no synchronisation per pivot; their Schur complements meet in the small dense separator
+// system (S*K = half-bandwidth unknowns), which wave 0 factors.  Back-substitution runs the
+// other way: separator first, then the two halves in parallel.  The sequential chain is
+// ~n/2 + bw pivots instead of n.
+//
+// This is the LDL' of P Q P' for the ordering
+//     [ depths 0..ts-1 ascending | depths T-1..ts+S descending (k descending) | separator ]
+// and the draw is  x = Q^-1 mu + P' L^-T D^-1/2 z  with z indexed in THAT order - the
+// ordering the build declares for this kernel (btf_get_V_order reports it; the oracle takes
+// it as `perm`).  Same distribution and same mean term as any other ordering
+// ("parity unpinned" note on CHOLMOD's own ordering).
+#pragma once
+#include "btf_banded_fast.h"
+
+namespace btf {
+
+constexpr int VT_THREADS = 256;
+
+struct TwLayout {
+  VbLayout L, R, S;      // left chain, right chain, separator: views for the shared routines
+  int m0, zs, P, Ql, flag;
+  int total;
+  int ts, nl, nr, ns, nL, nR;
+};
+
+__host__ __device__ inline int twist_ts(int T, int TF) { return (T - (TF + 1)) / 2; }
+__host__ __device__ inline bool twist_ok(int T, int K, int TF) {
+  return (TF + 1) * K >= 3 && T >= 2 * (TF + 1) + 2;
+}
+
+__host__ __device__ inline TwLayout tw_layout(int T, int K, int TF, int weighted) {
+  TwLayout W;
+  const int n = T * K, S = TF + 1, bw = S * K, D1 = TF + 2, KK = tri(K), R1 = bw + 1;
+  W.ts = twist_ts(T, TF);
+  W.ns = bw;
+  W.nl = W.ts * K;
+  W.nr = n - W.nl - W.ns;
+  W.nL = W.nl + W.ns;
+  W.nR = W.nr + W.ns;
+  int o = 0;
+  auto carve = [&](VbLayout& V, int nn) {
+    V.R1 = R1;
+    V.npad = nn + bw + 2;
+    V.FP = bw + 4;
+    V.band = o; o += V.npad * R1 + 64;
+    V.rhs = o + V.FP; o += V.FP + V.npad + 64;
+    V.invd = o; o += V.npad;
+    V.vsc = o; o += 64;
+    V.m0 = V.zs = V.P = V.Ql = V.flag = 0;
+    V.total = 0;
+  };
+  carve(W.L, W.nL);
+  carve(W.R, W.nR);
+  carve(W.S, W.ns);
+  // one dummy region for all views: idle lanes only ever park garbage there (races between the
+  // two concurrent chains are harmless), and its last word is never written (the zero source)
+  W.L.dummy = W.R.dummy = W.S.dummy = o; o += 64 * 9 + 8;
+  W.m0 = o; o += n;
+  W.zs = o; o += n;
+  W.P = o; o += T * D1;
+  W.Ql = o; o += weighted ? T * KK : KK;
+  W.flag = o; o += 8;
+  W.total = o;
+  return W;
+}
+__host__ __device__ inline size_t tw_lds_bytes(int T, int K, int TF, int weighted) {
+  return (size_t)tw_layout(T, K, TF, weighted).total * sizeof(double);
+}
+
+// position i in the elimination order -> depth-major index g = t*K + k
+__host__ __device__ inline int twist_order(int i, int n, int nl, int nr) {
+  if (i < nl) return i;
+  if (i < nl + nr) return n - 1 - (i - nl);
+  return nl + (i - nl - nr);
+}
+
+template <int NPL, bool ROW16>
+__global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a, int K) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = blockIdx.x, jg = a.col0 + j;
+  const int KK = tri(K), T = a.T, n = T * K, D1 = a.TF + 2, bw = (a.TF + 1) * K, R1 = bw + 1;
+  const int NV = a.weighted ? K + KK : K;
+  const TwLayout W = tw_layout(T, K, a.TF, a.weighted);
+  const int nl = W.nl, nr = W.nr, ns = W.ns, nL = W.nL, nR = W.nR;
+  double* m0 = lds + W.m0;
+  double* zs = lds + W.zs;
+  double* P = lds + W.P;
+  double* Ql = lds + W.Ql;
+  double* flag = lds + W.flag;
+  long long stamp[6];
+  stamp[0] = __builtin_amdgcn_s_memtime();
+
+  // ---- likelihood mean part / Gram blocks / prior band ---------------------------------------
+  auto chunk_sum = [&](const double* p) -> double {
+    double s = 0.0;
+    const size_t st = (size_t)NV * a.ld;
+    int c = 0;
+    for (; c + 4 <= a.nch; c += 4) {
+      const double x0 = p[(size_t)c * st], x1 = p[(size_t)(c + 1) * st], x2 = p[(size_t)(c + 2) * st], x3 = p[(size_t)(c + 3) * st];
+      s += x0; s += x1; s += x2; s += x3;
+    }
+    for (; c < a.nch; ++c) s += p[(size_t)c * st];
+    return s;
+  };
+  for (int idx = tid; idx < n; idx += VT_THREADS) {
+    const int t = idx / K, k = idx - t * K;
+    m0[idx] = chunk_sum(a.part + (size_t)k * a.ld + (size_t)j * T + t) * a.s;
+  }
+  if (a.weighted) {
+    for (int idx = tid; idx < T * KK; idx += VT_THREADS) {
+      const int t = idx / KK, q = idx - t * KK;
+      Ql[idx] = chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t) * a.s;
+    }
+  } else {
+    reduce_gram(a.gpart, a.ngp, KK, a.sR, lds + W.L.band, Ql);
+  }
+  for (int idx = tid; idx < T * D1; idx += VT_THREADS) P[idx] = a.pband[(size_t)j * T * D1 + idx];
+  // static zero regions of the three views: pads, scratch rows, dummy words
+  {
+    const VbLayout* views[3] = {&W.L, &W.R, &W.S};
+    for (int q = 0; q < 3; ++q) {
+      const VbLayout& V = *views[q];
+      for (int idx = tid; idx < 64; idx += VT_THREADS) {
+        lds[V.band + V.npad * R1 + idx] = 0.0;
+        lds[V.rhs + V.npad + idx] = 0.0;
+        lds[V.vsc + idx] = 0.0;
+      }
+      for (int idx = tid; idx < V.FP; idx += VT_THREADS) lds[V.rhs - V.FP + idx] = 0.0;
+    }
+    for (int idx = tid; idx < 64 * 9 + 8; idx += VT_THREADS) lds[W.L.dummy + idx] = 0.0;
+  }
+  __syncthreads();
+  stamp[1] = __builtin_amdgcn_s_memtime();
+
+  // entry (g + aa, g) of the precision, g = t*K + k depth-major, 0 <= aa <= bw
+  auto qentry = [&](int g, int aa, double shift) -> double {
+    const int t = g / K, k = g - t * K;
+    if (aa < K - k) {
+      double v = a.weighted ? Ql[t * KK + lidx(k + aa, k)] : Ql[lidx(k + aa, k)];
+      if (aa == 0) v += P[t * D1] + shift;
+      return v;
+    }
+    const int dd = aa / K;
+    if (dd * K == aa && dd < D1 && t + dd < T) return P[t * D1 + dd];
+    return 0.0;
+  };
+
+  double shift = 0.0, eps = a.eps0;
+  int tried = 0;
+  bool ok = false;
+  while (true) {
+    // ---- assemble the two bands -------------------------------------------------------------
+    // left view: index i = g, rows/cols < nl+ns.  right view: index m = n-1-g (mirrored), rows/cols
+    // >= nl, and its separator-by-separator block left at zero (it is counted once, on the left).
+    for (int idx = tid; idx < W.L.npad + W.R.npad; idx += VT_THREADS) {
+      if (idx < W.L.npad) {
+        const int i = idx;
+        double* colw = lds + W.L.band + (size_t)i * R1;
+        for (int aa = 0; aa < R1; ++aa) colw[aa] = (i < nL && i + aa < nL) ? qentry(i, aa, shift) : 0.0;
+      } else {
+        const int m = idx - W.L.npad;
+        double* colw = lds + W.R.band + (size_t)m * R1;
+        const int gc = n - 1 - m;                       // global column; row of the entry is gc - aa
+        for (int aa = 0; aa < R1; ++aa)
+          colw[aa] = (m < nr && gc - aa >= nl) ? qentry(gc - aa, aa, shift) : 0.0;
+      }
+    }
+    for (int idx = tid; idx < W.L.npad; idx += VT_THREADS) lds[W.L.rhs + idx] = idx < nL ? m0[idx] : 0.0;
+    for (int idx = tid; idx < W.R.npad; idx += VT_THREADS) lds[W.R.rhs + idx] = idx < nr ? m0[n - 1 - idx] : 0.0;
+    __syncthreads();
+    stamp[2] = __builtin_amdgcn_s_memtime();
+    // ---- the two chains, concurrently -------------------------------------------------------
+    if (wave == 0) {
+      const bool good = banded_ldl_forward<NPL, ROW16>(lds, W.L, nL, bw, nl);
+      if (tid == 0) flag[0] = good ? 1.0 : 0.0;
+    } else if (wave == 1) {
+      const bool good = banded_ldl_forward<NPL, ROW16>(lds, W.R, nR, bw, nr);
+      if (tid == 64) flag[1] = good ? 1.0 : 0.0;
+    } else if (tried == 0) {
+      // the normals of this column, indexed in elimination order (drawn once, whatever the retries)
+      for (int idx = tid - 2 * WAVE; idx < n; idx += VT_THREADS - 2 * WAVE)
+        zs[idx] = a.z ? a.z[(size_t)jg * n + idx] : philox_normal(a.seed, a.stream, (unsigned long long)jg * n + idx);
+    }
+    __syncthreads();
+    ok = flag[0] != 0.0 && flag[1] != 0.0;
+    if (ok) {
+      // ---- separator system: S = S_L + mirror(S_R), reduced right-hand side likewise ----------
+      for (int idx = tid; idx < W.S.npad * R1; idx += VT_THREADS) {
+        const int jj = idx / R1, aa = idx - jj * R1;
+        double v = 0.0;
+        if (jj < ns && jj + aa < ns)
+          v = lds[W.L.band + (nl + jj) * R1 + aa] + lds[W.R.band + (nr + ns - 1 - (jj + aa)) * R1 + aa];
+        lds[W.S.band + idx] = v;
+      }
+      for (int idx = tid; idx < W.S.npad; idx += VT_THREADS)
+        lds[W.S.rhs + idx] = idx < ns ? lds[W.L.rhs + nl + idx] + lds[W.R.rhs + nr + ns - 1 - idx] : 0.0;
+      __syncthreads();
+      // the halves' factors have no columns for the separator unknowns
+      for (int idx = tid; idx < ns * R1; idx += VT_THREADS) {
+        lds[W.L.band + nl * R1 + idx] = 0.0;
+        lds[W.R.band + nr * R1 + idx] = 0.0;
+      }
+      if (wave == 0) {
+        const bool good = banded_ldl_forward<NPL, ROW16>(lds, W.S, ns, bw);
+        if (tid == 0) flag[0] = good ? 1.0 : 0.0;
+      } else {
+        // meanwhile: w = D^-1 u + D^-1/2 z for the two interiors
+        for (int idx = tid - WAVE; idx < nl + nr; idx += VT_THREADS - WAVE) {
+          const bool left = idx < nl;
+          const int i = left ? idx : idx - nl;
+          const int ro = (left ? W.L.rhs : W.R.rhs) + i;
+          const double iv = lds[(left ? W.L.invd : W.R.invd) + i];
+          lds[ro] = fma(lds[ro], iv, zs[idx] * sqrt(iv));
+        }
+      }
+      __syncthreads();
+      ok = flag[0] != 0.0;
+    }
+    if (ok || tried >= a.attempts) break;
+    shift += eps;   // fast_mvn.py:64-68: cumulative eps, eps *= 10
+    eps *= 10.0;
+    ++tried;
+    __syncthreads();
+  }
+  if (tid == 0) a.tries[j] = tried;
+  if (!ok) {
+    if (tid == 0 && atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = jg;
+    return;
+  }
+  stamp[3] = __builtin_amdgcn_s_memtime();
+  // ---- separator: w, back-substitution ---------------------------------------------------------
+  if (tid < ns) {
+    const double iv = lds[W.S.invd + tid];
+    lds[W.S.rhs + tid] = fma(lds[W.S.rhs + tid], iv, zs[nl + nr + tid] * sqrt(iv));
+  }
+  __syncthreads();
+  if (wave == 0) banded_unit_backward(lds, W.S, ns, bw);
+  __syncthreads();
+  // known trailing unknowns of both halves
+  if (tid < ns) {
+    const double xs = lds[W.S.rhs + tid];
+    lds[W.L.rhs + nl + tid] = xs;
+    lds[W.R.rhs + nr + ns - 1 - tid] = xs;
+  }
+  __syncthreads();
+  stamp[4] = __builtin_amdgcn_s_memtime();
+  if (wave == 0) banded_unit_backward(lds, W.L, nL, bw);
+  else if (wave == 1) banded_unit_backward(lds, W.R, nR, bw);
+  __syncthreads();
+  stamp[5] = __builtin_amdgcn_s_memtime();
+  // ---- write V[j] (depth-major), Gram share --------------------------------------------------
+  double* xout = m0;                                     // m0 is dead: gather x in depth-major order
+  for (int g = tid; g < n; g += VT_THREADS)
+    xout[g] = g < nL ? lds[W.L.rhs + g] : lds[W.R.rhs + (n - 1 - g)];
+  __syncthreads();
+  for (int idx = tid; idx < n; idx += VT_THREADS) a.V[(size_t)jg * n + idx] = xout[idx];
+  if (a.gout) {
+    int ng = VT_THREADS / KK;
+    if (ng > 16) ng = 16;
+    if (ng < 1) ng = 1;
+    const int g = tid / KK, q = tid - g * KK;
+    int p = 0;
+    while ((p + 1) * (p + 2) / 2 <= q) ++p;
+    const int pq = q - p * (p + 1) / 2;
+    double* scratch = lds + W.L.band;                    // dead by now; >= (bw+2)*(bw+1)+64 >= 16*KK doubles
+    if (g < ng) {
+      double s = 0.0;
+      for (int t = g; t < T; t += ng) s = fma(xout[t * K + p], xout[t * K + pq], s);
+      scratch[g * KK + q] = s;
+    }
+    __syncthreads();
+    if (tid < KK) {
+      double s = 0.0;
+      for (int b = 0; b < ng; ++b) s += scratch[b * KK + tid];
+      a.gout[(size_t)j * KK + tid] = s;
+    }
+  }
+  if (a.dbg && tid == 0)
+    for (int i = 0; i < 6; ++i) a.dbg[(size_t)j * 6 + i] = stamp[i];
+}
+
+}  // namespace btf

@@ -384,6 +384,14 @@ class BayesianTensorFiltering(_BayesianModel):
         self._exchange.after_V()
         self._V_dev_new = True
 
+    def v_order(self):
+        """Elimination order of the V half-sweep's factorisation as depth-major indices t*K+k
+        (what CHOLMOD's P() is to fast_mvn.py:44): z[j][i] multiplies pivot i.  Known once the
+        data is bound (the kernel choice depends on the weighted / unweighted LDS footprint)."""
+        order = np.zeros(self.nembeds * self.ndepth, dtype=np.int32)
+        self._ctx.call("btf_get_V_order", order.ctypes.data_as(_native._c_ip))
+        return order
+
     def sync(self):
         """Wait for the GPU; raises NotPositiveDefiniteError if a factorisation failed."""
         self._ctx.call("btf_sync")

@@ -119,13 +119,20 @@ int btf_resample_W(btf_ctx* ctx, const double* z, uint64_t seed, int compat);
  * its call into sample_mvn_from_precision (fast_mvn.py:35-47, :62-68): for every
  * local column j the (K*T)x(K*T) precision  kron(W,I)'C kron(W,I) + I_K (x)
  * Delta' diag(1/(lam2 Tau2_j)) Delta  is formed in depth-major order (t,k), factored
- * as a block-banded Cholesky, and  V[j] = Q^-1 mu + P' L^-T z  is drawn.
+ * as a block-banded LDL' in the declared elimination order P (btf_get_V_order), and
+ * V[j] = Q^-1 mu + P' L^-T z  is drawn.
  * z: host (M, K*T) normals, row j for column j, indexed in the factor's
- * (depth-major) order, or NULL for device Philox.  eps0/attempts: the
+ * elimination order, or NULL for device Philox.  eps0/attempts: the
  * force_psd jitter schedule (eps0*10^a added cumulatively, <= attempts).      */
 int btf_resample_V(btf_ctx* ctx, const double* z, uint64_t seed, int compat,
                    double eps0, int attempts);
 int btf_get_V_attempts(btf_ctx* ctx, int32_t* tries /* (ncols_local) */);
+/* The elimination order P the V half-sweep of this context uses (after btf_set_data_*):
+ * order[i] = depth-major index t*K+k of the i-th pivot, i = 0..K*T-1.  Identity for the
+ * single-chain kernels; for the default twisted kernel: depths 0..ts-1 ascending, then depths
+ * T-1..ts+tf+1 descending (k descending), then the separator depths ts..ts+tf.  z[j][i] is
+ * the normal that multiplies pivot i (this is CHOLMOD's P() in fast_mvn.py:44).            */
+int btf_get_V_order(btf_ctx* ctx, int32_t* order /* (K*T) */);
 
 /* Residual sum of squares and observation count over the LOCAL rows: the two
  * numbers GaussianBTF._resample_nu2 (factor.py:411-416, genlasso.py:157-160)

@@ -71,6 +71,29 @@ def depth_major_perm(K, T):
     return (k * T + t).reshape(-1)
 
 
+def twisted_order(K, T, tf):
+    """Elimination order of the build's default ("twisted") V-step kernel as depth-major
+    indices g = t*K + k: depths 0..ts-1 ascending, depths T-1..ts+S descending (k
+    descending), then the separator depths ts..ts+S-1; S = tf+1, ts = (T-S)//2."""
+    S = tf + 1
+    ts = (T - S) // 2
+    n, nl = K * T, ts * K
+    left = np.arange(nl)
+    right = np.arange(n - 1, nl + S * K - 1, -1)
+    sep = np.arange(nl, nl + S * K)
+    return np.concatenate([left, right, sep])
+
+
+def perm_from_order(order, K, T):
+    """Depth-major pivot order -> the reference's k-major unknown indices (CHOLMOD's P())."""
+    order = np.asarray(order)
+    return (order % K) * T + order // K
+
+
+def twisted_perm(K, T, tf):
+    return perm_from_order(twisted_order(K, T, tf), K, T)
+
+
 # --------------------------------------------------------------------------
 # sufficient statistics              (factor.py:323-330 and :368-375)
 # --------------------------------------------------------------------------
@@ -247,7 +270,10 @@ def v_step(st, Y, Delta, perm="depth", z=None, compat="reference",
     M, T, K = V.shape
     st["_cnt"], st["_ybar"] = replicate_stats(Y)
     if isinstance(perm, str):
-        p = depth_major_perm(K, T) if perm == "depth" else np.arange(K * T)
+        if perm == "twist":
+            p = twisted_perm(K, T, (Delta.shape[0] + 1) // T - 1 if Delta.shape[0] != T else 0)
+        else:
+            p = depth_major_perm(K, T) if perm == "depth" else np.arange(K * T)
     else:
         p = np.asarray(perm)
     src = stale_column_sources(st["_ybar"]) if compat == "reference" else np.arange(M)

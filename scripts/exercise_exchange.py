@@ -25,7 +25,7 @@ for it in range(3):
     np.random.seed(10 + it); orc.w_step(st, Y)
     ew = rel(Wg, st["W"]); m.W = st["W"]
     np.random.seed(20 + it); m._resample_V(Y); Vg = m.V.copy()
-    np.random.seed(20 + it); orc.v_step(st, Y, D, compat="exact")
+    np.random.seed(20 + it); orc.v_step(st, Y, D, compat="exact", perm=orc.perm_from_order(m.v_order(), K, T))
     ev = rel(Vg, st["V"]); m.V = st["V"]
     print("sweep %d: rel err W %.2e V %.2e" % (it, ew, ev), flush=True)
     worst = max(worst, ew, ev * 1e-3)   # V: cond-limited (prior-drawn Tau2), 1e-6 allowed

@@ -96,6 +96,16 @@ def _install_shims():
                         "pypolyagamma": pg})
 
 
+def _twist_perm_factory(K, T, tf=2):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle.btf_oracle import twisted_perm
+
+    def f(n):
+        assert n == K * T
+        return twisted_perm(K, T, tf)
+    return f
+
+
 def _depth_perm_factory(K, T):
     def f(n):
         assert n == K * T
@@ -159,7 +169,7 @@ def half_sweeps(factor, model, data, K, T, seed, want_systems=True):
     out["W_after"] = model.W.copy()
     # ---- V step (state = after W step), depth-major then identity from same state
     st1 = snapshot(model)
-    for name, pf in (("depth", _depth_perm_factory(K, T)), ("ident", None)):
+    for name, pf in (("depth", _depth_perm_factory(K, T)), ("ident", None), ("twist", _twist_perm_factory(K, T))):
         model.V[:] = st1["V"]
         _cfg["perm"] = pf
         _cfg["log"] = []
@@ -239,6 +249,11 @@ def main():
     np.random.seed(22)
     res = model.run_gibbs(Y, nburn=3, nthin=2, nsamples=4, verbose=False)
     g6.update(pack("res_", {k: np.asarray(v) for k, v in res.items()}))
+    model = build(N, M, T, K, seed=21, nu2_init=1.0)            # same construction (depth-major prior draw)
+    _cfg["perm"] = _twist_perm_factory(K, T)
+    np.random.seed(22)
+    res = model.run_gibbs(Y, nburn=3, nthin=2, nsamples=4, verbose=False)
+    g6.update(pack("rest_", {k: np.asarray(v) for k, v in res.items()}))
     np.savez_compressed(os.path.join(HERE, "g6_c1_chain.npz"), **g6)
 
     # --------------------- G2: (64,32,16,2) K=3 complete data (Q1 cache path)
@@ -345,6 +360,22 @@ def main():
     assert tries[2] == 2 and tries.sum() == 2, tries
     g5["retry_V_after"] = model.V.copy()
     g5["retry_tries"] = tries
+    # the same forced retry under the twisted ordering
+    for k_, v_ in st.items():
+        if k_ in ("W", "V", "Tau2"):
+            getattr(model, k_)[:] = v_
+    _cfg["perm"] = _twist_perm_factory(K, T)
+    _cfg["log"] = []
+    np.random.seed(601)
+    signal.alarm(60)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model._resample_V(Y)
+    signal.alarm(0)
+    _, _, tries_t = collect_systems(_cfg["log"], M)
+    _cfg["log"] = None
+    g5["retry_V_after_twist"] = model.V.copy()
+    g5["retry_tries_twist"] = tries_t
     g5["retry_Q_final"] = Qs
     np.random.seed(601)
     g5["retry_z_V"] = np.random.normal(size=(M, K * T))

@@ -42,19 +42,26 @@ def test_w_step_vs_reference(golden, name, seed):
     assert relerr(model.W, g["W_after"]) < W_TOL
 
 
-@pytest.mark.parametrize("kernel", ["pipe", "fast", "generic"])
+@pytest.mark.parametrize("kernel", ["twist", "pipe", "fast", "generic"])
 @pytest.mark.parametrize("name,seed", GAUSS)
 def test_v_step_vs_reference(golden, name, seed, kernel):
     """All three samplers: the wave-specialised pipeline (default), the single-wave LDS
     LDL' kernel and the any-size generic one."""
     g = golden(name)
     model, _ = gaussian_model(g, "s0_")
-    if kernel != "fast":
-        model._ctx.call("btf_set_tuning", 0, -1 if kernel == "generic" else -3)
+    if kernel != "twist":
+        model._ctx.call("btf_set_tuning", 0, {"generic": -1, "fast": -2, "pipe": -3}[kernel])
     model.W = g["W_after"]
     np.random.seed(seed + 1)
     model._resample_V(g["Y"])
-    assert relerr(model.V, g["V_after_depth"]) < V_TOL
+    T, K = model.ndepth, model.nembeds
+    from oracle import btf_oracle as orc
+    if kernel == "twist":        # the declared elimination order of the default kernel
+        assert np.array_equal(model.v_order(), orc.twisted_order(K, T, 2))
+        assert relerr(model.V, g["V_after_twist"]) < V_TOL
+    else:
+        assert np.array_equal(model.v_order(), np.arange(K * T))
+        assert relerr(model.V, g["V_after_depth"]) < V_TOL
 
 
 def test_illconditioned_state(golden):
@@ -67,7 +74,7 @@ def test_illconditioned_state(golden):
     assert relerr(model.W, g["W_after"]) < W_TOL
     np.random.seed(601)
     model._resample_V(g["Y"])
-    assert relerr(model.V, g["V_after_depth"]) < 2e-3
+    assert relerr(model.V, g["V_after_twist"]) < 2e-3
 
 
 def test_jitter_retry_matches_reference_schedule(golden):
@@ -79,8 +86,15 @@ def test_jitter_retry_matches_reference_schedule(golden):
     V = model.V.copy()
     tries = np.zeros(model.ncols, dtype=np.int32)
     model._ctx.call("btf_get_V_attempts", tries.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert np.array_equal(tries, g["retry_tries_twist"])
+    assert relerr(V, g["retry_V_after_twist"]) < 1e-5
+    model, _ = gaussian_model(g, "retry_s0_")
+    model._ctx.call("btf_set_tuning", 0, -2)            # single-chain kernel: depth-major fixture
+    np.random.seed(601)
+    model._resample_V(g["Y"])
+    model._ctx.call("btf_get_V_attempts", tries.ctypes.data_as(C.POINTER(C.c_int32)))
     assert np.array_equal(tries, g["retry_tries"])
-    assert relerr(V, g["retry_V_after"]) < 1e-5
+    assert relerr(model.V, g["retry_V_after"]) < 1e-5
 
 
 def test_not_positive_definite_is_reported(golden):
@@ -143,8 +157,8 @@ def test_run_gibbs_chain_vs_reference(golden):
     res = model.run_gibbs(Y, nburn=3, nthin=2, nsamples=4, verbose=False)
     assert set(res) == {"W", "V", "sigma2", "lam2", "Tau2", "nu2"}
     for k in res:
-        assert res[k].shape == g["res_" + k].shape, k
-        assert relerr(res[k], g["res_" + k]) < 1e-5, k
+        assert res[k].shape == g["rest_" + k].shape, k
+        assert relerr(res[k], g["rest_" + k]) < 1e-5, k        # reference chain under the declared (twisted) order
 
 
 def test_banded_sampler_vs_oracle():
@@ -212,7 +226,7 @@ def test_binomial_half_sweeps_given_omega(golden, tag):
     assert relerr(model.W, g["W_after"]) < W_TOL
     np.random.seed(501)
     model._resample_V(data)
-    assert relerr(model.V, g["V_after_depth"]) < V_TOL
+    assert relerr(model.V, g["V_after_twist"]) < V_TOL
 
 
 def test_binomial_exact_mode_differs_from_reference_quirk(golden):
@@ -302,7 +316,8 @@ def test_pg_draw_fills_both_layouts_identically_and_masks_missing(golden):
     model._resample_V(data)
     Delta = orc.trend_penalty(model.ndepth, 2)
     with np.errstate(invalid="ignore"):
-        Vref = orc.binomial_v_step(st, g["Ysucc"], g["Ntrials"], Delta, z=z, compat="exact")
+        Vref = orc.binomial_v_step(st, g["Ysucc"], g["Ntrials"], Delta, z=z, compat="exact",
+                                   perm=orc.perm_from_order(model.v_order(), model.nembeds, model.ndepth))
     assert relerr(model.V, Vref) < V_TOL
 
 
@@ -378,7 +393,7 @@ def test_fused_gram_path_complete_data(golden):
     np.random.seed(301)
     model._resample_V(g["Y"])                 # W'W fused into w_solve
     assert relerr(model._W if not model._W_dev_new else model.W, g["W_after"]) < W_TOL
-    assert relerr(model.V, g["V_after_depth"]) < V_TOL
+    assert relerr(model.V, g["V_after_twist"]) < V_TOL
     ost = dict(st, W=g["W_after"].copy(), V=model.V.copy())
     model._V_host_new = False                 # keep the device copy (and its fused V'V) authoritative
     np.random.seed(302)

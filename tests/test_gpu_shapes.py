@@ -48,7 +48,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, -3])
+@pytest.mark.parametrize("variant", [0, -2, -3])
 @pytest.mark.parametrize("N,M,T,R,K,tf,missing", CASES)
 def test_half_sweeps_match_oracle(N, M, T, R, K, tf, missing, variant):
     from functionalmf_amd.factor import GaussianBayesianTensorFiltering
@@ -58,7 +58,7 @@ def test_half_sweeps_match_oracle(N, M, T, R, K, tf, missing, variant):
         N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
         W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"])
     assert model.Delta.shape[0] == st["Tau2"].shape[1]
-    model._ctx.call("btf_set_tuning", 0, variant)      # 0: default sampler, -3: wave-specialised pipeline
+    model._ctx.call("btf_set_tuning", 0, variant)      # 0: default (twisted), -2: single chain, -3: wave-specialised pipeline
     Delta = orc.trend_penalty(T, tf)
     nzw = sum(min(i + 1, K) for i in range(N))
     np.random.seed(5)
@@ -70,7 +70,7 @@ def test_half_sweeps_match_oracle(N, M, T, R, K, tf, missing, variant):
     model._resample_V(Y)
     orc.w_step(ost, Y, z=zw)
     assert relerr(model.W, ost["W"]) < 1e-10
-    orc.v_step(ost, Y, Delta, z=zv)
+    orc.v_step(ost, Y, Delta, z=zv, perm=orc.perm_from_order(model.v_order(), K, T))
     assert relerr(model.V, ost["V"]) < 1e-8
     # nu2 statistics on the new state
     np.random.seed(6)
@@ -98,7 +98,7 @@ def test_all_missing_column_and_row_are_prior_draws():
     model._resample_V(Y)
     ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
     orc.w_step(ost, Y, z=zw)
-    orc.v_step(ost, Y, orc.trend_penalty(8, 2), z=zv)
+    orc.v_step(ost, Y, orc.trend_penalty(8, 2), z=zv, perm=orc.perm_from_order(model.v_order(), 3, 8))
     assert relerr(model.W, ost["W"]) < 1e-10 and relerr(model.V, ost["V"]) < 1e-8
     off = sum(min(i + 1, 3) for i in range(7))
     assert np.allclose(model.W[7], np.sqrt(0.8) * zw[off:off + 3], rtol=1e-12)

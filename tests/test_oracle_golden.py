@@ -38,7 +38,7 @@ def test_w_step_consumes_legacy_stream_in_row_order(golden, name):
 
 
 @pytest.mark.parametrize("name", FIX)
-@pytest.mark.parametrize("perm", ["depth", "ident"])
+@pytest.mark.parametrize("perm", ["depth", "ident", "twist"])
 def test_v_step_gaussian(golden, name, perm):
     g = golden(name)
     N, M, T, R, K, tf = g["dims"]
@@ -46,7 +46,7 @@ def test_v_step_gaussian(golden, name, perm):
     st["W"] = g["W_after"].copy()
     Delta = orc.trend_penalty(int(T), int(tf))
     info = {}
-    V = orc.v_step(st, g["Y"], Delta, perm="depth" if perm == "depth" else "identity",
+    V = orc.v_step(st, g["Y"], Delta, perm={"depth": "depth", "ident": "identity", "twist": "twist"}[perm],
                    z=g["z_V"], info=info)
     # two fp64 factorisations of the same system agree to ~cond(Q)*eps (hard part 2)
     # G5 is deliberately extreme (cond(Q) up to 1.2e13): it pins control flow, not digits
@@ -93,7 +93,7 @@ def test_binomial_steps_given_omega(golden, tag):
     W = orc.binomial_w_step(st, g["Ysucc"], g["Ntrials"], z=g["z_W"])
     assert relerr(W, g["W_after"]) < 1e-11
     Delta = orc.trend_penalty(int(T), int(tf))
-    for perm, nm in (("depth", "depth"), ("identity", "ident")):
+    for perm, nm in (("depth", "depth"), ("identity", "ident"), ("twist", "twist")):
         st2 = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
         V = orc.binomial_v_step(st2, g["Ysucc"], g["Ntrials"], Delta, perm=perm, z=g["z_V"])
         assert relerr(V, g["V_after_" + nm]) < 1e-10
@@ -109,6 +109,10 @@ def test_jitter_retry(golden):
     assert np.array_equal(info["attempts"], g["retry_tries"])
     assert info["attempts"][2] == 2
     assert relerr(V, g["retry_V_after"]) < 1e-7     # min eigenvalue ~6e-6: cond ~1e9
+    st = state_from(g, "retry_s0_")
+    V = orc.v_step(st, g["Y"], Delta, z=g["retry_z_V"], info=info, perm="twist")
+    assert np.array_equal(info["attempts"], g["retry_tries_twist"])
+    assert relerr(V, g["retry_V_after_twist"]) < 1e-7
 
 
 def test_hyper_steps(golden):
@@ -153,10 +157,15 @@ def test_run_gibbs_chain(golden):
     np.random.seed(21)
     st, Delta = orc.init_state(N, M, T, K=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, nu2_init=1.0)
     np.random.seed(22)
+    st0 = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
     res = orc.run_gibbs(st, Y, Delta, nburn=3, nthin=2, nsamples=4)
     for k in ("W", "V", "sigma2", "lam2", "Tau2", "nu2"):
         assert res[k].shape == g["res_" + k].shape, k
         assert relerr(res[k], g["res_" + k]) < 1e-5, k
+    np.random.seed(22)
+    res = orc.run_gibbs(st0, Y, Delta, nburn=3, nthin=2, nsamples=4, perm="twist")
+    for k in ("W", "V", "sigma2", "lam2", "Tau2", "nu2"):
+        assert relerr(res[k], g["rest_" + k]) < 1e-5, k
 
 
 def test_pg_series_sampler_moments():
