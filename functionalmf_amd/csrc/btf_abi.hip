@@ -228,7 +228,8 @@ void launch_products(btf_ctx* c, const double* U, int Rdim, double* UU) {
 template <int K>
 void launch_wsolve(btf_ctx* c, const WSolveArgs& a) {
   Prof p(c, BTF_K_W_SOLVE);
-  p.launch(w_solve_kernel<K>, dim3((a.nl + WS_ROWS - 1) / WS_ROWS), dim3(WS_ROWS * ws_split(K)), 0, a);
+  if (a.weighted) p.launch(w_solve_kernel<K, true>, dim3((a.nl + WS_ROWS - 1) / WS_ROWS), dim3(WS_ROWS * ws_split(K)), 0, a);
+  else p.launch(w_solve_kernel<K, false>, dim3((a.nl + WS_ROWS - 1) / WS_ROWS), dim3(WS_ROWS * ws_split(K)), 0, a);
 }
 template <int K>
 hipError_t launch_vbanded(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {

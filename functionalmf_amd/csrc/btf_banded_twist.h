@@ -161,17 +161,56 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     // ---- assemble the two bands -------------------------------------------------------------
     // left view: index i = g, rows/cols < nl+ns.  right view: index m = n-1-g (mirrored), rows/cols
     // >= nl, and its separator-by-separator block left at zero (it is counted once, on the left).
+    // (one band column per thread; (t,k) of the moving row / column tracked incrementally: no divisions)
     for (int idx = tid; idx < W.L.npad + W.R.npad; idx += VT_THREADS) {
       if (idx < W.L.npad) {
-        const int i = idx;
+        const int i = idx;                              // column g = i, rows g+aa
         double* colw = lds + W.L.band + (size_t)i * R1;
-        for (int aa = 0; aa < R1; ++aa) colw[aa] = (i < nL && i + aa < nL) ? qentry(i, aa, shift) : 0.0;
+        if (i >= nL) {
+          for (int aa = 0; aa < R1; ++aa) colw[aa] = 0.0;
+          continue;
+        }
+        const int t = i / K, k = i - t * K;
+        const double* q = a.weighted ? Ql + t * KK : Ql;
+        int dd = 0, rem = 0;                            // aa = dd*K + rem
+        for (int aa = 0; aa < R1; ++aa) {
+          double v = 0.0;
+          if (i + aa < nL) {
+            if (aa < K - k) {
+              v = q[lidx(k + aa, k)];
+              if (aa == 0) v += P[t * D1] + shift;
+            } else if (rem == 0 && dd < D1 && t + dd < T) {
+              v = P[t * D1 + dd];
+            }
+          }
+          colw[aa] = v;
+          if (++rem == K) { rem = 0; ++dd; }
+        }
       } else {
-        const int m = idx - W.L.npad;
+        const int m = idx - W.L.npad;                   // mirrored column: global gc = n-1-m, rows gc-aa
         double* colw = lds + W.R.band + (size_t)m * R1;
-        const int gc = n - 1 - m;                       // global column; row of the entry is gc - aa
-        for (int aa = 0; aa < R1; ++aa)
-          colw[aa] = (m < nr && gc - aa >= nl) ? qentry(gc - aa, aa, shift) : 0.0;
+        if (m >= nr) {
+          for (int aa = 0; aa < R1; ++aa) colw[aa] = 0.0;
+          continue;
+        }
+        const int gc = n - 1 - m;
+        int tr = gc / K, kr = gc - tr * K;              // (t,k) of the row gr = gc - aa, walking down
+        const int kc = kr;
+        int dd = 0, rem = 0;
+        for (int aa = 0; aa < R1; ++aa) {
+          double v = 0.0;
+          if (gc - aa >= nl) {                          // entry (gr+aa, gr) = (gc, gr)
+            if (aa <= kc) {                             // same depth block: aa < K - kr  <=>  kr + aa = kc < K, tr == tc
+              v = (a.weighted ? Ql + tr * KK : Ql)[lidx(kc, kr)];
+              if (aa == 0) v += P[tr * D1] + shift;
+            } else if (rem == 0 && dd < D1) {
+              v = P[tr * D1 + dd];
+            }
+          }
+          colw[aa] = v;
+          if (++rem == K) { rem = 0; ++dd; }
+          if (--kr < 0) { kr = K - 1; --tr; }
+        }
       }
     }
     for (int idx = tid; idx < W.L.npad; idx += VT_THREADS) lds[W.L.rhs + idx] = idx < nL ? m0[idx] : 0.0;

@@ -161,7 +161,22 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const double* __rest
 __device__ inline void reduce_gram(const double* __restrict__ gpart, int ngp, int KK, double scale,
                                    double* stage, double* G) {
   const int nthr = blockDim.x;
-  for (int i = threadIdx.x; i < ngp * KK; i += nthr) stage[i] = gpart[i];
+  {   // all global loads of a thread are issued before the first LDS store (one memory latency, not one per element)
+    const int tot = ngp * KK;
+    int i = threadIdx.x;
+    for (; i + 7 * nthr < tot; i += 8 * nthr) {
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = gpart[i + u * nthr];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) stage[i + u * nthr] = x[u];
+    }
+    double x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = (i + u * nthr < tot) ? gpart[i + u * nthr] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (i + u * nthr < tot) stage[i + u * nthr] = x[u];
+  }
   __syncthreads();
   // two levels, fixed order: `lanes` threads per Gram entry each add a strided share, then one adds those
   int lanes = nthr / KK;
@@ -219,17 +234,18 @@ constexpr int WS_ROWS = 64;   // rows per workgroup (one per lane)
 // waves per workgroup: the chunk partials are summed WS_SPLIT-way in parallel (LDS-bounded)
 __host__ __device__ constexpr int ws_split(int K) { return K <= 6 ? 8 : (K <= 8 ? 4 : 2); }
 
-template <int K>
+template <int K, bool WEIGHTED>
 __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveArgs a) {
   constexpr int KK = tri(K);
   constexpr int WS_SPLIT = ws_split(K);
-  constexpr int NVMAX = K + KK;
-  const int NV = a.weighted ? K + KK : K;
+  constexpr int NVMAX = WEIGHTED ? K + KK : K;
+  constexpr int NV = NVMAX;
+  constexpr int UNR = WEIGHTED ? 2 : 4;                  // chunks whose loads are in flight together
   __shared__ double G[KK];
-  __shared__ double red[WS_SPLIT][NVMAX][WS_ROWS];
+  __shared__ double red[WS_SPLIT][K + KK][WS_ROWS];   // also the staging area of reduce_gram
   __shared__ double zsh[K][WS_ROWS];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  if (!a.weighted) reduce_gram(a.gpart, a.ngp, KK, a.sR, &red[0][0][0], G);
+  if constexpr (!WEIGHTED) reduce_gram(a.gpart, a.ngp, KK, a.sR, &red[0][0][0], G);
   const int il = blockIdx.x * WS_ROWS + lane;
   // the normals of row i (device RNG): component k by wave k % WS_SPLIT, in parallel with stage 1
   if (il < a.nl) {
@@ -245,11 +261,24 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
 #pragma unroll
     for (int v = 0; v < NVMAX; ++v) part[v] = 0.0;
     if (il < a.nl) {
-      for (int c = grp; c < a.nch; c += WS_SPLIT) {
-        const double* p = a.part + (size_t)c * NV * a.ld + il;
+      const size_t cst = (size_t)NV * a.ld;               // chunk stride
+      int c = grp;
+      for (; c + (UNR - 1) * WS_SPLIT < a.nch; c += UNR * WS_SPLIT) {   // UNR chunks' loads in flight, added in order
+        const double* p = a.part + (size_t)c * cst + il;
+        double x[UNR][NV];
 #pragma unroll
-        for (int v = 0; v < NVMAX; ++v)
-          if (v < NV) part[v] += p[(size_t)v * a.ld];
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+          for (int v = 0; v < NV; ++v) x[u][v] = p[(size_t)u * WS_SPLIT * cst + (size_t)v * a.ld];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+          for (int v = 0; v < NV; ++v) part[v] += x[u][v];
+      }
+      for (; c < a.nch; c += WS_SPLIT) {
+        const double* p = a.part + (size_t)c * cst + il;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) part[v] += p[(size_t)v * a.ld];
       }
     }
 #pragma unroll
@@ -270,7 +299,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
   }
 #pragma unroll
   for (int q = 0; q < KK; ++q) {
-    if (a.weighted) {
+    if constexpr (WEIGHTED) {
       double s = 0.0;
 #pragma unroll
       for (int w = 0; w < WS_SPLIT; ++w) s += red[w][K + q][lane];
