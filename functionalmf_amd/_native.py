@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "libbtf_hip.so")
+LIB_PATH = os.environ.get("BTF_LIB_PATH") or os.path.join(HERE, "libbtf_hip.so")   # override: A/B builds
 SOURCES = [os.path.join(CSRC, "btf_abi.hip")]
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
     [os.path.join(ROOT, "include", "btf.h")]

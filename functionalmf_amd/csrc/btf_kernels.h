@@ -18,11 +18,17 @@ namespace btf {
 // ============================================================================
 // streaming accumulation  (BTF_K_W_ACCUM / BTF_K_V_ACCUM)
 // ============================================================================
-constexpr int ACC_WAVES = 8;            // waves per workgroup
+#ifndef BTF_ACC_WAVES
+#define BTF_ACC_WAVES 16
+#endif
+#ifndef BTF_ACC_UNR
+#define BTF_ACC_UNR 2
+#endif
+constexpr int ACC_WAVES = BTF_ACC_WAVES;   // waves per workgroup
 constexpr int ACC_THREADS = ACC_WAVES * WAVE;
 constexpr int ACC_TILE = 2 * WAVE;      // outputs per workgroup along the lane axis
-constexpr int ACC_UNR = 8;              // rows in flight per wave
-constexpr int ACC_RG = 4;               // values reduced per LDS round
+constexpr int ACC_UNR = BTF_ACC_UNR;       // rows in flight per wave
+constexpr int ACC_RG = (ACC_THREADS / ACC_TILE) < 4 ? (ACC_THREADS / ACC_TILE) : 4;   // values reduced per LDS round
 
 // MODE 0: X only (complete data)
 // MODE 1: X, C and the outer products UU
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
         *reinterpret_cast<double2*>(&red[wave][v][2 * lane]) = make_double2(acc[g + v][0], acc[g + v][1]);
     }
     __syncthreads();
-    if (g + tv < NV) {
+    if (tv < ACC_RG && g + tv < NV) {
       double s = 0.0;
 #pragma unroll
       for (int w = 0; w < ACC_WAVES; ++w) s += red[w][tv][tc];
