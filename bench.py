@@ -190,6 +190,17 @@ def main():
     kt = model._ctx.kernel_times()
     model._ctx.call("btf_set_profiling", 0)
 
+    # full Gibbs sweep (nu2, sigma2, Tau2, lam2, W, V) - device Tau2 chain, host scalar draws
+    nfull = max(10, min(args.steps, 100))
+    for _ in range(3):
+        model.resample(data)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(nfull):
+        model.resample(data)
+    fence()
+    full_per_s = nfull / (time.perf_counter() - t0)
+
     sweeps_per_s = args.steps / dt
     units = world if weak else 1
     value = sweeps_per_s * units
@@ -222,6 +233,7 @@ def main():
                                % ("binomial" if args.variant == "binomial" else "gaussian", args.config, N, M, T, R, K, args.variant,
                                   "; %d-way row/column shards, RCCL all-gather of W and V" % world if world > 1 else ""),
                    "global_sweeps_per_s": round(sweeps_per_s, 2), "units_per_sweep": units,
+                   "full_resample_sweeps_per_s": round(full_per_s, 2),
                    "parallelism": "rows(W)/cols(V) x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "accum_kernel (w_accum + v_accum launches)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

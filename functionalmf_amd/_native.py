@@ -43,6 +43,9 @@ SIGNATURES = {
     "btf_set_V": (C.c_int, [_ctx, _c_dp]),
     "btf_get_V": (C.c_int, [_ctx, _c_dp]),
     "btf_set_hyper": (C.c_int, [_ctx, _c_dp, C.c_double, C.c_double]),
+    "btf_set_tau_chain": (C.c_int, [_ctx, _c_dp, _c_dp, _c_dp]),
+    "btf_get_tau": (C.c_int, [_ctx, _c_dp, _c_dp, _c_dp, _c_dp]),
+    "btf_resample_Tau2": (C.c_int, [_ctx, C.c_uint64, C.c_double, C.c_double, _c_dp]),
     "btf_set_nu2": (C.c_int, [_ctx, C.c_double]),
     "btf_set_omega": (C.c_int, [_ctx, _c_dp, _c_dp]),
     "btf_get_omega": (C.c_int, [_ctx, _c_dp]),

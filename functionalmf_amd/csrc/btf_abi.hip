@@ -57,6 +57,9 @@ struct btf_ctx {
   int banded_variant = 2;   // 2: twisted two-chain kernel (default), 1: single chain, 0: wave-specialised pipeline (experimental)
   long long* dbg = nullptr;
   double* pband = nullptr; bool pband_dirty = true;
+  double* Ta = nullptr; double* Tb = nullptr; double* Tc = nullptr; double* lsum = nullptr;   // horseshoe+ chain (device mode)
+  int* dr_ptr = nullptr; int* dr_col = nullptr; double* dr_val = nullptr;                   // Delta, CSR by row
+  bool have_chain = false;
   double* gpart_w = nullptr; int ngp_w = 0;   // W'W partials written by w_solve (valid until W changes otherwise)
   double* gpart_v = nullptr; int ngp_v = 0;   // V'V partials written by the fast banded sampler
   bool fuse_gram = true;
@@ -178,6 +181,22 @@ int build_stencil(btf_ctx* c) {
         }
       ptr[t * D1 + d + 1] = (int)row.size();
     }
+  {  // Delta itself, CSR by row (device Tau2 update)
+    std::vector<int> rp(nD + 1, 0), rc;
+    std::vector<double> rv;
+    for (int r = 0; r < nD; ++r) {
+      for (int t = 0; t < T; ++t)
+        if (Delta[(size_t)r * T + t] != 0.0) { rc.push_back(t); rv.push_back(Delta[(size_t)r * T + t]); }
+      rp[r + 1] = (int)rc.size();
+    }
+    int rc2;
+    if ((rc2 = dev_alloc(c, &c->dr_ptr, rp.size()))) return rc2;
+    if ((rc2 = dev_alloc(c, &c->dr_col, rc.size()))) return rc2;
+    if ((rc2 = dev_alloc(c, &c->dr_val, rv.size()))) return rc2;
+    HIPCHK(c, hipMemcpy(c->dr_ptr, rp.data(), rp.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dr_col, rc.data(), rc.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dr_val, rv.data(), rv.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   // sanity: nothing outside the band
   for (int r = 0; r < nD; ++r) {
     int lo = T, hi = -1;
@@ -536,7 +555,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->WW, c->VV, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -679,6 +698,58 @@ int btf_set_hyper(btf_ctx* c, const double* Tau2, double lam2, double sigma2) {
   c->lam2 = lam2; c->sigma2 = sigma2;
   return BTF_OK;
 }
+int btf_set_tau_chain(btf_ctx* c, const double* Ta, const double* Tb, const double* Tc) {
+  if (!c || !Ta || !Tb || !Tc) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  const size_t n = (size_t)c->M * c->nD;
+  int rc;
+  if (!c->Ta) {
+    if ((rc = dev_alloc(c, &c->Ta, n))) return rc;
+    if ((rc = dev_alloc(c, &c->Tb, n))) return rc;
+    if ((rc = dev_alloc(c, &c->Tc, n))) return rc;
+    if ((rc = dev_alloc(c, &c->lsum, (size_t)c->M))) return rc;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->Ta, Ta, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->Tb, Tb, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->Tc, Tc, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_chain = true;
+  return BTF_OK;
+}
+
+int btf_get_tau(btf_ctx* c, double* Tau2, double* Ta, double* Tb, double* Tc) {
+  if (!c || !Tau2) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  const size_t n = (size_t)c->M * c->nD * sizeof(double);
+  HIPCHK(c, hipMemcpyAsync(Tau2, c->Tau2, n, hipMemcpyDeviceToHost, c->stream));
+  if (Ta && c->Ta) {
+    HIPCHK(c, hipMemcpyAsync(Ta, c->Ta, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(Tb, c->Tb, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(Tc, c->Tc, n, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return BTF_OK;
+}
+
+int btf_resample_Tau2(btf_ctx* c, uint64_t seed, double lam2, double stability, double* lsum_out) {
+  if (!c || !(lam2 > 0.0) || !(stability > 0.0)) return fail(c, BTF_EINVAL, "bad Tau2 update arguments");
+  if (!c->have_V || !c->have_hyper || !c->have_chain) return fail(c, BTF_ESTATE, "set V, Tau2 and the horseshoe+ chain first");
+  HIPCHK(c, hipSetDevice(c->dev));
+  {
+    Prof p(c, BTF_K_PROD);
+    p.launch(tau2_kernel, dim3(c->M), dim3(256), 0, (const double*)c->V, c->T, c->K, c->nD, (const int*)c->dr_ptr,
+             (const int*)c->dr_col, (const double*)c->dr_val, lam2, stability, 1.0 / stability, c->Tau2, c->Ta, c->Tb,
+             c->Tc, c->lsum, (unsigned long long)seed);
+  }
+  HIPCHK(c, hipGetLastError());
+  c->pband_dirty = true;
+  if (lsum_out) {
+    HIPCHK(c, hipMemcpyAsync(lsum_out, c->lsum, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return BTF_OK;
+}
+
 int btf_set_nu2(btf_ctx* c, double nu2) {
   if (!c || !(nu2 > 0.0)) return fail(c, BTF_EINVAL, "nu2 must be positive");
   c->nu2 = nu2;

@@ -960,4 +960,46 @@ __global__ void pg_batch_kernel(const double* b, const double* psi, double* out,
   out[i] = pg_draw(b[i], psi[i], g);
 }
 
+// ============================================================================
+// Horseshoe+ local scales on the device (rng="device")
+//   factor.py:134-141 for every (column j, penalty row r), elementwise:
+//     rate = sum_k (Delta V_j)[r,k]^2 / (2 lam2) + 1/clip(c);  Tau2 = 1/Gamma((K+1)/2, 1/clip(rate))
+//     c = 1/Gamma(1, 1/clip(1/Tau2 + 1/b)); b = 1/Gamma(1, 1/clip(1/c + 1/a)); a = 1/Gamma(1, 1/clip(1/b + 1))
+//   plus the per-column sums  lsum[j] = sum_r dsq[j,r] / Tau2_new[j,r]  that the lam2 update needs
+//   (factor.py:148-150).  One workgroup per column; Philox keyed by (seed, j*nD + r).
+// ============================================================================
+__global__ __launch_bounds__(256) void tau2_kernel(const double* __restrict__ V, int T, int K, int nD,
+                                                   const int* __restrict__ dr_ptr, const int* __restrict__ dr_col,
+                                                   const double* __restrict__ dr_val, double lam2, double lo, double hi,
+                                                   double* __restrict__ Tau2, double* __restrict__ Ta,
+                                                   double* __restrict__ Tb, double* __restrict__ Tc,
+                                                   double* __restrict__ lsum, unsigned long long seed) {
+  __shared__ double red[4];
+  const int j = blockIdx.x;
+  const double* Vj = V + (size_t)j * T * K;
+  double acc = 0.0;
+  for (int r = threadIdx.x; r < nD; r += blockDim.x) {
+    double dsq = 0.0;
+    for (int k = 0; k < K; ++k) {
+      double d = 0.0;
+      for (int e = dr_ptr[r]; e < dr_ptr[r + 1]; ++e) d = fma(dr_val[e], Vj[(size_t)dr_col[e] * K + k], d);
+      dsq = fma(d, d, dsq);
+    }
+    const size_t o = (size_t)j * nD + r;
+    CellRng g(seed, (unsigned long long)o);
+    auto clip = [&](double x) { return fmin(fmax(x, lo), hi); };
+    const double rate = dsq / (2.0 * lam2) + 1.0 / clip(Tc[o]);
+    const double tau = clip(rate) / gamma_mt(0.5 * (K + 1), g);
+    const double c = clip(1.0 / tau + 1.0 / Tb[o]) / g.expo();
+    const double b = clip(1.0 / c + 1.0 / Ta[o]) / g.expo();
+    const double a = clip(1.0 / b + 1.0) / g.expo();
+    Tau2[o] = tau; Tc[o] = c; Tb[o] = b; Ta[o] = a;
+    acc += dsq / tau;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) lsum[j] = red[0] + red[1] + red[2] + red[3];
+}
+
 }  // namespace btf

@@ -182,16 +182,40 @@ class BayesianTensorFiltering(_BayesianModel):
         self._V = np.array(value, dtype=float)
         self._V_host_new, self._V_dev_new = True, False
 
-    # Tau2 is handed out the same way: any access may be followed by an in-place write
+    # Tau2 (and, in rng="device" mode, its three auxiliary horseshoe+ levels) are handed out the
+    # same way: refreshed from the GPU if a kernel wrote them, pushed back before the next kernel
+    # because any access may be followed by an in-place write.
+    def _pull_tau(self):
+        if getattr(self, "_tau_dev_new", False):
+            self._ctx.call("btf_get_tau", _native.dptr(self._Tau2), _native.dptr(self._Tau2_a),
+                           _native.dptr(self._Tau2_b), _native.dptr(self._Tau2_c))
+            self._tau_dev_new = False
+
     @property
     def Tau2(self):
+        self._pull_tau()
         self._tau_dirty = True
+        self._lsum_valid = False
         return self._Tau2
 
     @Tau2.setter
     def Tau2(self, value):
         self._Tau2 = value
         self._tau_dirty = True
+        self._tau_dev_new = False
+
+    def _chain_get(self, name):
+        self._pull_tau()
+        self._chain_dirty = True
+        return getattr(self, name)
+
+    def _chain_set(self, name, value):
+        setattr(self, name, value)
+        self._chain_dirty = True
+
+    Tau2_a = property(lambda self: self._chain_get("_Tau2_a"), lambda self, v: self._chain_set("_Tau2_a", v))
+    Tau2_b = property(lambda self: self._chain_get("_Tau2_b"), lambda self, v: self._chain_set("_Tau2_b", v))
+    Tau2_c = property(lambda self: self._chain_get("_Tau2_c"), lambda self, v: self._chain_set("_Tau2_c", v))
 
     def _pull_W(self):
         if self._W_dev_new:
@@ -212,7 +236,7 @@ class BayesianTensorFiltering(_BayesianModel):
             self._V = _native.as_f64(self._V)
             self._ctx.call("btf_set_V", _native.dptr(self._V))
             self._V_host_new = False
-        if self._tau_dirty:
+        if self._tau_dirty and not getattr(self, "_tau_dev_new", False):
             self._Tau2 = _native.as_f64(self._Tau2)
             self._ctx.call("btf_set_hyper", _native.dptr(self._Tau2), _scalar(self.lam2), _scalar(self.sigma2))
             self._tau_dirty = False
@@ -321,9 +345,27 @@ class BayesianTensorFiltering(_BayesianModel):
         d = np.einsum("rt,mtk->mrk", self.Delta.toarray(), self._V)
         return (d * d).sum(axis=2)
 
+    def _resample_Tau2_device(self):
+        """rng="device": all columns at once on the GPU (Philox gamma draws); also leaves the
+        per-column terms of the lam2 rate in self._lsum."""
+        self._push_state()
+        if getattr(self, "_chain_dirty", True):
+            for nm in ("_Tau2_a", "_Tau2_b", "_Tau2_c"):
+                setattr(self, nm, _native.as_f64(getattr(self, nm)))
+            self._ctx.call("btf_set_tau_chain", _native.dptr(self._Tau2_a), _native.dptr(self._Tau2_b),
+                           _native.dptr(self._Tau2_c))
+            self._chain_dirty = False
+        lsum = np.empty(self.ncols)
+        self._ctx.call("btf_resample_Tau2", self._next_seed(), _scalar(self.lam2), float(self.stability),
+                       _native.dptr(lsum))
+        self._lsum, self._lsum_valid = lsum, True
+        self._tau_dev_new, self._tau_dirty = True, False
+
     def _resample_Tau2(self):
         """Horseshoe+ local scales, one column after the other so that the legacy RNG
         stream matches the reference (4 vector gamma draws per column, factor.py:134-141)."""
+        if self.rng == "device" and hasattr(self, "_Tau2_a"):
+            return self._resample_Tau2_device()
         lo, hi = self.stability, 1 / self.stability
         dsq = self._penalised_differences()
         shape = (self.nembeds + 1) / 2
@@ -337,7 +379,10 @@ class BayesianTensorFiltering(_BayesianModel):
     def _resample_lam2(self):
         """Global scale.  compat="reference": the rate keeps only the LAST column's term
         (quirk Q3, factor.py:147-150); "exact": 1/lam2_a plus the sum over columns."""
-        terms = (self._penalised_differences() / self.Tau2).sum(axis=1) / 2
+        if self.rng == "device" and getattr(self, "_lsum_valid", False):
+            terms = self._lsum / 2          # from the device Tau2 update of this sweep
+        else:
+            terms = (self._penalised_differences() / self.Tau2).sum(axis=1) / 2
         rate = terms[-1] if self.compat == "reference" else 1 / self.lam2_a + terms.sum()
         shape = self.Delta.shape[0] * self.ncols * self.nembeds + 1
         self.lam2 = max(1e-5, 1 / np.random.gamma(shape / 2, 1 / rate))
@@ -383,6 +428,7 @@ class BayesianTensorFiltering(_BayesianModel):
                        float(o["force_psd_eps"]), int(o["force_psd_attempts"]) if o["force_psd"] else 0)
         self._exchange.after_V()
         self._V_dev_new = True
+        self._lsum_valid = False
 
     def v_order(self):
         """Elimination order of the V half-sweep's factorisation as depth-major indices t*K+k

@@ -102,6 +102,15 @@ int btf_get_W(btf_ctx* ctx, double* W);
 int btf_set_V(btf_ctx* ctx, const double* V);            /* (M,T,K)    */
 int btf_get_V(btf_ctx* ctx, double* V);
 int btf_set_hyper(btf_ctx* ctx, const double* Tau2 /* (M,nD) */, double lam2, double sigma2);
+/* Horseshoe+ local scales on the device (rng="device" only - the draws
+ * come from Philox, not from the legacy numpy stream).  btf_set_tau_chain uploads the three
+ * auxiliary levels Tau2_a/b/c (M,nD); btf_resample_Tau2 replaces the per-column loop of
+ * BTF._resample_Tau2 (factor.py:134-141) for all columns at once, updating Tau2 and the chain
+ * in place on the device, and returns lsum[j] = sum_r dsq[j,r]/Tau2_new[j,r] (the per-column
+ * terms of the lam2 rate, factor.py:148-150) when lsum_out != NULL (synchronises).          */
+int btf_set_tau_chain(btf_ctx* ctx, const double* Tau2_a, const double* Tau2_b, const double* Tau2_c);
+int btf_get_tau(btf_ctx* ctx, double* Tau2, double* Tau2_a, double* Tau2_b, double* Tau2_c); /* a,b,c may be NULL */
+int btf_resample_Tau2(btf_ctx* ctx, uint64_t seed, double lam2, double stability, double* lsum_out /* (M) or NULL */);
 int btf_set_nu2(btf_ctx* ctx, double nu2);               /* Gaussian scalar noise variance */
 int btf_set_omega(btf_ctx* ctx, const double* omega_rows, const double* omega_cols); /* Binomial: PG draws, slabs as data */
 int btf_get_omega(btf_ctx* ctx, double* omega_rows);     /* (nrows_local,M,T) */

@@ -402,3 +402,67 @@ def test_fused_gram_path_complete_data(golden):
     model._resample_W(g["Y"])                 # V'V fused into the banded sampler
     orc.w_step(ost, g["Y"], z=z)
     assert relerr(model.W, ost["W"]) < W_TOL
+
+
+def test_device_tau2_update_has_the_right_conditionals():
+    """rng='device': the horseshoe+ chain is drawn on the GPU (Philox).  Check every level
+    against its analytic conditional mean given the values it was drawn from."""
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    rs = np.random.RandomState(0)
+    N, M, T, K = 8, 400, 40, 3
+    V = 0.3 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    np.random.seed(1)
+    model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=1.0, lam2_init=0.4,
+                                            nu2_init=1.0, V_init=V, rng="device", device_seed=3)
+    a0, b0, c0 = model.Tau2_a.copy(), model.Tau2_b.copy(), model.Tau2_c.copy()
+    lo, hi = 1e-6, 1e6
+    D = model.Delta.toarray()
+    dsq = (np.einsum("rt,mtk->mrk", D, V) ** 2).sum(-1)
+    model._resample_Tau2()
+    tau, a, b, c = model.Tau2.copy(), model.Tau2_a.copy(), model.Tau2_b.copy(), model.Tau2_c.copy()
+    n = tau.size
+
+    def zscore(x, mean, var):
+        return (x - mean).sum() / np.sqrt(var.sum())
+    shape = (K + 1) / 2
+    rate = np.clip(dsq / (2 * 0.4) + 1 / np.clip(c0, lo, hi), lo, hi)
+    assert abs(zscore(1 / tau * rate, shape, np.full(n, shape))) < 5           # 1/tau ~ Gamma(shape, 1/rate)
+    x = np.clip(1 / tau + 1 / b0, lo, hi)
+    assert abs(zscore(x / c, 1.0, np.ones(n))) < 5                              # x/c ~ Exp(1)
+    x = np.clip(1 / c + 1 / a0, lo, hi)
+    assert abs(zscore(x / b, 1.0, np.ones(n))) < 5
+    x = np.clip(1 / b + 1, lo, hi)
+    assert abs(zscore(x / a, 1.0, np.ones(n))) < 5
+    assert relerr(model._lsum, (dsq / tau).sum(1)) < 1e-12
+    # the V step that follows must see the new Tau2 (prior band refreshed)
+    Y = rs.normal(size=(N, M, T))
+    model._resample_V(Y)
+    model.sync()
+    assert np.all(np.isfinite(model.V))
+
+
+def test_device_mode_chain_matches_host_mode_statistically():
+    """End to end in rng='device' mode (device normals + device horseshoe+ chain) against
+    rng='host' on the same problem.  lam2 and sigma2 are held fixed: with both free the model's
+    own scale feedback (lam2 collapsing to its floor, SURVEY hard part 2) makes single chains too
+    erratic to compare.  Bounds are ~3x the chain-to-chain spread seen over seeds."""
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    rs = np.random.RandomState(5)
+    N, M, T, R, K = 30, 12, 16, 3, 3
+    Wt = rs.normal(size=(N, K))
+    Vt = 0.4 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    Mu = np.einsum("nk,mtk->nmt", Wt, Vt)
+    Y = Mu[..., None] + rs.normal(0, 0.5, size=(N, M, T, R))
+    out = {}
+    for mode in ("device", "host"):
+        np.random.seed(6)
+        model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_true=1.0, lam2_true=0.05,
+                                                nu2_init=1.0, rng=mode, compat="exact", device_seed=6)
+        res = model.run_gibbs(Y, nburn=300, nthin=2, nsamples=200, verbose=False)
+        Mu_hat = np.einsum("znk,zmtk->znmt", res["W"], res["V"]).mean(0)
+        out[mode] = (res["nu2"].mean(), np.log(res["Tau2"]).mean(), np.sqrt(((Mu_hat - Mu) ** 2).mean()),
+                     np.corrcoef(Mu_hat.reshape(-1), Mu.reshape(-1))[0, 1])
+        assert out[mode][3] > 0.985, (mode, out[mode])
+        assert 0.24 < out[mode][0] < 0.36, (mode, out[mode])
+    d, h = out["device"], out["host"]
+    assert abs(d[0] - h[0]) < 0.05 and abs(d[1] - h[1]) < 1.2 and abs(d[2] - h[2]) / h[2] < 0.3, out
