@@ -982,7 +982,16 @@ int btf_pg_draw(btf_ctx* c, uint64_t seed) {
   if (!c->have_data || !c->binomial || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_pg_draw needs binomial data, W and V");
   HIPCHK(c, hipSetDevice(c->dev));
   const unsigned long long MT = (unsigned long long)c->M * c->T;
-  // every cell is drawn once per layout from the same (seed, cell) stream: identical values
+  if (c->nl == c->N && c->ml == c->M) {   // unsharded: one pass, both layouts (LDS tile transpose)
+    Prof p(c, BTF_K_PG);
+    dim3 grid((unsigned)((MT + 63) / 64), (unsigned)((c->N + 63) / 64));
+    K_SWITCH(c->K, p.launch(pg_tile_kernel<KT>, grid, dim3(256), 0, (const double*)c->B_v, c->C_v, c->C_wT,
+                            (const double*)c->W, (const double*)c->V, c->N, (int)MT, c->ldv, c->ldw,
+                            (unsigned long long)seed));
+    HIPCHK(c, hipGetLastError());
+    return BTF_OK;
+  }
+  // sharded: every cell is drawn once per layout from the same (seed, cell) stream: identical values
   if (c->nl > 0) {  // W layout [jt][i_local]: lanes = rows of W, reduction axis = (j,t)
     K_SWITCH(c->K, launch_pg<KT>(c, c->B_wT, c->C_wT, c->W + (size_t)c->row0 * c->K, c->V, c->nl, c->ldw, (int)MT,
                                  (unsigned long long)c->row0 * MT, 1ULL, MT, seed));

@@ -809,7 +809,8 @@ __device__ inline double log_ncdf(double x) {
 __device__ inline double pg_a(int n, double x) {
   const double Kc = (n + 0.5) * PG_PI;
   if (x > PG_T) return Kc * exp(-0.5 * Kc * Kc * x);
-  return exp(-1.5 * (log(0.5 * PG_PI) + log(x)) + log(Kc) - 2.0 * (n + 0.5) * (n + 0.5) / x);
+  const double r = 2.0 / (PG_PI * x);                       // (2/(pi x))^(3/2) without logarithms
+  return Kc * r * sqrt(r) * exp(-2.0 * (n + 0.5) * (n + 0.5) / x);
 }
 
 // probability of the exponential (right) piece of the proposal
@@ -949,6 +950,46 @@ __global__ __launch_bounds__(PG_THREADS) void pg_kernel(const double* __restrict
     const double b = B[(size_t)r * ld + l];
     CellRng g(seed, base + (unsigned long long)r * stride_r + (unsigned long long)l * stride_l);
     out[(size_t)r * ld + l] = pg_draw(b, psi, g);
+  }
+}
+
+// One-pass variant for an unsharded context: every cell is drawn once (lanes along (j,t)),
+// written to the V-layout array directly and to the W-layout array through an LDS tile
+// transpose.  Same (seed, cell) streams as pg_kernel, hence identical draws.
+template <int K>
+__global__ __launch_bounds__(256) void pg_tile_kernel(const double* __restrict__ Bv, double* __restrict__ Cv,
+                                                     double* __restrict__ CwT, const double* __restrict__ W,
+                                                     const double* __restrict__ V, int N, int MT, int ldv, int ldw,
+                                                     unsigned long long seed) {
+  __shared__ double tile[64][65];
+  const int col = threadIdx.x & 63;
+  const int rgrp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int jt0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+  const int jt = jt0 + col;
+  const bool vc = jt < MT;
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = vc ? V[(size_t)jt * K + k] : 0.0;
+  for (int q = 0; q < 16; ++q) {
+    const int r = rgrp + 4 * q, i = i0 + r;               // wave-uniform
+    double om = 0.0;
+    if (i < N) {
+      const double* __restrict__ w = W + (size_t)i * K;
+      double psi = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) psi = fma(w[k], v[k], psi);
+      const double b = vc ? Bv[(size_t)i * ldv + jt] : 0.0;
+      CellRng g(seed, (unsigned long long)i * MT + jt);
+      om = pg_draw(b, psi, g);
+      if (vc) Cv[(size_t)i * ldv + jt] = om;
+    }
+    tile[r][col] = om;
+  }
+  __syncthreads();
+  const int i = i0 + col;                                  // now lanes run along the rows
+  for (int q = 0; q < 16; ++q) {
+    const int c = rgrp + 4 * q, jj = jt0 + c;
+    if (jj < MT && i < N) CwT[(size_t)jj * ldw + i] = tile[col][c];
   }
 }
 
