@@ -415,14 +415,14 @@ class BayesianTensorFiltering(_BayesianModel):
 
     def _device_W_step(self):
         self._push_state()
-        z = self._w_normals()
+        z = self._keep_w = self._w_normals()     # kept alive until replaced: the upload is stream-ordered
         self._ctx.call("btf_resample_W", _native.dptr(z), self._next_seed(), _native.COMPAT[self.compat])
         self._exchange.after_W()
         self._W_dev_new = True
 
     def _device_V_step(self):
         self._push_state()
-        z = self._v_normals()
+        z = self._keep_v = self._v_normals()
         o = self.linalg_opts
         self._ctx.call("btf_resample_V", _native.dptr(z), self._next_seed(), _native.COMPAT[self.compat],
                        float(o["force_psd_eps"]), int(o["force_psd_attempts"]) if o["force_psd"] else 0)

@@ -496,3 +496,78 @@ def pg_draw_series(b, c, size, rng, nterms=256):
     kk = np.arange(nterms + 1, nterms + 200001)
     tail = (b / ((kk - 0.5) ** 2 + (c * c) / (4 * np.pi ** 2))).sum()
     return (x + tail) / (2 * np.pi ** 2)
+
+
+# --------------------------------------------------------------------------
+# "strong" CPU path: same conditionals, restructured for
+# the CPU - statistics hoisted, BLAS for the Gram / mean accumulation, banded
+# LAPACK per column.  Complete Gaussian data only (the headline workload).
+# Used by bench.py as the second CPU number; validated against w_step / v_step
+# in tests/test_oracle_golden.py.
+# --------------------------------------------------------------------------
+
+def hoisted_stats(Y):
+    """cnt, sum over replicates - computed once, outside the sweep."""
+    cnt, ybar = replicate_stats(Y)
+    if np.isnan(ybar).any() or (cnt != cnt.flat[0]).any():
+        raise ValueError("strong CPU path: complete data only")
+    return int(cnt.flat[0]), ybar
+
+
+def w_step_strong(st, R, ybar, z=None):
+    W, V = st["W"], st["V"]
+    N, K = W.shape
+    Vf = V.reshape(-1, K)
+    s = R / st["nu2"]
+    G = s * (Vf.T @ Vf)
+    Mpart = s * (ybar.reshape(N, -1) @ Vf)                       # (N,K)   one GEMM
+    nz = sum(min(i + 1, K) for i in range(N))
+    if z is None:
+        z = np.random.normal(size=nz)
+    zpos = 0
+    for i in range(min(N, K)):                                    # triangular head
+        d = i + 1
+        L = np.linalg.cholesky(G[:d, :d] + np.eye(d) / st["sigma2"])
+        W[i, :d] = sla.cho_solve((L, True), Mpart[i, :d]) + sla.solve_triangular(L.T, z[zpos:zpos + d], lower=False)
+        zpos += d
+    if N > K:                                                     # all other rows share one factor
+        L = np.linalg.cholesky(G + np.eye(K) / st["sigma2"])
+        Z = z[zpos:].reshape(N - K, K)
+        W[K:] = sla.cho_solve((L, True), Mpart[K:].T).T + sla.solve_triangular(L.T, Z.T, lower=False).T
+    return W
+
+
+def v_step_strong(st, R, ybar, Delta, z=None):
+    """Depth-major banded Cholesky per column (scipy.linalg.cholesky_banded)."""
+    W, V = st["W"], st["V"]
+    M, T, K = V.shape
+    N = W.shape[0]
+    s = R / st["nu2"]
+    G = s * (W.T @ W)                                             # shared likelihood block
+    mu = s * np.einsum("nk,nmt->mtk", W, ybar)                    # (M,T,K) depth-major
+    tf1 = int(np.max(np.abs(np.subtract(*np.nonzero(Delta.T @ Delta)))))    # tf+1
+    bw = tf1 * K
+    n = T * K
+    if z is None:
+        z = np.random.normal(size=(M, n))
+    DtD = [Delta[:, :T - d] * Delta[:, d:] for d in range(tf1 + 1)]         # (nD, T-d) coefficient products
+    kk = np.arange(K)
+    for j in range(M):
+        lam = 1.0 / (st["lam2"] * st["Tau2"][j])
+        ab = np.zeros((bw + 1, n))                                # lower form: ab[i-j, j] = A[i, j]
+        for d in range(tf1 + 1):
+            pd = lam @ DtD[d]                                     # prior band entry (t+d, t)
+            for k in range(K):
+                ab[d * K, k:(T - d) * K:K] += pd
+        for a in range(K):                                        # likelihood block on every depth
+            for k in range(K - a):
+                ab[a, k::K] += G[k + a, k]
+        cb = sla.cholesky_banded(ab, lower=True)
+        y = sla.cho_solve_banded((cb, True), mu[j].reshape(-1))
+        # L' x = z  with L lower banded: L' is upper banded
+        up = np.zeros_like(cb)
+        for a in range(bw + 1):
+            up[bw - a, a:] = cb[a, :n - a]
+        x = sla.solve_banded((0, bw), up, z[j])
+        V[j] = (y + x).reshape(T, K)
+    return V

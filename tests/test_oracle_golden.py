@@ -175,3 +175,16 @@ def test_pg_series_sampler_moments():
         m, v = orc.pg_mean(b, c), orc.pg_var(b, c)
         assert abs(x.mean() - m) < 5 * np.sqrt(v / x.size)
         assert abs(x.var() - v) / v < 0.08
+
+
+def test_strong_cpu_path_equals_reference_faithful_path(golden):
+    """The vectorised / banded-LAPACK CPU baseline computes the same draws (depth-major order)."""
+    g = golden("g2_c2_complete.npz")
+    N, M, T, R, K, tf = [int(x) for x in g["dims"]]
+    Delta = orc.trend_penalty(T, tf)
+    Rr, ybar = orc.hoisted_stats(g["Y"])
+    st = state_from(g, "s0_")
+    W = orc.w_step_strong(st, Rr, ybar, z=g["z_W"])
+    assert relerr(W, g["W_after"]) < 1e-11
+    V = orc.v_step_strong(st, Rr, ybar, Delta, z=g["z_V"])
+    assert relerr(V, g["V_after_depth"]) < 1e-6
