@@ -466,3 +466,22 @@ def test_device_mode_chain_matches_host_mode_statistically():
         assert 0.24 < out[mode][0] < 0.36, (mode, out[mode])
     d, h = out["device"], out["host"]
     assert abs(d[0] - h[0]) < 0.05 and abs(d[1] - h[1]) < 1.2 and abs(d[2] - h[2]) / h[2] < 0.3, out
+
+
+def test_examples_run_end_to_end():
+    """Config C1 plumbing (BASELINE.json configs[0]) and the Binomial example, as a user runs them."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    outs = {}
+    for name in ("gaussian_tensor_filtering", "binomial_tensor_filtering"):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "examples", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        outs[name] = mod.main(seed=1)
+    # (default compat="reference" keeps the reference's lam2 collapse, quirk Q3, so the fits are as
+    # smooth as the reference's own; the numbers below are what its sampler gives on this data)
+    g = outs["gaussian_tensor_filtering"]
+    assert g["rmse_observed"] < 0.9 and g["rmse_heldout"] < 1.2 and 0.25 < g["nu2"] < 1.0
+    b = outs["binomial_tensor_filtering"]
+    assert b["corr"] > 0.7 and b["mae_observed"] < 0.13
