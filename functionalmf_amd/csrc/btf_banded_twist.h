@@ -111,6 +111,12 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     for (; c < a.nch; ++c) s += p[(size_t)c * st];
     return s;
   };
+  double pb_reg[4];                                        // prior band of this column: loaded now, stored later
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + u * VT_THREADS;
+    pb_reg[u] = idx < T * D1 ? a.pband[(size_t)j * T * D1 + idx] : 0.0;
+  }
   for (int idx = tid; idx < n; idx += VT_THREADS) {
     const int t = idx / K, k = idx - t * K;
     m0[idx] = chunk_sum(a.part + (size_t)k * a.ld + (size_t)j * T + t) * a.s;
@@ -123,7 +129,12 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   } else {
     reduce_gram(a.gpart, a.ngp, KK, a.sR, lds + W.L.band, Ql);
   }
-  for (int idx = tid; idx < T * D1; idx += VT_THREADS) P[idx] = a.pband[(size_t)j * T * D1 + idx];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + u * VT_THREADS;
+    if (idx < T * D1) P[idx] = pb_reg[u];
+  }
+  for (int idx = tid + 4 * VT_THREADS; idx < T * D1; idx += VT_THREADS) P[idx] = a.pband[(size_t)j * T * D1 + idx];
   // static zero regions of the three views: pads, scratch rows, dummy words
   {
     const VbLayout* views[3] = {&W.L, &W.R, &W.S};
@@ -161,55 +172,65 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     // ---- assemble the two bands -------------------------------------------------------------
     // left view: index i = g, rows/cols < nl+ns.  right view: index m = n-1-g (mirrored), rows/cols
     // >= nl, and its separator-by-separator block left at zero (it is counted once, on the left).
-    // (one band column per thread; (t,k) of the moving row / column tracked incrementally: no divisions)
-    for (int idx = tid; idx < W.L.npad + W.R.npad; idx += VT_THREADS) {
-      if (idx < W.L.npad) {
-        const int i = idx;                              // column g = i, rows g+aa
-        double* colw = lds + W.L.band + (size_t)i * R1;
-        if (i >= nL) {
-          for (int aa = 0; aa < R1; ++aa) colw[aa] = 0.0;
-          continue;
+    // Only K-k (same depth block) + tf+1 (prior couplings) of the bw+1 entries of a band column
+    // are non-zero: clear both bands with wide stores, then write just those.  LS lanes per
+    // column (lane = slot), VT_THREADS/LS columns per pass; no divisions inside the loops.
+    {
+      double2* zb = reinterpret_cast<double2*>(lds + W.L.band);      // L and R bands (and what lies between) are contiguous
+      const int nz2 = (W.R.band + W.R.npad * R1 - W.L.band + 1) / 2;
+      for (int idx = tid; idx < nz2; idx += VT_THREADS) zb[idx] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    {
+      const int NS = K + D1 - 1;                          // slots: K same-block offsets, then d = 1..tf+1
+      const int LS = NS <= 8 ? 8 : 16;
+      const int CPP = VT_THREADS / LS;
+      const int slot = tid % LS, grp = tid / LS;
+      const bool same_blk = slot < K;
+      const int dslot = slot - K + 1;                      // prior coupling distance for slot >= K
+      const int aa = same_blk ? slot : dslot * K;
+      const bool slot_on = slot < NS;
+      const int stepk = CPP % K, stept = CPP / K;
+      {  // left view: column i (global g = i), entry (g+aa, g)
+        int t = grp / K, k = grp - t * K;
+        for (int i = grp; i < nL; i += CPP) {
+          if (slot_on && i + aa < nL) {
+            double v = 0.0;
+            bool put = false;
+            if (same_blk) {
+              if (aa < K - k) {
+                v = (a.weighted ? Ql + t * KK : Ql)[lidx(k + aa, k)];
+                if (aa == 0) v += P[t * D1] + shift;
+                put = true;
+              }
+            } else if (t + dslot < T) {
+              v = P[t * D1 + dslot];
+              put = true;
+            }
+            if (put) lds[W.L.band + i * R1 + aa] = v;
+          }
+          k += stepk; t += stept;
+          if (k >= K) { k -= K; ++t; }
         }
-        const int t = i / K, k = i - t * K;
-        const double* q = a.weighted ? Ql + t * KK : Ql;
-        int dd = 0, rem = 0;                            // aa = dd*K + rem
-        for (int aa = 0; aa < R1; ++aa) {
-          double v = 0.0;
-          if (i + aa < nL) {
-            if (aa < K - k) {
-              v = q[lidx(k + aa, k)];
-              if (aa == 0) v += P[t * D1] + shift;
-            } else if (rem == 0 && dd < D1 && t + dd < T) {
-              v = P[t * D1 + dd];
+      }
+      {  // right view: mirrored column m (global gc = n-1-m), entry (gc, gc-aa)
+        const int g0 = n - 1 - grp;
+        int tc = g0 >= 0 ? g0 / K : 0, kc = g0 >= 0 ? g0 - tc * K : 0;
+        for (int m = grp; m < nr; m += CPP) {
+          const int gc = n - 1 - m;
+          if (slot_on && gc - aa >= nl) {
+            if (same_blk) {
+              if (aa <= kc) {                              // row (tc, kc-aa): same depth block
+                double v = (a.weighted ? Ql + tc * KK : Ql)[lidx(kc, kc - aa)];
+                if (aa == 0) v += P[tc * D1] + shift;
+                lds[W.R.band + m * R1 + aa] = v;
+              }
+            } else {
+              lds[W.R.band + m * R1 + aa] = P[(tc - dslot) * D1 + dslot];   // row (tc-d, kc)
             }
           }
-          colw[aa] = v;
-          if (++rem == K) { rem = 0; ++dd; }
-        }
-      } else {
-        const int m = idx - W.L.npad;                   // mirrored column: global gc = n-1-m, rows gc-aa
-        double* colw = lds + W.R.band + (size_t)m * R1;
-        if (m >= nr) {
-          for (int aa = 0; aa < R1; ++aa) colw[aa] = 0.0;
-          continue;
-        }
-        const int gc = n - 1 - m;
-        int tr = gc / K, kr = gc - tr * K;              // (t,k) of the row gr = gc - aa, walking down
-        const int kc = kr;
-        int dd = 0, rem = 0;
-        for (int aa = 0; aa < R1; ++aa) {
-          double v = 0.0;
-          if (gc - aa >= nl) {                          // entry (gr+aa, gr) = (gc, gr)
-            if (aa <= kc) {                             // same depth block: aa < K - kr  <=>  kr + aa = kc < K, tr == tc
-              v = (a.weighted ? Ql + tr * KK : Ql)[lidx(kc, kr)];
-              if (aa == 0) v += P[tr * D1] + shift;
-            } else if (rem == 0 && dd < D1) {
-              v = P[tr * D1 + dd];
-            }
-          }
-          colw[aa] = v;
-          if (++rem == K) { rem = 0; ++dd; }
-          if (--kr < 0) { kr = K - 1; --tr; }
+          kc -= stepk; tc -= stept;
+          if (kc < 0) { kc += K; --tc; }
         }
       }
     }
