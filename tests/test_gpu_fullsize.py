@@ -1,0 +1,99 @@
+"""Parity at BASELINE.json's full headline size (512,256,64,4) K=5: the half-sweeps against the
+vectorised CPU oracle (validated against the reference fixtures in test_oracle_golden.py) from
+identical state and normals, plus size-independent properties (linearity of the conditional
+means in the data, order-invariance of the mean term).  Needs an MI355X."""
+import numpy as np
+import pytest
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+N, M, T, R, K = 512, 256, 64, 4, 5
+
+
+@pytest.fixture(scope="module")
+def c3():
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    from oracle import btf_oracle as orc
+    rs = np.random.RandomState(1)
+    Wt = rs.normal(size=(N, K))
+    Wt[np.triu_indices(K, 1)] = 0
+    Vt = 0.1 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    Y = np.einsum("nk,mtk->nmt", Wt, Vt)[..., None] + rs.normal(0, 0.5, size=(N, M, T, R))
+    np.random.seed(2)
+    model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, nu2_init=1.0)
+    for _ in range(2):                       # leave the prior draw (host-RNG sweeps)
+        model.resample(Y)
+    Delta = orc.trend_penalty(T, 2)
+    Rr, ybar = orc.hoisted_stats(Y)
+    return model, Y, Delta, Rr, ybar
+
+
+def snapshot(model):
+    return dict(W=model.W.copy(), V=model.V.copy(), Tau2=np.array(model.Tau2, float).copy(), lam2=float(model.lam2),
+                sigma2=float(model.sigma2), nu2=float(model.nu2))
+
+
+def test_full_size_half_sweeps_vs_cpu(c3):
+    from oracle import btf_oracle as orc
+    model, Y, Delta, Rr, ybar = c3
+    model._ctx.call("btf_set_tuning", 0, -2)            # depth-major single-chain kernel: same order as the CPU path
+    st = snapshot(model)
+    np.random.seed(7)
+    zw = np.random.normal(size=K * (K + 1) // 2 + (N - K) * K)
+    zv = np.random.normal(size=(M, K * T))
+    np.random.seed(7)
+    model._resample_W(Y)
+    model._resample_V(Y)
+    orc.w_step_strong(st, Rr, ybar, z=zw)
+    assert relerr(model.W, st["W"]) < 1e-10
+    orc.v_step_strong(st, Rr, ybar, Delta, z=zv)
+    assert relerr(model.V, st["V"]) < 1e-6
+    model._ctx.call("btf_set_tuning", 0, 0)
+
+
+def test_full_size_mean_term_is_order_invariant_and_matches_cpu(c3, monkeypatch):
+    """z = 0: V = Q^-1 mu does not depend on the elimination order - the default twisted kernel
+    must agree with the depth-major CPU solve."""
+    from oracle import btf_oracle as orc
+    model, Y, Delta, Rr, ybar = c3
+    st = snapshot(model)
+    monkeypatch.setattr(model, "_v_normals", lambda: np.zeros((M, K * T)))
+    model._resample_V(Y)
+    orc.v_step_strong(st, Rr, ybar, Delta, z=np.zeros((M, K * T)))
+    assert relerr(model.V, st["V"]) < 1e-6
+
+
+def test_full_size_conditional_means_are_linear_in_the_data(c3, monkeypatch):
+    """With the noise switched off the W and V updates are linear maps of the observations."""
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    model, Y, Delta, Rr, ybar = c3
+    st = snapshot(model)
+    rs = np.random.RandomState(3)
+    Y2 = rs.normal(size=Y.shape)
+    outs = []
+    for data in (Y, Y2, Y + 2.0 * Y2):
+        m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                            nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"])
+        monkeypatch.setattr(m, "_w_normals", lambda: np.zeros(K * (K + 1) // 2 + (N - K) * K))
+        monkeypatch.setattr(m, "_v_normals", lambda: np.zeros((M, K * T)))
+        m._resample_W(data)
+        Wd = m.W.copy()
+        m.W = st["W"]                          # V step from the common W
+        m._resample_V(data)
+        outs.append((Wd, m.V.copy()))
+        del m
+    assert relerr(outs[2][0], outs[0][0] + 2.0 * outs[1][0]) < 1e-10
+    assert relerr(outs[2][1], outs[0][1] + 2.0 * outs[1][1]) < 1e-7
+
+
+def test_full_size_sse_matches_cpu(c3):
+    from oracle import btf_oracle as orc
+    model, Y, Delta, Rr, ybar = c3
+    import ctypes
+    st = snapshot(model)
+    model._push_state()
+    sse, nobs = ctypes.c_double(), ctypes.c_double()
+    model._ctx.call("btf_sse", ctypes.byref(sse), ctypes.byref(nobs))
+    ref, n = orc.sse_and_count(st, Y)
+    assert abs(sse.value - ref) / ref < 1e-11 and nobs.value == n
