@@ -253,22 +253,40 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   if constexpr (!WEIGHTED) reduce_gram(a.gpart, a.ngp, KK, a.sR, &red[0][0][0], G);
   const int il = blockIdx.x * WS_ROWS + lane;
-  // the normals of row i (device RNG): component k by wave k % WS_SPLIT, in parallel with stage 1
-  if (il < a.nl) {
-    const int i = a.row0 + il;
-    const long long zoff = w_z_offset(i, K);
-    const int d = i + 1 < K ? i + 1 : K;
-    for (int k = grp; k < K; k += WS_SPLIT)
-      zsh[k][lane] = k < d ? (a.z ? a.z[zoff + k] : philox_normal(a.seed, a.stream, (unsigned long long)(zoff + k))) : 0.0;
-  }
-  // stage 1: wave `grp` sums chunks grp, grp+WS_SPLIT, ... (fixed order => deterministic)
+  // stage 1: wave `grp` sums chunks grp, grp+WS_SPLIT, ... (fixed order => deterministic).  The first
+  // batch of loads is issued BEFORE the Philox normals of the row are computed (component k by wave
+  // k % WS_SPLIT), so the transcendental work hides under the memory latency.
   {
     double part[NVMAX];
 #pragma unroll
     for (int v = 0; v < NVMAX; ++v) part[v] = 0.0;
-    if (il < a.nl) {
-      const size_t cst = (size_t)NV * a.ld;               // chunk stride
-      int c = grp;
+    const size_t cst = (size_t)NV * a.ld;               // chunk stride
+    const bool live1 = il < a.nl;
+    int c = grp;
+    double x0[UNR][NV];
+    const bool first = live1 && c + (UNR - 1) * WS_SPLIT < a.nch;
+    if (first) {
+      const double* p = a.part + (size_t)c * cst + il;
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) x0[u][v] = p[(size_t)u * WS_SPLIT * cst + (size_t)v * a.ld];
+    }
+    if (live1) {
+      const int i = a.row0 + il;
+      const long long zoff = w_z_offset(i, K);
+      const int d = i + 1 < K ? i + 1 : K;
+      for (int k = grp; k < K; k += WS_SPLIT)
+        zsh[k][lane] = k < d ? (a.z ? a.z[zoff + k] : philox_normal(a.seed, a.stream, (unsigned long long)(zoff + k))) : 0.0;
+    }
+    if (first) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) part[v] += x0[u][v];
+      c += UNR * WS_SPLIT;
+    }
+    if (live1) {
       for (; c + (UNR - 1) * WS_SPLIT < a.nch; c += UNR * WS_SPLIT) {   // UNR chunks' loads in flight, added in order
         const double* p = a.part + (size_t)c * cst + il;
         double x[UNR][NV];
@@ -325,8 +343,9 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
       for (int c = 0; c <= r; ++c) Q[lidx(r, c)] = (r == c) ? 1.0 : 0.0;
     }
   }
-  // in-register Cholesky (lower, packed)
+  // in-register Cholesky (lower, packed); 1/L_cc kept so that the solves multiply instead of divide
   bool ok = true;
+  double invl[K];
 #pragma unroll
   for (int c = 0; c < K; ++c) {
     double p = Q[lidx(c, c)];
@@ -335,6 +354,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
     if (!(p > 0.0)) ok = false;
     const double l = sqrt(p);
     const double inv = 1.0 / l;
+    invl[c] = inv;
     Q[lidx(c, c)] = l;
 #pragma unroll
     for (int r = c + 1; r < K; ++r) {
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
     double v = m[r];
 #pragma unroll
     for (int c = 0; c < r; ++c) v = fma(-Q[lidx(r, c)], y[c], v);
-    y[r] = v / Q[lidx(r, r)];
+    y[r] = v * invl[r];
   }
 #pragma unroll
   for (int r = 0; r < K; ++r)
@@ -362,7 +382,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
     double v = y[r];
 #pragma unroll
     for (int c = r + 1; c < K; ++c) v = fma(-Q[lidx(c, r)], y[c], v);
-    y[r] = v / Q[lidx(r, r)];
+    y[r] = v * invl[r];
   }
   // the row as it now stands (entries >= d keep their stored value), written back and
   // folded into this workgroup's share of W'W for the next V half-sweep
