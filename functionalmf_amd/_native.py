@@ -54,6 +54,8 @@ SIGNATURES = {
     "btf_get_V_attempts": (C.c_int, [_ctx, _c_ip]),
     "btf_get_V_order": (C.c_int, [_ctx, _c_ip]),
     "btf_sse": (C.c_int, [_ctx, _c_dp, _c_dp]),
+    "btf_sse_begin": (C.c_int, [_ctx]),
+    "btf_sse_end": (C.c_int, [_ctx, _c_dp, _c_dp, _c_dp]),
     "btf_pg_draw": (C.c_int, [_ctx, C.c_uint64]),
     "btf_pg_batch": (C.c_int, [C.c_int, C.c_int64, _c_dp, _c_dp, C.c_uint64, _c_dp]),
     "btf_sync": (C.c_int, [_ctx]),

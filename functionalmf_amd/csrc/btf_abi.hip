@@ -60,6 +60,9 @@ struct btf_ctx {
   double* Ta = nullptr; double* Tb = nullptr; double* Tc = nullptr; double* lsum = nullptr;   // horseshoe+ chain (device mode)
   int* dr_ptr = nullptr; int* dr_col = nullptr; double* dr_val = nullptr;                   // Delta, CSR by row
   bool have_chain = false;
+  double* pin = nullptr; size_t pin_elems = 0;   // pinned host staging (async SSE partials + W)
+  size_t sse_nb = 0; bool sse_pending = false;
+  double* pin_lsum = nullptr;
   double* gpart_w = nullptr; int ngp_w = 0;   // W'W partials written by w_solve (valid until W changes otherwise)
   double* gpart_v = nullptr; int ngp_v = 0;   // V'V partials written by the fast banded sampler
   bool fuse_gram = true;
@@ -557,6 +560,8 @@ void btf_destroy(btf_ctx* c) {
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
                   c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (c->pin) (void)hipHostFree(c->pin);
+  if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -743,9 +748,11 @@ int btf_resample_Tau2(btf_ctx* c, uint64_t seed, double lam2, double stability, 
   }
   HIPCHK(c, hipGetLastError());
   c->pband_dirty = true;
-  if (lsum_out) {
-    HIPCHK(c, hipMemcpyAsync(lsum_out, c->lsum, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (lsum_out) {   // through pinned memory: a pageable destination makes the small copy several times slower
+    if (!c->pin_lsum) HIPCHK(c, hipHostMalloc((void**)&c->pin_lsum, (size_t)c->M * sizeof(double), hipHostMallocDefault));
+    HIPCHK(c, hipMemcpyAsync(c->pin_lsum, c->lsum, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(lsum_out, c->pin_lsum, (size_t)c->M * sizeof(double));
   }
   return BTF_OK;
 }
@@ -945,8 +952,10 @@ int btf_get_V_attempts(btf_ctx* c, int32_t* tries) {
 }
 
 // -------------------------------------------------------------------------- SSE
-int btf_sse(btf_ctx* c, double* sse, double* nobs) {
-  if (!c || !sse || !nobs) return BTF_EINVAL;
+// launch the SSE reduction and queue the device-to-host copies of its block partials and of W
+// into pinned memory; nothing is waited for (keeps a full sweep to two host syncs)
+int btf_sse_begin(btf_ctx* c) {
+  if (!c) return BTF_EINVAL;
   if (!c->have_data || c->binomial || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_sse needs Gaussian data, W and V");
   HIPCHK(c, hipSetDevice(c->dev));
   const int ncols = c->ml * c->T;
@@ -954,27 +963,50 @@ int btf_sse(btf_ctx* c, double* sse, double* nobs) {
   int nrb = std::max(1, std::min(c->N / 16, 2048 / std::max(1, gx)));
   const int rpb = (c->N + nrb - 1) / nrb;
   nrb = (c->N + rpb - 1) / rpb;
-  const size_t nb = (size_t)gx * nrb;
+  const size_t nb = ncols > 0 ? (size_t)gx * nrb : 0;
   int rc;
   if (nb > c->bsum_elems) {
     if ((rc = dev_alloc(c, &c->bsum, nb))) return rc;
     c->bsum_elems = nb;
   }
+  const size_t need = nb + (size_t)c->N * c->K;
+  if (need > c->pin_elems) {
+    if (c->pin) (void)hipHostFree(c->pin);
+    c->pin = nullptr;
+    HIPCHK(c, hipHostMalloc((void**)&c->pin, need * sizeof(double), hipHostMallocDefault));
+    c->pin_elems = need;
+  }
   if (ncols > 0) { K_SWITCH(c->K, launch_sse<KT>(c, c->A_v, c->C_v, (double)c->R, ncols, c->ldv, rpb, nrb)); }
   HIPCHK(c, hipGetLastError());
-  std::vector<double> h(nb);
-  if (ncols > 0) {
-    HIPCHK(c, hipMemcpyAsync(h.data(), c->bsum, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
+  if (nb) HIPCHK(c, hipMemcpyAsync(c->pin, c->bsum, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->pin + nb, c->W, (size_t)c->N * c->K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  c->sse_nb = nb;
+  c->sse_pending = true;
+  return BTF_OK;
+}
+
+int btf_sse_end(btf_ctx* c, double* sse, double* nobs, double* W_out) {
+  if (!c || !sse || !nobs) return BTF_EINVAL;
+  if (!c->sse_pending) return fail(c, BTF_ESTATE, "btf_sse_end without btf_sse_begin");
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->sse_pending = false;
   double s = 0.0;
-  for (size_t b = 0; b < (ncols > 0 ? nb : 0); ++b) s += h[b];
+  for (size_t b = 0; b < c->sse_nb; ++b) s += c->pin[b];     // fixed order
   // NOTE: in a sharded run this is the column-slab share of the between-cell part; the
   // within-cell part (ssw) and nobs were reduced over the ROW slab.  The host adds the
   // two kinds over ranks (see functionalmf_amd/factor.py).
   *sse = s + c->ssw;
   *nobs = c->nobs;
-  return BTF_OK;
+  if (W_out) std::memcpy(W_out, c->pin + c->sse_nb, (size_t)c->N * c->K * sizeof(double));
+  return check_status(c);
+}
+
+int btf_sse(btf_ctx* c, double* sse, double* nobs) {
+  int rc = btf_sse_begin(c);
+  if (rc) return rc;
+  rc = btf_sse_end(c, sse, nobs, nullptr);
+  return rc == BTF_ENOTPD ? rc : rc;
 }
 
 int btf_pg_draw(btf_ctx* c, uint64_t seed) {

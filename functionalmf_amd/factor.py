@@ -429,6 +429,10 @@ class BayesianTensorFiltering(_BayesianModel):
         self._exchange.after_V()
         self._V_dev_new = True
         self._lsum_valid = False
+        self._after_V_step()
+
+    def _after_V_step(self):
+        pass
 
     def v_order(self):
         """Elimination order of the V half-sweep's factorisation as depth-major indices t*K+k
@@ -450,6 +454,8 @@ class BayesianTensorFiltering(_BayesianModel):
 
 
 class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
+    _queue_sse = True      # scalar-noise model: nu2 needs the residual sum of squares every sweep
+
     def __init__(self, nrows, ncols, ndepth,
                  nu2_init=None, nu2_true=None,
                  nu2_a=0.1, nu2_b=0.1, **kwargs):
@@ -481,9 +487,13 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
                        stale_col_sources(miss.all(axis=3)).ctypes.data_as(_native._c_ip))
 
     def resample(self, data):
-        if self.sample_nu2:
-            self._resample_nu2(data)
-        super().resample(data)
+        self._in_sweep = True
+        try:
+            if self.sample_nu2:
+                self._resample_nu2(data)
+            super().resample(data)
+        finally:
+            self._in_sweep = False
 
     def _set_noise(self):
         self._ctx.call("btf_set_nu2", _scalar(self.nu2))
@@ -498,13 +508,28 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
         self._set_noise()
         self._device_V_step()
 
+    def _after_V_step(self):
+        # rng="device": queue the next sweep's residual reduction (and a copy of W for the sigma2
+        # update) right behind the V draw, so that a full sweep waits for the GPU only twice
+        # (only inside resample(): a caller driving _resample_W/_resample_V by hand pays nothing extra)
+        if getattr(self, "_in_sweep", False) and self._queue_sse and self.rng == "device" and self.sample_nu2 \
+                and self._plan.world == 1 and not self._exchange.active:
+            self._ctx.call("btf_sse_begin")
+            self._sse_queued = True
+
     def _resample_nu2(self, data):
         """nu2 | rest: residual sum of squares reduced on the device (factor.py:411-416)."""
         self._bind_data(data)
-        self._push_state()
         import ctypes
         sse, nobs = ctypes.c_double(), ctypes.c_double()
-        self._ctx.call("btf_sse", ctypes.byref(sse), ctypes.byref(nobs))
+        if getattr(self, "_sse_queued", False) and not (self._W_host_new or self._V_host_new):
+            self._sse_queued = False
+            self._ctx.call("btf_sse_end", ctypes.byref(sse), ctypes.byref(nobs), _native.dptr(self._W))
+            self._W_dev_new = False                       # the mirror of W came along
+        else:
+            self._sse_queued = False
+            self._push_state()
+            self._ctx.call("btf_sse", ctypes.byref(sse), ctypes.byref(nobs))
         sse, nobs = self._exchange.sum_scalars(sse.value, nobs.value)
         self.nu2 = 1 / self.nu2_model.resample_from_stats(sse, nobs)
 
@@ -517,6 +542,8 @@ class BinomialBayesianTensorFiltering(GaussianBayesianTensorFiltering):
     """Logistic-Binomial likelihood through Polya-Gamma augmentation
     (factor.py:425-460): omega ~ PG(N, w.v) on the device, then the weighted
     Gaussian half-sweeps with pseudo-data kappa = Y - N/2."""
+
+    _queue_sse = False     # nu2 here is the tensor 1/omega (PG draw), not a variance to update from residuals
 
     def __init__(self, nrows, ncols, ndepth, pg_seed=42, **kwargs):
         super().__init__(nrows, ncols, ndepth, **kwargs)

@@ -147,6 +147,11 @@ int btf_get_V_order(btf_ctx* ctx, int32_t* order /* (K*T) */);
  * numbers GaussianBTF._resample_nu2 (factor.py:411-416, genlasso.py:157-160)
  * reduces the whole tensor for.  Synchronises.                                */
 int btf_sse(btf_ctx* ctx, double* sse, double* nobs);
+/* The same in two halves: btf_sse_begin enqueues the reduction (and a copy of W) without
+ * waiting; btf_sse_end synchronises, returns the two numbers and, if W_out != NULL, the
+ * (N,K) factor as it was when btf_sse_begin was called.  Lets the host queue a whole sweep. */
+int btf_sse_begin(btf_ctx* ctx);
+int btf_sse_end(btf_ctx* ctx, double* sse, double* nobs, double* W_out);
 /* omega_ijt ~ PG(Ntrials_ijt, w_i . v_jt) on the device: replaces the
  * pypolyagamma call at factor.py:459 (own RNG: Philox keyed by seed).         */
 int btf_pg_draw(btf_ctx* ctx, uint64_t seed);

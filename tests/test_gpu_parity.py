@@ -505,3 +505,18 @@ def test_bitwise_reproducible(golden):
             model._resample_V(g["Y"])
         runs.append((model.W.copy(), model.V.copy()))
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+
+
+def test_binomial_device_rng_mode_runs():
+    """rng='device' with the Binomial model: device normals + device Tau2 chain + device PG."""
+    from functionalmf_amd.factor import BinomialBayesianTensorFiltering
+    rs = np.random.RandomState(2)
+    N, M, T, K = 16, 6, 10, 2
+    P = 1 / (1 + np.exp(-rs.normal(size=(N, M, T))))
+    Nt = np.full((N, M, T), 8.0)
+    Ys = rs.binomial(8, P).astype(float)
+    np.random.seed(3)
+    model = BinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=1, sigma2_init=1.0, lam2_init=0.1,
+                                            rng="device", compat="exact")
+    res = model.run_gibbs((Ys, Nt), nburn=20, nthin=1, nsamples=10, verbose=False)
+    assert np.all(np.isfinite(res["W"])) and np.all(np.isfinite(res["V"])) and res["nu2"].shape == (10, N, M, T)
