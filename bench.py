@@ -35,6 +35,7 @@ CONFIGS = {
     "c2": dict(N=64, M=32, T=16, R=2, K=3),
     "c3": dict(N=512, M=256, T=64, R=4, K=5),
     "c5": dict(N=4096, M=1024, T=64, R=4, K=8),
+    "c3k8": dict(N=512, M=256, T=64, R=4, K=8),      # tuning aid: C3 cells with C5's embedding size
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 

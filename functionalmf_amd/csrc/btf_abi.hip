@@ -222,10 +222,10 @@ template <int K>
 void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const double* U,
                   const double* UU, const int* srcmap, int Rdim, int ld, int rpb, int nch) {
   Prof p(c, kid);
-  dim3 grid(ld / ACC_TILE, nch), block(ACC_THREADS);
-  if (mode == 2) p.launch(accum_kernel<K, 2>, grid, block, 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
-  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, block, 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
-  else p.launch(accum_kernel<K, 0>, grid, block, 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
+  dim3 grid(ld / ACC_TILE, nch);
+  if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
+  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
+  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
 }
 template <int K>
 void launch_pg(btf_ctx* c, const double* B, double* out, const double* Lf, const double* Uf, int nl, int ld, int Rdim,

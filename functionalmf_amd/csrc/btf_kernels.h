@@ -35,13 +35,19 @@ constexpr int ACC_RG = (ACC_THREADS / ACC_TILE) < 4 ? (ACC_THREADS / ACC_TILE) :
 // MODE 2: as 1, but the precision weight of output l is read from output srcmap[l] of the
 //         same row and the linear statistic is rescaled by C_src/C_own - the reference's
 //         stale cached weights (factor.py:349 and :394-401)
-template <int K, int MODE>
-__global__ __launch_bounds__(ACC_THREADS) void accum_kernel(
+// waves per workgroup: 16 wherever the accumulators fit 128 VGPRs (1024-thread launch bound);
+// the weighted modes of K >= 6 would spill there and run with 8 waves (256-VGPR budget)
+__host__ __device__ constexpr int acc_waves(int K, int MODE) { return (MODE >= 1 && K >= 6) ? 8 : ACC_WAVES; }
+
+template <int K, int MODE, int WAVES = acc_waves(K, MODE)>
+__global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     const double* __restrict__ X, const double* __restrict__ Cx, const double* __restrict__ U,
     const double* __restrict__ UU, const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
     int rows_per_block) {
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
+  constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
+  constexpr int ACC_RG = (WAVES * WAVE / ACC_TILE) < 4 ? (WAVES * WAVE / ACC_TILE) : 4;
   __shared__ double red[ACC_WAVES][ACC_RG][ACC_TILE];
 
   const int lane = threadIdx.x & 63;
