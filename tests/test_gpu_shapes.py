@@ -45,6 +45,12 @@ CASES = [
     (3, 4, 8, 2, 5, 2, False),      # fewer rows than embeddings
     (1, 3, 6, 2, 2, 1, False),      # a single row
     (130, 67, 5, 1, 3, 2, True),    # odd sizes across the 128-wide tiles
+    (6, 3, 2, 2, 1, 2, False),      # shortest depth axis the reference accepts, one embedding
+    (6, 3, 2, 2, 5, 2, False),      # T = 2 with a band wider than the whole system
+    (7, 2, 3, 1, 2, 1, True),
+    (7, 2, 4, 2, 5, 2, False),
+    (9, 2, 8, 2, 3, 2, False),      # T = 2(tf+1)+2: smallest depth the twisted kernel takes
+    (9, 2, 7, 2, 3, 2, False),      # one less: single chain
 ]
 
 
