@@ -106,6 +106,7 @@ class BayesianTensorFiltering(_BayesianModel):
         self._W_host_new = self._V_host_new = True      # host copy must be pushed before the next kernel
         self._W_dev_new = self._V_dev_new = False       # device copy is newer than the host mirror
         self._tau_dirty = True
+        self._v_version = 0
 
         # trend-filtering prior (factor.py:50)
         self.Delta = bayes_grid_penalty(ndepth, tf_order)
@@ -175,12 +176,14 @@ class BayesianTensorFiltering(_BayesianModel):
     def V(self):
         self._pull_V()
         self._V_host_new = True
+        self._v_version += 1           # may be written through the returned array
         return self._V
 
     @V.setter
     def V(self, value):
         self._V = np.array(value, dtype=float)
         self._V_host_new, self._V_dev_new = True, False
+        self._v_version += 1
 
     # Tau2 (and, in rng="device" mode, its three auxiliary horseshoe+ levels) are handed out the
     # same way: refreshed from the GPU if a kernel wrote them, pushed back before the next kernel
@@ -226,6 +229,7 @@ class BayesianTensorFiltering(_BayesianModel):
         if self._V_dev_new:
             self._ctx.call("btf_get_V", _native.dptr(self._V))
             self._V_dev_new = False
+            self._v_version += 1
 
     def _push_state(self):
         if self._W_host_new:
@@ -313,6 +317,7 @@ class BayesianTensorFiltering(_BayesianModel):
         x, _ = sample_banded_batch(band, z=z, seed=self._next_seed(), device=self.device, **self.linalg_opts)
         self._V = x.reshape(M, T, K).clip(-10, 10)
         self._V_host_new, self._V_dev_new = True, False
+        self._v_version += 1
 
     # ---- one Gibbs sweep over the shared parameters (factor.py:112-128) -----------
     def resample(self, data, **kwargs):
@@ -340,10 +345,18 @@ class BayesianTensorFiltering(_BayesianModel):
         self.sigma2 = 1 / self.sigma2_model.resample_from_stats(float(w @ w), w.size)
 
     def _penalised_differences(self):
-        """sum_k (Delta V_j)[r,k]^2 for every column j and penalty row r: (M, nD)."""
+        """sum_k (Delta V_j)[r,k]^2 for every column j and penalty row r: (M, nD).  One sparse
+        product for all columns (the reference does Delta.dot(V[j]) per column, factor.py:136,149);
+        cached while V is unchanged (the Tau2 and lam2 updates of one sweep share it)."""
         self._pull_V()
-        d = np.einsum("rt,mtk->mrk", self.Delta.toarray(), self._V)
-        return (d * d).sum(axis=2)
+        key = (id(self._V), self._v_version)
+        if getattr(self, "_dsq_key", None) != key:
+            T = self.ndepth
+            d = self.Delta.dot(np.ascontiguousarray(self._V.transpose(1, 0, 2)).reshape(T, -1))   # (nD, M*K)
+            d = d.reshape(-1, self.ncols, self.nembeds)
+            self._dsq = np.ascontiguousarray((d * d).sum(axis=2).T)                              # (M, nD)
+            self._dsq_key = key
+        return self._dsq
 
     def _resample_Tau2_device(self):
         """rng="device": all columns at once on the GPU (Philox gamma draws); also leaves the
@@ -369,12 +382,16 @@ class BayesianTensorFiltering(_BayesianModel):
         lo, hi = self.stability, 1 / self.stability
         dsq = self._penalised_differences()
         shape = (self.nembeds + 1) / 2
+        T2, Ta, Tb, Tc = self.Tau2, self.Tau2_a, self.Tau2_b, self.Tau2_c
+        # first level: everything but the draw itself is the same for all columns -> vectorised;
+        # the gamma calls stay per column, in the reference's order (Tau2, c, b, a for column j, then j+1)
+        scale1 = 1 / (dsq / (2 * self.lam2) + 1 / Tc.clip(lo, hi)).clip(lo, hi)
+        gamma = np.random.gamma
         for j in range(self.ncols):
-            rate = dsq[j] / (2 * self.lam2) + 1 / self.Tau2_c[j].clip(lo, hi)
-            self.Tau2[j] = 1 / np.random.gamma(shape, 1 / rate.clip(lo, hi))
-            self.Tau2_c[j] = 1 / np.random.gamma(1, 1 / (1 / self.Tau2[j] + 1 / self.Tau2_b[j]).clip(lo, hi))
-            self.Tau2_b[j] = 1 / np.random.gamma(1, 1 / (1 / self.Tau2_c[j] + 1 / self.Tau2_a[j]).clip(lo, hi))
-            self.Tau2_a[j] = 1 / np.random.gamma(1, 1 / (1 / self.Tau2_b[j] + 1).clip(lo, hi))
+            t = T2[j] = 1 / gamma(shape, scale1[j])
+            c = Tc[j] = 1 / gamma(1, 1 / (1 / t + 1 / Tb[j]).clip(lo, hi))
+            b = Tb[j] = 1 / gamma(1, 1 / (1 / c + 1 / Ta[j]).clip(lo, hi))
+            Ta[j] = 1 / gamma(1, 1 / (1 / b + 1).clip(lo, hi))
 
     def _resample_lam2(self):
         """Global scale.  compat="reference": the rate keeps only the LAST column's term
