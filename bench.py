@@ -78,6 +78,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BTF_FORCE_DEVICE") is not None:      # rehearsal aid: several ranks on one GPU
+        local_rank = int(os.environ["BTF_FORCE_DEVICE"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))

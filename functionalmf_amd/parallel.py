@@ -87,9 +87,26 @@ class Exchange:
             self._Vt = torch.as_tensor(_DevView(lib.btf_dev_V(self.ctx.h), (p.world * p.col_chunk * T * K,)), device=dev)
         return self._Wt, self._Vt
 
+    def _staged(self):
+        """True when the process group cannot move device memory (e.g. gloo): the exchange is then
+        staged through the host (used to rehearse several ranks on one GPU; RCCL refuses that)."""
+        import torch.distributed as dist
+        return dist.get_backend(self.group) != "nccl"
+
+    def _staged_gather(self, getter, setter, shape, block0, blocklen, gather):
+        import ctypes as C
+        full = np.empty(shape)
+        dp = C.POINTER(C.c_double)
+        self.ctx.call(getter, full.ctypes.data_as(dp))
+        full = np.ascontiguousarray(gather(full[block0:block0 + blocklen]))
+        self.ctx.call(setter, full.ctypes.data_as(dp))
+
     def after_W(self):
         if not self.active:
             return
+        if self._staged():
+            N, M, T, K, _ = self.ctx.dims
+            return self._staged_gather("btf_get_W", "btf_set_W", (N, K), self.plan.row0, self.plan.nl, self.gather_rows_host)
         import torch.distributed as dist
         Wt, _ = self._views()
         K = self.ctx.dims[3]
@@ -99,6 +116,9 @@ class Exchange:
     def after_V(self):
         if not self.active:
             return
+        if self._staged():
+            N, M, T, K, _ = self.ctx.dims
+            return self._staged_gather("btf_get_V", "btf_set_V", (M, T, K), self.plan.col0, self.plan.ml, self.gather_cols_host)
         import torch.distributed as dist
         _, Vt = self._views()
         _, _, T, K, _ = self.ctx.dims

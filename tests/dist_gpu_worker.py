@@ -1,0 +1,55 @@
+"""Worker of test_two_ranks_share_one_gpu: two processes (gloo control plane, exchange staged
+through the host because RCCL refuses two ranks on one device) run the SHARDED kernels - row
+and column offsets, local slabs, per-rank partial SSE - on cuda:0 and must reproduce the
+unsharded oracle."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_golden, state_from  # noqa: E402
+from oracle import btf_oracle as orc  # noqa: E402
+from functionalmf_amd.factor import GaussianBayesianTensorFiltering  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    for name in ("g2_c2_complete.npz", "g1_c1_heldout.npz"):
+        g = load_golden(name)
+        N, M, T, R, K, tf = [int(x) for x in g["dims"]]
+        st = state_from(g, "s0_")
+        model = GaussianBayesianTensorFiltering(
+            N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
+            W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], compat="exact", shard=(rank, world), device=0)
+        assert model._exchange.active and model._plan.world == world
+        Delta = orc.trend_penalty(T, tf)
+        ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+        for it in range(2):
+            np.random.seed(40 + it)                    # every rank draws the same host normals
+            model._resample_W(g["Y"])
+            model._resample_V(g["Y"])
+            np.random.seed(40 + it)
+            orc.w_step(ost, g["Y"])
+            orc.v_step(ost, g["Y"], Delta, compat="exact", perm=orc.perm_from_order(model.v_order(), K, T))
+            ew = np.abs(model.W - ost["W"]).max() / np.abs(ost["W"]).max()
+            ev = np.abs(model.V - ost["V"]).max() / np.abs(ost["V"]).max()
+            assert ew < 1e-10 and ev < 1e-6, (name, it, ew, ev)
+            model.W, model.V = ost["W"], ost["V"]       # keep both chains on the same state
+        np.random.seed(50)
+        model._resample_nu2(g["Y"])
+        sse, n = orc.sse_and_count(ost, g["Y"])
+        np.random.seed(50)
+        ref = 1.0 / np.random.gamma(0.1 + n / 2.0, 1.0 / (0.1 + sse / 2.0))
+        assert abs(model.nu2 - ref) / ref < 1e-10, (model.nu2, ref)
+    print("SHARD_GPU_OK rank", rank, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

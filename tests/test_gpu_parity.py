@@ -520,3 +520,19 @@ def test_binomial_device_rng_mode_runs():
                                             rng="device", compat="exact")
     res = model.run_gibbs((Ys, Nt), nburn=20, nthin=1, nsamples=10, verbose=False)
     assert np.all(np.isfinite(res["W"])) and np.all(np.isfinite(res["V"])) and res["nu2"].shape == (10, N, M, T)
+
+
+@pytest.mark.timeout(400)
+def test_two_ranks_share_one_gpu():
+    """The sharded compute path (nonzero row / column offsets, local slabs, partial SSE) on real
+    hardware: two processes on cuda:0, gloo process group, host-staged exchange."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29581", os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=380)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("SHARD_GPU_OK") == 2, out.stdout[-2000:]
