@@ -55,6 +55,11 @@ SIGNATURES = {
     "btf_get_V_order": (C.c_int, [_ctx, _c_ip]),
     "btf_sse": (C.c_int, [_ctx, _c_dp, _c_dp]),
     "btf_sse_begin": (C.c_int, [_ctx]),
+    "btf_device_scalars": (C.c_int, [_ctx, C.c_int]),
+    "btf_set_scalars": (C.c_int, [_ctx, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "btf_get_scalars": (C.c_int, [_ctx, _c_dp]),
+    "btf_draw_scalars": (C.c_int, [_ctx, C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "btf_draw_lam2": (C.c_int, [_ctx, C.c_uint64, C.c_int]),
     "btf_sse_end": (C.c_int, [_ctx, _c_dp, _c_dp, _c_dp]),
     "btf_pg_draw": (C.c_int, [_ctx, C.c_uint64]),
     "btf_pg_batch": (C.c_int, [C.c_int, C.c_int64, _c_dp, _c_dp, C.c_uint64, _c_dp]),

@@ -63,6 +63,9 @@ struct btf_ctx {
   double* pin = nullptr; size_t pin_elems = 0;   // pinned host staging (async SSE partials + W)
   size_t sse_nb = 0; bool sse_pending = false;
   double* pin_lsum = nullptr;
+  double* hyp = nullptr;        // device-resident scalars [HYP_COUNT] (nu2, sigma2, lam2, lam2_a, ...)
+  bool dev_scalars = false;     // kernels read nu2 / sigma2 / lam2 from hyp instead of the host copies
+  double* pin_hyp = nullptr;
   double* gpart_w = nullptr; int ngp_w = 0;   // W'W partials written by w_solve (valid until W changes otherwise)
   double* gpart_v = nullptr; int ngp_v = 0;   // V'V partials written by the fast banded sampler
   bool fuse_gram = true;
@@ -562,6 +565,8 @@ void btf_destroy(btf_ctx* c) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
+  if (c->pin_hyp) (void)hipHostFree(c->pin_hyp);
+  if (c->hyp) (void)hipFree(c->hyp);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -737,14 +742,16 @@ int btf_get_tau(btf_ctx* c, double* Tau2, double* Ta, double* Tb, double* Tc) {
 }
 
 int btf_resample_Tau2(btf_ctx* c, uint64_t seed, double lam2, double stability, double* lsum_out) {
-  if (!c || !(lam2 > 0.0) || !(stability > 0.0)) return fail(c, BTF_EINVAL, "bad Tau2 update arguments");
+  if (!c || !(stability > 0.0)) return fail(c, BTF_EINVAL, "bad Tau2 update arguments");
+  if (c->dev_scalars) lam2 = 1.0;   // the kernel reads the device-resident value
+  if (!(lam2 > 0.0)) return fail(c, BTF_EINVAL, "bad Tau2 update arguments");
   if (!c->have_V || !c->have_hyper || !c->have_chain) return fail(c, BTF_ESTATE, "set V, Tau2 and the horseshoe+ chain first");
   HIPCHK(c, hipSetDevice(c->dev));
   {
     Prof p(c, BTF_K_PROD);
     p.launch(tau2_kernel, dim3(c->M), dim3(256), 0, (const double*)c->V, c->T, c->K, c->nD, (const int*)c->dr_ptr,
              (const int*)c->dr_col, (const double*)c->dr_val, lam2, stability, 1.0 / stability, c->Tau2, c->Ta, c->Tb,
-             c->Tc, c->lsum, (unsigned long long)seed);
+             c->Tc, c->lsum, (unsigned long long)seed, (const double*)(c->dev_scalars ? c->hyp : nullptr));
   }
   HIPCHK(c, hipGetLastError());
   c->pband_dirty = true;
@@ -829,6 +836,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
     a.sR = a.s * c->R;
     a.inv_sigma2 = 1.0 / c->sigma2;
+    a.hyp = c->dev_scalars ? c->hyp : nullptr; a.Rrep = c->R; a.hyp_noise = c->binomial ? 0 : 1;
     a.W = c->W; a.row0 = c->row0; a.nl = c->nl;
     a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_w + 0x10000ULL;
     a.status = c->status;
@@ -888,6 +896,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
     a.sR = a.s * c->R;
     a.Tau2 = c->Tau2; a.lam2 = c->lam2; a.nD = c->nD;
+    a.hyp = c->dev_scalars ? c->hyp : nullptr; a.Rrep = c->R; a.hyp_noise = c->binomial ? 0 : 1;
     a.st_ptr = c->st_ptr; a.st_row = c->st_row; a.st_coef = c->st_coef;
     a.T = T; a.TF = c->TF; a.col0 = c->col0; a.ml = c->ml;
     a.V = c->V; a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_v + 0x10001ULL;
@@ -902,7 +911,8 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       if (c->pband_dirty) {
         Prof p(c, BTF_K_PROD);
         p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
-                 (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband);
+                 (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
+                 (const double*)(c->dev_scalars ? c->hyp : nullptr));
         c->pband_dirty = false;
       }
       a.pband = c->pband;
@@ -954,10 +964,9 @@ int btf_get_V_attempts(btf_ctx* c, int32_t* tries) {
 // -------------------------------------------------------------------------- SSE
 // launch the SSE reduction and queue the device-to-host copies of its block partials and of W
 // into pinned memory; nothing is waited for (keeps a full sweep to two host syncs)
-int btf_sse_begin(btf_ctx* c) {
-  if (!c) return BTF_EINVAL;
-  if (!c->have_data || c->binomial || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_sse needs Gaussian data, W and V");
-  HIPCHK(c, hipSetDevice(c->dev));
+namespace {
+// launch the SSE block reduction into c->bsum (nb block partials); no copies, no waits
+int sse_launch(btf_ctx* c, size_t* nb_out) {
   const int ncols = c->ml * c->T;
   const int gx = (ncols + SSE_THREADS - 1) / SSE_THREADS;
   int nrb = std::max(1, std::min(c->N / 16, 2048 / std::max(1, gx)));
@@ -969,6 +978,30 @@ int btf_sse_begin(btf_ctx* c) {
     if ((rc = dev_alloc(c, &c->bsum, nb))) return rc;
     c->bsum_elems = nb;
   }
+  if (ncols > 0) { K_SWITCH(c->K, launch_sse<KT>(c, c->A_v, c->C_v, (double)c->R, ncols, c->ldv, rpb, nrb)); }
+  HIPCHK(c, hipGetLastError());
+  *nb_out = nb;
+  return BTF_OK;
+}
+int ensure_hyp(btf_ctx* c) {
+  if (c->hyp) return BTF_OK;
+  int rc;
+  if ((rc = dev_alloc(c, &c->hyp, (size_t)HYP_COUNT))) return rc;
+  HIPCHK(c, hipHostMalloc((void**)&c->pin_hyp, HYP_COUNT * sizeof(double), hipHostMallocDefault));
+  for (int i = 0; i < HYP_COUNT; ++i) c->pin_hyp[i] = 1.0;
+  HIPCHK(c, hipMemcpyAsync(c->hyp, c->pin_hyp, HYP_COUNT * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return BTF_OK;
+}
+}  // namespace
+
+int btf_sse_begin(btf_ctx* c) {
+  if (!c) return BTF_EINVAL;
+  if (!c->have_data || c->binomial || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_sse needs Gaussian data, W and V");
+  HIPCHK(c, hipSetDevice(c->dev));
+  size_t nb = 0;
+  int rc;
+  if ((rc = sse_launch(c, &nb))) return rc;
   const size_t need = nb + (size_t)c->N * c->K;
   if (need > c->pin_elems) {
     if (c->pin) (void)hipHostFree(c->pin);
@@ -976,12 +1009,83 @@ int btf_sse_begin(btf_ctx* c) {
     HIPCHK(c, hipHostMalloc((void**)&c->pin, need * sizeof(double), hipHostMallocDefault));
     c->pin_elems = need;
   }
-  if (ncols > 0) { K_SWITCH(c->K, launch_sse<KT>(c, c->A_v, c->C_v, (double)c->R, ncols, c->ldv, rpb, nrb)); }
-  HIPCHK(c, hipGetLastError());
   if (nb) HIPCHK(c, hipMemcpyAsync(c->pin, c->bsum, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->pin + nb, c->W, (size_t)c->N * c->K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   c->sse_nb = nb;
   c->sse_pending = true;
+  return BTF_OK;
+}
+
+// ---------------------------------------------------------- device-resident scalars
+int btf_device_scalars(btf_ctx* c, int enable) {
+  if (!c) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (enable) {
+    if (c->nl != c->N || c->ml != c->M) return fail(c, BTF_ESTATE, "device-resident scalars need an unsharded context");
+    int rc;
+    if ((rc = ensure_hyp(c))) return rc;
+  }
+  c->dev_scalars = enable != 0;
+  c->pband_dirty = true;
+  return BTF_OK;
+}
+
+int btf_set_scalars(btf_ctx* c, double nu2, double sigma2, double lam2, double lam2_a) {
+  if (!c || !(sigma2 > 0.0) || !(lam2 > 0.0) || !(nu2 > 0.0) || !(lam2_a > 0.0)) return fail(c, BTF_EINVAL, "scalars must be positive");
+  HIPCHK(c, hipSetDevice(c->dev));
+  int rc;
+  if ((rc = ensure_hyp(c))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // the staging word may still be in flight
+  if (lam2 != c->lam2) c->pband_dirty = true;
+  c->nu2 = nu2; c->sigma2 = sigma2; c->lam2 = lam2;
+  c->pin_hyp[HYP_NU2] = nu2; c->pin_hyp[HYP_SIGMA2] = sigma2; c->pin_hyp[HYP_LAM2] = lam2; c->pin_hyp[HYP_LAM2A] = lam2_a;
+  HIPCHK(c, hipMemcpyAsync(c->hyp, c->pin_hyp, 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  c->pband_dirty = true;
+  return BTF_OK;
+}
+
+int btf_get_scalars(btf_ctx* c, double* out) {
+  if (!c || !out) return BTF_EINVAL;
+  if (!c->hyp) return fail(c, BTF_ESTATE, "no device-resident scalars yet");
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipMemcpyAsync(c->pin_hyp, c->hyp, HYP_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 6; ++i) out[i] = c->pin_hyp[i];
+  c->nu2 = out[HYP_NU2]; c->sigma2 = out[HYP_SIGMA2]; c->lam2 = out[HYP_LAM2];
+  return BTF_OK;
+}
+
+int btf_draw_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double nu2_b, double sigma2_a, double sigma2_b) {
+  if (!c || !c->dev_scalars) return fail(c, BTF_ESTATE, "enable device-resident scalars first");
+  if ((which & 1) && (!c->have_data || c->binomial)) return fail(c, BTF_ESTATE, "the scalar nu2 draw needs Gaussian data");
+  if (!c->have_W || ((which & 1) && !c->have_V)) return fail(c, BTF_ESTATE, "set W and V first");
+  HIPCHK(c, hipSetDevice(c->dev));
+  size_t nb = 0;
+  int rc;
+  if (which & 1) { if ((rc = sse_launch(c, &nb))) return rc; }
+  const int h = std::min(c->K, c->N);
+  const double nfree = (double)c->N * c->K - (double)h * (h - 1) / 2.0 - (double)(c->K - h) * c->N;   // factor.py:155-174
+  {
+    Prof p(c, BTF_K_PROD);
+    p.launch(scalars_kernel, dim3(1), dim3(256), 0, (const double*)c->bsum, (int)nb, c->ssw, c->nobs, (const double*)c->W,
+             c->N, c->K, nfree, nu2_a, nu2_b, sigma2_a, sigma2_b, which, (unsigned long long)seed, c->hyp);
+  }
+  HIPCHK(c, hipGetLastError());
+  return BTF_OK;
+}
+
+int btf_draw_lam2(btf_ctx* c, uint64_t seed, int compat) {
+  if (!c || !c->dev_scalars) return fail(c, BTF_ESTATE, "enable device-resident scalars first");
+  if (!c->lsum || !c->have_chain) return fail(c, BTF_ESTATE, "btf_draw_lam2 follows btf_resample_Tau2");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const double shape = (double)c->nD * c->M * c->K + 1.0;
+  {
+    Prof p(c, BTF_K_PROD);
+    p.launch(lam2_kernel, dim3(1), dim3(256), 0, (const double*)c->lsum, c->M, shape, compat == BTF_COMPAT_EXACT ? 1 : 0,
+             (unsigned long long)seed, c->hyp);
+  }
+  HIPCHK(c, hipGetLastError());
+  c->pband_dirty = true;
   return BTF_OK;
 }
 

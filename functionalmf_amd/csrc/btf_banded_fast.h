@@ -270,6 +270,7 @@ __device__ inline void banded_unit_backward(double* lds, const VbLayout L, int n
 
 template <int NPL, bool ROW16>
 __global__ __launch_bounds__(VB_THREADS) void v_banded_fast_kernel(VBandArgs a, int K) {
+  vband_load_hyp(a);
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -257,6 +257,7 @@ __device__ inline void vp_backward(double* lds, const VpLayout L, int n, int bw)
 
 template <int NPLH, bool ROW16>
 __global__ __launch_bounds__(VP_THREADS) void v_banded_pipe_kernel(VBandArgs a, int K) {
+  vband_load_hyp(a);
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -83,6 +83,7 @@ __host__ __device__ inline int twist_order(int i, int n, int nl, int nr) {
 
 template <int NPL, bool ROW16>
 __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a, int K) {
+  vband_load_hyp(a);
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

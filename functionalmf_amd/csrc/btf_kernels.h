@@ -240,7 +240,14 @@ struct WSolveArgs {
   const double* z; unsigned long long seed; unsigned long long stream;
   int* status;     // [0] = failure flag, [1] = first failing row
   double* gout;    // [gridDim.x][KK] Gram partial of the rows this workgroup wrote (W'W for the V half-sweep)
+  const double* hyp;   // device-resident scalars (HYP_*) or nullptr: when set they override s, sR, inv_sigma2
+  double Rrep;         // nreps (sR = s * Rrep)
+  int hyp_noise;       // 1: the noise scale s comes from hyp[HYP_NU2] (scalar-nu2 models only)
 };
+
+// device-resident scalar hyper-parameters (rng="device": drawn by scalars_kernel / lam2_kernel,
+// read by the half-sweep kernels, so that a full sweep needs no host round trip)
+enum { HYP_NU2 = 0, HYP_SIGMA2 = 1, HYP_LAM2 = 2, HYP_LAM2A = 3, HYP_SSE = 4, HYP_WSQ = 5, HYP_COUNT = 8 };
 
 constexpr int WS_ROWS = 64;   // rows per workgroup (one per lane)
 // waves per workgroup: the chunk partials are summed WS_SPLIT-way in parallel (LDS-bounded)
@@ -257,6 +264,10 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
   __shared__ double red[WS_SPLIT][K + KK][WS_ROWS];   // also the staging area of reduce_gram
   __shared__ double zsh[K][WS_ROWS];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  if (a.hyp) {
+    if (a.hyp_noise) { a.s = 1.0 / a.hyp[HYP_NU2]; a.sR = a.s * a.Rrep; }
+    a.inv_sigma2 = 1.0 / a.hyp[HYP_SIGMA2];
+  }
   if constexpr (!WEIGHTED) reduce_gram(a.gpart, a.ngp, KK, a.sR, &red[0][0][0], G);
   const int il = blockIdx.x * WS_ROWS + lane;
   // stage 1: wave `grp` sums chunks grp, grp+WS_SPLIT, ... (fixed order => deterministic).  The first
@@ -442,7 +453,16 @@ struct VBandArgs {
   long long* dbg; // diagnostic phase stamps [ml][6] (nullptr in normal runs)
   double* gout;   // [ml][KK] V_j'V_j of the freshly drawn column (V'V partials for the next W half-sweep) or nullptr
   const double* pband; // [ml][T][TF+2] prior band Delta' diag(1/(lam2 Tau2_j)) Delta, entry (t+d,t) (fast kernel)
+  const double* hyp;   // device-resident scalars or nullptr (see WSolveArgs)
+  double Rrep;
+  int hyp_noise;
 };
+__device__ __forceinline__ void vband_load_hyp(VBandArgs& a) {
+  if (a.hyp) {
+    if (a.hyp_noise) { a.s = 1.0 / a.hyp[HYP_NU2]; a.sR = a.s * a.Rrep; }
+    a.lam2 = a.hyp[HYP_LAM2];
+  }
+}
 
 // Prior band of every local column at once (depends on the hyper-parameters only, so it is
 // recomputed when they change, not per half-sweep): one thread per (column, t, d), Delta
@@ -450,9 +470,10 @@ struct VBandArgs {
 __global__ void prior_band_kernel(const double* __restrict__ Tau2, double lam2, int nD,
                                   const int* __restrict__ st_ptr, const int* __restrict__ st_row,
                                   const double* __restrict__ st_coef, int TD1, int col0, int ml,
-                                  double* __restrict__ pband) {
+                                  double* __restrict__ pband, const double* __restrict__ hyp) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= ml * TD1) return;
+  if (hyp) lam2 = hyp[HYP_LAM2];
   const int j = idx / TD1, e0 = idx - j * TD1;
   const double* tau = Tau2 + (size_t)(col0 + j) * nD;
   double s = 0.0;
@@ -523,6 +544,7 @@ __device__ inline void banded_backward(const double* Bc, double* rhs, const doub
 
 template <int K>
 __global__ __launch_bounds__(WAVE) void v_banded_kernel(VBandArgs a) {
+  vband_load_hyp(a);
   constexpr int KK = tri(K);
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
@@ -1040,9 +1062,11 @@ __global__ __launch_bounds__(256) void tau2_kernel(const double* __restrict__ V,
                                                    const double* __restrict__ dr_val, double lam2, double lo, double hi,
                                                    double* __restrict__ Tau2, double* __restrict__ Ta,
                                                    double* __restrict__ Tb, double* __restrict__ Tc,
-                                                   double* __restrict__ lsum, unsigned long long seed) {
+                                                   double* __restrict__ lsum, unsigned long long seed,
+                                                   const double* __restrict__ hyp) {
   __shared__ double red[4];
   const int j = blockIdx.x;
+  if (hyp) lam2 = hyp[HYP_LAM2];
   const double* Vj = V + (size_t)j * T * K;
   double acc = 0.0;
   for (int r = threadIdx.x; r < nD; r += blockDim.x) {
@@ -1067,6 +1091,72 @@ __global__ __launch_bounds__(256) void tau2_kernel(const double* __restrict__ V,
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) lsum[j] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ============================================================================
+// Scalar hyper-parameters on the device (rng="device")
+//   nu2    | rest : 1/Gamma(a + n/2, scale 1/(b + SSE/2))               factor.py:411-416, genlasso.py:160-164
+//   sigma2 | rest : 1/Gamma(a + nW/2, scale 1/(b + sum W_free^2/2))      factor.py:130-132
+//   lam2   | rest : max(1e-5, 1/Gamma(shape/2, scale 1/rate)), then lam2_a = 1/Gamma(1, 1/(1/lam2 + 1))
+//                   rate = last column's term (compat="reference", quirk Q3) or 1/lam2_a + sum   factor.py:143-153
+//   One workgroup; the reductions are fixed-order (thread-strided partial sums, then a serial
+//   sum over the 256 lanes' partials), the draws are made by thread 0 from Philox streams
+//   keyed (seed, HYP_* id).  Results land in hyp[] where the half-sweep kernels read them.
+// ============================================================================
+__device__ inline double block_sum_fixed(double x, double* red) {   // all 256 threads; deterministic
+  x = wave_sum(x);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  const double s = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return s;
+}
+
+// which: bit 0 = nu2 (needs the SSE block partials), bit 1 = sigma2
+__global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__ bsum, int nb, double ssw, double nobs,
+                                                      const double* __restrict__ W, int N, int K, double nfree,
+                                                      double nu2_a, double nu2_b, double sig_a, double sig_b, int which,
+                                                      unsigned long long seed, double* __restrict__ hyp) {
+  __shared__ double red[4];
+  if (which & 1) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) acc += bsum[b];
+    const double sse = block_sum_fixed(acc, red) + ssw;
+    if (threadIdx.x == 0) {
+      CellRng g(seed, (unsigned long long)HYP_NU2);
+      hyp[HYP_SSE] = sse;
+      hyp[HYP_NU2] = (nu2_b + 0.5 * sse) / gamma_mt(nu2_a + 0.5 * nobs, g);
+    }
+  }
+  if (which & 2) {
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < N * K; e += 256) { const double w = W[e]; acc = fma(w, w, acc); }   // the structural zeros add 0
+    const double wsq = block_sum_fixed(acc, red);
+    if (threadIdx.x == 0) {
+      CellRng g(seed, (unsigned long long)HYP_SIGMA2);
+      hyp[HYP_WSQ] = wsq;
+      hyp[HYP_SIGMA2] = (sig_b + 0.5 * wsq) / gamma_mt(sig_a + 0.5 * nfree, g);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lam2_kernel(const double* __restrict__ lsum, int M, double shape, int exact,
+                                                   unsigned long long seed, double* __restrict__ hyp) {
+  __shared__ double red[4];
+  double rate;
+  if (exact) {
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < M; j += 256) acc += lsum[j];
+    rate = 1.0 / hyp[HYP_LAM2A] + 0.5 * block_sum_fixed(acc, red);
+  } else {
+    rate = 0.5 * lsum[M - 1];
+  }
+  if (threadIdx.x == 0) {
+    CellRng g(seed, (unsigned long long)HYP_LAM2);
+    const double lam2 = fmax(1e-5, rate / gamma_mt(0.5 * shape, g));
+    hyp[HYP_LAM2] = lam2;
+    hyp[HYP_LAM2A] = (1.0 / lam2 + 1.0) / g.expo();
+  }
 }
 
 }  // namespace btf

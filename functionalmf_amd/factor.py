@@ -107,6 +107,12 @@ class BayesianTensorFiltering(_BayesianModel):
         self._W_dev_new = self._V_dev_new = False       # device copy is newer than the host mirror
         self._tau_dirty = True
         self._v_version = 0
+        # scalar hyper-parameters: host values, or (rng="device", unsharded) device-resident
+        self._sc = {"nu2": 1.0, "sigma2": 1.0, "lam2": 1.0, "lam2_a": 1.0}
+        self._sc_host_new, self._sc_dev_new = False, False
+        self._dev_scalars = rng == "device" and self._plan.world == 1 and not self._exchange.active
+        if self._dev_scalars:
+            self._ctx.call("btf_device_scalars", 1)
 
         # trend-filtering prior (factor.py:50)
         self.Delta = bayes_grid_penalty(ndepth, tf_order)
@@ -199,6 +205,7 @@ class BayesianTensorFiltering(_BayesianModel):
         self._pull_tau()
         self._tau_dirty = True
         self._lsum_valid = False
+        self._lsum_on_device = False
         return self._Tau2
 
     @Tau2.setter
@@ -220,6 +227,33 @@ class BayesianTensorFiltering(_BayesianModel):
     Tau2_b = property(lambda self: self._chain_get("_Tau2_b"), lambda self, v: self._chain_set("_Tau2_b", v))
     Tau2_c = property(lambda self: self._chain_get("_Tau2_c"), lambda self, v: self._chain_set("_Tau2_c", v))
 
+    # sigma2, lam2, lam2_a (and the Gaussian model's scalar nu2): in rng="device" mode they are
+    # drawn on the GPU (btf_draw_scalars / btf_draw_lam2) and fetched when somebody looks.
+    def _pull_scalars(self):
+        if self._sc_dev_new:
+            out = np.zeros(6)
+            self._ctx.call("btf_get_scalars", _native.dptr(out))
+            self._sc["nu2"], self._sc["sigma2"], self._sc["lam2"], self._sc["lam2_a"] = (float(x) for x in out[:4])
+            self._sc_dev_new = False
+
+    def _push_scalars(self):
+        if self._dev_scalars and self._sc_host_new:
+            self._ctx.call("btf_set_scalars", *(_scalar(self._sc[k]) for k in ("nu2", "sigma2", "lam2", "lam2_a")))
+            self._sc_host_new = False
+
+    def _sc_get(self, name):
+        self._pull_scalars()
+        return self._sc[name]
+
+    def _sc_set(self, name, value):
+        self._pull_scalars()
+        self._sc[name] = value
+        self._sc_host_new = True
+
+    sigma2 = property(lambda self: self._sc_get("sigma2"), lambda self, v: self._sc_set("sigma2", v))
+    lam2 = property(lambda self: self._sc_get("lam2"), lambda self, v: self._sc_set("lam2", v))
+    lam2_a = property(lambda self: self._sc_get("lam2_a"), lambda self, v: self._sc_set("lam2_a", v))
+
     def _pull_W(self):
         if self._W_dev_new:
             self._ctx.call("btf_get_W", _native.dptr(self._W))
@@ -240,12 +274,15 @@ class BayesianTensorFiltering(_BayesianModel):
             self._V = _native.as_f64(self._V)
             self._ctx.call("btf_set_V", _native.dptr(self._V))
             self._V_host_new = False
+        self._push_scalars()
+        # (with device-resident scalars the kernels ignore the two host values below)
+        lam2, sigma2 = _scalar(self._sc["lam2"]), _scalar(self._sc["sigma2"])
         if self._tau_dirty and not getattr(self, "_tau_dev_new", False):
             self._Tau2 = _native.as_f64(self._Tau2)
-            self._ctx.call("btf_set_hyper", _native.dptr(self._Tau2), _scalar(self.lam2), _scalar(self.sigma2))
+            self._ctx.call("btf_set_hyper", _native.dptr(self._Tau2), lam2, sigma2)
             self._tau_dirty = False
-        else:
-            self._ctx.call("btf_set_hyper", None, _scalar(self.lam2), _scalar(self.sigma2))
+        elif not self._dev_scalars:
+            self._ctx.call("btf_set_hyper", None, lam2, sigma2)
 
     def _next_seed(self):
         self._draws += 1
@@ -340,6 +377,14 @@ class BayesianTensorFiltering(_BayesianModel):
         return np.concatenate([W[np.tril_indices(h)], W[h:].reshape(-1)])
 
     def _resample_sigma2(self):
+        if self._dev_scalars:
+            if getattr(self, "_sigma2_drawn", False):      # drawn together with nu2 (one launch)
+                self._sigma2_drawn = False
+                return
+            self._push_state()
+            self._ctx.call("btf_draw_scalars", self._next_seed(), 2, 0.0, 0.0, float(self.sigma2_a), float(self.sigma2_b))
+            self._sc_dev_new = True
+            return
         self._pull_W()
         w = self._pack_W(self._W)
         self.sigma2 = 1 / self.sigma2_model.resample_from_stats(float(w @ w), w.size)
@@ -368,10 +413,14 @@ class BayesianTensorFiltering(_BayesianModel):
             self._ctx.call("btf_set_tau_chain", _native.dptr(self._Tau2_a), _native.dptr(self._Tau2_b),
                            _native.dptr(self._Tau2_c))
             self._chain_dirty = False
-        lsum = np.empty(self.ncols)
-        self._ctx.call("btf_resample_Tau2", self._next_seed(), _scalar(self.lam2), float(self.stability),
-                       _native.dptr(lsum))
-        self._lsum, self._lsum_valid = lsum, True
+        if self._dev_scalars:       # lam2 is read, and the lam2-rate terms are left, on the device
+            self._ctx.call("btf_resample_Tau2", self._next_seed(), 1.0, float(self.stability), None)
+            self._lsum_on_device, self._lsum_valid = True, False
+        else:
+            lsum = np.empty(self.ncols)
+            self._ctx.call("btf_resample_Tau2", self._next_seed(), _scalar(self.lam2), float(self.stability),
+                           _native.dptr(lsum))
+            self._lsum, self._lsum_valid = lsum, True
         self._tau_dev_new, self._tau_dirty = True, False
 
     def _resample_Tau2(self):
@@ -396,6 +445,12 @@ class BayesianTensorFiltering(_BayesianModel):
     def _resample_lam2(self):
         """Global scale.  compat="reference": the rate keeps only the LAST column's term
         (quirk Q3, factor.py:147-150); "exact": 1/lam2_a plus the sum over columns."""
+        if self._dev_scalars and getattr(self, "_lsum_on_device", False):
+            self._lsum_on_device = False
+            self._push_scalars()
+            self._ctx.call("btf_draw_lam2", self._next_seed(), _native.COMPAT[self.compat])
+            self._sc_dev_new = True
+            return
         if self.rng == "device" and getattr(self, "_lsum_valid", False):
             terms = self._lsum / 2          # from the device Tau2 update of this sweep
         else:
@@ -446,6 +501,7 @@ class BayesianTensorFiltering(_BayesianModel):
         self._exchange.after_V()
         self._V_dev_new = True
         self._lsum_valid = False
+        self._lsum_on_device = False
         self._after_V_step()
 
     def _after_V_step(self):
@@ -472,6 +528,9 @@ class BayesianTensorFiltering(_BayesianModel):
 
 class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
     _queue_sse = True      # scalar-noise model: nu2 needs the residual sum of squares every sweep
+    _scalar_noise = True   # nu2 is one number (device-resident in rng="device" mode)
+
+    nu2 = property(lambda self: self._sc_get("nu2"), lambda self, v: self._sc_set("nu2", v))
 
     def __init__(self, nrows, ncols, ndepth,
                  nu2_init=None, nu2_true=None,
@@ -513,7 +572,8 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
             self._in_sweep = False
 
     def _set_noise(self):
-        self._ctx.call("btf_set_nu2", _scalar(self.nu2))
+        if not self._dev_scalars:
+            self._ctx.call("btf_set_nu2", _scalar(self.nu2))
 
     def _resample_W(self, data):
         self._bind_data(data)
@@ -530,13 +590,24 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
         # update) right behind the V draw, so that a full sweep waits for the GPU only twice
         # (only inside resample(): a caller driving _resample_W/_resample_V by hand pays nothing extra)
         if getattr(self, "_in_sweep", False) and self._queue_sse and self.rng == "device" and self.sample_nu2 \
-                and self._plan.world == 1 and not self._exchange.active:
+                and self._plan.world == 1 and not self._exchange.active and not self._dev_scalars:
             self._ctx.call("btf_sse_begin")
             self._sse_queued = True
 
     def _resample_nu2(self, data):
         """nu2 | rest: residual sum of squares reduced on the device (factor.py:411-416)."""
         self._bind_data(data)
+        if self._dev_scalars and self._scalar_noise:
+            # residual reduction + inverse-gamma draw on the device; sigma2 rides along when the
+            # sweep is going to draw it next anyway (same conditionals: sigma2 | W does not depend on nu2)
+            which = 1
+            if getattr(self, "_in_sweep", False) and self.sample_sigma2:
+                which, self._sigma2_drawn = 3, True
+            self._push_state()
+            self._ctx.call("btf_draw_scalars", self._next_seed(), which, float(self.nu2_a), float(self.nu2_b),
+                           float(self.sigma2_a), float(self.sigma2_b))
+            self._sc_dev_new = True
+            return
         import ctypes
         sse, nobs = ctypes.c_double(), ctypes.c_double()
         if getattr(self, "_sse_queued", False) and not (self._W_host_new or self._V_host_new):
@@ -561,6 +632,7 @@ class BinomialBayesianTensorFiltering(GaussianBayesianTensorFiltering):
     Gaussian half-sweeps with pseudo-data kappa = Y - N/2."""
 
     _queue_sse = False     # nu2 here is the tensor 1/omega (PG draw), not a variance to update from residuals
+    _scalar_noise = False
 
     def __init__(self, nrows, ncols, ndepth, pg_seed=42, **kwargs):
         super().__init__(nrows, ncols, ndepth, **kwargs)

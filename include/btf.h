@@ -107,11 +107,28 @@ int btf_set_hyper(btf_ctx* ctx, const double* Tau2 /* (M,nD) */, double lam2, do
  * auxiliary levels Tau2_a/b/c (M,nD); btf_resample_Tau2 replaces the per-column loop of
  * BTF._resample_Tau2 (factor.py:134-141) for all columns at once, updating Tau2 and the chain
  * in place on the device, and returns lsum[j] = sum_r dsq[j,r]/Tau2_new[j,r] (the per-column
- * terms of the lam2 rate, factor.py:148-150) when lsum_out != NULL (synchronises).          */
+ * terms of the lam2 rate, factor.py:148-150) when lsum_out != NULL (synchronises).  With
+ * device-resident scalars enabled the lam2 argument is ignored.                             */
 int btf_set_tau_chain(btf_ctx* ctx, const double* Tau2_a, const double* Tau2_b, const double* Tau2_c);
 int btf_get_tau(btf_ctx* ctx, double* Tau2, double* Tau2_a, double* Tau2_b, double* Tau2_c); /* a,b,c may be NULL */
 int btf_resample_Tau2(btf_ctx* ctx, uint64_t seed, double lam2, double stability, double* lsum_out /* (M) or NULL */);
 int btf_set_nu2(btf_ctx* ctx, double nu2);               /* Gaussian scalar noise variance */
+/* Device-resident scalar hyper-parameters (rng="device" only, unsharded
+ * contexts).  After btf_device_scalars(ctx,1) the half-sweep, prior-band and Tau2 kernels read
+ * nu2 (Gaussian data), sigma2 and lam2 from a small device array instead of the host copies, and
+ *   btf_draw_scalars: nu2 | rest (which&1; runs the residual reduction of factor.py:411-416 and the
+ *                     inverse-gamma draw of genlasso.py:160-164) and sigma2 | rest (which&2;
+ *                     factor.py:130-132) - priors InvGamma(a,b);
+ *   btf_draw_lam2:    lam2, lam2_a | rest (factor.py:143-153; compat selects quirk Q3's rate), from
+ *                     the per-column sums the preceding btf_resample_Tau2 left on the device
+ * draw them there from Philox streams, so that a full Gibbs sweep queues without a host round
+ * trip.  btf_set_scalars uploads values, btf_get_scalars (synchronises) returns
+ * {nu2, sigma2, lam2, lam2_a, SSE of the last nu2 draw, sum W^2 of the last sigma2 draw}.      */
+int btf_device_scalars(btf_ctx* ctx, int enable);
+int btf_set_scalars(btf_ctx* ctx, double nu2, double sigma2, double lam2, double lam2_a);
+int btf_get_scalars(btf_ctx* ctx, double* out6);
+int btf_draw_scalars(btf_ctx* ctx, uint64_t seed, int which, double nu2_a, double nu2_b, double sigma2_a, double sigma2_b);
+int btf_draw_lam2(btf_ctx* ctx, uint64_t seed, int compat);
 int btf_set_omega(btf_ctx* ctx, const double* omega_rows, const double* omega_cols); /* Binomial: PG draws, slabs as data */
 int btf_get_omega(btf_ctx* ctx, double* omega_rows);     /* (nrows_local,M,T) */
 
