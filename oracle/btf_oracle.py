@@ -499,6 +499,78 @@ def pg_draw_series(b, c, size, rng, nterms=256):
 
 
 # --------------------------------------------------------------------------
+# Negative-Binomial rate update      (factor.py:462-563)
+#   counts y ~ NB(R, p), p = ilogit(w.v): given R the augmented model is the
+#   Binomial one with Y = sum_r y_r successes out of N = sum_r (y_r + R) trials.
+#   R is updated by `nmetropolis` random-walk MH steps on log R; rdims are the
+#   dims of (rows, cols, depth) a single R value is shared across.
+# --------------------------------------------------------------------------
+
+def nb_rate_shape(dims, rdims):
+    """Shape of R: 1 along shared dims (factor.py:560-561)."""
+    return tuple(1 if i in rdims else c for i, c in enumerate(dims))
+
+
+def nb_init_rate(dims, rdims, rstdev=1.0):
+    """exp(N(0, rstdev)) + 1  (factor.py:560-563)."""
+    return np.exp(np.random.normal(0, rstdev, size=nb_rate_shape(dims, rdims))) + 1
+
+
+def nb_log1m_p(W, V):
+    """log(1 - ilogit(clip(w.v, -10, 10)))  (factor.py:519, :534)."""
+    x = np.einsum("nk,mtk->nmt", W, V).clip(-10, 10)
+    return -np.log1p(np.exp(x))
+
+
+def nb_loglik_ratio(data, R, candR, l1p, rdims):
+    """Log-likelihood ratio candidate/current, summed over replicates and the shared dims;
+    NaN observations drop out with their whole term (factor.py:533-538).  data (N,M,T,r);
+    R, candR broadcastable (.,.,.); returns the array over the unshared dims."""
+    from scipy.special import gammaln
+    R4, C4 = R[..., None], candR[..., None]
+    term = (gammaln(data + C4) - gammaln(C4) - gammaln(data + R4) + gammaln(R4)
+            + (C4 - R4) * l1p[..., None])
+    for dim in [3] + sorted(rdims)[::-1]:
+        term = np.nansum(term, axis=dim)
+    return term
+
+
+def nb_resample_rate(st, data, rdims=(0, 1, 2), nmetropolis=30, rpropstdev=0.1, rstdev=1.0):
+    """factor.py:513-554: st["R"] updated in place (global legacy RNG: per step one normal and
+    one uniform array of R's shape); returns the Binomial trial counts N = nansum(data + R)."""
+    from scipy.stats import norm
+    if data.ndim == 3:
+        data = data[..., None]
+    R = st["R"]
+    logR = np.log(R)
+    l1p = nb_log1m_p(st["W"], st["V"])
+    for _ in range(nmetropolis):
+        cand_log = logR + np.random.normal(0, rpropstdev, size=logR.shape)
+        cand = np.exp(cand_log)
+        a_prior = norm.logpdf(cand_log, loc=0, scale=rstdev) - norm.logpdf(logR, loc=0, scale=rstdev)
+        a_lik = nb_loglik_ratio(data, R, cand, l1p, rdims)
+        a_prior = np.squeeze(a_prior).reshape(a_lik.shape)
+        prob = np.exp(np.clip(a_prior + a_lik, -10, 1)).reshape(R.shape)
+        acc = np.random.random(size=prob.shape) <= prob
+        acc = acc & (cand > 1)
+        logR[acc] = cand_log[acc]
+        R[acc] = np.exp(cand_log[acc])
+    return nb_trials(data, R)
+
+
+def nb_trials(data, R):
+    """Binomial pseudo-data of the augmented model (factor.py:503-505, :552):
+    Y = nansum(data) with NaN where every replicate is missing; N = nansum(data + R)
+    (0, not NaN, where every replicate is missing)."""
+    if data.ndim == 3:
+        data = data[..., None]
+    missing = np.all(np.isnan(data), axis=-1)
+    Y = np.nansum(data, axis=-1)
+    Y[missing] = np.nan
+    return Y, np.nansum(data + R[..., None], axis=-1)
+
+
+# --------------------------------------------------------------------------
 # "strong" CPU path (BASELINE.md section 4b): same conditionals, restructured for
 # the CPU - statistics hoisted, BLAS for the Gram / mean accumulation, banded
 # LAPACK per column.  Complete Gaussian data only (the headline workload).

@@ -188,3 +188,46 @@ def test_strong_cpu_path_equals_reference_faithful_path(golden):
     assert relerr(W, g["W_after"]) < 1e-11
     V = orc.v_step_strong(st, Rr, ybar, Delta, z=g["z_V"])
     assert relerr(V, g["V_after_depth"]) < 1e-6
+
+
+NB_TAGS = ["scalar", "rows", "cells", "cols_depth"]
+
+
+@pytest.mark.parametrize("tag", NB_TAGS)
+def test_negbinom_rate_update(golden, tag):
+    """the random-walk MH update of the Negative-Binomial rate R
+    (factor.py:513-554) replayed from the same legacy-RNG seed must walk the same path."""
+    g = golden("g7_negbinom_%s.npz" % tag)
+    rdims = tuple(int(d) for d in g["rdims"])
+    st = state_from(g, "s0_")
+    st["R"] = g["R_before"].copy()
+    assert st["R"].shape == orc.nb_rate_shape(g["data"].shape[:3], rdims)
+    np.random.seed(int(g["seed_R"]))
+    Y, Ntr = orc.nb_resample_rate(st, g["data"], rdims=rdims)
+    assert relerr(st["R"], g["R_after"]) < 1e-12
+    assert relerr(Ntr, g["N_after"]) < 1e-12
+    assert np.array_equal(np.isnan(Y), np.all(np.isnan(g["data"]), axis=-1))
+
+
+@pytest.mark.parametrize("tag", ["scalar", "rows"])
+def test_negbinom_full_sweep_given_omega(golden, tag):
+    """One whole NB sweep of the reference (R update, then the Binomial sweep on the pseudo-data
+    Y = sum of counts, N = sum of counts + R) given the Polya-Gamma draws."""
+    g = golden("g7_negbinom_%s.npz" % tag)
+    N, M, T, R, K, tf = [int(x) for x in g["dims"]]
+    rdims = tuple(int(d) for d in g["rdims"])
+    st = state_from(g, "s0_")
+    st["R"] = g["R_before"].copy()
+    Delta = orc.trend_penalty(T, tf)
+    np.random.seed(int(g["seed_full"]))
+    Y, Ntr = orc.nb_resample_rate(st, g["data"], rdims=rdims)
+    assert relerr(st["R"], g["full_R"]) < 1e-12 and relerr(Ntr, g["full_N"]) < 1e-12
+    with np.errstate(divide="ignore"):
+        st["nu2"] = 1 / g["omega"]                       # factor.py:455-460 through the PG stand-in
+    orc.sigma2_step(st)
+    orc.tau2_step(st, Delta)
+    orc.lam2_step(st, Delta)
+    orc.binomial_w_step(st, Y, Ntr)
+    orc.binomial_v_step(st, Y, Ntr, Delta, perm="twist")
+    for k, tol in (("sigma2", 1e-12), ("lam2", 1e-12), ("Tau2", 1e-10), ("W", 1e-10), ("V", 1e-8)):
+        assert relerr(st[k], g["full_" + k]) < tol, k
