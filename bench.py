@@ -69,9 +69,10 @@ def main():
     ap.add_argument("--strong", action="store_true", help="fixed global tensor instead of weak scaling")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--rpb", type=int, nargs=2, default=[0, 0], help="rows per workgroup (W, V) tuning override")
-    ap.add_argument("--variant", default="complete", choices=["complete", "heldout", "missing5", "binomial"],
+    ap.add_argument("--variant", default="complete", choices=["complete", "heldout", "missing5", "binomial", "negbinom"],
                     help="complete: headline; heldout: Y[:3,:3]=NaN; missing5: 5%% curves + 5%% single replicates NaN; "
-                         "binomial: 4 trials per cell, device Polya-Gamma draw included in the step (config C4)")
+                         "binomial: 4 trials per cell, device Polya-Gamma draw included in the step (config C4); "
+                         "negbinom: NB(4, p) counts, step = 30 MH steps on the rate R + PG draw + W + V (SURVEY 8(f) rank 2)")
     ap.add_argument("--burn", type=int, default=3, help="full Gibbs sweeps before timing (leave the initial state)")
     args = ap.parse_args()
 
@@ -94,7 +95,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from functionalmf_amd.factor import GaussianBayesianTensorFiltering, BinomialBayesianTensorFiltering
+    from functionalmf_amd.factor import (GaussianBayesianTensorFiltering, BinomialBayesianTensorFiltering,
+                                         NegativeBinomialBayesianTensorFiltering)
     from functionalmf_amd.parallel import ShardPlan
 
     cfg = dict(CONFIGS[args.config])
@@ -129,6 +131,10 @@ def main():
         elif args.variant == "missing5":
             Y[rs.rand(N, M) < 0.05] = np.nan
             Y[rs.rand(N, M, T, R) < 0.05] = np.nan
+        elif args.variant == "negbinom":
+            Mu = np.einsum("nk,mtk->nmt", synth_rows(1, range(N), M, T, 1, K, Vt, noise=0.0)[1], Vt)
+            P = 1 / (1 + np.exp(-Mu))
+            Y = rs.negative_binomial(4.0, 1 - np.repeat(P[..., None], R, axis=-1)).astype(float)
         else:
             Mu = np.einsum("nk,mtk->nmt", synth_rows(1, range(N), M, T, 1, K, Vt, noise=0.0)[1], Vt)
             Ntr = np.full((N, M, T), 4.0)
@@ -140,6 +146,8 @@ def main():
                   shard=(rank, world) if world > 1 else None, device_seed=1)
     if args.variant == "binomial":
         model = BinomialBayesianTensorFiltering(N, M, T, **common)
+    elif args.variant == "negbinom":
+        model = NegativeBinomialBayesianTensorFiltering(N, M, T, **common)
     else:
         model = GaussianBayesianTensorFiltering(N, M, T, nu2_init=1.0, **common)
     if args.rpb != [0, 0]:
@@ -154,7 +162,13 @@ def main():
         model.resample(data)
     model.sync()
 
-    if args.variant == "binomial":
+    if args.variant == "negbinom":
+        def step():                       # rate update (30 MH steps) + PG draw + W + V
+            model._resample_R(data)
+            model._resample_nu2(data)
+            model._resample_W(data)
+            model._resample_V(data)
+    elif args.variant == "binomial":
         def step():                       # C4: full Binomial sweep of the device part: PG draw + W + V
             model._resample_nu2(data)
             model._resample_W(data)
@@ -233,7 +247,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%s_btf %s (%d,%d,%d,%d) nembeds=%d tf_order=2 %s data, W+V update, rng=device%s"
-                               % ("binomial" if args.variant == "binomial" else "gaussian", args.config, N, M, T, R, K, args.variant,
+                               % ({"binomial": "binomial", "negbinom": "negbinom"}.get(args.variant, "gaussian"), args.config, N, M, T, R, K, args.variant,
                                   "; %d-way row/column shards, RCCL all-gather of W and V" % world if world > 1 else ""),
                    "global_sweeps_per_s": round(sweeps_per_s, 2), "units_per_sweep": units,
                    "full_resample_sweeps_per_s": round(full_per_s, 2),
@@ -245,7 +259,7 @@ def main():
         "kernels_us": kernels_us,
     }
 
-    if world == 1 and not args.no_cpu and args.variant != "binomial":
+    if world == 1 and not args.no_cpu and args.variant not in ("binomial", "negbinom"):
         out["cpu_baseline"] = cpu_baseline(Y, model, cfg)
 
     if rank == 0:

@@ -21,7 +21,7 @@ HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith("
 
 BTF_OK, BTF_EINVAL, BTF_EHIP, BTF_ENOTPD, BTF_ESTATE = 0, 1, 2, 3, 4
 COMPAT = {"reference": 0, "exact": 1}
-KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw"]
+KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw", "nb_loglik"]
 
 # every symbol include/btf.h declares: (name, restype, argtypes)
 _c_dp = C.POINTER(C.c_double)
@@ -55,6 +55,9 @@ SIGNATURES = {
     "btf_get_V_order": (C.c_int, [_ctx, _c_ip]),
     "btf_sse": (C.c_int, [_ctx, _c_dp, _c_dp]),
     "btf_sse_begin": (C.c_int, [_ctx]),
+    "btf_set_data_counts": (C.c_int, [_ctx, _c_dp, C.c_int]),
+    "btf_nb_loglik": (C.c_int, [_ctx, _c_dp, _c_dp, _c_ip, _c_dp]),
+    "btf_nb_set_rate": (C.c_int, [_ctx, _c_dp, _c_ip]),
     "btf_device_scalars": (C.c_int, [_ctx, C.c_int]),
     "btf_set_scalars": (C.c_int, [_ctx, C.c_double, C.c_double, C.c_double, C.c_double]),
     "btf_get_scalars": (C.c_int, [_ctx, _c_dp]),

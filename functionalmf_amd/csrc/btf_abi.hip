@@ -63,6 +63,12 @@ struct btf_ctx {
   double* pin = nullptr; size_t pin_elems = 0;   // pinned host staging (async SSE partials + W)
   size_t sse_nb = 0; bool sse_pending = false;
   double* pin_lsum = nullptr;
+  // Negative-Binomial counts: raw replicates, per-cell sums / counts, rate buffers
+  double* nb_data = nullptr; double* nb_S = nullptr; double* nb_cnt = nullptr;
+  double* nb_R = nullptr; double* nb_C = nullptr; size_t nb_relems = 0;
+  double* nb_tmp = nullptr; size_t nb_tmp_elems = 0;
+  double* nb_out = nullptr; size_t nb_out_elems = 0;
+  int nb_Rr = 0; bool counts = false;
   double* hyp = nullptr;        // device-resident scalars [HYP_COUNT] (nu2, sigma2, lam2, lam2_a, ...)
   bool dev_scalars = false;     // kernels read nu2 / sigma2 / lam2 from hyp instead of the host copies
   double* pin_hyp = nullptr;
@@ -566,6 +572,8 @@ void btf_destroy(btf_ctx* c) {
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
   if (c->pin_hyp) (void)hipHostFree(c->pin_hyp);
+  for (void* p : {(void*)c->nb_data, (void*)c->nb_S, (void*)c->nb_cnt, (void*)c->nb_R, (void*)c->nb_C, (void*)c->nb_tmp, (void*)c->nb_out})
+    if (p) (void)hipFree(p);
   if (c->hyp) (void)hipFree(c->hyp);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -601,7 +609,7 @@ static int finish_data(btf_ctx* c) {
 int btf_set_data_gaussian(btf_ctx* c, const double* y_rows, const double* y_cols, int nreps) {
   if (!c || !y_rows || !y_cols || nreps < 1) return fail(c, BTF_EINVAL, "bad data arguments");
   HIPCHK(c, hipSetDevice(c->dev));
-  c->R = nreps; c->binomial = false;
+  c->R = nreps; c->binomial = false; c->counts = false;
   const int MT = c->M * c->T;
   c->ldw = round_up(std::max(c->nl, 1), ACC_TILE);
   c->ldv = round_up(std::max(c->ml * c->T, 1), ACC_TILE);
@@ -619,7 +627,7 @@ int btf_set_data_binomial(btf_ctx* c, const double* succ_rows, const double* tri
                           const double* trials_cols) {
   if (!c || !succ_rows || !trials_rows || !succ_cols || !trials_cols) return fail(c, BTF_EINVAL, "bad data arguments");
   HIPCHK(c, hipSetDevice(c->dev));
-  c->R = 1; c->binomial = true;
+  c->R = 1; c->binomial = true; c->counts = false;
   const int MT = c->M * c->T;
   c->ldw = round_up(std::max(c->nl, 1), ACC_TILE);
   c->ldv = round_up(std::max(c->ml * c->T, 1), ACC_TILE);
@@ -1013,6 +1021,128 @@ int btf_sse_begin(btf_ctx* c) {
   HIPCHK(c, hipMemcpyAsync(c->pin + nb, c->W, (size_t)c->N * c->K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   c->sse_nb = nb;
   c->sse_pending = true;
+  return BTF_OK;
+}
+
+// ------------------------------------------------------- Negative-Binomial counts
+namespace {
+size_t nb_rate_elems(const btf_ctx* c, const int32_t* sh) {
+  return (size_t)(sh[0] ? 1 : c->N) * (sh[1] ? 1 : c->M) * (sh[2] ? 1 : c->T);
+}
+void nb_strides(const btf_ctx* c, const int32_t* sh, long long* sr) {   // R is C-contiguous over its unshared dims
+  const long long e1 = sh[1] ? 1 : c->M, e2 = sh[2] ? 1 : c->T;
+  sr[0] = sh[0] ? 0 : e1 * e2;
+  sr[1] = sh[1] ? 0 : e2;
+  sr[2] = sh[2] ? 0 : 1;
+}
+int nb_upload_rate(btf_ctx* c, const double* R, const double* cand, const int32_t* sh) {
+  const size_t n = nb_rate_elems(c, sh);
+  int rc;
+  if (n > c->nb_relems) {
+    if ((rc = dev_alloc(c, &c->nb_R, n))) return rc;
+    if ((rc = dev_alloc(c, &c->nb_C, n))) return rc;
+    c->nb_relems = n;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->nb_R, R, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (cand) HIPCHK(c, hipMemcpyAsync(c->nb_C, cand, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return BTF_OK;
+}
+}  // namespace
+
+int btf_set_data_counts(btf_ctx* c, const double* counts, int nreps) {
+  if (!c || !counts || nreps < 1) return fail(c, BTF_EINVAL, "bad data arguments");
+  if (c->nl != c->N || c->ml != c->M) return fail(c, BTF_EINVAL, "count data need an unsharded context");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const int MT = c->M * c->T;
+  const size_t cells = (size_t)c->N * MT;
+  c->R = 1; c->binomial = true; c->counts = true; c->nb_Rr = nreps;
+  c->ldw = round_up(c->N, ACC_TILE);
+  c->ldv = round_up(MT, ACC_TILE);
+  int rc;
+  if ((rc = dev_alloc(c, &c->nb_data, cells * nreps))) return rc;
+  if ((rc = dev_alloc(c, &c->nb_S, cells))) return rc;
+  if ((rc = dev_alloc(c, &c->nb_cnt, cells))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->nb_data, counts, cells * nreps * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(nb_stats_kernel, dim3((unsigned)std::min<size_t>(4096, (cells + 255) / 256)), dim3(256), 0, c->stream,
+                     (const double*)c->nb_data, nreps, cells, c->nb_S, c->nb_cnt);
+  HIPCHK(c, hipGetLastError());
+  const size_t ew = (size_t)MT * c->ldw, ev = (size_t)c->N * c->ldv;
+  for (double** p : {&c->A_wT, &c->C_wT, &c->B_wT}) {
+    if ((rc = dev_alloc(c, p, ew))) return rc;
+    HIPCHK(c, hipMemsetAsync(*p, 0, ew * sizeof(double), c->stream));
+  }
+  for (double** p : {&c->A_v, &c->C_v, &c->B_v}) {
+    if ((rc = dev_alloc(c, p, ev))) return rc;
+    HIPCHK(c, hipMemsetAsync(*p, 0, ev * sizeof(double), c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->weighted = true;
+  c->have_data = true;
+  c->ssw = 0.0; c->nobs = 0.0;
+  return BTF_OK;
+}
+
+int btf_nb_loglik(btf_ctx* c, const double* R, const double* cand, const int32_t* shared, double* ll) {
+  if (!c || !R || !cand || !shared || !ll) return BTF_EINVAL;
+  if (!c->counts || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_nb_loglik needs count data, W and V");
+  HIPCHK(c, hipSetDevice(c->dev));
+  int rc;
+  if ((rc = nb_upload_rate(c, R, cand, shared))) return rc;
+  const int MT = c->M * c->T;
+  const size_t nR = nb_rate_elems(c, shared);
+  long long sr[3];
+  nb_strides(c, shared, sr);
+  // a few workgroups per row: enough to fill the chip at N >= 64, each amortising its table over many cells
+  const int nbx = std::max(1, std::min((MT + 255) / 256, std::max(1, 4096 / std::max(c->N, 1))));
+  const bool shared_jt = shared[1] && shared[2];
+  const size_t tmp_need = shared_jt ? (size_t)c->N * nbx : (size_t)c->N * MT;
+  const bool direct = !shared[0] && !shared[1] && !shared[2];      // nothing to reduce: per-cell terms are the answer
+  if (tmp_need > c->nb_tmp_elems) { if ((rc = dev_alloc(c, &c->nb_tmp, tmp_need))) return rc; c->nb_tmp_elems = tmp_need; }
+  if (nR > c->nb_out_elems) { if ((rc = dev_alloc(c, &c->nb_out, nR))) return rc; c->nb_out_elems = nR; }
+  {
+    Prof p(c, BTF_K_NB);
+#define NB_LAUNCH(RRT)                                                                                              \
+    K_SWITCH(c->K, p.launch(nb_loglik_kernel<KT, RRT>, dim3(nbx, c->N), dim3(256), 0, (const double*)c->nb_data,        \
+                            c->nb_Rr, (const double*)c->W, (const double*)c->V, MT, c->T, (const double*)c->nb_R,      \
+                            (const double*)c->nb_C, sr[0], sr[1], sr[2], shared_jt ? 1 : 0, direct ? c->nb_out : c->nb_tmp))
+    switch (c->nb_Rr) {
+      case 1: NB_LAUNCH(1); break;
+      case 2: NB_LAUNCH(2); break;
+      case 3: NB_LAUNCH(3); break;
+      case 4: NB_LAUNCH(4); break;
+      default: NB_LAUNCH(0); break;
+    }
+#undef NB_LAUNCH
+  }
+  HIPCHK(c, hipGetLastError());
+  if (!direct) {
+    Prof p(c, BTF_K_PROD);
+    if (shared_jt) p.launch(nb_reduce_kernel, dim3((unsigned)nR), dim3(256), 0, (const double*)c->nb_tmp, c->N, nbx, 1, (int)shared[0], 1, 1, c->nb_out);
+    else p.launch(nb_reduce_kernel, dim3((unsigned)nR), dim3(256), 0, (const double*)c->nb_tmp, c->N, c->M, c->T, (int)shared[0], (int)shared[1], (int)shared[2], c->nb_out);
+    HIPCHK(c, hipGetLastError());
+  }
+  HIPCHK(c, hipMemcpyAsync(ll, c->nb_out, nR * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return BTF_OK;
+}
+
+int btf_nb_set_rate(btf_ctx* c, const double* R, const int32_t* shared) {
+  if (!c || !R || !shared) return BTF_EINVAL;
+  if (!c->counts) return fail(c, BTF_ESTATE, "btf_nb_set_rate follows btf_set_data_counts");
+  HIPCHK(c, hipSetDevice(c->dev));
+  int rc;
+  if ((rc = nb_upload_rate(c, R, nullptr, shared))) return rc;
+  long long sr[3];
+  nb_strides(c, shared, sr);
+  const int MT = c->M * c->T;
+  {
+    Prof p(c, BTF_K_STATS);
+    p.launch(nb_trials_kernel, dim3((MT + 63) / 64, (c->N + 63) / 64), dim3(256), 0, (const double*)c->nb_S,
+             (const double*)c->nb_cnt, (const double*)c->nb_R, sr[0], sr[1], sr[2], c->N, MT, c->T, c->ldv, c->ldw, c->A_v,
+             c->B_v, c->A_wT, c->B_wT);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // R is a borrowed host buffer
   return BTF_OK;
 }
 

@@ -830,21 +830,52 @@ __global__ __launch_bounds__(SSE_THREADS) void sse_kernel(const double* __restri
 constexpr double PG_T = 0.64;
 constexpr double PG_PI = 3.141592653589793238462643383279502884;
 constexpr int PG_NORMAL_B = 200;
+constexpr int PG_DEVROYE_MAX = 12;   // integer b up to here: exact alternating-series draws, one per unit of b
+constexpr int PG_SERIES_NT = 16;     // terms of the sum-of-gammas series drawn for every other b (8 for b >= 8), + 2|psi|/(2 pi)
+constexpr int PG_SERIES_NT_MAX = 96;
 
 struct CellRng {
   uint64_t seed, cell, ctr;
-  uint32_t buf[4];
-  int have;
-  __device__ CellRng(uint64_t s, uint64_t c) : seed(s), cell(c), ctr(0), have(0) {}
-  __device__ double uniform() {
-    if (have == 0) { Philox::gen(seed, cell, ctr++, buf); have = 2; }
+  uint32_t b0, b1, b2, b3;   // one Philox block as four named words (an indexed array would live in scratch)
+  int have;            // unread 64-bit halves of the current Philox block
+  uint32_t w32;        // leftover 32-bit word of a half split by uniform32()
+  bool has32;
+  double spare;        // second Box-Muller variate
+  bool has_spare;
+  __device__ CellRng(uint64_t s, uint64_t c)
+      : seed(s), cell(c), ctr(0), b0(0), b1(0), b2(0), b3(0), have(0), w32(0), has32(false), spare(0.0), has_spare(false) {}
+  __device__ __forceinline__ void half(uint32_t& lo, uint32_t& hi) {
+    if (have == 0) {
+      uint32_t r[4];
+      Philox::gen(seed, cell, ctr++, r);
+      b0 = r[0]; b1 = r[1]; b2 = r[2]; b3 = r[3];
+      have = 2;
+    }
     --have;
-    return u01(buf[2 * have], buf[2 * have + 1]);
+    lo = have ? b2 : b0;
+    hi = have ? b3 : b1;
   }
-  __device__ double expo() { return -log(uniform()); }
-  __device__ double normal() {
+  __device__ __forceinline__ double uniform() {                 // 53-bit, never 0 or 1
+    uint32_t lo, hi;
+    half(lo, hi);
+    return u01(lo, hi);
+  }
+  __device__ __forceinline__ double uniform32() {               // 32-bit resolution: accept/reject decisions only
+    uint32_t w;
+    if (has32) { w = w32; has32 = false; }
+    else { uint32_t hi; half(w, hi); w32 = hi; has32 = true; }
+    return ((double)w + 0.5) * (1.0 / 4294967296.0);
+  }
+  __device__ __forceinline__ double expo() { return -log(uniform()); }
+  __device__ __forceinline__ double normal() {                  // Box-Muller, both variates used
+    if (has_spare) { has_spare = false; return spare; }
     const double u1 = uniform(), u2 = uniform();
-    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+    const double r = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    spare = r * sn;
+    has_spare = true;
+    return r * cs;
   }
 };
 
@@ -873,7 +904,7 @@ __device__ inline double pg_mass_texpon(double z) {
 }
 
 // inverse-Gaussian(1/z, 1) truncated to (0, PG_T)
-__device__ inline double pg_rtigauss(double z, CellRng& g) {
+__device__ __forceinline__ double pg_rtigauss(double z, CellRng& g) {
   double X = PG_T + 1.0;
   if (1.0 / z > PG_T) {  // mu > t
     double alpha = 0.0;
@@ -897,10 +928,10 @@ __device__ inline double pg_rtigauss(double z, CellRng& g) {
   return X;
 }
 
-__device__ inline double pg_one(double z /* = |psi|/2 */, double p_exp, CellRng& g) {
+__device__ __forceinline__ double pg_one(double z /* = |psi|/2 */, double p_exp, CellRng& g) {
   const double fz = 0.125 * PG_PI * PG_PI + 0.5 * z * z;
   while (true) {
-    const double X = (g.uniform() < p_exp) ? PG_T + g.expo() / fz : pg_rtigauss(z, g);
+    const double X = (g.uniform32() < p_exp) ? PG_T + g.expo() / fz : pg_rtigauss(z, g);
     double S = pg_a(0, X);
     const double Y = g.uniform() * S;
     int n = 0;
@@ -932,7 +963,7 @@ __device__ inline double pg_var_dev(double b, double c) {
 }
 
 // Gamma(shape,1), Marsaglia & Tsang (2000); shape < 1 by the U^(1/shape) boost
-__device__ inline double gamma_mt(double shape, CellRng& g) {
+__device__ __forceinline__ double gamma_mt(double shape, CellRng& g) {
   double boost = 1.0;
   if (shape < 1.0) { boost = pow(g.uniform(), 1.0 / shape); shape += 1.0; }
   const double d = shape - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
@@ -940,13 +971,13 @@ __device__ inline double gamma_mt(double shape, CellRng& g) {
     double x, v;
     do { x = g.normal(); v = 1.0 + cc * x; } while (v <= 0.0);
     v = v * v * v;
-    const double u = g.uniform();
+    const double u = g.uniform32();
     if (u < 1.0 - 0.0331 * x * x * x * x) return boost * d * v;
     if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return boost * d * v;
   }
 }
 
-__device__ inline double pg_draw(double b, double psi, CellRng& g) {
+__device__ __forceinline__ double pg_draw(double b, double psi, CellRng& g) {
   if (!(b > 0.0)) return 0.0;
   if (b >= PG_NORMAL_B) {
     const double m = pg_mean_dev(b, psi), sd = sqrt(pg_var_dev(b, psi));
@@ -954,32 +985,42 @@ __device__ inline double pg_draw(double b, double psi, CellRng& g) {
     do { x = m + sd * g.normal(); } while (x <= 0.0);
     return x;
   }
-  const double z = 0.5 * fabs(psi);
-  const int nb = (int)floor(b);
-  const double frac = b - nb;
-  double sum = 0.0;
-  if (nb > 0) {
+  const double fl = floor(b);
+  if (b == fl && b <= (double)PG_DEVROYE_MAX) {     // small integer b: sum of exact PG(1, psi) draws
+    const double z = 0.5 * fabs(psi);
     const double p_exp = pg_mass_texpon(z);
-    for (int i = 0; i < nb; ++i) sum += pg_one(z, p_exp, g);
+    double sum = 0.0;
+    for (int i = 0; i < (int)fl; ++i) sum += pg_one(z, p_exp, g);
+    return sum;
   }
-  if (frac > 1e-12) {  // PG(frac, psi) = 1/(2 pi^2) sum_k g_k / ((k-1/2)^2 + psi^2/(4 pi^2))
-    constexpr int NT = 128;
-    const double c2 = psi * psi / (4.0 * PG_PI * PG_PI);
-    double s = 0.0;
-    for (int k = 1; k <= NT; ++k) s += gamma_mt(frac, g) / ((k - 0.5) * (k - 0.5) + c2);
-    // tail mean: frac * sum_{k>NT} 1/((k-1/2)^2 + c2) ~ frac * atan-type integral
-    const double sc = sqrt(c2);
-    const double tail = sc > 1e-8 ? (0.5 * PG_PI - atan((double)NT / sc)) / sc : 1.0 / NT;
-    sum += (s + frac * tail) / (2.0 * PG_PI * PG_PI);
+  // any other b: PG(b, psi) = 1/(2 pi^2) sum_k g_k / ((k-1/2)^2 + c2), g_k ~ Gamma(b, 1), c2 = psi^2/(4 pi^2).
+  // The first NT terms are drawn; the remainder - a sum of many comparably small independent terms -
+  // enters through a normal with its exact mean  b int_NT^inf dx/(x^2+c2)  and variance
+  // b int_NT^inf dx/(x^2+c2)^2  (midpoint rule; share of the total variance 5e-6 at psi = 0, 6 % at |psi| = 60)
+  const double c2 = psi * psi / (4.0 * PG_PI * PG_PI);
+  const double sc = sqrt(c2);
+  // the weights are flat up to k ~ sc: start the tail only where they decay (k^-2)
+  const int NT = min(PG_SERIES_NT_MAX, (b >= 8.0 ? PG_SERIES_NT / 2 : PG_SERIES_NT) + (int)(2.0 * sc));
+  double s = 0.0;
+  for (int k = 1; k <= NT; ++k) s += gamma_mt(b, g) / ((k - 0.5) * (k - 0.5) + c2);
+  double tmean, tvar;
+  if (sc > 1e-4 * NT) {
+    const double phi = atan(sc / NT);                       // = pi/2 - atan(NT/sc)
+    tmean = phi / sc;
+    tvar = (phi - 0.5 * sin(2.0 * phi)) / (2.0 * c2 * sc);
+  } else {
+    tmean = 1.0 / NT;
+    tvar = 1.0 / (3.0 * (double)NT * NT * NT);
   }
-  return sum;
+  const double x = s + b * tmean + sqrt(b * tvar) * g.normal();
+  return fmax(x, 1e-300) / (2.0 * PG_PI * PG_PI);
 }
 
 constexpr int PG_THREADS = 256;
 
 // out[r][l] = PG(B[r][l], L[l0+l] . U[r]);  global cell id = base + r*stride_r + l*stride_l
 template <int K>
-__global__ __launch_bounds__(PG_THREADS) void pg_kernel(const double* __restrict__ B, double* __restrict__ out,
+__global__ __launch_bounds__(PG_THREADS, 2) void pg_kernel(const double* __restrict__ B, double* __restrict__ out,
                                                         const double* __restrict__ Lf, const double* __restrict__ Uf,
                                                         int nl, int ld, int Rdim, int rows_per_block,
                                                         unsigned long long base, unsigned long long stride_r,
@@ -1005,7 +1046,7 @@ __global__ __launch_bounds__(PG_THREADS) void pg_kernel(const double* __restrict
 // written to the V-layout array directly and to the W-layout array through an LDS tile
 // transpose.  Same (seed, cell) streams as pg_kernel, hence identical draws.
 template <int K>
-__global__ __launch_bounds__(256) void pg_tile_kernel(const double* __restrict__ Bv, double* __restrict__ Cv,
+__global__ __launch_bounds__(256, 2) void pg_tile_kernel(const double* __restrict__ Bv, double* __restrict__ Cv,
                                                      double* __restrict__ CwT, const double* __restrict__ W,
                                                      const double* __restrict__ V, int N, int MT, int ldv, int ldw,
                                                      unsigned long long seed) {
@@ -1156,6 +1197,211 @@ __global__ __launch_bounds__(256) void lam2_kernel(const double* __restrict__ ls
     const double lam2 = fmax(1e-5, rate / gamma_mt(0.5 * shape, g));
     hyp[HYP_LAM2] = lam2;
     hyp[HYP_LAM2A] = (1.0 / lam2 + 1.0) / g.expo();
+  }
+}
+
+// ============================================================================
+// Negative-Binomial rate update  (factor.py:513-554)
+//   counts y_r ~ NB(R, p), p = ilogit(clip(w_i.v_jt, -10, 10)).  One random-walk MH step needs, for
+//   every R element, the log-likelihood ratio candidate/current summed over the replicates
+//   and over the dims R is shared across:
+//     sum_r [ lgamma(y+c) - lgamma(c) - lgamma(y+R) + lgamma(R) + (c-R) log(1-p) ]   (NaN y: term dropped)
+//   nb_loglik_kernel: lanes along (j,t), one row i per blockIdx.y; small integer counts use
+//     lgamma(y+c) - lgamma(c) = sum_{k<y} log(c+k) as ONE log of a ratio of products.
+//     shared_jt != 0: fixed-order block sum -> out[i][blockIdx.x]; else per cell out[i][jt].
+//   nb_reduce_kernel: one workgroup per R element sums its slice of a (d0,d1,d2) array in a
+//     fixed order (deterministic).
+//   nb_trials_kernel: Binomial pseudo-data of the augmented model in both device layouts:
+//     trials N = S + cnt R, A = S - N/2 (S = sum of observed counts, cnt = number observed).
+// ============================================================================
+constexpr int NB_FAST_MAX = 32;    // integer counts up to here: product form when R varies inside a block
+constexpr int NB_TAB = 1024;       // integer counts below this: LDS table when R is constant inside a block
+
+// lgamma(x) for x >= NB_STIRLING_MIN by Stirling's series (truncation error < 1/(1188 x^9) = 4e-17 at x = 33)
+constexpr double NB_STIRLING_MIN = 33.0;
+__device__ __forceinline__ double lgamma_big(double x) {
+  const double ix = 1.0 / x, ix2 = ix * ix;
+  const double ser = ix * (8.3333333333333333e-2 + ix2 * (-2.7777777777777778e-3 + ix2 * (7.9365079365079365e-4 + ix2 * -5.9523809523809524e-4)));
+  return (x - 0.5) * log(x) - x + 0.91893853320467274178 + ser;
+}
+
+// lgamma(a) - lgamma(b) for a, b > 0 without libm's lgamma (which costs ~200 registers): both arguments
+// are shifted up by the same n until Stirling applies,
+//   lgamma(a) - lgamma(b) = lgamma_big(a+n) - lgamma_big(b+n) - log( prod_{k<n}(a+k) / prod_{k<n}(b+k) ).
+__device__ inline double lgamma_diff(double a, double b) {
+  const double lo = fmin(a, b);
+  if (lo >= NB_STIRLING_MIN) return lgamma_big(a) - lgamma_big(b);
+  const int n = (int)ceil(NB_STIRLING_MIN - lo);                                   // <= 33
+  double pa = 1.0, pb = 1.0;
+  for (int k = 0; k < n; ++k) { pa *= a + k; pb *= b + k; }                        // < 66^33: no overflow
+  return lgamma_big(a + n) - lgamma_big(b + n) - log(pa / pb);
+}
+
+// count part of one replicate's term: lgamma(y+c) - lgamma(c) - lgamma(y+r) + lgamma(r);
+// base = lgamma(r) - lgamma(c) (NaN: not computed yet - filled on first use)
+__device__ inline double nb_count_part(double y, double r, double c, double& base) {
+  if (y >= 0.0 && y <= (double)NB_FAST_MAX && y == floor(y)) {   // = log prod_{k<y} (c+k)/(r+k)
+    double num = 1.0, den = 1.0;
+    const int n = (int)y;
+    for (int k = 0; k < n; ++k) { num *= c + k; den *= r + k; }
+    return log(num / den);
+  }
+  if (!(base == base)) base = lgamma_diff(r, c);
+  return lgamma_diff(y + c, y + r) + base;
+}
+
+// `row_rate` != 0: R does not vary along (j,t) (sr1 = sr2 = 0), so the count part of the term is a
+// function of y alone inside a block: tabulated once in LDS for integer y < NB_TAB (a prefix sum of
+// log((c+k)/(r+k))); everything else goes through nb_count_part.
+// RR > 0: number of replicates known at compile time (all loads of a cell in flight together).
+template <int K, int RR>
+__global__ __launch_bounds__(256) void nb_loglik_kernel(const double* __restrict__ data, int Rr,
+                                                       const double* __restrict__ W, const double* __restrict__ V,
+                                                       int MT, int T, const double* __restrict__ Rv,
+                                                       const double* __restrict__ Cv, long long sr0, long long sr1,
+                                                       long long sr2, int shared_jt, double* __restrict__ out) {
+  __shared__ double red[4];
+  __shared__ double tab[NB_TAB + 1];     // tab[y] = sum_{k<y} log((c+k)/(r+k)), y < NB_TAB; tab[NB_TAB] = lgamma(r) - lgamma(c)
+  __shared__ double wsum[4];
+  const int i = blockIdx.y;
+  const bool row_rate = sr1 == 0 && sr2 == 0;
+  if (row_rate) {   // inclusive scan of the NB_TAB log-ratios: 4 per thread, wave scan, then the three wave offsets
+    static_assert(NB_TAB == 1024, "4 table entries per thread of a 256-thread block");
+    const double r = Rv[(long long)i * sr0], c = Cv[(long long)i * sr0];
+    const int k0 = 4 * threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double l[4], run = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { run += log((c + (k0 + q)) / (r + (k0 + q))); l[q] = run; }
+    double incl = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double up = __shfl_up(incl, d, WAVE);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    if (threadIdx.x == 0) tab[NB_TAB] = lgamma_diff(r, c);
+    __syncthreads();
+    double off = incl - run;                       // exclusive prefix inside the wave
+    for (int u = 0; u < wv; ++u) off += wsum[u];
+    if (threadIdx.x == 0) tab[0] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (k0 + q + 1 < NB_TAB) tab[k0 + q + 1] = off + l[q];
+    __syncthreads();
+  }
+  // grid-stride over the (j,t) cells of row i: the table is built once per block, not once per cell
+  double bterm = 0.0;
+  const double* __restrict__ w = W + (size_t)i * K;
+  const int nrep = RR > 0 ? RR : Rr;
+  for (int jt = blockIdx.x * 256 + threadIdx.x; jt < MT; jt += gridDim.x * 256) {
+    const double* __restrict__ y = data + ((size_t)i * MT + jt) * nrep;
+    double yv[RR > 0 ? RR : 1];
+    if constexpr (RR > 0) {
+#pragma unroll
+      for (int q = 0; q < RR; ++q) yv[q] = y[q];
+    }
+    const int j = jt / T, t = jt - j * T;
+    const long long ri = (long long)i * sr0 + (long long)j * sr1 + (long long)t * sr2;
+    const double r = Rv[ri], c = Cv[ri];
+    double psi = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) psi = fma(w[k], V[(size_t)jt * K + k], psi);
+    psi = fmin(fmax(psi, -10.0), 10.0);
+    const double dl = (c - r) * -log1p(exp(psi));          // (c - R) log(1 - p), once per observed replicate
+    double base = row_rate ? tab[NB_TAB] : __builtin_nan("");
+    double term = 0.0;
+    for (int q = 0; q < nrep; ++q) {
+      double yy;
+      if constexpr (RR > 0) yy = yv[q]; else yy = y[q];
+      if (yy == yy) {
+        const bool tabbed = row_rate && yy >= 0.0 && yy < (double)NB_TAB && yy == floor(yy);
+        term += dl + (tabbed ? tab[(int)yy] : nb_count_part(yy, r, c, base));
+      }
+    }
+    if (shared_jt) bterm += term;
+    else out[(size_t)i * MT + jt] = term;
+  }
+  if (shared_jt) {
+    bterm = wave_sum(bterm);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bterm;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(size_t)i * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+// out[o] = sum over the shared dims of src[(a0,a1,a2)], src C-contiguous (d0,d1,d2); sh* flag the shared dims
+__global__ __launch_bounds__(256) void nb_reduce_kernel(const double* __restrict__ src, int d0, int d1, int d2, int sh0,
+                                                       int sh1, int sh2, double* __restrict__ out) {
+  __shared__ double red[4];
+  const int u0 = sh0 ? 1 : d0, u1 = sh1 ? 1 : d1, u2 = sh2 ? 1 : d2;   // unshared extents
+  const int s0 = sh0 ? d0 : 1, s1 = sh1 ? d1 : 1, s2 = sh2 ? d2 : 1;   // shared extents
+  int o = blockIdx.x;
+  const int b2 = o % u2; o /= u2;
+  const int b1 = o % u1; o /= u1;
+  const int b0 = o;
+  const long long ns = (long long)s0 * s1 * s2;
+  double acc = 0.0;
+  for (long long q = threadIdx.x; q < ns; q += 256) {
+    long long x = q;
+    const int c2 = (int)(x % s2); x /= s2;
+    const int c1 = (int)(x % s1); x /= s1;
+    const int c0 = (int)x;
+    const int a0 = sh0 ? c0 : b0, a1 = sh1 ? c1 : b1, a2 = sh2 ? c2 : b2;
+    acc += src[((size_t)a0 * d1 + a1) * d2 + a2];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// S[cell] = sum of observed counts, cnt[cell] = number of observed replicates
+__global__ void nb_stats_kernel(const double* __restrict__ data, int Rr, size_t cells, double* __restrict__ S,
+                                double* __restrict__ cnt) {
+  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
+    double s = 0.0, n = 0.0;
+    for (int q = 0; q < Rr; ++q) {
+      const double y = data[c * Rr + q];
+      if (y == y) { s += y; n += 1.0; }
+    }
+    S[c] = s; cnt[c] = n;
+  }
+}
+
+// 64 x 64 tiles of the (N, MT) cell grid: V layout written directly, W layout through an LDS transpose
+__global__ __launch_bounds__(256) void nb_trials_kernel(const double* __restrict__ S, const double* __restrict__ cnt,
+                                                       const double* __restrict__ Rv, long long sr0, long long sr1,
+                                                       long long sr2, int N, int MT, int T, int ldv, int ldw,
+                                                       double* __restrict__ Av, double* __restrict__ Bv,
+                                                       double* __restrict__ AwT, double* __restrict__ BwT) {
+  __shared__ double ta[64][65], tb[64][65];
+  const int col = threadIdx.x & 63;
+  const int rgrp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int jt0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+  const int jt = jt0 + col;
+  const int j = jt / T, t = jt - j * T;
+  for (int q = 0; q < 16; ++q) {
+    const int r = rgrp + 4 * q, i = i0 + r;
+    double a = 0.0, b = 0.0;
+    if (i < N && jt < MT) {
+      const size_t cell = (size_t)i * MT + jt;
+      const double n = cnt[cell], s = S[cell];
+      if (n > 0.0) {
+        b = s + n * Rv[(long long)i * sr0 + (long long)j * sr1 + (long long)t * sr2];
+        a = s - 0.5 * b;
+      }
+      Av[(size_t)i * ldv + jt] = a;
+      Bv[(size_t)i * ldv + jt] = b;
+    }
+    ta[r][col] = a; tb[r][col] = b;
+  }
+  __syncthreads();
+  const int i = i0 + col;
+  for (int q = 0; q < 16; ++q) {
+    const int c = rgrp + 4 * q, jj = jt0 + c;
+    if (jj < MT && i < N) {
+      AwT[(size_t)jj * ldw + i] = ta[col][c];
+      BwT[(size_t)jj * ldw + i] = tb[col][c];
+    }
   }
 }
 

@@ -689,3 +689,116 @@ class BinomialBayesianTensorFiltering(GaussianBayesianTensorFiltering):
         self._ctx.call("btf_pg_draw", seed)
         self._omega_dev_new = True
         self._omega_host_new = False
+
+
+class NegativeBinomialBayesianTensorFiltering(BinomialBayesianTensorFiltering):
+    """Negative-Binomial counts y ~ NB(R, ilogit(w.v)) (factor.py:462-563): given the rate R the
+    augmented model is the Binomial one on Y = sum_r y_r, N = sum_r (y_r + R); R itself is
+    updated by `nmetropolis` random-walk Metropolis-Hastings steps on log R per sweep.
+
+    The counts stay on the GPU: the data-sized part of every MH step (the log-likelihood ratio,
+    `btf_nb_loglik`) and the rebuild of the Binomial pseudo-data after R moved
+    (`btf_nb_set_rate`) are kernels; proposals and accept/reject decisions are drawn on the
+    host from the legacy numpy stream in the reference's order, so that a seeded chain walks
+    the reference's path.  `rdims`: dims of (rows, cols, depth) one R value is shared across.
+
+    Deviation: with `R_true` the reference never defines `self.N` and fails in `resample`
+    (factor.py:476-478 vs :508); here N is built from R_true."""
+
+    def __init__(self, nrows, ncols, ndepth, R_true=None, R_init=None, nmetropolis=30, rpropstdev=0.1,
+                 rstdev=1, rdims=(0, 1, 2), **kwargs):
+        super().__init__(nrows, ncols, ndepth, **kwargs)
+        if self._plan.world > 1:
+            raise NotImplementedError("NegativeBinomialBayesianTensorFiltering: unsharded runs only")
+        self._shared = tuple(sorted(int(d) for d in (rdims if rdims is not None else ())))
+        self.rdims = [3] + list(self._shared[::-1])                      # factor.py:485
+        self.nmetropolis, self.rpropstdev, self.rstdev = nmetropolis, rpropstdev, rstdev
+        self.sample_R = R_true is None
+        if R_true is not None:
+            self.R = np.array(R_true, dtype=float)
+        elif R_init is not None:
+            self.R = np.array(R_init, dtype=float)
+        else:
+            self._init_R()
+        self._rate_key = None
+
+    def _rate_shape(self):
+        return tuple(1 if i in self._shared else c for i, c in enumerate((self.nrows, self.ncols, self.ndepth)))
+
+    def _init_R(self):
+        """exp(N(0, rstdev)) + 1 (factor.py:560-563)."""
+        self.R = np.exp(np.random.normal(0, self.rstdev, size=self._rate_shape())) + 1
+
+    def _shared_flags(self):
+        return np.array([1 if d in self._shared else 0 for d in range(3)], dtype=np.int32)
+
+    # ---- data: the raw replicate counts, uploaded once --------------------------------------
+    @staticmethod
+    def _counts4(data):
+        if isinstance(data, (tuple, list)):
+            raise ValueError("negative-binomial data is the count tensor itself, not a (Y, N) pair")
+        return data[..., None] if data.ndim == 3 else data
+
+    def _upload(self, data):
+        d4 = _native.as_f64(self._counts4(data))
+        if d4.ndim != 4 or d4.shape[:3] != (self.nrows, self.ncols, self.ndepth):
+            raise ValueError("data shape %r does not match the model" % (data.shape,))
+        self._ctx.call("btf_set_data_counts", _native.dptr(d4), int(d4.shape[3]))
+        miss = np.all(np.isnan(d4), axis=-1)
+        self._ctx.call("btf_set_stale_sources",
+                       stale_row_sources(self.nrows, self.nembeds, bool(miss.any())).ctypes.data_as(_native._c_ip),
+                       stale_col_sources(miss).ctypes.data_as(_native._c_ip))
+        self._nb_sum = np.nansum(d4, axis=-1)
+        self._nb_cnt = (~np.isnan(d4)).sum(axis=-1).astype(float)
+        self._rate_key = None
+        self._omega_host_new = True
+
+    @property
+    def N(self):
+        """Binomial trial counts of the augmented model, nansum(data + R) (factor.py:552)."""
+        return self._nb_sum + self._nb_cnt * np.broadcast_to(self.R, self._nb_sum.shape)
+
+    def _push_rate(self):
+        R = _native.as_f64(np.broadcast_to(self.R, self._rate_shape()))
+        key = R.tobytes() if R.size <= 4096 else (id(self.R), float(R.sum()), float((R * R).sum()))
+        if key != self._rate_key:
+            self._ctx.call("btf_nb_set_rate", _native.dptr(R), self._shared_flags().ctypes.data_as(_native._c_ip))
+            self._rate_key = key
+
+    def _bind_data(self, data):
+        super()._bind_data(data)
+        self._push_rate()
+
+    def resample(self, data):
+        self._bind_data(data)
+        if self.sample_R:
+            self._resample_R(data)
+        super().resample(data)
+
+    def _resample_R(self, data):
+        """Random-walk MH on log R (factor.py:513-554): per step one normal and one uniform array
+        of R's shape from the legacy stream; the likelihood ratio comes from the GPU."""
+        self._bind_data(data)
+        self._push_state()
+        shp = self._rate_shape()
+        s2 = float(self.rstdev) ** 2
+        R = _native.as_f64(np.broadcast_to(self.R, shp)).copy()
+        logR = np.log(R)
+        flags = self._shared_flags().ctypes.data_as(_native._c_ip)
+        ll = np.zeros(shp)
+        for _ in range(self.nmetropolis):
+            cand_log = logR + np.random.normal(0, self.rpropstdev, size=shp)
+            cand = np.exp(cand_log)
+            a_prior = (logR * logR - cand_log * cand_log) / (2 * s2)      # N(0, rstdev) log-density ratio
+            self._ctx.call("btf_nb_loglik", _native.dptr(R), _native.dptr(cand), flags, _native.dptr(ll))
+            prob = np.exp(np.clip(a_prior + ll, -10, 1))
+            acc = np.random.random(size=shp) <= prob
+            acc &= cand > 1                                      # the reference's "TEMP" floor (factor.py:547)
+            logR[acc] = cand_log[acc]
+            R[acc] = np.exp(cand_log[acc])
+        self.R = R
+        self._push_rate()
+
+    def _inferred_variables(self, var_map):
+        super()._inferred_variables(var_map)
+        var_map['R'] = np.copy(self.R)

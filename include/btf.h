@@ -58,7 +58,8 @@ enum {
   BTF_K_PROD = 6,    /* per-row outer products u u' (weighted path)         */
   BTF_K_SSE = 7,     /* residual sum of squares for nu2                     */
   BTF_K_PG = 8,      /* Polya-Gamma draws                                   */
-  BTF_K_COUNT = 9
+  BTF_K_NB = 9,      /* Negative-Binomial rate update: MH log-likelihood ratio */
+  BTF_K_COUNT = 10
 };
 
 /* ---- lifetime ------------------------------------------------------------
@@ -95,6 +96,21 @@ int btf_set_data_binomial(btf_ctx* ctx, const double* succ_rows, const double* t
  * NULL = identity.  Only consulted by the weighted kernels.  Call after
  * btf_set_data_*; a source outside this ctx's shard is BTF_EINVAL.             */
 int btf_set_stale_sources(btf_ctx* ctx, const int32_t* src_row, const int32_t* src_col);
+
+/* ---- Negative-Binomial counts (unsharded contexts) -----------------
+ * counts: (N,M,T,nreps) C-order, NaN = missing; kept on the device.  The model is the
+ * Binomial one on pseudo-data Y = sum_r y_r, N = sum_r (y_r + R) (factor.py:494-511, :552):
+ * btf_nb_set_rate builds those (both layouts) from the rate R; afterwards btf_pg_draw /
+ * btf_resample_W / btf_resample_V run as for btf_set_data_binomial.
+ * shared[d] != 0: one R value is shared along dim d of (rows, cols, depth) (the reference's
+ * `rdims`); R and cand are C-contiguous over the unshared dims.
+ * btf_nb_loglik replaces the data-sized part of one random-walk MH step of
+ * NegativeBinomialBTF._resample_R (factor.py:533-541): ll[e] = sum over replicates and shared
+ * dims of lgamma(y+cand)-lgamma(cand)-lgamma(y+R)+lgamma(R)+(cand-R) log(1-p),
+ * p = ilogit(clip(w.v,-10,10)), NaN observations dropped.  Synchronises.                   */
+int btf_set_data_counts(btf_ctx* ctx, const double* counts, int nreps);
+int btf_nb_loglik(btf_ctx* ctx, const double* R, const double* cand, const int32_t* shared3, double* ll);
+int btf_nb_set_rate(btf_ctx* ctx, const double* R, const int32_t* shared3);
 
 /* ---- state ---------------------------------------------------------------- */
 int btf_set_W(btf_ctx* ctx, const double* W);            /* (N,K)      */

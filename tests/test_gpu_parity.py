@@ -267,7 +267,7 @@ def pg_batch(b, psi, seed):
     return out
 
 
-@pytest.mark.parametrize("b", [1, 2, 4, 10, 100.5, 300])
+@pytest.mark.parametrize("b", [1, 2, 4, 10, 1.3, 7.5, 13, 40, 33.7, 100.5, 300])
 @pytest.mark.parametrize("c", [0.0, 0.5, 2.0, 8.0, 60.0])
 def test_pg_moments(b, c):
     from oracle import btf_oracle as orc
@@ -279,7 +279,7 @@ def test_pg_moments(b, c):
     assert abs(x.var() - v) / v < 0.03, (x.var(), v)
 
 
-@pytest.mark.parametrize("b,c", [(1, 0.0), (1, 3.0), (4, 1.0), (2.5, 2.0)])
+@pytest.mark.parametrize("b,c", [(1, 0.0), (1, 3.0), (4, 1.0), (2.5, 2.0), (1.2, 0.0), (16, 0.7), (27.3, 4.0)])
 def test_pg_distribution_ks(b, c):
     """Two-sample KS against the definition-based series sampler of the oracle."""
     from scipy.stats import ks_2samp
@@ -481,7 +481,7 @@ def test_examples_run_end_to_end():
     import os
     from conftest import ROOT
     outs = {}
-    for name in ("gaussian_tensor_filtering", "binomial_tensor_filtering"):
+    for name in ("gaussian_tensor_filtering", "binomial_tensor_filtering", "negbinom_tensor_filtering"):
         spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "examples", name + ".py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
@@ -492,6 +492,8 @@ def test_examples_run_end_to_end():
     assert g["rmse_observed"] < 0.9 and g["rmse_heldout"] < 1.2 and 0.25 < g["nu2"] < 1.0
     b = outs["binomial_tensor_filtering"]
     assert b["corr"] > 0.7 and b["mae_observed"] < 0.13
+    nb = outs["negbinom_tensor_filtering"]
+    assert nb["corr_observed"] > 0.7 and nb["rel_mae_observed"] < 0.4
 
 
 def test_bitwise_reproducible(golden):
@@ -618,3 +620,95 @@ def test_full_device_sweep_needs_no_host_value_and_matches_host_scalars():
     assert abs(d[0] - h[0]) < 0.004, out
     assert 0.24 < d[0] < 0.26, out
     assert abs(d[1] - h[1]) < 1.5, out
+
+
+# ---- Negative-Binomial rate update ------------------------------------
+NB_TAGS = ["scalar", "rows", "cells", "cols_depth"]
+
+
+def negbinom_model(g, **kw):
+    from functionalmf_amd.factor import NegativeBinomialBayesianTensorFiltering
+    N, M, T, R, K, tf = [int(x) for x in g["dims"]]
+    st = state_from(g, "s0_")
+    model = NegativeBinomialBayesianTensorFiltering(
+        N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], W_init=st["W"],
+        V_init=st["V"], Tau2_init=st["Tau2"], R_init=g["R_before"].copy(),
+        rdims=tuple(int(d) for d in g["rdims"]), **kw)
+    for k in ("Tau2_a", "Tau2_b", "Tau2_c"):
+        setattr(model, k, st[k].copy())
+    model.lam2_a = st["lam2_a"]
+    return model, st
+
+
+@pytest.mark.parametrize("tag", NB_TAGS)
+def test_negbinom_loglik_ratio_vs_oracle(golden, tag):
+    """The data-sized part of one MH step (btf_nb_loglik) against the oracle's gammaln form, for
+    every sharing pattern of R; counts include NaNs, zeros and values beyond the product fast path."""
+    from oracle import btf_oracle as orc
+    from functionalmf_amd import _native
+    g = golden("g7_negbinom_%s.npz" % tag)
+    model, st = negbinom_model(g)
+    model._bind_data(g["data"])
+    model._push_state()
+    rs = np.random.RandomState(3)
+    rdims = tuple(int(d) for d in g["rdims"])
+    R = 1 + rs.gamma(2.0, 1.5, size=g["R_before"].shape)
+    cand = R * np.exp(rs.normal(0, 0.3, size=R.shape))
+    ll = np.zeros(R.shape)
+    model._ctx.call("btf_nb_loglik", _native.dptr(R), _native.dptr(cand),
+                    model._shared_flags().ctypes.data_as(_native._c_ip), _native.dptr(ll))
+    ref = orc.nb_loglik_ratio(g["data"], R, cand, orc.nb_log1m_p(st["W"], st["V"]), rdims)
+    assert relerr(ll.reshape(ref.shape), ref) < 1e-11
+
+
+@pytest.mark.parametrize("tag", NB_TAGS)
+def test_negbinom_rate_update_vs_reference(golden, tag):
+    """30 random-walk MH steps from the reference's seed: same accept/reject path, same R, same
+    Binomial trial counts (factor.py:513-554)."""
+    g = golden("g7_negbinom_%s.npz" % tag)
+    model, _ = negbinom_model(g)
+    np.random.seed(int(g["seed_R"]))
+    model._resample_R(g["data"])
+    assert relerr(model.R, g["R_after"]) < 1e-10
+    assert relerr(model.N, g["N_after"]) < 1e-10
+
+
+@pytest.mark.parametrize("tag", ["scalar", "rows"])
+def test_negbinom_full_sweep_vs_reference(golden, tag):
+    """One whole sweep of the reference's NegativeBinomial model (R, then the Binomial sweep on the
+    rebuilt pseudo-data) given the injected Polya-Gamma draws."""
+    g = golden("g7_negbinom_%s.npz" % tag)
+    model, _ = negbinom_model(g)
+    model.sample_nu2 = False
+    with np.errstate(divide="ignore"):
+        model.nu2 = 1 / g["omega"]
+    np.random.seed(int(g["seed_full"]))
+    model.resample(g["data"])
+    assert relerr(model.R, g["full_R"]) < 1e-10 and relerr(model.N, g["full_N"]) < 1e-10
+    for k, tol in (("sigma2", 1e-10), ("lam2", 1e-10), ("Tau2", 1e-9), ("W", 1e-9), ("V", V_TOL)):
+        assert relerr(getattr(model, k), g["full_" + k]) < tol, k
+
+
+def test_negbinom_chain_recovers_rate_and_mean():
+    """End to end (device PG draws): counts simulated from NB(R=5, p) - the chain must put R near 5
+    and the fitted mean R p/(1-p) near the truth."""
+    from functionalmf_amd.factor import NegativeBinomialBayesianTensorFiltering
+    rs = np.random.RandomState(12)
+    N, M, T, Rr, K = 24, 10, 12, 4, 2
+    Wt = 0.7 * rs.normal(size=(N, K))
+    Vt = 0.3 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    P = 1 / (1 + np.exp(-np.einsum("nk,mtk->nmt", Wt, Vt)))
+    data = rs.negative_binomial(5.0, 1 - P[..., None].repeat(Rr, -1)).astype(float)
+    data[:2, :2] = np.nan
+    np.random.seed(13)
+    model = NegativeBinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1,
+                                                    nmetropolis=10)
+    res = model.run_gibbs(data, nburn=300, nthin=2, nsamples=150, verbose=False)
+    assert res["R"].shape == (150, 1, 1, 1)
+    R_hat = res["R"].mean()
+    assert 3.5 < R_hat < 7.0, R_hat
+    Ps = 1 / (1 + np.exp(-np.einsum("znk,zmtk->znmt", res["W"], res["V"]).clip(-10, 10)))
+    Mu_hat = (res["R"] * Ps / (1 - Ps)).mean(0)
+    Mu = 5.0 * P / (1 - P)
+    obs = ~np.isnan(data[..., 0])
+    assert np.corrcoef(Mu_hat[obs], Mu[obs])[0, 1] > 0.9
