@@ -830,8 +830,8 @@ __global__ __launch_bounds__(SSE_THREADS) void sse_kernel(const double* __restri
 constexpr double PG_T = 0.64;
 constexpr double PG_PI = 3.141592653589793238462643383279502884;
 constexpr int PG_NORMAL_B = 200;
-constexpr int PG_DEVROYE_MAX = 12;   // integer b up to here: exact alternating-series draws, one per unit of b
-constexpr int PG_SERIES_NT = 16;     // terms of the sum-of-gammas series drawn for every other b (8 for b >= 8), + 2|psi|/(2 pi)
+constexpr int PG_DEVROYE_MAX = 2;   // integer b up to here: exact alternating-series draws, one per unit of b
+constexpr int PG_SERIES_NT = 16;     // terms of the sum-of-gammas series drawn for every other b (8 for b >= 3), + 2|psi|/(2 pi)
 constexpr int PG_SERIES_NT_MAX = 96;
 
 struct CellRng {
@@ -867,6 +867,21 @@ struct CellRng {
     return ((double)w + 0.5) * (1.0 / 4294967296.0);
   }
   __device__ __forceinline__ double expo() { return -log(uniform()); }
+  // Box-Muller evaluated with the f32 hardware transcendentals (v_log_f32 / v_sin_f32 / v_cos_f32 /
+  // v_sqrt_f32): a standard normal VARIATE good to ~1e-6 relative, |z| <= 6.7 - for rejection
+  // samplers whose output is a random draw anyway (the Polya-Gamma series); ~15 instructions
+  // instead of ~300 for the f64 log / sqrt / sincospi.  One 64-bit half gives two variates.
+  __device__ __forceinline__ double normal32() {
+    if (has_spare) { has_spare = false; return spare; }
+    uint32_t lo, hi;
+    half(lo, hi);
+    const float u1 = ((float)(lo >> 1) + 0.5f) * (1.0f / 2147483648.0f);      // (0,1), exact for the small values
+    const float u2 = (float)(hi >> 8) * (1.0f / 16777216.0f);                 // [0,1) revolutions
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+    spare = (double)(r * __builtin_amdgcn_sinf(u2));
+    has_spare = true;
+    return (double)(r * __builtin_amdgcn_cosf(u2));
+  }
   __device__ __forceinline__ double normal() {                  // Box-Muller, both variates used
     if (has_spare) { has_spare = false; return spare; }
     const double u1 = uniform(), u2 = uniform();
@@ -962,14 +977,16 @@ __device__ inline double pg_var_dev(double b, double c) {
                   : b / (4.0 * a * a * a) * (sinh(a) - a) / (ch * ch);
 }
 
-// Gamma(shape,1), Marsaglia & Tsang (2000); shape < 1 by the U^(1/shape) boost
+// Gamma(shape,1), Marsaglia & Tsang (2000); shape < 1 by the U^(1/shape) boost.
+// FAST: normals from CellRng::normal32 (f32 hardware transcendentals; see there).
+template <bool FAST = false>
 __device__ __forceinline__ double gamma_mt(double shape, CellRng& g) {
   double boost = 1.0;
   if (shape < 1.0) { boost = pow(g.uniform(), 1.0 / shape); shape += 1.0; }
   const double d = shape - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
   while (true) {
     double x, v;
-    do { x = g.normal(); v = 1.0 + cc * x; } while (v <= 0.0);
+    do { x = FAST ? g.normal32() : g.normal(); v = 1.0 + cc * x; } while (v <= 0.0);
     v = v * v * v;
     const double u = g.uniform32();
     if (u < 1.0 - 0.0331 * x * x * x * x) return boost * d * v;
@@ -1000,9 +1017,33 @@ __device__ __forceinline__ double pg_draw(double b, double psi, CellRng& g) {
   const double c2 = psi * psi / (4.0 * PG_PI * PG_PI);
   const double sc = sqrt(c2);
   // the weights are flat up to k ~ sc: start the tail only where they decay (k^-2)
-  const int NT = min(PG_SERIES_NT_MAX, (b >= 8.0 ? PG_SERIES_NT / 2 : PG_SERIES_NT) + (int)(2.0 * sc));
+  const int NT = min(PG_SERIES_NT_MAX, (b >= 3.0 ? PG_SERIES_NT / 2 : PG_SERIES_NT) + (int)(2.0 * sc));
   double s = 0.0;
-  for (int k = 1; k <= NT; ++k) s += gamma_mt(b, g) / ((k - 0.5) * (k - 0.5) + c2);
+  if (b < 1.0) {
+    for (int k = 1; k <= NT; ++k) s += gamma_mt<true>(b, g) / ((k - 0.5) * (k - 0.5) + c2);
+  } else {
+    // NT Marsaglia-Tsang Gamma(b) draws as ONE flat loop: every trip each lane tries one candidate and,
+    // if it is accepted, adds it to its current term - a wave runs ~NT + 3 trips instead of NT rejection
+    // loops that each last as long as the unluckiest lane.  Candidate normal and the acceptance test use
+    // the f32 hardware log (threshold good to ~1e-6: the bias is far below the Monte-Carlo noise).
+    const double d = b - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
+    const float df = (float)d;
+    int k = 1;
+    double wk = 1.0 / (0.25 + c2);
+    while (k <= NT) {
+      const double x = g.normal32();
+      const double v1 = 1.0 + cc * x;
+      const double v = v1 * v1 * v1;
+      const float xf = (float)x, vf = (float)v;
+      const float lnu = 0.69314718f * __builtin_amdgcn_logf((float)g.uniform32());
+      const float rhs = 0.5f * xf * xf + df * (1.0f - vf + 0.69314718f * __builtin_amdgcn_logf(vf));
+      if (v1 > 0.0 && lnu < rhs) {
+        s = fma(d * v, wk, s);
+        ++k;
+        wk = 1.0 / ((k - 0.5) * (k - 0.5) + c2);
+      }
+    }
+  }
   double tmean, tvar;
   if (sc > 1e-4 * NT) {
     const double phi = atan(sc / NT);                       // = pi/2 - atan(NT/sc)

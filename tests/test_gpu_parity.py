@@ -289,6 +289,22 @@ def test_pg_distribution_ks(b, c):
     assert ks_2samp(x, y).pvalue > 1e-3
 
 
+@pytest.mark.parametrize("b,c", [(3, 0.0), (4, 1.0), (1.2, 0.0), (8, 0.3), (27.3, 4.0), (60, 12.0)])
+def test_pg_series_sampler_ks_large_sample(b, c):
+    """The sum-of-gammas path (every b but the integers 1, 2): 8-16 Gamma(b) terms from f32-transcendental
+    variates + a normal remainder.  200 k draws against the oracle's 256-term f64 series sampler:
+    a two-sample KS at this size sees CDF differences of ~0.4 %."""
+    from scipy.stats import ks_2samp
+    from oracle import btf_oracle as orc
+    n = 200000
+    x = pg_batch(np.full(n, float(b)), np.full(n, c), seed=4242 + int(7 * b))
+    y = orc.pg_draw_series(b, c, n, np.random.default_rng(11))
+    assert ks_2samp(x, y).pvalue > 1e-3
+    # third central moment (the skewness the normal remainder could lose): within 5 % + noise
+    m3x, m3y = ((x - x.mean()) ** 3).mean(), ((y - y.mean()) ** 3).mean()
+    assert abs(m3x - m3y) < 0.05 * abs(m3y) + 8 * x.std() ** 3 / np.sqrt(n / 15), (m3x, m3y)
+
+
 def test_pg_draw_fills_both_layouts_identically_and_masks_missing(golden):
     g = golden("g4_binomial_nan.npz")
     data = (g["Ysucc"], g["Ntrials"])
