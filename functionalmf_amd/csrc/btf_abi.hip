@@ -69,6 +69,12 @@ struct btf_ctx {
   double* nb_tmp = nullptr; size_t nb_tmp_elems = 0;
   double* nb_out = nullptr; size_t nb_out_elems = 0;
   int nb_Rr = 0; bool counts = false;
+  unsigned int* nb_H = nullptr; double* nb_Hd = nullptr; double* nb_Hs = nullptr;   // per-row count histograms (u32, f64) and their sum over rows
+  double* nb_L = nullptr;            // [N + 1]: per-row sum cnt*log(1-p), then the total
+  int* nb_optr = nullptr; double* nb_oval = nullptr; int nb_nout = 0;   // per-row outlier lists (CSR)
+  bool nb_tabulable = false;        // every observed count is an integer in [0, NB_TAB)
+  bool nb_L_valid = false;          // nb_L matches the current W, V
+  bool nb_no_hist = false;          // test hook: keep the full-tensor kernel
   double* hyp = nullptr;        // device-resident scalars [HYP_COUNT] (nu2, sigma2, lam2, lam2_a, ...)
   bool dev_scalars = false;     // kernels read nu2 / sigma2 / lam2 from hyp instead of the host copies
   double* pin_hyp = nullptr;
@@ -572,7 +578,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
   if (c->pin_hyp) (void)hipHostFree(c->pin_hyp);
-  for (void* p : {(void*)c->nb_data, (void*)c->nb_S, (void*)c->nb_cnt, (void*)c->nb_R, (void*)c->nb_C, (void*)c->nb_tmp, (void*)c->nb_out})
+  for (void* p : {(void*)c->nb_data, (void*)c->nb_S, (void*)c->nb_cnt, (void*)c->nb_R, (void*)c->nb_C, (void*)c->nb_tmp, (void*)c->nb_out, (void*)c->nb_H, (void*)c->nb_Hd, (void*)c->nb_Hs, (void*)c->nb_L, (void*)c->nb_optr, (void*)c->nb_oval})
     if (p) (void)hipFree(p);
   if (c->hyp) (void)hipFree(c->hyp);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -679,6 +685,7 @@ int btf_set_W(btf_ctx* c, const double* W) {
   HIPCHK(c, hipMemcpyAsync(c->W, W, (size_t)c->N * c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_W = true;
+  c->nb_L_valid = false;
   c->ngp_w = 0;
   return BTF_OK;
 }
@@ -694,6 +701,7 @@ int btf_set_V(btf_ctx* c, const double* V) {
   HIPCHK(c, hipMemcpyAsync(c->V, V, (size_t)c->M * c->T * c->K * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_V = true;
+  c->nb_L_valid = false;
   c->ngp_v = 0;
   return BTF_OK;
 }
@@ -853,6 +861,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     c->ngp_v = 0;   // V'V partials are consumed once; any other W/V change must recompute
   }
   c->sweep_w++;
+  c->nb_L_valid = false;
   HIPCHK(c, hipGetLastError());
   return BTF_OK;
 }
@@ -945,6 +954,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     HIPCHK(c, e);
   }
   c->sweep_v++;
+  c->nb_L_valid = false;
   HIPCHK(c, hipGetLastError());
   return BTF_OK;
 }
@@ -1075,6 +1085,44 @@ int btf_set_data_counts(btf_ctx* c, const double* counts, int nreps) {
     if ((rc = dev_alloc(c, p, ev))) return rc;
     HIPCHK(c, hipMemsetAsync(*p, 0, ev * sizeof(double), c->stream));
   }
+  // per-row histograms of the counts (for rates shared along (j,t): see nb_hist_loglik_kernel)
+  {
+    const size_t hn = (size_t)c->N * NB_TAB;
+    if ((rc = dev_alloc(c, &c->nb_H, hn))) return rc;
+    if ((rc = dev_alloc(c, &c->nb_Hd, hn))) return rc;
+    if ((rc = dev_alloc(c, &c->nb_Hs, (size_t)NB_TAB))) return rc;
+    if ((rc = dev_alloc(c, &c->nb_L, (size_t)c->N + 1))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->nb_H, 0, hn * sizeof(unsigned int), c->stream));
+    if ((rc = dev_alloc(c, &c->nb_optr, (size_t)c->N + 1))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->nb_optr, 0, ((size_t)c->N + 1) * sizeof(int), c->stream));
+    const int hbx = std::max(1, std::min((int)(((size_t)MT * nreps + 255) / 256), std::max(1, 4096 / c->N)));
+    hipLaunchKernelGGL(nb_hist_kernel, dim3(hbx, c->N), dim3(256), 0, c->stream, (const double*)c->nb_data, nreps, MT, c->nb_H,
+                       c->nb_optr);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(u32_to_f64_kernel, dim3((unsigned)((hn + 255) / 256)), dim3(256), 0, c->stream,
+                       (const unsigned int*)c->nb_H, c->nb_Hd, hn);
+    hipLaunchKernelGGL(nb_reduce_kernel, dim3(NB_TAB), dim3(256), 0, c->stream, (const double*)c->nb_Hd, c->N, NB_TAB, 1, 1, 0, 1, c->nb_Hs);
+    HIPCHK(c, hipGetLastError());
+    // outlier counts per row -> CSR row pointers (exclusive scan on the host: N is small)
+    std::vector<int> cntv((size_t)c->N + 1, 0);
+    HIPCHK(c, hipMemcpyAsync(cntv.data(), c->nb_optr, (size_t)c->N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    long long tot = 0;
+    for (int i = 0; i <= c->N; ++i) { const int k = cntv[i]; cntv[i] = (int)std::min<long long>(tot, 0x7fffffff); tot += k; }
+    // few outliers: per-row lists summed term by term; many: the histograms buy nothing, keep the full kernel
+    bool bad = tot > (long long)(cells * nreps / 8) || tot > 0x3fffffff;
+    c->nb_nout = bad ? 0 : (int)tot;
+    if (!bad && tot > 0) {
+      if ((rc = dev_alloc(c, &c->nb_oval, (size_t)tot))) return rc;
+      HIPCHK(c, hipMemcpyAsync(c->nb_optr, cntv.data(), ((size_t)c->N + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(nb_outlier_fill_kernel, dim3(c->N), dim3(256), 0, c->stream, (const double*)c->nb_data, nreps, MT,
+                         (const int*)c->nb_optr, c->nb_oval);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipStreamSynchronize(c->stream));      // cntv is a host temporary
+    }
+    c->nb_tabulable = !bad;
+    c->nb_L_valid = false;
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->weighted = true;
   c->have_data = true;
@@ -1090,6 +1138,34 @@ int btf_nb_loglik(btf_ctx* c, const double* R, const double* cand, const int32_t
   if ((rc = nb_upload_rate(c, R, cand, shared))) return rc;
   const int MT = c->M * c->T;
   const size_t nR = nb_rate_elems(c, shared);
+  if (shared[1] && shared[2] && c->nb_tabulable && !c->nb_no_hist) {   // rate constant along (j,t), integer counts: histogram form
+    if (!c->nb_L_valid) {
+      const int lbx = std::max(1, std::min((MT + 255) / 256, std::max(1, 4096 / c->N)));
+      if ((size_t)c->N * lbx > c->nb_tmp_elems) { if ((rc = dev_alloc(c, &c->nb_tmp, (size_t)c->N * lbx))) return rc; c->nb_tmp_elems = (size_t)c->N * lbx; }
+      Prof p(c, BTF_K_NB);
+      K_SWITCH(c->K, p.launch(nb_l1p_kernel<KT>, dim3(lbx, c->N), dim3(256), 0, (const double*)c->nb_cnt, (const double*)c->W,
+                              (const double*)c->V, MT, c->nb_tmp));
+      hipLaunchKernelGGL(nb_reduce_kernel, dim3(c->N), dim3(256), 0, c->stream, (const double*)c->nb_tmp, c->N, lbx, 1, 0, 1, 1, c->nb_L);
+      hipLaunchKernelGGL(nb_reduce_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_L, c->N, 1, 1, 1, 1, 1, c->nb_L + c->N);
+      HIPCHK(c, hipGetLastError());
+      c->nb_L_valid = true;
+    }
+    if (nR > c->nb_out_elems) { if ((rc = dev_alloc(c, &c->nb_out, nR))) return rc; c->nb_out_elems = nR; }
+    {
+      Prof p(c, BTF_K_NB);
+      const int* optr = c->nb_nout > 0 ? c->nb_optr : nullptr;
+      if ((size_t)c->N > c->nb_tmp_elems) { if ((rc = dev_alloc(c, &c->nb_tmp, (size_t)c->N))) return rc; c->nb_tmp_elems = (size_t)c->N; }
+      p.launch(nb_hist_loglik_kernel, dim3(c->N), dim3(256), 0, (const double*)c->nb_Hd, (const double*)c->nb_L,
+               (const double*)c->nb_R, (const double*)c->nb_C, optr, (const double*)c->nb_oval, shared[0] ? 0 : 1,
+               shared[0] ? c->nb_tmp : c->nb_out);
+      if (shared[0])
+        hipLaunchKernelGGL(nb_reduce_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_tmp, c->N, 1, 1, 1, 1, 1, c->nb_out);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(ll, c->nb_out, nR * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BTF_OK;
+  }
   long long sr[3];
   nb_strides(c, shared, sr);
   // a few workgroups per row: enough to fill the chip at N >= 64, each amortising its table over many cells
@@ -1143,6 +1219,69 @@ int btf_nb_set_rate(btf_ctx* c, const double* R, const int32_t* shared) {
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));      // R is a borrowed host buffer
+  return BTF_OK;
+}
+
+// whole random-walk MH loop on the device (rng="device"): needs the histogram form (rate shared along
+// (cols, depth), few outliers); BTF_ESTATE otherwise - the caller then drives btf_nb_loglik step by step
+int btf_nb_mh(btf_ctx* c, uint64_t seed, int nsteps, double rpropstdev, double rstdev, const int32_t* shared,
+              const double* R_in) {
+  if (!c || !shared || nsteps < 0 || !(rpropstdev > 0.0) || !(rstdev > 0.0)) return fail(c, BTF_EINVAL, "bad MH arguments");
+  if (!c->counts || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_nb_mh needs count data, W and V");
+  if (!(shared[1] && shared[2] && c->nb_tabulable && !c->nb_no_hist))
+    return fail(c, BTF_ESTATE, "device MH loop needs a rate shared along (cols, depth) and tabulable counts");
+  HIPCHK(c, hipSetDevice(c->dev));
+  int rc;
+  const size_t nR = nb_rate_elems(c, shared);
+  if (R_in) { if ((rc = nb_upload_rate(c, R_in, nullptr, shared))) return rc; }
+  else if (nR > c->nb_relems) return fail(c, BTF_ESTATE, "no rate on the device yet");
+  const int MT = c->M * c->T;
+  if (!c->nb_L_valid) {
+    const int lbx = std::max(1, std::min((MT + 255) / 256, std::max(1, 4096 / c->N)));
+    if ((size_t)c->N * lbx > c->nb_tmp_elems) { if ((rc = dev_alloc(c, &c->nb_tmp, (size_t)c->N * lbx))) return rc; c->nb_tmp_elems = (size_t)c->N * lbx; }
+    Prof p(c, BTF_K_NB);
+    K_SWITCH(c->K, p.launch(nb_l1p_kernel<KT>, dim3(lbx, c->N), dim3(256), 0, (const double*)c->nb_cnt, (const double*)c->W,
+                            (const double*)c->V, MT, c->nb_tmp));
+    hipLaunchKernelGGL(nb_reduce_kernel, dim3(c->N), dim3(256), 0, c->stream, (const double*)c->nb_tmp, c->N, lbx, 1, 0, 1, 1, c->nb_L);
+    HIPCHK(c, hipGetLastError());
+    c->nb_L_valid = true;
+  }
+  if ((size_t)c->N > c->nb_out_elems) { if ((rc = dev_alloc(c, &c->nb_out, (size_t)c->N))) return rc; c->nb_out_elems = (size_t)c->N; }
+  const int scalar = shared[0] ? 1 : 0;
+  const int* optr = c->nb_nout > 0 ? c->nb_optr : nullptr;
+  hipLaunchKernelGGL(nb_mh_step_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_out, c->N, (int)nR, scalar, c->nb_R,
+                     c->nb_C, rpropstdev, rstdev, -1, (unsigned long long)seed);
+  for (int sidx = 0; sidx < nsteps; ++sidx) {
+    {
+      Prof p(c, BTF_K_NB);
+      p.launch(nb_hist_loglik_kernel, dim3(c->N), dim3(256), 0, (const double*)c->nb_Hd, (const double*)c->nb_L,
+               (const double*)c->nb_R, (const double*)c->nb_C, optr, (const double*)c->nb_oval, scalar ? 0 : 1, c->nb_out);
+    }
+    hipLaunchKernelGGL(nb_mh_step_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_out, c->N, (int)nR, scalar, c->nb_R,
+                       c->nb_C, rpropstdev, rstdev, sidx, (unsigned long long)seed);
+  }
+  HIPCHK(c, hipGetLastError());
+  // Binomial pseudo-data for the new rate
+  long long sr[3];
+  nb_strides(c, shared, sr);
+  {
+    Prof p(c, BTF_K_STATS);
+    p.launch(nb_trials_kernel, dim3((MT + 63) / 64, (c->N + 63) / 64), dim3(256), 0, (const double*)c->nb_S,
+             (const double*)c->nb_cnt, (const double*)c->nb_R, sr[0], sr[1], sr[2], c->N, MT, c->T, c->ldv, c->ldw, c->A_v,
+             c->B_v, c->A_wT, c->B_wT);
+  }
+  HIPCHK(c, hipGetLastError());
+  if (R_in) HIPCHK(c, hipStreamSynchronize(c->stream));      // borrowed host buffer
+  return BTF_OK;
+}
+
+int btf_nb_get_rate(btf_ctx* c, double* R, const int32_t* shared) {
+  if (!c || !R || !shared) return BTF_EINVAL;
+  const size_t nR = nb_rate_elems(c, shared);
+  if (!c->nb_R || nR > c->nb_relems) return fail(c, BTF_ESTATE, "no rate on the device yet");
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipMemcpyAsync(R, c->nb_R, nR * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return BTF_OK;
 }
 
@@ -1395,6 +1534,9 @@ int btf_set_tuning(btf_ctx* c, int rows_per_block_w, int rows_per_block_v) {
   if (!c) return BTF_EINVAL;
   // sampler selection hooks: rows_per_block_v == -1 generic (any-size) kernel, -2 single-chain LDS
   // kernel, -3 wave-specialised pipeline; anything else the default (twisted where it applies)
+  // rows_per_block_w == -1: Negative-Binomial rate update always through the full-tensor kernel (no histograms)
+  c->nb_no_hist = rows_per_block_w == -1;
+  if (rows_per_block_w < 0) rows_per_block_w = 0;
   c->force_generic_banded = rows_per_block_v == -1;
   c->banded_variant = rows_per_block_v == -3 ? 0 : (rows_per_block_v == -2 ? 1 : 2);
   c->rpb_w = rows_per_block_w; c->rpb_v = rows_per_block_v < 0 ? 0 : rows_per_block_v;

@@ -1291,6 +1291,29 @@ __device__ inline double nb_count_part(double y, double r, double c, double& bas
   return lgamma_diff(y + c, y + r) + base;
 }
 
+// table of sum_{k<y} log((c+k)/(r+k)), y = 0..NB_TAB-1, by all 256 threads of a block (4 entries each)
+__device__ inline void nb_build_table(double r, double c, double* tab, double* wsum) {
+  static_assert(NB_TAB == 1024, "4 table entries per thread of a 256-thread block");
+  const int k0 = 4 * threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double l[4], run = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { run += log((c + (k0 + q)) / (r + (k0 + q))); l[q] = run; }
+  double incl = run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double up = __shfl_up(incl, d, WAVE);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  double off = incl - run;                       // exclusive prefix inside the wave
+  for (int u = 0; u < wv; ++u) off += wsum[u];
+  if (threadIdx.x == 0) tab[0] = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) if (k0 + q + 1 < NB_TAB) tab[k0 + q + 1] = off + l[q];
+  __syncthreads();
+}
+
 // `row_rate` != 0: R does not vary along (j,t) (sr1 = sr2 = 0), so the count part of the term is a
 // function of y alone inside a block: tabulated once in LDS for integer y < NB_TAB (a prefix sum of
 // log((c+k)/(r+k))); everything else goes through nb_count_part.
@@ -1306,28 +1329,10 @@ __global__ __launch_bounds__(256) void nb_loglik_kernel(const double* __restrict
   __shared__ double wsum[4];
   const int i = blockIdx.y;
   const bool row_rate = sr1 == 0 && sr2 == 0;
-  if (row_rate) {   // inclusive scan of the NB_TAB log-ratios: 4 per thread, wave scan, then the three wave offsets
-    static_assert(NB_TAB == 1024, "4 table entries per thread of a 256-thread block");
+  if (row_rate) {
     const double r = Rv[(long long)i * sr0], c = Cv[(long long)i * sr0];
-    const int k0 = 4 * threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double l[4], run = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { run += log((c + (k0 + q)) / (r + (k0 + q))); l[q] = run; }
-    double incl = run;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const double up = __shfl_up(incl, d, WAVE);
-      if (lane >= d) incl += up;
-    }
-    if (lane == 63) wsum[wv] = incl;
     if (threadIdx.x == 0) tab[NB_TAB] = lgamma_diff(r, c);
-    __syncthreads();
-    double off = incl - run;                       // exclusive prefix inside the wave
-    for (int u = 0; u < wv; ++u) off += wsum[u];
-    if (threadIdx.x == 0) tab[0] = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) if (k0 + q + 1 < NB_TAB) tab[k0 + q + 1] = off + l[q];
-    __syncthreads();
+    nb_build_table(r, c, tab, wsum);
   }
   // grid-stride over the (j,t) cells of row i: the table is built once per block, not once per cell
   double bterm = 0.0;
@@ -1443,6 +1448,153 @@ __global__ __launch_bounds__(256) void nb_trials_kernel(const double* __restrict
       AwT[(size_t)jj * ldw + i] = ta[col][c];
       BwT[(size_t)jj * ldw + i] = tb[col][c];
     }
+  }
+}
+
+// ---- count histograms: when R is shared along (j,t) the MH log-likelihood ratio of row i is
+//        sum_y H[i][y] * tab_y(R_i, c_i) + (c_i - R_i) * L[i],
+//      H[i][y] = number of observed replicates in row i equal to y (data only: built once at upload),
+//      L[i]    = sum_(j,t) cnt * log(1 - p_ijt)                  (W, V only: built once per sweep),
+//      so the 30 MH steps of a sweep read 8 KB per row instead of the whole count tensor.
+// H via integer atomics (exact, order-free).  Observed values that are not integers in [0, NB_TAB)
+// ("outliers": large counts, fractional pseudo-counts) are counted per row, then compacted IN DATA
+// ORDER into per-row lists (nb_outlier_fill_kernel) and summed term by term in that fixed order.
+__global__ __launch_bounds__(256) void nb_hist_kernel(const double* __restrict__ data, int Rr, int MT,
+                                                     unsigned int* __restrict__ H, int* __restrict__ nout) {
+  __shared__ unsigned int h[NB_TAB];
+  const int i = blockIdx.y;
+  for (int y = threadIdx.x; y < NB_TAB; y += 256) h[y] = 0u;
+  __syncthreads();
+  const size_t n = (size_t)MT * Rr;
+  const double* __restrict__ row = data + (size_t)i * n;
+  int b = 0;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const double y = row[e];
+    if (y == y) {
+      if (y >= 0.0 && y < (double)NB_TAB && y == floor(y)) atomicAdd(&h[(int)y], 1u);
+      else ++b;
+    }
+  }
+  if (b) atomicAdd(&nout[i], b);
+  __syncthreads();
+  for (int y = threadIdx.x; y < NB_TAB; y += 256)
+    if (h[y]) atomicAdd(&H[(size_t)i * NB_TAB + y], h[y]);
+}
+
+// in-order compaction of row i's outliers into val[ptr[i] ..): one block per row, chunks of 256 in order
+__global__ __launch_bounds__(256) void nb_outlier_fill_kernel(const double* __restrict__ data, int Rr, int MT,
+                                                             const int* __restrict__ ptr, double* __restrict__ val) {
+  __shared__ int wcnt[4];
+  __shared__ int base_s;
+  const int i = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t n = (size_t)MT * Rr;
+  const double* __restrict__ row = data + (size_t)i * n;
+  if (threadIdx.x == 0) base_s = ptr[i];
+  __syncthreads();
+  for (size_t e0 = 0; e0 < n; e0 += 256) {
+    const size_t e = e0 + threadIdx.x;
+    const double y = e < n ? row[e] : 0.0;
+    const bool out = e < n && y == y && !(y >= 0.0 && y < (double)NB_TAB && y == floor(y));
+    const unsigned long long m = __ballot(out);
+    if (lane == 0) wcnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int u = 0; u < wv; ++u) off += wcnt[u];
+    if (out) val[off + __popcll(m & ((1ull << lane) - 1ull))] = y;
+    __syncthreads();
+    if (threadIdx.x == 0) base_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+}
+
+__global__ void u32_to_f64_kernel(const unsigned int* __restrict__ src, double* __restrict__ dst, size_t n) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) dst[e] = (double)src[e];
+}
+
+// part[i][blockIdx.x] = sum over this block's (j,t) of cnt * log(1 - ilogit(clip(w_i.v_jt)))
+template <int K>
+__global__ __launch_bounds__(256) void nb_l1p_kernel(const double* __restrict__ cnt, const double* __restrict__ W,
+                                                    const double* __restrict__ V, int MT, double* __restrict__ part) {
+  __shared__ double red[4];
+  const int i = blockIdx.y;
+  const double* __restrict__ w = W + (size_t)i * K;
+  double acc = 0.0;
+  for (int jt = blockIdx.x * 256 + threadIdx.x; jt < MT; jt += gridDim.x * 256) {
+    const double n = cnt[(size_t)i * MT + jt];
+    double psi = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) psi = fma(w[k], V[(size_t)jt * K + k], psi);
+    psi = fmin(fmax(psi, -10.0), 10.0);
+    if (n > 0.0) acc = fma(n, -log1p(exp(psi)), acc);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)i * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// one block per row; rate_stride = 1: R per row, 0: one R for all rows (the caller then sums ll over rows):
+//   ll[i] = sum_y H[i][y] tab_y(R, c) + (c - R) L[i] + sum over row i's outliers
+__global__ __launch_bounds__(256) void nb_hist_loglik_kernel(const double* __restrict__ Hd, const double* __restrict__ L,
+                                                            const double* __restrict__ Rv, const double* __restrict__ Cv,
+                                                            const int* __restrict__ optr, const double* __restrict__ oval,
+                                                            int rate_stride, double* __restrict__ ll) {
+  __shared__ double tab[NB_TAB];
+  __shared__ double wsum[4];
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  const double r = Rv[b * rate_stride], c = Cv[b * rate_stride];
+  nb_build_table(r, c, tab, wsum);
+  double acc = 0.0;
+  for (int y = threadIdx.x; y < NB_TAB; y += 256) acc = fma(Hd[(size_t)b * NB_TAB + y], tab[y], acc);
+  if (optr) {
+    const int e0 = optr[b], e1 = optr[b + 1];
+    if (e1 > e0) {
+      const double base = lgamma_diff(r, c);
+      for (int e = e0 + threadIdx.x; e < e1; e += 256) acc += lgamma_diff(oval[e] + c, oval[e] + r) + base;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) ll[b] = red[0] + red[1] + red[2] + red[3] + (c - r) * L[b];
+}
+
+// One random-walk MH step on log R for every rate element, entirely on the device (rng="device";
+// factor.py:523-549): accept the pending candidate C[e] with probability exp(clip(prior + ll, -10, 1))
+// (and only if C[e] > 1, the reference's floor), then propose the next one,
+//   C[e] = exp(log R[e] + rpropstdev * z).
+// llrow: per-row log-likelihood ratios; scalar != 0: one rate, ll = fixed-order sum of the nrow entries.
+// step < 0: propose only (start of the loop).  Philox streams keyed (seed, element), counters advance
+// with the step so that every step sees fresh numbers.  One block; elements strided over its threads.
+__global__ __launch_bounds__(256) void nb_mh_step_kernel(const double* __restrict__ llrow, int nrow, int nelem,
+                                                        int scalar, double* __restrict__ Rv, double* __restrict__ Cv,
+                                                        double rpropstdev, double rstdev, int step,
+                                                        unsigned long long seed) {
+  __shared__ double red[4];
+  double lls = 0.0;
+  if (scalar && step >= 0) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nrow; i += 256) acc += llrow[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    lls = red[0] + red[1] + red[2] + red[3];
+  }
+  for (int e = threadIdx.x; e < nelem; e += 256) {
+    CellRng g(seed, (unsigned long long)e);
+    g.ctr = 2ull * (unsigned long long)(step + 1);           // two Philox blocks per step and element
+    double r = Rv[e];
+    if (step >= 0) {
+      const double c = Cv[e];
+      const double lr = log(r), lc = log(c);
+      const double prior = (lr * lr - lc * lc) / (2.0 * rstdev * rstdev);
+      const double ll = scalar ? lls : llrow[e];
+      const double prob = exp(fmin(fmax(prior + ll, -10.0), 1.0));
+      if (g.uniform() <= prob && c > 1.0) { r = c; Rv[e] = c; }
+    }
+    Cv[e] = exp(log(r) + rpropstdev * g.normal());
   }
 }
 

@@ -725,6 +725,26 @@ class NegativeBinomialBayesianTensorFiltering(BinomialBayesianTensorFiltering):
     def _rate_shape(self):
         return tuple(1 if i in self._shared else c for i, c in enumerate((self.nrows, self.ncols, self.ndepth)))
 
+    # R: host array, refreshed from the GPU when the device-side MH loop (rng="device") moved it
+    @property
+    def R(self):
+        if getattr(self, "_R_dev_new", False):
+            out = np.zeros(self._rate_shape())
+            self._ctx.call("btf_nb_get_rate", _native.dptr(out), self._shared_flags().ctypes.data_as(_native._c_ip))
+            self._R = out
+            self._R_dev_new = False
+            self._rate_key = self._key_of(out)          # the device already holds exactly this rate
+        return self._R
+
+    @R.setter
+    def R(self, value):
+        self._R = value
+        self._R_dev_new = False
+
+    @staticmethod
+    def _key_of(R):
+        return R.tobytes() if R.size <= 4096 else (float(R.sum()), float((R * R).sum()), R.shape)
+
     def _init_R(self):
         """exp(N(0, rstdev)) + 1 (factor.py:560-563)."""
         self.R = np.exp(np.random.normal(0, self.rstdev, size=self._rate_shape())) + 1
@@ -759,8 +779,10 @@ class NegativeBinomialBayesianTensorFiltering(BinomialBayesianTensorFiltering):
         return self._nb_sum + self._nb_cnt * np.broadcast_to(self.R, self._nb_sum.shape)
 
     def _push_rate(self):
+        if getattr(self, "_R_dev_new", False):          # rate and pseudo-data already current on the device
+            return
         R = _native.as_f64(np.broadcast_to(self.R, self._rate_shape()))
-        key = R.tobytes() if R.size <= 4096 else (id(self.R), float(R.sum()), float((R * R).sum()))
+        key = self._key_of(R)
         if key != self._rate_key:
             self._ctx.call("btf_nb_set_rate", _native.dptr(R), self._shared_flags().ctypes.data_as(_native._c_ip))
             self._rate_key = key
@@ -781,6 +803,19 @@ class NegativeBinomialBayesianTensorFiltering(BinomialBayesianTensorFiltering):
         self._bind_data(data)
         self._push_state()
         shp = self._rate_shape()
+        if self.rng == "device" and getattr(self, "_mh_on_device", True):
+            # the whole loop on the GPU (Philox proposals / decisions); needs the histogram form of the
+            # likelihood ratio - otherwise fall through to the host-driven loop below
+            start = None if getattr(self, "_R_dev_new", False) else _native.as_f64(np.broadcast_to(self.R, shp))
+            try:
+                self._ctx.call("btf_nb_mh", self._next_seed(), int(self.nmetropolis), float(self.rpropstdev),
+                               float(self.rstdev), self._shared_flags().ctypes.data_as(_native._c_ip), _native.dptr(start))
+                self._R_dev_new = True
+                return
+            except _native.BTFError as e:
+                if e.code != _native.BTF_ESTATE:
+                    raise
+                self._mh_on_device = False
         s2 = float(self.rstdev) ** 2
         R = _native.as_f64(np.broadcast_to(self.R, shp)).copy()
         logR = np.log(R)

@@ -107,10 +107,20 @@ int btf_set_stale_sources(btf_ctx* ctx, const int32_t* src_row, const int32_t* s
  * btf_nb_loglik replaces the data-sized part of one random-walk MH step of
  * NegativeBinomialBTF._resample_R (factor.py:533-541): ll[e] = sum over replicates and shared
  * dims of lgamma(y+cand)-lgamma(cand)-lgamma(y+R)+lgamma(R)+(cand-R) log(1-p),
- * p = ilogit(clip(w.v,-10,10)), NaN observations dropped.  Synchronises.                   */
+ * p = ilogit(clip(w.v,-10,10)), NaN observations dropped.  Synchronises.  When R is shared
+ * along (cols, depth) and every count is an integer < 1024 the sum is evaluated from per-row
+ * count histograms (built once at upload) and one pass per sweep for sum cnt*log(1-p): an MH
+ * step then reads 8 KB per row instead of the count tensor.                               */
 int btf_set_data_counts(btf_ctx* ctx, const double* counts, int nreps);
 int btf_nb_loglik(btf_ctx* ctx, const double* R, const double* cand, const int32_t* shared3, double* ll);
 int btf_nb_set_rate(btf_ctx* ctx, const double* R, const int32_t* shared3);
+/* rng="device": the whole MH loop of NegativeBinomialBTF._resample_R (nsteps random-walk steps,
+ * proposals and accept/reject from Philox) plus the pseudo-data rebuild, without a host round
+ * trip.  R_in: start value (NULL: continue from the rate on the device).  Needs the histogram
+ * form (see btf_nb_loglik); BTF_ESTATE otherwise.  btf_nb_get_rate fetches R (synchronises).   */
+int btf_nb_mh(btf_ctx* ctx, uint64_t seed, int nsteps, double rpropstdev, double rstdev, const int32_t* shared3,
+              const double* R_in);
+int btf_nb_get_rate(btf_ctx* ctx, double* R, const int32_t* shared3);
 
 /* ---- state ---------------------------------------------------------------- */
 int btf_set_W(btf_ctx* ctx, const double* W);            /* (N,K)      */
@@ -211,7 +221,10 @@ int btf_mvn_banded(int device, int batch, int n, int bw, const double* band,
  * BTF_K_* id (arrays of BTF_K_COUNT).                                         */
 int btf_set_profiling(btf_ctx* ctx, int on);
 int btf_kernel_times(btf_ctx* ctx, double* ms_total, int64_t* launches);
-/* Launch geometry of the streaming kernels (tuning knob; 0 = default).        */
+/* Launch geometry of the streaming kernels (tuning knob; 0 = default).  Negative values are
+ * test hooks: rows_per_block_v = -1 / -2 / -3 selects the generic / single-chain / pipelined
+ * banded sampler, rows_per_block_w = -1 keeps the Negative-Binomial rate update on the
+ * full-tensor kernel (no count histograms).                                   */
 int btf_set_tuning(btf_ctx* ctx, int rows_per_block_w, int rows_per_block_v);
 
 #ifdef __cplusplus

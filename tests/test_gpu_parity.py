@@ -656,14 +656,17 @@ def negbinom_model(g, **kw):
     return model, st
 
 
+@pytest.mark.parametrize("hist", [True, False])
 @pytest.mark.parametrize("tag", NB_TAGS)
-def test_negbinom_loglik_ratio_vs_oracle(golden, tag):
+def test_negbinom_loglik_ratio_vs_oracle(golden, tag, hist):
     """The data-sized part of one MH step (btf_nb_loglik) against the oracle's gammaln form, for
     every sharing pattern of R; counts include NaNs, zeros and values beyond the product fast path."""
     from oracle import btf_oracle as orc
     from functionalmf_amd import _native
     g = golden("g7_negbinom_%s.npz" % tag)
     model, st = negbinom_model(g)
+    if not hist:                       # full-tensor kernel even where the count histograms apply
+        model._ctx.call("btf_set_tuning", -1, 0)
     model._bind_data(g["data"])
     model._push_state()
     rs = np.random.RandomState(3)
@@ -705,9 +708,10 @@ def test_negbinom_full_sweep_vs_reference(golden, tag):
         assert relerr(getattr(model, k), g["full_" + k]) < tol, k
 
 
-def test_negbinom_chain_recovers_rate_and_mean():
+@pytest.mark.parametrize("rng", ["host", "device"])
+def test_negbinom_chain_recovers_rate_and_mean(rng):
     """End to end (device PG draws): counts simulated from NB(R=5, p) - the chain must put R near 5
-    and the fitted mean R p/(1-p) near the truth."""
+    and the fitted mean R p/(1-p) near the truth.  rng="device": the MH loop itself runs on the GPU."""
     from functionalmf_amd.factor import NegativeBinomialBayesianTensorFiltering
     rs = np.random.RandomState(12)
     N, M, T, Rr, K = 24, 10, 12, 4, 2
@@ -718,9 +722,10 @@ def test_negbinom_chain_recovers_rate_and_mean():
     data[:2, :2] = np.nan
     np.random.seed(13)
     model = NegativeBinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1,
-                                                    nmetropolis=10)
+                                                    nmetropolis=10, rng=rng, device_seed=3)
     res = model.run_gibbs(data, nburn=300, nthin=2, nsamples=150, verbose=False)
     assert res["R"].shape == (150, 1, 1, 1)
+    assert getattr(model, "_mh_on_device", True)
     R_hat = res["R"].mean()
     assert 3.5 < R_hat < 7.0, R_hat
     Ps = 1 / (1 + np.exp(-np.einsum("znk,zmtk->znmt", res["W"], res["V"]).clip(-10, 10)))
@@ -728,3 +733,67 @@ def test_negbinom_chain_recovers_rate_and_mean():
     Mu = 5.0 * P / (1 - P)
     obs = ~np.isnan(data[..., 0])
     assert np.corrcoef(Mu_hat[obs], Mu[obs])[0, 1] > 0.9
+
+
+@pytest.mark.parametrize("tag", ["scalar", "rows"])
+def test_negbinom_histogram_path_with_outliers(golden, tag):
+    """Counts beyond the LDS table (>= 1024) and fractional pseudo-counts ride along the histogram
+    form as per-row outlier lists, summed in data order."""
+    from oracle import btf_oracle as orc
+    from functionalmf_amd import _native
+    g = golden("g7_negbinom_%s.npz" % tag)
+    data = g["data"].copy()
+    data[3, 2, 1, 0], data[3, 2, 1, 1], data[3, 4, 0, 2] = 2500.0, 1024.0, 1023.0
+    data[6, 5, 7, 2], data[6, 0, 0, 0], data[2, 3, 3, 1] = 3.5, 40000.0, 0.25
+    model, st = negbinom_model(g)
+    model._bind_data(data)
+    model._push_state()
+    rs = np.random.RandomState(4)
+    rdims = tuple(int(d) for d in g["rdims"])
+    ll = np.zeros(g["R_before"].shape)
+    flags = model._shared_flags().ctypes.data_as(_native._c_ip)
+    for _ in range(2):          # second call: cached sum cnt*log(1-p)
+        R = 1 + rs.gamma(2.0, 1.5, size=ll.shape)
+        cand = R * np.exp(rs.normal(0, 0.3, size=R.shape))
+        model._ctx.call("btf_nb_loglik", _native.dptr(R), _native.dptr(cand), flags, _native.dptr(ll))
+        ref = orc.nb_loglik_ratio(data, R, cand, orc.nb_log1m_p(st["W"], st["V"]), rdims)
+        assert relerr(ll.reshape(ref.shape), ref) < 1e-11
+    # after W moves the cached row sums must be rebuilt
+    model.W = st["W"] * 0.9
+    model._push_state()
+    model._ctx.call("btf_nb_loglik", _native.dptr(R), _native.dptr(cand), flags, _native.dptr(ll))
+    ref = orc.nb_loglik_ratio(data, R, cand, orc.nb_log1m_p(st["W"] * 0.9, st["V"]), rdims)
+    assert relerr(ll.reshape(ref.shape), ref) < 1e-11
+
+
+@pytest.mark.parametrize("rdims", [(0, 1, 2), (1, 2)])
+def test_negbinom_device_mh_loop_samples_the_same_posterior(rdims):
+    """R | W, V sampled by the host-driven loop (legacy RNG, reference path) and by the device loop
+    (btf_nb_mh, Philox) with W and V held fixed: same posterior mean and spread of log R."""
+    from functionalmf_amd.factor import NegativeBinomialBayesianTensorFiltering
+    rs = np.random.RandomState(21)
+    N, M, T, Rr, K = 6, 8, 10, 2, 2
+    Wt = 0.7 * rs.normal(size=(N, K))
+    Vt = 0.3 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    P = 1 / (1 + np.exp(-np.einsum("nk,mtk->nmt", Wt, Vt)))
+    data = rs.negative_binomial(3.0, 1 - P[..., None].repeat(Rr, -1)).astype(float)
+    data[0, 0, 0, 0] = 1500.0               # an outlier beyond the count table
+    out = {}
+    for rng in ("host", "device"):
+        np.random.seed(22)
+        model = NegativeBinomialBayesianTensorFiltering(N, M, T, nembeds=K, W_true=Wt, V_true=Vt, sigma2_true=1.0,
+                                                        lam2_true=0.1, Tau2_true=np.ones((M, 3 * T - 1)),
+                                                        rdims=rdims, nmetropolis=5, rng=rng, device_seed=5)
+        model._bind_data(data)
+        draws = []
+        for sweep in range(1500):
+            model._resample_R(data)
+            if sweep >= 300:
+                draws.append(np.log(np.array(model.R)).reshape(-1).copy())
+        d = np.array(draws)
+        out[rng] = (d.mean(0), d.std(0))
+        if rng == "device":
+            assert getattr(model, "_mh_on_device", True) and model._R_dev_new is not None
+    (mh, sh), (md, sd) = out["host"], out["device"]
+    assert np.all(np.abs(mh - md) < 0.25 * np.maximum(sh, sd) + 0.02), (mh, md, sh, sd)
+    assert np.all(np.abs(sh - sd) < 0.35 * np.maximum(sh, sd) + 0.01), (sh, sd)
