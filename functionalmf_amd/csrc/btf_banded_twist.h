@@ -304,7 +304,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     lds[W.S.rhs + tid] = fma(lds[W.S.rhs + tid], iv, zs[nl + nr + tid] * sqrt(iv));
   }
   __syncthreads();
-  if (wave == 0) banded_unit_backward(lds, W.S, ns, bw);
+  if (wave == 0) banded_unit_backward(lds, W.S, ns, bw);       // (separator: dense, ns = bw: the window routine)
   __syncthreads();
   // known trailing unknowns of both halves
   if (tid < ns) {
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   }
   __syncthreads();
   stamp[4] = __builtin_amdgcn_s_memtime();
-  if (wave == 0) banded_unit_backward(lds, W.L, nL, bw);
-  else if (wave == 1) banded_unit_backward(lds, W.R, nR, bw);
+  if (wave == 0) banded_unit_backward_auto<ROW16>(lds, W.L, nL, bw);
+  else if (wave == 1) banded_unit_backward_auto<ROW16>(lds, W.R, nR, bw);
   __syncthreads();
   stamp[5] = __builtin_amdgcn_s_memtime();
   // ---- write V[j] (depth-major), Gram share --------------------------------------------------
