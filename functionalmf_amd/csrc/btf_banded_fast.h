@@ -94,12 +94,21 @@ __device__ __forceinline__ double shift_down2(double v) {
   }
 }
 
-// LDS access by BYTE offset from the dynamic-LDS base (one ds_read/ds_write, no shift)
+// LDS access by BYTE offset from the dynamic-LDS base (one ds_read/ds_write, no shift, no add).
+// The kernels that use these declare no static __shared__ data, so the dynamic block starts at LDS
+// address 0 and the offset IS the address: going through `(char*)lds + boff` cost one
+// `v_add_u32 x, 0, off` per access in the ISA.  `lds_base_is_zero` is checked once per kernel.
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ bool lds_base_is_zero(const double* lds) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) double*)lds == 0u;
+}
 __device__ __forceinline__ double ldsr(const double* lds, int boff) {
-  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds) + boff);
+  (void)lds;
+  return *(const lds_f64*)(size_t)(unsigned)boff;
 }
 __device__ __forceinline__ void ldsw(double* lds, int boff, double x) {
-  *reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + boff) = x;
+  (void)lds;
+  *(lds_f64*)(size_t)(unsigned)boff = x;
 }
 
 // LDL' of the band with the forward substitution of rhs folded in.  Wave 0 only.
@@ -172,9 +181,12 @@ __device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, 
   double wn = ldsr(lds, wo);
   double u = lds[L.rhs];                                     // rhs[0]
   __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): enter the loop with nothing pending
+  // a non-positive (or NaN) pivot is only RECORDED: the loop has no data-dependent addresses, so it
+  // runs to the end on garbage and the caller retries with jitter (rare) - no compare-and-branch per pivot
+  bool bad = false;
   for (int nn = 0; nn < n_elim; ++nn) {
     const double p = bcast_first(v);
-    if (!(p > 0.0)) return false;
+    bad |= !(p > 0.0);
     // ---- dependent chain
     const double inv = rcp_nr(p);
     const double y = v * inv;                                // L[nn+lane, nn]  (lane 0: 1)
@@ -215,7 +227,7 @@ __device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, 
     lds[L.band + n_elim * R1 + lane] = v;
     lds[L.band + (n_elim + 1) * R1 + lane] = w;
   }
-  return true;
+  return !bad;
 }
 
 // x = L^-T w for the unit-lower band factor; w = rhs in/out.  Wave 0 only; bw >= 3.
@@ -383,6 +395,10 @@ __global__ __launch_bounds__(VB_THREADS) void v_banded_fast_kernel(VBandArgs a, 
   vband_load_hyp(a);
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
+  if (!lds_base_is_zero(lds)) {      // ldsr / ldsw address LDS absolutely (see btf_banded_fast.h); never taken
+    if (tid == 0) { a.status[0] = 1; a.status[1] = -7; }
+    return;
+  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = blockIdx.x, jg = a.col0 + j;
   const int KK = tri(K), T = a.T, n = T * K, D1 = a.TF + 2, bw = (a.TF + 1) * K, R1 = bw + 1;

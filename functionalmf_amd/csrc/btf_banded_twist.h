@@ -86,6 +86,10 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   vband_load_hyp(a);
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
+  if (!lds_base_is_zero(lds)) {      // ldsr / ldsw address LDS absolutely (see btf_banded_fast.h); never taken
+    if (tid == 0) { a.status[0] = 1; a.status[1] = -7; }
+    return;
+  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = blockIdx.x, jg = a.col0 + j;
   const int KK = tri(K), T = a.T, n = T * K, D1 = a.TF + 2, bw = (a.TF + 1) * K, R1 = bw + 1;
