@@ -138,7 +138,7 @@ __device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, 
 #pragma unroll
   for (int s = 0; s < NPL; ++s) {
     const int q = lane + WAVE * s;
-    if (q < npairs) {   // q = (a-3)(a-2)/2 + (b-3)
+    if (q < npairs) {   // q = (a-3)(a-2)/2 + (b-3)   (row-major; a column-major order measured 8 % slower)
       int a = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5) + 3;
       while ((a - 3) * (a - 2) / 2 > q) --a;
       while ((a - 2) * (a - 1) / 2 <= q) ++a;
@@ -195,11 +195,23 @@ __device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, 
     const double vnext = fma(-shift_down1<ROW16>(v), y1, w);   // column nn+1, final
     const double wnext = fma(-shift_down2<ROW16>(v), y2, wn);  // column nn+2 after this step
     const double rnew = fma(-y, u, rt);                      // rhs[nn+lane] - L[nn+lane,nn] u
-    // ---- trailing updates  A[nn+a, nn+b] -= A[nn+a,nn] A[nn+b,nn] / D   (b >= 3)
+    // ---- trailing updates  A[nn+a, nn+b] -= A[nn+a,nn] A[nn+b,nn] / D   (b >= 3), kept in registers for now
+    // (scaled by inv FIRST: consuming the LDS-loaded operands only after the rcp chain keeps their
+    //  s_waitcnt off the top of the loop)
+    double tn[NPL];
+#pragma unroll
+    for (int s = 0; s < NPL; ++s) tn[s] = fma(-(xa[s] * inv), xb[s], t[s]);
+    // ---- the next pivot column is known: park it and fetch the operands of step nn+1 now
+    ldsw(lds, vo, vnext);
 #pragma unroll
     for (int s = 0; s < NPL; ++s) {
-      const double prod = xa[s] * xb[s];                     // independent of the rcp chain
-      ldsw(lds, to[s], fma(-prod, inv, t[s]));
+      xa[s] = ldsr(lds, ao[s]);
+      xb[s] = ldsr(lds, bo[s]);
+    }
+    // ---- stores of this step, then the loads that must see them (in-order LDS)
+#pragma unroll
+    for (int s = 0; s < NPL; ++s) {
+      ldsw(lds, to[s], tn[s]);
       to[s] += tinc[s];
     }
     ldsw(lds, co, y);
@@ -212,14 +224,8 @@ __device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, 
     v = vnext;                                               // lanes outside the band: 0 by construction
     w = wnext;
     u = bcast_lane(rnew, 1);                                 // rhs[nn+1], final after this step
-    // ---- issue the loads of step nn+1 (after the stores above: in-order LDS sees them)
-    ldsw(lds, vo, v);
 #pragma unroll
-    for (int s = 0; s < NPL; ++s) {
-      t[s] = ldsr(lds, to[s]);
-      xa[s] = ldsr(lds, ao[s]);
-      xb[s] = ldsr(lds, bo[s]);
-    }
+    for (int s = 0; s < NPL; ++s) t[s] = ldsr(lds, to[s]);
     rt = ldsr(lds, ro);
     wn = ldsr(lds, wo);
   }

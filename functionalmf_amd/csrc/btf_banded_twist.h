@@ -122,15 +122,43 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     const int idx = tid + u * VT_THREADS;
     pb_reg[u] = idx < T * D1 ? a.pband[(size_t)j * T * D1 + idx] : 0.0;
   }
-  for (int idx = tid; idx < n; idx += VT_THREADS) {
-    const int t = idx / K, k = idx - t * K;
-    m0[idx] = chunk_sum(a.part + (size_t)k * a.ld + (size_t)j * T + t) * a.s;
+  double gx[8];
+  const bool g_early = !a.weighted && a.ngp * KK <= 8 * VT_THREADS;     // Gram partials: fetched now, summed below
+  if (g_early) reduce_gram_fetch(a.gpart, a.ngp, KK, gx);
+  if (n <= 2 * VT_THREADS) {   // both elements of a thread at once: one round of global-load latency, not two
+    // element e = k*T + t: consecutive lanes read consecutive depths t of one factor row k (coalesced 8-B
+    // words of the partials; the depth-major scatter m0[t*K + k] happens on the LDS side)
+    const int i0 = tid, i1 = tid + VT_THREADS;
+    const bool h0 = i0 < n, h1 = i1 < n;
+    const int e0 = h0 ? i0 : 0, e1 = h1 ? i1 : e0;       // clamped: idle slots re-read a valid word
+    const int k0 = e0 / T, t0 = e0 - k0 * T, k1 = e1 / T, t1 = e1 - k1 * T;
+    const double* p0 = a.part + (size_t)k0 * a.ld + (size_t)j * T + t0;
+    const double* p1 = a.part + (size_t)k1 * a.ld + (size_t)j * T + t1;
+    const size_t st = (size_t)NV * a.ld;
+    double s0 = 0.0, s1 = 0.0;
+    int c = 0;
+    for (; c + 4 <= a.nch; c += 4) {                     // fixed order c ascending, as chunk_sum
+      const double x0 = p0[(size_t)c * st], x1 = p0[(size_t)(c + 1) * st], x2 = p0[(size_t)(c + 2) * st], x3 = p0[(size_t)(c + 3) * st];
+      const double y0 = p1[(size_t)c * st], y1 = p1[(size_t)(c + 1) * st], y2 = p1[(size_t)(c + 2) * st], y3 = p1[(size_t)(c + 3) * st];
+      s0 += x0; s0 += x1; s0 += x2; s0 += x3;
+      s1 += y0; s1 += y1; s1 += y2; s1 += y3;
+    }
+    for (; c < a.nch; ++c) { s0 += p0[(size_t)c * st]; s1 += p1[(size_t)c * st]; }
+    if (h0) m0[t0 * K + k0] = s0 * a.s;
+    if (h1) m0[t1 * K + k1] = s1 * a.s;
+  } else {
+    for (int idx = tid; idx < n; idx += VT_THREADS) {
+      const int t = idx / K, k = idx - t * K;
+      m0[idx] = chunk_sum(a.part + (size_t)k * a.ld + (size_t)j * T + t) * a.s;
+    }
   }
   if (a.weighted) {
     for (int idx = tid; idx < T * KK; idx += VT_THREADS) {
       const int t = idx / KK, q = idx - t * KK;
       Ql[idx] = chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t) * a.s;
     }
+  } else if (g_early) {
+    reduce_gram_finish(gx, a.ngp, KK, a.sR, lds + W.L.band, Ql);
   } else {
     reduce_gram(a.gpart, a.ngp, KK, a.sR, lds + W.L.band, Ql);
   }

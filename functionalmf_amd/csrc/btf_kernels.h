@@ -210,6 +210,38 @@ __device__ inline void reduce_gram(const double* __restrict__ gpart, int ngp, in
   __syncthreads();
 }
 
+// reduce_gram in two halves for callers that want the global loads in flight early: the partials of a
+// thread (ngp*KK <= 8*blockDim.x) are fetched by reduce_gram_fetch and staged / summed later.
+__device__ __forceinline__ void reduce_gram_fetch(const double* __restrict__ gpart, int ngp, int KK, double (&x)[8]) {
+  const int tot = ngp * KK, nthr = blockDim.x;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) x[u] = ((int)threadIdx.x + u * nthr < tot) ? gpart[threadIdx.x + u * nthr] : 0.0;
+}
+__device__ inline void reduce_gram_finish(const double (&x)[8], int ngp, int KK, double scale, double* stage, double* G) {
+  const int tot = ngp * KK, nthr = blockDim.x;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) if ((int)threadIdx.x + u * nthr < tot) stage[threadIdx.x + u * nthr] = x[u];
+  __syncthreads();
+  // two levels, fixed order: `lanes` threads per Gram entry each add a strided share, then one adds those
+  int lanes = nthr / KK;
+  if (lanes > 16) lanes = 16;
+  if (lanes < 1) lanes = 1;
+  double* lvl = stage + ngp * KK;          // lanes*KK doubles of scratch after the staged partials
+  const int q = threadIdx.x % KK, l = threadIdx.x / KK;
+  if (l < lanes) {
+    double s = 0.0;
+    for (int b = l; b < ngp; b += lanes) s += stage[b * KK + q];
+    lvl[l * KK + q] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < KK) {
+    double s = 0.0;
+    for (int b = 0; b < lanes; ++b) s += lvl[b * KK + threadIdx.x];
+    G[threadIdx.x] = s * scale;
+  }
+  __syncthreads();
+}
+
 template <int K>
 __global__ void products_kernel(const double* __restrict__ U, int Rdim, double* __restrict__ UU) {
   constexpr int KK = tri(K);
