@@ -8,7 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from functionalmf_amd.factor import BinomialBayesianTensorFiltering   # was: functionalmf.factor
-from functionalmf_amd.utils import ilogit
+from functionalmf_amd.utils import ilogit, posterior_summary
 
 
 def main(seed=1, nburn=2000, nthin=2, nsamples=500):
@@ -28,7 +28,7 @@ def main(seed=1, nburn=2000, nthin=2, nsamples=500):
     model = BinomialBayesianTensorFiltering(nrows, ncols, ndepth, nembeds=nembeds, tf_order=2,
                                             sigma2_init=0.5, nthreads=1, lam2_init=0.1)
     results = model.run_gibbs((Y_missing, N_missing), nburn=nburn, nthin=nthin, nsamples=nsamples, verbose=False)
-    P_hat = ilogit(np.einsum('znk,zmtk->znmt', results['W'], results['V'])).mean(0)
+    P_hat, _ = posterior_summary(results['W'], results['V'], q=(), transform="ilogit")   # mean of ilogit(W V') over samples
     held = np.isnan(Y_missing)
     out = dict(mae_observed=float(np.abs(P_hat - P)[~held].mean()), mae_heldout=float(np.abs(P_hat - P)[held].mean()),
                corr=float(np.corrcoef(P_hat.reshape(-1), P.reshape(-1))[0, 1]))

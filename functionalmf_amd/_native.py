@@ -68,6 +68,8 @@ SIGNATURES = {
     "btf_sse_end": (C.c_int, [_ctx, _c_dp, _c_dp, _c_dp]),
     "btf_pg_draw": (C.c_int, [_ctx, C.c_uint64]),
     "btf_pg_batch": (C.c_int, [C.c_int, C.c_int64, _c_dp, _c_dp, C.c_uint64, _c_dp]),
+    "btf_posterior_summary": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, C.c_int, _c_dp,
+                                        C.c_int, _c_dp, _c_dp]),
     "btf_sync": (C.c_int, [_ctx]),
     "btf_mvn_banded": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_uint64,
                                  C.c_double, C.c_int, _c_dp, _c_ip]),

@@ -1409,6 +1409,55 @@ int btf_pg_draw(btf_ctx* c, uint64_t seed) {
   return BTF_OK;
 }
 
+// ---------------------------------------------------------------- posterior summaries
+int btf_posterior_summary(int device, int nsamples, int nrows, int ncols, int ndepth, int nembeds, const double* Ws,
+                          const double* Vs, int transform, const double* q, int nq, double* mean_out, double* q_out) {
+  if (nsamples < 1 || nsamples > 16384 || nrows < 1 || ncols < 1 || ndepth < 1 || nembeds < 1 || nembeds > MAX_K || !Ws || !Vs ||
+      !mean_out || nq < 0 || (nq > 0 && (!q || !q_out)) || transform < 0 || transform > 2)
+    return fail(nullptr, BTF_EINVAL, "bad posterior_summary arguments");
+  for (int k = 0; k < nq; ++k)
+    if (!(q[k] >= 0.0 && q[k] <= 100.0)) return fail(nullptr, BTF_EINVAL, "percentiles must lie in [0, 100]");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, BTF_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  const int MT = ncols * ndepth;
+  const size_t cellsN = (size_t)nrows * MT;
+  double *dW = nullptr, *dV = nullptr, *dq = nullptr, *dm = nullptr, *dqo = nullptr;
+  auto cleanup = [&]() { for (void* p : {(void*)dW, (void*)dV, (void*)dq, (void*)dm, (void*)dqo}) if (p) (void)hipFree(p); };
+#define PS(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return fail(nullptr, BTF_EHIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+  const size_t nW = (size_t)nsamples * nrows * nembeds, nV = (size_t)nsamples * MT * nembeds;
+  PS(hipMalloc((void**)&dW, nW * sizeof(double)));
+  PS(hipMalloc((void**)&dV, nV * sizeof(double)));
+  PS(hipMalloc((void**)&dm, cellsN * sizeof(double)));
+  PS(hipMalloc((void**)&dq, (size_t)std::max(nq, 1) * sizeof(double)));
+  PS(hipMalloc((void**)&dqo, std::max<size_t>(1, (size_t)nq * cellsN) * sizeof(double)));
+  PS(hipMemcpy(dW, Ws, nW * sizeof(double), hipMemcpyHostToDevice));
+  PS(hipMemcpy(dV, Vs, nV * sizeof(double), hipMemcpyHostToDevice));
+  if (nq) PS(hipMemcpy(dq, q, (size_t)nq * sizeof(double), hipMemcpyHostToDevice));
+  int P = 2;
+  while (P < nsamples) P <<= 1;
+  const int cells = std::max(1, std::min(16, (int)((128 * 1024) / ((size_t)P * sizeof(double)))));
+  const size_t lds = (size_t)cells * P * sizeof(double);
+  dim3 grid((MT + cells - 1) / cells, nrows);
+#define PS_LAUNCH(KT_)                                                                                           \
+  case KT_: {                                                                                                    \
+    PS(hipFuncSetAttribute((const void*)posterior_summary_kernel<KT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(posterior_summary_kernel<KT_>, grid, dim3(256), lds, 0, (const double*)dW, (const double*)dV, nsamples, \
+                       nrows, MT, P, cells, transform, (const double*)dq, nq, dm, dqo);                         \
+  } break;
+  switch (nembeds) {
+    PS_LAUNCH(1) PS_LAUNCH(2) PS_LAUNCH(3) PS_LAUNCH(4) PS_LAUNCH(5) PS_LAUNCH(6) PS_LAUNCH(7) PS_LAUNCH(8) PS_LAUNCH(9) PS_LAUNCH(10)
+    default: break;
+  }
+#undef PS_LAUNCH
+  PS(hipGetLastError());
+  PS(hipDeviceSynchronize());
+  PS(hipMemcpy(mean_out, dm, cellsN * sizeof(double), hipMemcpyDeviceToHost));
+  if (nq) PS(hipMemcpy(q_out, dqo, (size_t)nq * cellsN * sizeof(double), hipMemcpyDeviceToHost));
+#undef PS
+  cleanup();
+  return BTF_OK;
+}
+
 int btf_pg_batch(int device, int64_t n, const double* b, const double* psi, uint64_t seed, double* out) {
   if (n < 1 || !b || !psi || !out) return fail(nullptr, BTF_EINVAL, "bad pg_batch arguments");
   hipError_t e = hipSetDevice(device);

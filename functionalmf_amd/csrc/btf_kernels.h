@@ -1630,4 +1630,72 @@ __global__ __launch_bounds__(256) void nb_mh_step_kernel(const double* __restric
   }
 }
 
+// ============================================================================
+// Posterior summaries over the kept samples  
+//   what the reference's example scripts do on the host with
+//     Mu = einsum('znk,zmtk->znmt', Ws, Vs);  Mu.mean(0);  np.percentile(Mu, q, axis=0)
+//   (examples/gaussian_tensor_filtering.py:82-85) - an (S, N, M, T) tensor (67 GB at C3, S = 1000) that is
+//   never materialised here: a workgroup takes `cells` consecutive (j,t) cells of one row i, computes
+//   their S values f(w_s . v_s) into LDS (rows padded to a power of two with +inf), sorts every row
+//   with a bitonic network, and reads the mean and the order statistics off the sorted rows.
+//   Percentiles follow numpy's default ('linear'): pos = q/100 (S-1), x[lo] + frac (x[lo+1] - x[lo]).
+//   transform: 0 identity, 1 ilogit (Binomial examples), 2 square.
+// ============================================================================
+template <int K>
+__global__ __launch_bounds__(256) void posterior_summary_kernel(const double* __restrict__ Ws, const double* __restrict__ Vs,
+                                                               int S, int N, int MT, int P, int cells, int transform,
+                                                               const double* __restrict__ q, int nq,
+                                                               double* __restrict__ mean_out, double* __restrict__ q_out) {
+  extern __shared__ double srt[];                 // [cells][P]
+  const int i = blockIdx.y, jt0 = blockIdx.x * cells;
+  const int nc = min(cells, MT - jt0);
+  // ---- values: thread -> (cell c, sample s); V[s][jt0 + c][:] is contiguous over c
+  for (int e = threadIdx.x; e < cells * P; e += 256) {
+    const int c = e % cells, sidx = e / cells;
+    double val = __builtin_inf();
+    if (sidx < S && c < nc) {
+      const double* __restrict__ w = Ws + ((size_t)sidx * N + i) * K;
+      const double* __restrict__ v = Vs + ((size_t)sidx * MT + jt0 + c) * K;
+      double x = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) x = fma(w[k], v[k], x);
+      val = transform == 1 ? 1.0 / (1.0 + exp(-x)) : (transform == 2 ? x * x : x);
+    }
+    srt[(size_t)c * P + sidx] = val;
+  }
+  __syncthreads();
+  // ---- bitonic sort of every row (ascending); P/2 compare-exchanges per row and stage
+  const int half = P >> 1;
+  for (int kk = 2; kk <= P; kk <<= 1) {
+    for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+      for (int e = threadIdx.x; e < cells * half; e += 256) {
+        const int c = e / half, pidx = e - c * half;
+        const int i1 = ((pidx / jj) * 2 * jj) + (pidx % jj), i2 = i1 + jj;
+        double* row = srt + (size_t)c * P;
+        const double a = row[i1], b = row[i2];
+        const bool up = (i1 & kk) == 0;
+        if ((a > b) == up) { row[i1] = b; row[i2] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- mean (fixed order: ascending values) and percentiles
+  for (int c = threadIdx.x; c < nc; c += 256) {
+    const double* row = srt + (size_t)c * P;
+    double sum = 0.0;
+    for (int sidx = 0; sidx < S; ++sidx) sum += row[sidx];
+    mean_out[(size_t)i * MT + jt0 + c] = sum / S;
+  }
+  for (int e = threadIdx.x; e < nc * nq; e += 256) {
+    const int c = e % nc, qi = e / nc;
+    const double* row = srt + (size_t)c * P;
+    const double pos = q[qi] * 0.01 * (S - 1);
+    int lo = (int)floor(pos);
+    lo = max(0, min(lo, S - 1));
+    const int hi = min(lo + 1, S - 1);
+    const double frac = pos - lo;
+    q_out[((size_t)qi * N + i) * MT + jt0 + c] = row[lo] + frac * (row[hi] - row[lo]);
+  }
+}
+
 }  // namespace btf

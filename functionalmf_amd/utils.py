@@ -69,3 +69,34 @@ def sample_horseshoe(size=1):
     """(utils.py:122-124)"""
     a = 1 / np.random.gamma(0.5, 1, size=size)
     return 1 / np.random.gamma(0.5, a), a
+
+
+def posterior_summary(Ws, Vs, q=(5, 95), transform=None, device=0):
+    """Mean and percentiles over the kept samples of f(w_s[i] . v_s[j,t]) for every cell, on the GPU.
+
+    The reference's example scripts do this on the host
+    (examples/gaussian_tensor_filtering.py:82-85):
+
+        Mu_hat = np.einsum('znk,zmtk->znmt', Ws, Vs)        # (S, N, M, T): 67 GB at S=1000, (512,256,64)
+        mean, lo, hi = Mu_hat.mean(0), np.percentile(Mu_hat, 5, axis=0), np.percentile(Mu_hat, 95, axis=0)
+
+    Here the (S, N, M, T) tensor is never materialised (btf_posterior_summary: per-cell bitonic sort in
+    LDS).  `transform`: None, "ilogit" (the Binomial examples) or "square".  Returns (mean, quantiles)
+    with shapes (N, M, T) and (len(q), N, M, T); percentiles use numpy's default linear interpolation.
+    There is no CPU fallback."""
+    from . import _native
+    Ws, Vs = _native.as_f64(Ws), _native.as_f64(Vs)
+    if Ws.ndim != 3 or Vs.ndim != 4 or Ws.shape[0] != Vs.shape[0] or Ws.shape[2] != Vs.shape[3]:
+        raise ValueError("Ws must be (S, N, K) and Vs (S, M, T, K)")
+    code = {None: 0, "identity": 0, "ilogit": 1, "square": 2}[transform]
+    S, N, K = Ws.shape
+    M, T = Vs.shape[1:3]
+    qs = _native.as_f64(np.atleast_1d(q))
+    mean = np.zeros((N, M, T))
+    quant = np.zeros((len(qs), N, M, T))
+    lib = _native.load()
+    rc = lib.btf_posterior_summary(int(device), S, N, M, T, K, _native.dptr(Ws), _native.dptr(Vs), code,
+                                   _native.dptr(qs), len(qs), _native.dptr(mean), _native.dptr(quant))
+    if rc != _native.BTF_OK:
+        raise _native.BTFError(rc, lib.btf_last_error(None).decode())
+    return mean, quant

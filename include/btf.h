@@ -215,6 +215,17 @@ int btf_mvn_banded(int device, int batch, int n, int bw, const double* band,
                    const double* mu_part, const double* z, uint64_t seed,
                    double eps0, int attempts, double* x_out, int32_t* tries_out);
 
+/* ---- posterior summaries (stateless) --------------------------------
+ * Mean and percentiles over the kept samples of f(w_s[i] . v_s[j,t]) for every cell: what the
+ * reference's example scripts compute on the host as einsum('znk,zmtk->znmt', Ws, Vs).mean(0) /
+ * np.percentile(., q, axis=0) (examples/gaussian_tensor_filtering.py:82-85), without materialising
+ * the (S,N,M,T) tensor.  Ws (S,N,K), Vs (S,M,T,K) as run_gibbs returns them; transform 0 identity,
+ * 1 ilogit, 2 square; q in [0,100], numpy's default linear interpolation; mean_out (N,M,T),
+ * q_out (nq,N,M,T).  nsamples <= 16384.                                                      */
+int btf_posterior_summary(int device, int nsamples, int nrows, int ncols, int ndepth, int nembeds,
+                          const double* Ws, const double* Vs, int transform, const double* q, int nq,
+                          double* mean_out, double* q_out);
+
 /* ---- measurement ----------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by hipEvents on the ctx
  * stream; btf_kernel_times drains them: total milliseconds and launch count per

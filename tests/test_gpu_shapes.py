@@ -117,3 +117,25 @@ def test_rejects_unsupported_shapes():
         GaussianBayesianTensorFiltering(8, 4, 6, nembeds=11, tf_order=2)
     with pytest.raises(BTFError):
         GaussianBayesianTensorFiltering(8, 4, 6, nembeds=3, tf_order=4)
+
+
+@pytest.mark.parametrize("S,N,M,T,K,transform", [(37, 5, 4, 6, 3, None), (200, 9, 7, 5, 2, "ilogit"),
+                                                  (1000, 3, 5, 11, 5, None), (1025, 2, 3, 4, 1, "square"),
+                                                  (2, 4, 3, 2, 4, None), (1, 3, 2, 2, 2, "ilogit")])
+def test_posterior_summary_matches_numpy(S, N, M, T, K, transform):
+    """mean / percentiles over kept samples against the reference scripts' host
+    computation (einsum + mean + np.percentile, examples/gaussian_tensor_filtering.py:82-85)."""
+    from functionalmf_amd.utils import posterior_summary
+    rs = np.random.RandomState(S + N)
+    Ws = rs.normal(size=(S, N, K))
+    Vs = rs.normal(size=(S, M, T, K))
+    q = (5, 50, 95, 0, 100, 33.3)
+    mean, quant = posterior_summary(Ws, Vs, q=q, transform=transform)
+    Mu = np.einsum("znk,zmtk->znmt", Ws, Vs)
+    if transform == "ilogit":
+        Mu = 1 / (1 + np.exp(-Mu))
+    elif transform == "square":
+        Mu = Mu ** 2
+    assert np.max(np.abs(mean - Mu.mean(0))) < 1e-12 * max(1.0, np.abs(Mu).max())
+    ref = np.percentile(Mu, q, axis=0)
+    assert np.max(np.abs(quant - ref)) < 1e-12 * max(1.0, np.abs(Mu).max())
