@@ -70,6 +70,10 @@ SIGNATURES = {
     "btf_pg_batch": (C.c_int, [C.c_int, C.c_int64, _c_dp, _c_dp, C.c_uint64, _c_dp]),
     "btf_posterior_summary": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, C.c_int, _c_dp,
                                         C.c_int, _c_dp, _c_dp]),
+    "btf_collect_begin": (C.c_int, [_ctx, C.c_int]),
+    "btf_collect": (C.c_int, [_ctx, C.c_int]),
+    "btf_collect_end": (C.c_int, [_ctx, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
+    "btf_collect_summary": (C.c_int, [_ctx, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp]),
     "btf_sync": (C.c_int, [_ctx]),
     "btf_mvn_banded": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_uint64,
                                  C.c_double, C.c_int, _c_dp, _c_ip]),

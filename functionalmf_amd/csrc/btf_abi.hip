@@ -75,6 +75,8 @@ struct btf_ctx {
   bool nb_tabulable = false;        // every observed count is an integer in [0, NB_TAB)
   bool nb_L_valid = false;          // nb_L matches the current W, V
   bool nb_no_hist = false;          // test hook: keep the full-tensor kernel
+  // on-device sample collection (run_gibbs, rng="device"): [nsamp] slots of W, V, Tau2 and the scalars
+  double* smp_W = nullptr; double* smp_V = nullptr; double* smp_T = nullptr; double* smp_s = nullptr; int smp_n = 0;
   double* hyp = nullptr;        // device-resident scalars [HYP_COUNT] (nu2, sigma2, lam2, lam2_a, ...)
   bool dev_scalars = false;     // kernels read nu2 / sigma2 / lam2 from hyp instead of the host copies
   double* pin_hyp = nullptr;
@@ -578,7 +580,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
   if (c->pin_hyp) (void)hipHostFree(c->pin_hyp);
-  for (void* p : {(void*)c->nb_data, (void*)c->nb_S, (void*)c->nb_cnt, (void*)c->nb_R, (void*)c->nb_C, (void*)c->nb_tmp, (void*)c->nb_out, (void*)c->nb_H, (void*)c->nb_Hd, (void*)c->nb_Hs, (void*)c->nb_L, (void*)c->nb_optr, (void*)c->nb_oval})
+  for (void* p : {(void*)c->nb_data, (void*)c->nb_S, (void*)c->nb_cnt, (void*)c->nb_R, (void*)c->nb_C, (void*)c->nb_tmp, (void*)c->nb_out, (void*)c->nb_H, (void*)c->nb_Hd, (void*)c->nb_Hs, (void*)c->nb_L, (void*)c->nb_optr, (void*)c->nb_oval, (void*)c->smp_W, (void*)c->smp_V, (void*)c->smp_T, (void*)c->smp_s})
     if (p) (void)hipFree(p);
   if (c->hyp) (void)hipFree(c->hyp);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1282,6 +1284,84 @@ int btf_nb_get_rate(btf_ctx* c, double* R, const int32_t* shared) {
   HIPCHK(c, hipSetDevice(c->dev));
   HIPCHK(c, hipMemcpyAsync(R, c->nb_R, nR * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return BTF_OK;
+}
+
+// ------------------------------------------------------------ on-device sample collection
+int btf_collect_begin(btf_ctx* c, int nsamples) {
+  if (!c || nsamples < 1) return fail(c, BTF_EINVAL, "bad sample count");
+  if (c->nl != c->N || c->ml != c->M) return fail(c, BTF_ESTATE, "on-device sample collection needs an unsharded context");
+  HIPCHK(c, hipSetDevice(c->dev));
+  int rc;
+  if ((rc = dev_alloc(c, &c->smp_W, (size_t)nsamples * c->N * c->K))) return rc;
+  if ((rc = dev_alloc(c, &c->smp_V, (size_t)nsamples * c->M * c->T * c->K))) return rc;
+  if ((rc = dev_alloc(c, &c->smp_T, (size_t)nsamples * c->M * c->nD))) return rc;
+  if ((rc = dev_alloc(c, &c->smp_s, (size_t)nsamples * HYP_COUNT))) return rc;
+  c->smp_n = nsamples;
+  return BTF_OK;
+}
+
+int btf_collect(btf_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= c->smp_n) return fail(c, BTF_EINVAL, "sample slot out of range");
+  if (!c->have_W || !c->have_V || !c->have_hyper) return fail(c, BTF_ESTATE, "nothing to collect yet");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const size_t nW = (size_t)c->N * c->K, nV = (size_t)c->M * c->T * c->K, nT = (size_t)c->M * c->nD;
+  HIPCHK(c, hipMemcpyAsync(c->smp_W + slot * nW, c->W, nW * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->smp_V + slot * nV, c->V, nV * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->smp_T + slot * nT, c->Tau2, nT * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  if (c->hyp) HIPCHK(c, hipMemcpyAsync(c->smp_s + (size_t)slot * HYP_COUNT, c->hyp, HYP_COUNT * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return BTF_OK;
+}
+
+int btf_collect_end(btf_ctx* c, int nsamples, double* W, double* V, double* Tau2, double* scalars) {
+  if (!c || nsamples < 1 || nsamples > c->smp_n) return fail(c, BTF_EINVAL, "bad sample count");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const size_t nW = (size_t)c->N * c->K, nV = (size_t)c->M * c->T * c->K, nT = (size_t)c->M * c->nD;
+  if (W) HIPCHK(c, hipMemcpyAsync(W, c->smp_W, nsamples * nW * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (V) HIPCHK(c, hipMemcpyAsync(V, c->smp_V, nsamples * nV * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (Tau2) HIPCHK(c, hipMemcpyAsync(Tau2, c->smp_T, nsamples * nT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (scalars) HIPCHK(c, hipMemcpyAsync(scalars, c->smp_s, (size_t)nsamples * HYP_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  return check_status(c);
+}
+
+// posterior summaries straight from the collected samples (no upload); see btf_posterior_summary
+int btf_collect_summary(btf_ctx* c, int nsamples, int transform, const double* q, int nq, double* mean_out, double* q_out) {
+  if (!c || nsamples < 1 || nsamples > c->smp_n || nsamples > 16384 || !mean_out || nq < 0 || (nq > 0 && (!q || !q_out)) ||
+      transform < 0 || transform > 2)
+    return fail(c, BTF_EINVAL, "bad collect_summary arguments");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const int MT = c->M * c->T;
+  const size_t cellsN = (size_t)c->N * MT;
+  double *dq = nullptr, *dm = nullptr, *dqo = nullptr;
+  int rc;
+  if ((rc = dev_alloc(c, &dm, cellsN))) return rc;
+  if ((rc = dev_alloc(c, &dq, (size_t)std::max(nq, 1)))) { (void)hipFree(dm); return rc; }
+  if ((rc = dev_alloc(c, &dqo, std::max<size_t>(1, (size_t)nq * cellsN)))) { (void)hipFree(dm); (void)hipFree(dq); return rc; }
+  auto cleanup = [&]() { (void)hipFree(dm); (void)hipFree(dq); (void)hipFree(dqo); };
+#define CS(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return fail(c, BTF_EHIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+  if (nq) CS(hipMemcpyAsync(dq, q, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  int P = 2;
+  while (P < nsamples) P <<= 1;
+  const int cells = std::max(1, std::min(16, (int)((128 * 1024) / ((size_t)P * sizeof(double)))));
+  const size_t lds = (size_t)cells * P * sizeof(double);
+  dim3 grid((MT + cells - 1) / cells, c->N);
+#define CS_LAUNCH(KT_)                                                                                           \
+  case KT_: {                                                                                                    \
+    CS(hipFuncSetAttribute((const void*)posterior_summary_kernel<KT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(posterior_summary_kernel<KT_>, grid, dim3(256), lds, c->stream, (const double*)c->smp_W,  \
+                       (const double*)c->smp_V, nsamples, c->N, MT, P, cells, transform, (const double*)dq, nq, dm, dqo); \
+  } break;
+  switch (c->K) {
+    CS_LAUNCH(1) CS_LAUNCH(2) CS_LAUNCH(3) CS_LAUNCH(4) CS_LAUNCH(5) CS_LAUNCH(6) CS_LAUNCH(7) CS_LAUNCH(8) CS_LAUNCH(9) CS_LAUNCH(10)
+    default: break;
+  }
+#undef CS_LAUNCH
+  CS(hipGetLastError());
+  CS(hipMemcpyAsync(mean_out, dm, cellsN * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (nq) CS(hipMemcpyAsync(q_out, dqo, (size_t)nq * cellsN * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  CS(hipStreamSynchronize(c->stream));
+#undef CS
+  cleanup();
   return BTF_OK;
 }
 

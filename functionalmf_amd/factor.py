@@ -472,6 +472,51 @@ class BayesianTensorFiltering(_BayesianModel):
     def _set_hyperparameters(self, hyperparams):
         self.lam2 = hyperparams['lam2']
 
+    # ---- sample collection ------------------------------------------------------------
+    def _collects_on_device(self):
+        return self._dev_scalars and getattr(self, "_scalar_noise", False)
+
+    def run_gibbs(self, data, nburn=1000, nthin=1, nsamples=1000, verbose=True, print_freq=100,
+                  callback=None, **kwargs):
+        """genlasso.py:37-66.  rng="device" (scalar-noise model, no callback): the kept states are copied
+        device-to-device into preallocated slots right behind the sweep that produced them and come
+        back in one download at the end - the loop never waits for the GPU (the reference's per-sample
+        `inferred_variables()` copies cost 380 us per kept sample here, 4x the sweep itself)."""
+        if callback is not None or not self._collects_on_device() or nsamples < 1:
+            return super().run_gibbs(data, nburn=nburn, nthin=nthin, nsamples=nsamples, verbose=verbose,
+                                     print_freq=print_freq, callback=callback, **kwargs)
+        self._ctx.call("btf_collect_begin", int(nsamples))
+        self._collected = 0
+        for step in range(nburn + nthin * nsamples):
+            if verbose and step % print_freq == 0:
+                print('\tStep {}'.format(step))
+            self.resample(data, **kwargs)
+            kept, rem = divmod(step - nburn, nthin)
+            if step >= nburn and rem == 0:
+                self._push_state()                     # (anything the caller touched between sweeps)
+                self._ctx.call("btf_collect", kept)
+        N, M, T, K, nD = self.nrows, self.ncols, self.ndepth, self.nembeds, self.Delta.shape[0]
+        out = {"W": np.zeros((nsamples, N, K)), "V": np.zeros((nsamples, M, T, K)), "Tau2": np.zeros((nsamples, M, nD))}
+        sc = np.zeros((nsamples, 8))
+        self._ctx.call("btf_collect_end", int(nsamples), _native.dptr(out["W"]), _native.dptr(out["V"]),
+                       _native.dptr(out["Tau2"]), _native.dptr(sc))
+        self._collected = nsamples
+        out["nu2"], out["sigma2"], out["lam2"] = sc[:, 0:1].copy(), sc[:, 1:2].copy(), sc[:, 2:3].copy()
+        return out
+
+    def posterior_summary(self, q=(5, 95), transform=None):
+        """Mean and percentiles of f(W V') over the samples the last device-collecting run_gibbs kept,
+        computed where they lie (btf_collect_summary); see functionalmf_amd.utils.posterior_summary."""
+        n = getattr(self, "_collected", 0)
+        if n < 1:
+            raise RuntimeError("no samples collected on the device (run_gibbs with rng='device' first)")
+        code = {None: 0, "identity": 0, "ilogit": 1, "square": 2}[transform]
+        qs = _native.as_f64(np.atleast_1d(q))
+        mean = np.zeros((self.nrows, self.ncols, self.ndepth))
+        quant = np.zeros((len(qs),) + mean.shape)
+        self._ctx.call("btf_collect_summary", int(n), code, _native.dptr(qs), len(qs), _native.dptr(mean), _native.dptr(quant))
+        return mean, quant
+
     # ---- the two half-sweeps (device) ----------------------------------------------
     def _w_normals(self):
         if self.rng != "host":

@@ -226,6 +226,18 @@ int btf_posterior_summary(int device, int nsamples, int nrows, int ncols, int nd
                           const double* Ws, const double* Vs, int transform, const double* q, int nq,
                           double* mean_out, double* q_out);
 
+/* ---- on-device sample collection (rng="device"; replaces the per-sample copies of
+ * genlasso.py:51-65) ---------------------------------------------------------------------
+ * btf_collect_begin allocates nsamples slots for W, V, Tau2 and the device-resident scalars;
+ * btf_collect(slot) queues device-to-device copies of the current state (no synchronisation);
+ * btf_collect_end downloads the first nsamples slots (W (S,N,K), V (S,M,T,K), Tau2 (S,M,nD),
+ * scalars (S,8): nu2, sigma2, lam2, lam2_a, ...; any may be NULL) and synchronises;
+ * btf_collect_summary is btf_posterior_summary on the collected samples, without an upload.   */
+int btf_collect_begin(btf_ctx* ctx, int nsamples);
+int btf_collect(btf_ctx* ctx, int slot);
+int btf_collect_end(btf_ctx* ctx, int nsamples, double* W, double* V, double* Tau2, double* scalars8);
+int btf_collect_summary(btf_ctx* ctx, int nsamples, int transform, const double* q, int nq, double* mean_out, double* q_out);
+
 /* ---- measurement ----------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by hipEvents on the ctx
  * stream; btf_kernel_times drains them: total milliseconds and launch count per

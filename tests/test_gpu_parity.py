@@ -797,3 +797,32 @@ def test_negbinom_device_mh_loop_samples_the_same_posterior(rdims):
     (mh, sh), (md, sd) = out["host"], out["device"]
     assert np.all(np.abs(mh - md) < 0.25 * np.maximum(sh, sd) + 0.02), (mh, md, sh, sd)
     assert np.all(np.abs(sh - sd) < 0.35 * np.maximum(sh, sd) + 0.01), (sh, sd)
+
+
+def test_run_gibbs_device_collection_equals_per_sample_copies():
+    """rng='device': run_gibbs collects the kept states on the GPU (btf_collect*).  Same seeds -> the same
+    Philox streams, so the result dict must equal, bit for bit, what per-sample host copies
+    (genlasso.py:51-65, forced through a no-op callback) return; and the summary computed from the
+    device-resident samples must equal numpy on the downloaded ones."""
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    rs = np.random.RandomState(31)
+    N, M, T, R, K = 14, 9, 10, 2, 3
+    Y = np.einsum("nk,mtk->nmt", rs.normal(size=(N, K)), 0.3 * np.cumsum(rs.normal(size=(M, T, K)), axis=1))[..., None] \
+        + rs.normal(0, 0.5, size=(N, M, T, R))
+    Y[:2, :2] = np.nan
+    res = {}
+    for how in ("device", "host"):
+        np.random.seed(32)
+        model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1,
+                                                nu2_init=1.0, rng="device", device_seed=33)
+        cb = None if how == "device" else (lambda m, d, step: None)
+        res[how] = model.run_gibbs(Y, nburn=7, nthin=3, nsamples=12, verbose=False, callback=cb)
+        if how == "device":
+            mean, quant = model.posterior_summary(q=(5, 95))
+    assert sorted(res["device"]) == sorted(res["host"])
+    for k in res["host"]:
+        assert res["device"][k].shape == res["host"][k].shape, k
+        assert np.array_equal(res["device"][k], res["host"][k]), k
+    Mu = np.einsum("znk,zmtk->znmt", res["device"]["W"], res["device"]["V"])
+    assert np.max(np.abs(mean - Mu.mean(0))) < 1e-12 * np.abs(Mu).max()
+    assert np.max(np.abs(quant - np.percentile(Mu, (5, 95), axis=0))) < 1e-12 * np.abs(Mu).max()
