@@ -75,6 +75,7 @@ struct btf_ctx {
   bool nb_tabulable = false;        // every observed count is an integer in [0, NB_TAB)
   bool nb_L_valid = false;          // nb_L matches the current W, V
   bool nb_no_hist = false;          // test hook: keep the full-tensor kernel
+  bool no_panel4 = false;           // test hook: twisted sampler without the panelised MFMA factorisation
   // on-device sample collection (run_gibbs, rng="device"): [nsamp] slots of W, V, Tau2 and the scalars
   double* smp_W = nullptr; double* smp_V = nullptr; double* smp_T = nullptr; double* smp_s = nullptr; int smp_n = 0;
   double* hyp = nullptr;        // device-resident scalars [HYP_COUNT] (nu2, sigma2, lam2, lam2_a, ...)
@@ -916,6 +917,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     a.sR = a.s * c->R;
     a.Tau2 = c->Tau2; a.lam2 = c->lam2; a.nD = c->nD;
     a.hyp = c->dev_scalars ? c->hyp : nullptr; a.Rrep = c->R; a.hyp_noise = c->binomial ? 0 : 1;
+    a.panel4 = c->no_panel4 ? 0 : 1;
     a.st_ptr = c->st_ptr; a.st_row = c->st_row; a.st_coef = c->st_coef;
     a.T = T; a.TF = c->TF; a.col0 = c->col0; a.ml = c->ml;
     a.V = c->V; a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_v + 0x10001ULL;
@@ -1666,6 +1668,7 @@ int btf_set_tuning(btf_ctx* c, int rows_per_block_w, int rows_per_block_v) {
   // rows_per_block_w == -1: Negative-Binomial rate update always through the full-tensor kernel (no histograms)
   c->nb_no_hist = rows_per_block_w == -1;
   if (rows_per_block_w < 0) rows_per_block_w = 0;
+  c->no_panel4 = rows_per_block_v == -4;
   c->force_generic_banded = rows_per_block_v == -1;
   c->banded_variant = rows_per_block_v == -3 ? 0 : (rows_per_block_v == -2 ? 1 : 2);
   c->rpb_w = rows_per_block_w; c->rpb_v = rows_per_block_v < 0 ? 0 : rows_per_block_v;

@@ -53,6 +53,7 @@ struct VbLayout {     // offsets (doubles) inside the dynamic LDS block
   int rhs;            // FP + npad + 64 right-hand side, FP zeros in front
   int m0, zs, invd;   // npad each
   int P, Ql, flag, vsc, dummy;
+  int vs4;            // 64     unscaled pivot columns of the current panel (panelised factorisation)
   int total;
   int FP, npad, R1;
 };
@@ -72,6 +73,7 @@ __host__ __device__ inline VbLayout vb_layout(int T, int K, int TF, int weighted
   L.Ql = o; o += weighted ? T * KK : KK;
   L.flag = o; o += 8;
   L.vsc = o; o += 64;
+  L.vs4 = o; o += 64;
   L.dummy = o; o += 64 * 9 + 8;
   L.total = o;
   return L;
@@ -234,6 +236,121 @@ __device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, 
     lds[L.band + (n_elim + 1) * R1 + lane] = w;
   }
   return !bad;
+}
+
+// Panelised variant of banded_ldl_forward for bw == 15 (band stride 16 doubles): four pivots per panel,
+// the whole trailing update of a panel done by ONE v_mfma_f64_16x16x4.
+//   * the panel's four columns (16 entries each, replicated in all four lane groups) live in registers;
+//     pivot k updates the later panel columns with DPP row_shl lane shifts and a readlane multiplier,
+//     exactly like the two-column chain of banded_ldl_forward;
+//   * the 16 x 16 trailing window, rows / columns c+4 .. c+19, is the MFMA accumulator: element (i,j) sits
+//     in register i/4, lane 16 (i%4) + j, so  D = C - Y V'  with  A[i][k] = L[c+4+i, c+k]  (lane (k,i)) and
+//     B[k][j] = unscaled column entry (lane (k,j)) - both re-read from LDS in exactly that lane order;
+//   * column 15 of the window (matrix column c+19) is never touched by a panel at c (reach c+18), so it
+//     carries the right-hand side instead: lanes with j == 15 address rhs[c+4+i], and B[k][15] = u_k (the
+//     panel's finished rhs entries, a 4 x 4 forward substitution on wave-uniform values): the forward
+//     substitution of all later rows rides along in the same MFMA.
+// Only the lower triangle of the window is loaded / stored (other lanes park garbage in private dummies).
+// n_elim % 4 leftover pivots go through banded_ldl_forward on a shifted view.  ~29 instructions per pivot
+// instead of 52.
+typedef double v4f64_t __attribute__((ext_vector_type(4)));
+
+template <int S>
+__device__ __forceinline__ double row_shl_zero(double v) {       // lane i <- lane i+S inside its 16-lane row, else 0
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + S, 0xF, 0xF, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + S, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+template <int NPL>
+__device__ inline bool banded_ldl_forward_p4(double* lds, const VbLayout L, int n, int n_elim) {
+  constexpr int bw = 15, R1 = 16;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, j = lane & 15;
+  if (n_elim < 0) n_elim = n;
+  const int npan = n_elim / 4;
+  const int zero = 8 * (L.dummy + 64 * 9);                    // never written
+  // uniform-stride addresses (all lanes valid; the four lane groups hold / store identical copies)
+  int cl = 8 * (L.band + j);                                   // column c+q, entry j       at +128 q
+  int ia = 8 * L.invd;                                         // invd[c+q]                 at +8 q
+  int ra = 8 * L.rhs;                                          // rhs[c+q]                  at +8 q
+  const int va = 8 * (L.vs4 + j);                              // vs4[q][j]                 at +128 q
+  // window (accumulator) addresses: register r, lane (g,j) <-> element (4r+g, j)
+  int ca[4], cs[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + g;
+    if (j == 15) { ca[r] = 8 * (L.rhs + 4 + i); cs[r] = 32; }                                   // rhs[c+4+i]
+    else if (i >= j) { ca[r] = 8 * (L.band + (4 + j) * R1 + (i - j)); cs[r] = 4 * R1 * 8; }     // A[c+4+i, c+4+j]
+    else { ca[r] = 8 * (L.dummy + 64 * (1 + r) + lane); cs[r] = 0; }                            // upper triangle: unused
+  }
+  // MFMA operands: lane (k = g, i|j = j)
+  const bool aval = 4 + j - g <= 15;
+  int aa = aval ? 8 * (L.band + g * R1 + (4 + j - g)) : zero;                  // L[c+4+i, c+k] = band[(c+k) R1 + 4+i-k]
+  const int as = aval ? 4 * R1 * 8 : 0;
+  int ba = j == 15 ? 8 * (L.rhs + g) : (aval ? 8 * (L.vs4 + g * R1 + (4 + j - g)) : zero);
+  const int bs = j == 15 ? 32 : 0;
+  bool bad = false;
+  for (int pnl = 0; pnl < npan; ++pnl) {
+    // ---- loads: panel columns, window, panel rhs
+    double C0 = ldsr(lds, cl), C1 = ldsr(lds, cl + 128), C2 = ldsr(lds, cl + 256), C3 = ldsr(lds, cl + 384);
+    v4f64_t W;
+    W[0] = ldsr(lds, ca[0]); W[1] = ldsr(lds, ca[1]); W[2] = ldsr(lds, ca[2]); W[3] = ldsr(lds, ca[3]);
+    const double r0 = ldsr(lds, ra), r1 = ldsr(lds, ra + 8), r2 = ldsr(lds, ra + 16), r3 = ldsr(lds, ra + 24);
+    // ---- pivot 0
+    const double p0 = bcast_first(C0);
+    bad |= !(p0 > 0.0);
+    const double i0 = rcp_nr(p0);
+    const double Y0 = C0 * i0;
+    const double y01 = bcast_lane(Y0, 1), y02 = bcast_lane(Y0, 2), y03 = bcast_lane(Y0, 3);
+    C1 = fma(-row_shl_zero<1>(C0), y01, C1);
+    C2 = fma(-row_shl_zero<2>(C0), y02, C2);
+    C3 = fma(-row_shl_zero<3>(C0), y03, C3);
+    // ---- pivot 1
+    const double p1 = bcast_first(C1);
+    bad |= !(p1 > 0.0);
+    const double i1 = rcp_nr(p1);
+    const double Y1 = C1 * i1;
+    const double y11 = bcast_lane(Y1, 1), y12 = bcast_lane(Y1, 2);
+    C2 = fma(-row_shl_zero<1>(C1), y11, C2);
+    C3 = fma(-row_shl_zero<2>(C1), y12, C3);
+    // ---- pivot 2
+    const double p2 = bcast_first(C2);
+    bad |= !(p2 > 0.0);
+    const double i2 = rcp_nr(p2);
+    const double Y2 = C2 * i2;
+    const double y21 = bcast_lane(Y2, 1);
+    C3 = fma(-row_shl_zero<1>(C2), y21, C3);
+    // ---- pivot 3
+    const double p3 = bcast_first(C3);
+    bad |= !(p3 > 0.0);
+    const double i3 = rcp_nr(p3);
+    const double Y3 = C3 * i3;
+    // ---- the panel's rhs entries (wave-uniform 4 x 4 forward substitution)
+    const double u0 = r0;
+    const double u1 = fma(-y01, u0, r1);
+    const double u2 = fma(-y11, u1, fma(-y02, u0, r2));
+    const double u3 = fma(-y21, u2, fma(-y12, u1, fma(-y03, u0, r3)));
+    // ---- stores: L columns (in place), unscaled columns, 1/D, finished rhs
+    ldsw(lds, cl, Y0); ldsw(lds, cl + 128, Y1); ldsw(lds, cl + 256, Y2); ldsw(lds, cl + 384, Y3);
+    ldsw(lds, va, C0); ldsw(lds, va + 128, C1); ldsw(lds, va + 256, C2); ldsw(lds, va + 384, C3);
+    ldsw(lds, ia, i0); ldsw(lds, ia + 8, i1); ldsw(lds, ia + 16, i2); ldsw(lds, ia + 24, i3);
+    ldsw(lds, ra, u0); ldsw(lds, ra + 8, u1); ldsw(lds, ra + 16, u2); ldsw(lds, ra + 24, u3);
+    // ---- trailing window: W -= Y V'  (column 15: rhs[c+4+i] -= sum_k L[c+4+i, c+k] u_k)
+    const double A = ldsr(lds, aa);
+    const double B = ldsr(lds, ba);
+    W = __builtin_amdgcn_mfma_f64_16x16x4f64(-A, B, W, 0, 0, 0);
+    ldsw(lds, ca[0], W[0]); ldsw(lds, ca[1], W[1]); ldsw(lds, ca[2], W[2]); ldsw(lds, ca[3], W[3]);
+    cl += 4 * R1 * 8; ia += 32; ra += 32; aa += as; ba += bs;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ca[r] += cs[r];
+  }
+  // ---- leftover pivots (and the flush of the register-resident columns) on a view shifted by 4 npan
+  VbLayout L2 = L;
+  const int nn0 = 4 * npan;
+  L2.band += nn0 * R1; L2.rhs += nn0; L2.invd += nn0;
+  const bool rest = banded_ldl_forward<NPL, true>(lds, L2, n - nn0, bw, n_elim - nn0);
+  return rest && !bad;
 }
 
 // x = L^-T w for the unit-lower band factor; w = rhs in/out.  Wave 0 only; bw >= 3.
@@ -489,7 +606,9 @@ __global__ __launch_bounds__(VB_THREADS) void v_banded_fast_kernel(VBandArgs a, 
     __syncthreads();
     stamp[2] = __builtin_amdgcn_s_memtime();
     if (wave == 0) {
-      const bool good = banded_ldl_forward<NPL, ROW16>(lds, L, n, bw);
+      bool good;
+      if constexpr (ROW16) good = (a.panel4 && bw == 15) ? banded_ldl_forward_p4<NPL>(lds, L, n, n) : banded_ldl_forward<NPL, ROW16>(lds, L, n, bw);
+      else good = banded_ldl_forward<NPL, ROW16>(lds, L, n, bw);
       if (tid == 0) flag[0] = good ? 1.0 : 0.0;
     } else if (tried == 0) {
       // the normals of this column, depth-major index (drawn once, whatever the retries)

@@ -53,6 +53,7 @@ __host__ __device__ inline TwLayout tw_layout(int T, int K, int TF, int weighted
     V.rhs = o + V.FP; o += V.FP + V.npad + 64;
     V.invd = o; o += V.npad;
     V.vsc = o; o += 64;
+    V.vs4 = o; o += 64;
     V.m0 = V.zs = V.P = V.Ql = V.flag = 0;
     V.total = 0;
   };
@@ -273,10 +274,14 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     stamp[2] = __builtin_amdgcn_s_memtime();
     // ---- the two chains, concurrently -------------------------------------------------------
     if (wave == 0) {
-      const bool good = banded_ldl_forward<NPL, ROW16>(lds, W.L, nL, bw, nl);
+      bool good;
+      if constexpr (ROW16) good = (a.panel4 && bw == 15) ? banded_ldl_forward_p4<NPL>(lds, W.L, nL, nl) : banded_ldl_forward<NPL, ROW16>(lds, W.L, nL, bw, nl);
+      else good = banded_ldl_forward<NPL, ROW16>(lds, W.L, nL, bw, nl);
       if (tid == 0) flag[0] = good ? 1.0 : 0.0;
     } else if (wave == 1) {
-      const bool good = banded_ldl_forward<NPL, ROW16>(lds, W.R, nR, bw, nr);
+      bool good;
+      if constexpr (ROW16) good = (a.panel4 && bw == 15) ? banded_ldl_forward_p4<NPL>(lds, W.R, nR, nr) : banded_ldl_forward<NPL, ROW16>(lds, W.R, nR, bw, nr);
+      else good = banded_ldl_forward<NPL, ROW16>(lds, W.R, nR, bw, nr);
       if (tid == 64) flag[1] = good ? 1.0 : 0.0;
     } else if (tried == 0) {
       // the normals of this column, indexed in elimination order (drawn once, whatever the retries)
@@ -303,7 +308,9 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
         lds[W.R.band + nr * R1 + idx] = 0.0;
       }
       if (wave == 0) {
-        const bool good = banded_ldl_forward<NPL, ROW16>(lds, W.S, ns, bw);
+        bool good;
+        if constexpr (ROW16) good = (a.panel4 && bw == 15) ? banded_ldl_forward_p4<NPL>(lds, W.S, ns, ns) : banded_ldl_forward<NPL, ROW16>(lds, W.S, ns, bw);
+        else good = banded_ldl_forward<NPL, ROW16>(lds, W.S, ns, bw);
         if (tid == 0) flag[0] = good ? 1.0 : 0.0;
       } else {
         // meanwhile: w = D^-1 u + D^-1/2 z for the two interiors

@@ -488,6 +488,7 @@ struct VBandArgs {
   const double* hyp;   // device-resident scalars or nullptr (see WSolveArgs)
   double Rrep;
   int hyp_noise;
+  int panel4;          // 1: panelised MFMA factorisation where it applies (bw == 15)
 };
 __device__ __forceinline__ void vband_load_hyp(VBandArgs& a) {
   if (a.hyp) {

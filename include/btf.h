@@ -246,7 +246,7 @@ int btf_set_profiling(btf_ctx* ctx, int on);
 int btf_kernel_times(btf_ctx* ctx, double* ms_total, int64_t* launches);
 /* Launch geometry of the streaming kernels (tuning knob; 0 = default).  Negative values are
  * test hooks: rows_per_block_v = -1 / -2 / -3 selects the generic / single-chain / pipelined
- * banded sampler, rows_per_block_w = -1 keeps the Negative-Binomial rate update on the
+ * banded sampler, -4 the twisted sampler without the panelised MFMA factorisation, rows_per_block_w = -1 keeps the Negative-Binomial rate update on the
  * full-tensor kernel (no count histograms).                                   */
 int btf_set_tuning(btf_ctx* ctx, int rows_per_block_w, int rows_per_block_v);
 

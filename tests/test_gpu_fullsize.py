@@ -61,7 +61,10 @@ def test_full_size_mean_term_is_order_invariant_and_matches_cpu(c3, monkeypatch)
     monkeypatch.setattr(model, "_v_normals", lambda: np.zeros((M, K * T)))
     model._resample_V(Y)
     orc.v_step_strong(st, Rr, ybar, Delta, z=np.zeros((M, K * T)))
-    assert relerr(model.V, st["V"]) < 1e-6
+    # (after two sweeps lam2 sits on its 1e-5 floor and Tau2 spans 1e-7..2e6: two correct fp64 solves in
+    #  different elimination orders agree to cond*eps ~ 1e-6 here - scripts/p4err.py: twisted vs CPU 1.2e-6,
+    #  generic GPU kernel vs CPU 0.6e-6, panelised vs unpanelised twisted kernel 5e-10)
+    assert relerr(model.V, st["V"]) < 4e-6
 
 
 def test_full_size_conditional_means_are_linear_in_the_data(c3, monkeypatch):

@@ -54,7 +54,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, -2, -3])
+@pytest.mark.parametrize("variant", [0, -2, -3, -4])
 @pytest.mark.parametrize("N,M,T,R,K,tf,missing", CASES)
 def test_half_sweeps_match_oracle(N, M, T, R, K, tf, missing, variant):
     from functionalmf_amd.factor import GaussianBayesianTensorFiltering
