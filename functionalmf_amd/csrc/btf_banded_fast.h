@@ -292,11 +292,13 @@ __device__ inline bool banded_ldl_forward_p4(double* lds, const VbLayout L, int 
   const int bs = j == 15 ? 32 : 0;
   bool bad = false;
   for (int pnl = 0; pnl < npan; ++pnl) {
-    // ---- loads: panel columns, window, panel rhs
+    // ---- loads: panel columns first (the pivot chain waits for nothing else), then the panel's rhs entries
+    //      and the window, which are not needed before the chain is through
     double C0 = ldsr(lds, cl), C1 = ldsr(lds, cl + 128), C2 = ldsr(lds, cl + 256), C3 = ldsr(lds, cl + 384);
+    const double r0 = ldsr(lds, ra), r1 = ldsr(lds, ra + 8), r2 = ldsr(lds, ra + 16), r3 = ldsr(lds, ra + 24);
+    __builtin_amdgcn_sched_barrier(0);       // keep the window loads BEHIND the column loads (the scheduler hoists them)
     v4f64_t W;
     W[0] = ldsr(lds, ca[0]); W[1] = ldsr(lds, ca[1]); W[2] = ldsr(lds, ca[2]); W[3] = ldsr(lds, ca[3]);
-    const double r0 = ldsr(lds, ra), r1 = ldsr(lds, ra + 8), r2 = ldsr(lds, ra + 16), r3 = ldsr(lds, ra + 24);
     // ---- pivot 0
     const double p0 = bcast_first(C0);
     bad |= !(p0 > 0.0);
