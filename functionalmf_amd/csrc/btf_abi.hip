@@ -71,6 +71,7 @@ struct btf_ctx {
   int nb_Rr = 0; bool counts = false;
   unsigned int* nb_H = nullptr; double* nb_Hd = nullptr; double* nb_Hs = nullptr;   // per-row count histograms (u32, f64) and their sum over rows
   double* nb_L = nullptr;            // [N + 1]: per-row sum cnt*log(1-p), then the total
+  int* fill_tab = nullptr; int fill_n = 0; int fill_key = -1;   // band assembly program of the twisted kernel
   int* nb_optr = nullptr; double* nb_oval = nullptr; int nb_nout = 0;   // per-row outlier lists (CSR)
   bool nb_tabulable = false;        // every observed count is an integer in [0, NB_TAB)
   bool nb_L_valid = false;          // nb_L matches the current W, V
@@ -345,6 +346,41 @@ hipError_t launch_vbanded_twist(btf_ctx* c, const VBandArgs& a, size_t lds_bytes
   p.launch(v_banded_twist_kernel<NPL, ROW16>, dim3(a.ml), dim3(VT_THREADS), lds_bytes, a, c->K);
   return hipSuccess;
 }
+// Band assembly program of v_banded_twist_kernel: one entry per structurally non-zero band word of the left
+// and right views, {destination, source, diagonal source or -1, 0} as LDS word offsets of tw_layout: the K-k
+// same-depth-block entries come from the Gram block(s) Ql, the tf+1 prior couplings from the prior band P
+// (btf_banded_twist.h, "assemble the two bands").  Padded to a multiple of the workgroup size with reads of
+// P[0] written to a dummy word.
+int make_fill_table(btf_ctx* c, bool weighted) {
+  const int key = weighted ? 1 : 0;
+  if (c->fill_tab && c->fill_key == key) return BTF_OK;
+  const int T = c->T, K = c->K, TF = c->TF, KK = c->KK, D1 = TF + 2, n = T * K;
+  const TwLayout W = tw_layout(T, K, TF, weighted ? 1 : 0);
+  const int R1 = W.L.R1, nl = W.nl, nr = W.nr, nL = W.nL;
+  std::vector<int> tab;
+  auto put = [&](int dst, int src, int dia) { tab.push_back(dst); tab.push_back(src); tab.push_back(dia); tab.push_back(0); };
+  for (int i = 0; i < nL; ++i) {                       // left view: column i (global g = i), entry (g+aa, g)
+    const int t = i / K, k = i - t * K;
+    for (int aa = 0; aa < K - k; ++aa)
+      if (i + aa < nL) put(W.L.band + i * R1 + aa, W.Ql + (weighted ? t * KK : 0) + lidx(k + aa, k), aa == 0 ? W.P + t * D1 : -1);
+    for (int d = 1; d < D1; ++d)
+      if (t + d < T && i + d * K < nL) put(W.L.band + i * R1 + d * K, W.P + t * D1 + d, -1);
+  }
+  for (int m = 0; m < nr; ++m) {                       // right view: mirrored column m (global gc = n-1-m), entry (gc, gc-aa)
+    const int gc = n - 1 - m, tc = gc / K, kc = gc - tc * K;
+    for (int aa = 0; aa <= kc; ++aa)
+      if (gc - aa >= nl) put(W.R.band + m * R1 + aa, W.Ql + (weighted ? tc * KK : 0) + lidx(kc, kc - aa), aa == 0 ? W.P + tc * D1 : -1);
+    for (int d = 1; d < D1; ++d)
+      if (gc - d * K >= nl) put(W.R.band + m * R1 + d * K, W.P + (tc - d) * D1 + d, -1);
+  }
+  while ((tab.size() / 4) % VT_THREADS) put(W.L.dummy + 1, W.P, -1);
+  int rc;
+  if ((rc = dev_alloc(c, &c->fill_tab, tab.size()))) return rc;
+  HIPCHK(c, hipMemcpy(c->fill_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+  c->fill_n = (int)(tab.size() / 4);
+  c->fill_key = key;
+  return BTF_OK;
+}
 hipError_t dispatch_vbanded_twist(btf_ctx* c, const VBandArgs& a, int bw, size_t lds_bytes, bool* handled) {
   const int npairs = (bw - 1) * (bw - 2) / 2;
   const int npl = std::max(1, (npairs + WAVE - 1) / WAVE);
@@ -581,7 +617,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
   if (c->pin_hyp) (void)hipHostFree(c->pin_hyp);
-  for (void* p : {(void*)c->nb_data, (void*)c->nb_S, (void*)c->nb_cnt, (void*)c->nb_R, (void*)c->nb_C, (void*)c->nb_tmp, (void*)c->nb_out, (void*)c->nb_H, (void*)c->nb_Hd, (void*)c->nb_Hs, (void*)c->nb_L, (void*)c->nb_optr, (void*)c->nb_oval, (void*)c->smp_W, (void*)c->smp_V, (void*)c->smp_T, (void*)c->smp_s})
+  for (void* p : {(void*)c->nb_data, (void*)c->nb_S, (void*)c->nb_cnt, (void*)c->nb_R, (void*)c->nb_C, (void*)c->nb_tmp, (void*)c->nb_out, (void*)c->nb_H, (void*)c->nb_Hd, (void*)c->nb_Hs, (void*)c->nb_L, (void*)c->nb_optr, (void*)c->nb_oval, (void*)c->fill_tab, (void*)c->smp_W, (void*)c->smp_V, (void*)c->smp_T, (void*)c->smp_s})
     if (p) (void)hipFree(p);
   if (c->hyp) (void)hipFree(c->hyp);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -947,7 +983,11 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     }
     c->ngp_v = emit_gv ? c->ml : 0;
     c->ngp_w = 0;
-    if (choice == 2) e = dispatch_vbanded_twist(c, a, bw, tw_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
+    if (choice == 2) {
+      if ((rc = make_fill_table(c, wt))) return rc;
+      a.fill = c->fill_tab; a.nfill = c->fill_n;
+      e = dispatch_vbanded_twist(c, a, bw, tw_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
+    }
     HIPCHK(c, e);
     if (choice == 0) e = dispatch_vbanded_pipe(c, a, bw, vp_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
     HIPCHK(c, e);

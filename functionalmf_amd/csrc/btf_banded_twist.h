@@ -117,6 +117,19 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     for (; c < a.nch; ++c) s += p[(size_t)c * st];
     return s;
   };
+  // band assembly program (host-made, btf_abi.hip:make_fill_table): this thread's first FILL_REG entries are
+  // fetched now, under the latency of the partial sums
+  constexpr int FILL_REG = 12;
+  int fdst[FILL_REG], fsrc[FILL_REG], fdia[FILL_REG];
+  const int nfe = a.fill ? a.nfill / VT_THREADS : 0;          // entries per thread
+  if (a.fill) {
+#pragma unroll
+    for (int u = 0; u < FILL_REG; ++u) {
+      const int e = (u < nfe ? u : 0) * VT_THREADS + tid;
+      const int4 f = reinterpret_cast<const int4*>(a.fill)[e];      // {dst, src, diag-src or -1, 0}: one 16-B load
+      fdst[u] = f.x; fsrc[u] = f.y; fdia[u] = f.z;
+    }
+  }
   double pb_reg[4];                                        // prior band of this column: loaded now, stored later
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -215,6 +228,26 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
       for (int idx = tid; idx < nz2; idx += VT_THREADS) zb[idx] = make_double2(0.0, 0.0);
     }
     __syncthreads();
+    if (a.fill) {
+      // table-driven: every entry is an independent LDS read -> write (the loops below did one dependent
+      // read -> write per column and trip, eleven trips per view, with one wave per SIMD to hide it)
+      double val[FILL_REG];
+#pragma unroll
+      for (int u = 0; u < FILL_REG; ++u) {
+        val[u] = lds[fsrc[u]];
+        if (fdia[u] >= 0) val[u] += lds[fdia[u]] + shift;
+      }
+#pragma unroll
+      for (int u = 0; u < FILL_REG; ++u) if (u < nfe) lds[fdst[u]] = val[u];
+      for (int u = FILL_REG; u < nfe; ++u) {               // (larger systems: the rest on demand)
+        const int e = u * VT_THREADS + tid;
+        const int4 f = reinterpret_cast<const int4*>(a.fill)[e];
+        const int dst = f.x, src = f.y, dia = f.z;
+        double v = lds[src];
+        if (dia >= 0) v += lds[dia] + shift;
+        lds[dst] = v;
+      }
+    } else
     {
       const int NS = K + D1 - 1;                          // slots: K same-block offsets, then d = 1..tf+1
       const int LS = NS <= 8 ? 8 : 16;

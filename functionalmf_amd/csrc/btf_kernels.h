@@ -489,6 +489,8 @@ struct VBandArgs {
   double Rrep;
   int hyp_noise;
   int panel4;          // 1: panelised MFMA factorisation where it applies (bw == 15)
+  const int* fill;     // band assembly program of the twisted kernel: [nfill][4] = {dst, src, diag-src or -1, 0} (LDS word offsets)
+  int nfill;           // multiple of the workgroup size (padded with writes to a dummy word)
 };
 __device__ __forceinline__ void vband_load_hyp(VBandArgs& a) {
   if (a.hyp) {
