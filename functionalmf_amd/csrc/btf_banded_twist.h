@@ -130,12 +130,6 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
       fdst[u] = f.x; fsrc[u] = f.y; fdia[u] = f.z;
     }
   }
-  double pb_reg[4];                                        // prior band of this column: loaded now, stored later
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int idx = tid + u * VT_THREADS;
-    pb_reg[u] = idx < T * D1 ? a.pband[(size_t)j * T * D1 + idx] : 0.0;
-  }
   double gx[8];
   const bool g_early = !a.weighted && a.ngp * KK <= 8 * VT_THREADS;     // Gram partials: fetched now, summed below
   if (g_early) reduce_gram_fetch(a.gpart, a.ngp, KK, gx);
@@ -149,6 +143,14 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     const double* p0 = a.part + (size_t)k0 * a.ld + (size_t)j * T + t0;
     const double* p1 = a.part + (size_t)k1 * a.ld + (size_t)j * T + t1;
     const size_t st = (size_t)NV * a.ld;
+    // (the prior band of this column rides in the same batch of loads: issued any earlier, the register-starved
+    //  compiler sinks it below the Gram reduction and a second global round trip shows up)
+    double pb_reg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + u * VT_THREADS;
+      pb_reg[u] = idx < T * D1 ? a.pband[(size_t)j * T * D1 + idx] : 0.0;
+    }
     double s0 = 0.0, s1 = 0.0;
     int c = 0;
     for (; c + 4 <= a.nch; c += 4) {                     // fixed order c ascending, as chunk_sum
@@ -160,11 +162,18 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     for (; c < a.nch; ++c) { s0 += p0[(size_t)c * st]; s1 += p1[(size_t)c * st]; }
     if (h0) m0[t0 * K + k0] = s0 * a.s;
     if (h1) m0[t1 * K + k1] = s1 * a.s;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + u * VT_THREADS;
+      if (idx < T * D1) P[idx] = pb_reg[u];
+    }
+    for (int idx = tid + 4 * VT_THREADS; idx < T * D1; idx += VT_THREADS) P[idx] = a.pband[(size_t)j * T * D1 + idx];
   } else {
     for (int idx = tid; idx < n; idx += VT_THREADS) {
       const int t = idx / K, k = idx - t * K;
       m0[idx] = chunk_sum(a.part + (size_t)k * a.ld + (size_t)j * T + t) * a.s;
     }
+    for (int idx = tid; idx < T * D1; idx += VT_THREADS) P[idx] = a.pband[(size_t)j * T * D1 + idx];
   }
   if (a.weighted) {
     for (int idx = tid; idx < T * KK; idx += VT_THREADS) {
@@ -176,24 +185,20 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   } else {
     reduce_gram(a.gpart, a.ngp, KK, a.sR, lds + W.L.band, Ql);
   }
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int idx = tid + u * VT_THREADS;
-    if (idx < T * D1) P[idx] = pb_reg[u];
-  }
-  for (int idx = tid + 4 * VT_THREADS; idx < T * D1; idx += VT_THREADS) P[idx] = a.pband[(size_t)j * T * D1 + idx];
-  // static zero regions of the three views: pads, scratch rows, dummy words
+  // static zero regions of the three views: pads, scratch rows, dummy words (written out per view: an array of
+  // view pointers indexed in a loop put the layout structs into scratch memory - 5 k cycles for a few stores)
   {
-    const VbLayout* views[3] = {&W.L, &W.R, &W.S};
-    for (int q = 0; q < 3; ++q) {
-      const VbLayout& V = *views[q];
-      for (int idx = tid; idx < 64; idx += VT_THREADS) {
-        lds[V.band + V.npad * R1 + idx] = 0.0;
-        lds[V.rhs + V.npad + idx] = 0.0;
-        lds[V.vsc + idx] = 0.0;
+    auto zero_view = [&](const VbLayout& V) {
+      if (tid < 64) {
+        lds[V.band + V.npad * R1 + tid] = 0.0;
+        lds[V.rhs + V.npad + tid] = 0.0;
+        lds[V.vsc + tid] = 0.0;
       }
-      for (int idx = tid; idx < V.FP; idx += VT_THREADS) lds[V.rhs - V.FP + idx] = 0.0;
-    }
+      if (tid < V.FP) lds[V.rhs - V.FP + tid] = 0.0;       // FP = bw + 4 <= 256
+    };
+    zero_view(W.L);
+    zero_view(W.R);
+    zero_view(W.S);
     for (int idx = tid; idx < 64 * 9 + 8; idx += VT_THREADS) lds[W.L.dummy + idx] = 0.0;
   }
   __syncthreads();

@@ -219,6 +219,17 @@ __device__ __forceinline__ void reduce_gram_fetch(const double* __restrict__ gpa
 }
 __device__ inline void reduce_gram_finish(const double (&x)[8], int ngp, int KK, double scale, double* stage, double* G) {
   const int tot = ngp * KK, nthr = blockDim.x;
+  if (tot <= nthr) {      // one partial per thread (the usual case: N/64 or M blocks of KK): stage, sum in block order
+    if ((int)threadIdx.x < tot) stage[threadIdx.x] = x[0];
+    __syncthreads();
+    if ((int)threadIdx.x < KK) {
+      double s = 0.0;
+      for (int b = 0; b < ngp; ++b) s += stage[b * KK + threadIdx.x];
+      G[threadIdx.x] = s * scale;
+    }
+    __syncthreads();
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < 8; ++u) if ((int)threadIdx.x + u * nthr < tot) stage[threadIdx.x + u * nthr] = x[u];
   __syncthreads();
