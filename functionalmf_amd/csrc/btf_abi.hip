@@ -37,6 +37,7 @@ struct btf_ctx {
   bool have_data = false, binomial = false, weighted = false;
   double* A_wT = nullptr; double* C_wT = nullptr; double* A_v = nullptr; double* C_v = nullptr;
   double* B_wT = nullptr; double* B_v = nullptr;   // binomial: trials (0 where missing)
+  unsigned char* C8_wT = nullptr; unsigned char* C8_v = nullptr;   // Gaussian data with missing replicates: counts as bytes (C_* freed)
   double* W = nullptr; double* V = nullptr; double* WW = nullptr; double* VV = nullptr;
   double* Tau2 = nullptr;
   double lam2 = 1.0, sigma2 = 1.0, nu2 = 1.0;
@@ -238,11 +239,14 @@ int build_stencil(btf_ctx* c) {
 
 // ---- templated launch tables -------------------------------------------------
 template <int K>
-void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const double* U,
+void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const unsigned char* C8, const double* U,
                   const double* UU, const int* srcmap, int Rdim, int ld, int rpb, int nch) {
   Prof p(c, kid);
   dim3 grid(ld / ACC_TILE, nch);
-  if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
+  if (mode >= 1 && C8) {       // byte weights (Gaussian replicate counts)
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, UU, srcmap, c->part, Rdim, ld, rpb);
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, UU, srcmap, c->part, Rdim, ld, rpb);
+  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
   else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
   else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
 }
@@ -442,8 +446,10 @@ template <int K>
 void launch_sse(btf_ctx* c, const double* A, const double* C, double Rc, int ncols, int ld, int rpb, int nrb) {
   Prof p(c, BTF_K_SSE);
   dim3 grid((ncols + SSE_THREADS - 1) / SSE_THREADS, nrb);
-  p.launch(sse_kernel<K>, grid, dim3(SSE_THREADS), 0, A, C, Rc, (const double*)c->W, (const double*)c->V, c->N, ncols, ld, rpb,
-           (size_t)c->col0 * c->T, c->bsum);
+  if (c->C8_v) p.launch(sse_kernel<K, unsigned char>, grid, dim3(SSE_THREADS), 0, A, (const unsigned char*)c->C8_v, Rc, (const double*)c->W,
+                        (const double*)c->V, c->N, ncols, ld, rpb, (size_t)c->col0 * c->T, c->bsum);
+  else p.launch(sse_kernel<K>, grid, dim3(SSE_THREADS), 0, A, C, Rc, (const double*)c->W, (const double*)c->V, c->N, ncols, ld, rpb,
+                (size_t)c->col0 * c->T, c->bsum);
 }
 
 #define K_SWITCH(K, CALL)                                          \
@@ -617,7 +623,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
   if (c->pin_hyp) (void)hipHostFree(c->pin_hyp);
-  for (void* p : {(void*)c->nb_data, (void*)c->nb_S, (void*)c->nb_cnt, (void*)c->nb_R, (void*)c->nb_C, (void*)c->nb_tmp, (void*)c->nb_out, (void*)c->nb_H, (void*)c->nb_Hd, (void*)c->nb_Hs, (void*)c->nb_L, (void*)c->nb_optr, (void*)c->nb_oval, (void*)c->fill_tab, (void*)c->smp_W, (void*)c->smp_V, (void*)c->smp_T, (void*)c->smp_s})
+  for (void* p : {(void*)c->nb_data, (void*)c->nb_S, (void*)c->nb_cnt, (void*)c->nb_R, (void*)c->nb_C, (void*)c->nb_tmp, (void*)c->nb_out, (void*)c->nb_H, (void*)c->nb_Hd, (void*)c->nb_Hs, (void*)c->nb_L, (void*)c->nb_optr, (void*)c->nb_oval, (void*)c->fill_tab, (void*)c->C8_wT, (void*)c->C8_v, (void*)c->smp_W, (void*)c->smp_V, (void*)c->smp_T, (void*)c->smp_s})
     if (p) (void)hipFree(p);
   if (c->hyp) (void)hipFree(c->hyp);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -643,7 +649,20 @@ static int finish_data(btf_ctx* c) {
   int flag = 0;
   HIPCHK(c, hipMemcpy(&flag, c->status + 2, sizeof(int), hipMemcpyDeviceToHost));
   c->weighted = c->binomial || flag != 0;
+  if (c->C8_wT) { (void)hipFree(c->C8_wT); c->C8_wT = nullptr; }
+  if (c->C8_v) { (void)hipFree(c->C8_v); c->C8_v = nullptr; }
   if (!c->weighted) {  // complete Gaussian data: counts are the constant R, drop them
+    (void)hipFree(c->C_wT); c->C_wT = nullptr;
+    (void)hipFree(c->C_v); c->C_v = nullptr;
+  } else if (!c->binomial && c->R <= 255) {   // replicate counts 0..R: one byte per cell instead of eight
+    const size_t ew = (size_t)c->M * c->T * c->ldw, ev = (size_t)c->N * c->ldv;
+    int rc;
+    if ((rc = dev_alloc(c, &c->C8_wT, ew))) return rc;
+    if ((rc = dev_alloc(c, &c->C8_v, ev))) return rc;
+    hipLaunchKernelGGL(f64_to_u8_kernel, dim3((unsigned)std::min<size_t>(4096, (ew + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->C_wT, c->C8_wT, ew);
+    hipLaunchKernelGGL(f64_to_u8_kernel, dim3((unsigned)std::min<size_t>(4096, (ev + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->C_v, c->C8_v, ev);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->C_wT); c->C_wT = nullptr;
     (void)hipFree(c->C_v); c->C_v = nullptr;
   }
@@ -879,7 +898,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     const bool use_gv = !wt && whole && c->fuse_gram && c->ngp_v > 0;
     if (wt) { K_SWITCH(K, launch_products<KT>(c, c->V, MT, c->VV)); }
     else if (!use_gv) { K_SWITCH(K, launch_gram<KT>(c, c->V, MT)); }
-    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->V, c->VV, c->srcmap_w, MT, c->ldw, rpb, nch));
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->VV, c->srcmap_w, MT, c->ldw, rpb, nch));
     WSolveArgs a{};
     a.part = c->part; a.nch = nch; a.ld = c->ldw; a.weighted = wt ? 1 : 0;
     a.gpart = use_gv ? c->gpart_v : c->gpart; a.ngp = use_gv ? c->ngp_v : GRAM_BLOCKS;
@@ -932,7 +951,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     const bool use_gw = !wt && whole && c->fuse_gram && c->ngp_w > 0;
     if (wt) { K_SWITCH(K, launch_products<KT>(c, c->W, c->N, c->WW)); }
     else if (!use_gw) { K_SWITCH(K, launch_gram<KT>(c, c->W, c->N)); }
-    K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->W, c->WW, c->srcmap_v, c->N, c->ldv, rpb, nch));
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->WW, c->srcmap_v, c->N, c->ldv, rpb, nch));
     const int bw = (c->TF + 1) * K, R1 = bw + 1, D1 = c->TF + 2;
     size_t lds_fixed = (size_t)(3 * n + T * D1 + (wt ? T * KK : KK) + (bw * (bw + 1) / 2 + 3) / 4) * sizeof(double);
     size_t lds_band = (size_t)n * R1 * sizeof(double);
@@ -1110,6 +1129,8 @@ int btf_set_data_counts(btf_ctx* c, const double* counts, int nreps) {
   const int MT = c->M * c->T;
   const size_t cells = (size_t)c->N * MT;
   c->R = 1; c->binomial = true; c->counts = true; c->nb_Rr = nreps;
+  if (c->C8_wT) { (void)hipFree(c->C8_wT); c->C8_wT = nullptr; }
+  if (c->C8_v) { (void)hipFree(c->C8_v); c->C8_v = nullptr; }
   c->ldw = round_up(c->N, ACC_TILE);
   c->ldv = round_up(MT, ACC_TILE);
   int rc;

@@ -39,9 +39,11 @@ constexpr int ACC_RG = (ACC_THREADS / ACC_TILE) < 4 ? (ACC_THREADS / ACC_TILE) :
 // the weighted modes of K >= 6 would spill there and run with 8 waves (256-VGPR budget)
 __host__ __device__ constexpr int acc_waves(int K, int MODE) { return (MODE >= 1 && K >= 6) ? 8 : ACC_WAVES; }
 
-template <int K, int MODE, int WAVES = acc_waves(K, MODE)>
+// CT: storage type of the weights C: double (Binomial: the Polya-Gamma draws) or unsigned char (Gaussian data with
+// missing replicates: C is the replicate count 0..R, 1 byte instead of 8 per cell: 9 instead of 16 B/cell)
+template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double>
 __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
-    const double* __restrict__ X, const double* __restrict__ Cx, const double* __restrict__ U,
+    const double* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const double* __restrict__ UU, const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
     int rows_per_block) {
   constexpr int KK = tri(K);
@@ -75,9 +77,16 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
       const int r = rb + u * ACC_WAVES;  // wave-uniform
       if (r < r1) {
         x[u] = *reinterpret_cast<const double2*>(X + (size_t)r * ld + col);
-        if constexpr (MODE >= 1) c[u] = *reinterpret_cast<const double2*>(Cx + (size_t)r * ld + col);
+        if constexpr (MODE >= 1) {
+          if constexpr (sizeof(CT) == 1) {
+            const uchar2 cc = *reinterpret_cast<const uchar2*>(Cx + (size_t)r * ld + col);
+            c[u] = make_double2((double)cc.x, (double)cc.y);
+          } else {
+            c[u] = *reinterpret_cast<const double2*>(Cx + (size_t)r * ld + col);
+          }
+        }
         if constexpr (MODE == 2) {
-          const double cs0 = Cx[(size_t)r * ld + s0], cs1 = Cx[(size_t)r * ld + s1];
+          const double cs0 = (double)Cx[(size_t)r * ld + s0], cs1 = (double)Cx[(size_t)r * ld + s1];
           if (s0 != (int)col) x[u].x = c[u].x != 0.0 ? x[u].x * cs0 / c[u].x : 0.0;
           if (s1 != (int)col + 1) x[u].y = c[u].y != 0.0 ? x[u].y * cs1 / c[u].y : 0.0;
           c[u] = make_double2(cs0, cs1);
@@ -817,6 +826,11 @@ __global__ void relayout_kernel(const double* src, int rows, int cols, double* d
   }
 }
 
+__global__ void f64_to_u8_kernel(const double* __restrict__ src, unsigned char* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = (unsigned char)src[i];
+}
+
 __global__ void mask_kernel(double* C, const double* B, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     if (!(B[i] > 0.0)) C[i] = 0.0;
@@ -829,8 +843,8 @@ __global__ void mask_kernel(double* C, const double* B, size_t n) {
 // ============================================================================
 constexpr int SSE_THREADS = 256;
 
-template <int K>
-__global__ __launch_bounds__(SSE_THREADS) void sse_kernel(const double* __restrict__ A, const double* __restrict__ C,
+template <int K, typename CT = double>
+__global__ __launch_bounds__(SSE_THREADS) void sse_kernel(const double* __restrict__ A, const CT* __restrict__ C,
                                                           double Rconst, const double* __restrict__ W,
                                                           const double* __restrict__ V, int N, int ncell_cols,
                                                           int ld, int rows_per_block, size_t vcol0,
@@ -849,7 +863,7 @@ __global__ __launch_bounds__(SSE_THREADS) void sse_kernel(const double* __restri
 #pragma unroll
       for (int k = 0; k < K; ++k) mu = fma(w[k], v[k], mu);
       const double x = A[(size_t)i * ld + col];
-      const double c = C ? C[(size_t)i * ld + col] : Rconst;
+      const double c = C ? (double)C[(size_t)i * ld + col] : Rconst;
       const double e = x - c * mu;
       if (c > 0.0) acc += e * e / c;
     }
