@@ -228,7 +228,8 @@ def main():
     acc_ms = kt["w_accum"][0] + kt["v_accum"][0]
     acc_n = kt["w_accum"][1] + kt["v_accum"][1]
     acc_us = 1e3 * acc_ms / max(acc_n, 1)
-    alg_bytes = (8.0 if args.variant == "complete" else 16.0) * cells_local
+    # complete data: the linear statistic only; missing data: + a byte of replicate count; Binomial: + f64 weights
+    alg_bytes = {"complete": 8.0, "heldout": 9.0, "missing5": 9.0}.get(args.variant, 16.0) * cells_local
     achieved = alg_bytes / (acc_us * 1e-6) / 1e9 if acc_us > 0 else 0.0
     kernels_us = {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in kt.items() if v[1] > 0}
     traffic = pmc_traffic("accum_kernel") if (world == 1 and args.config == "c3") else None
