@@ -468,13 +468,28 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
       if (!(ok && r < d)) wrow[r] = a.W[(size_t)i * K + r];
   }
   if (a.gout) {
+    // W'W of this workgroup's 64 rows as a 16 x 16 x 64 f64 MFMA product (K <= 10 of the 16 rows / columns
+    // used): the rows are staged in LDS as [k][row]; step s takes rows 4s..4s+3, lane (kk = lane>>4,
+    // i = lane&15) holds W[4s+kk][i] and is both the A and the B operand.  (Fifteen 6-stage wave
+    // reductions cost 3.6 of this kernel's 10.9 us.)
+    typedef double v4f64_w __attribute__((ext_vector_type(4)));
+    double* stg = &red[0][0][0];                     // free again: [K][64]
 #pragma unroll
-    for (int p = 0; p < K; ++p)
+    for (int r = 0; r < K; ++r) stg[r * WS_ROWS + lane] = wrow[r];
+    const int kk = lane >> 4, ii = lane & 15;
+    const double* src = stg + (ii < K ? ii : 0) * WS_ROWS + kk;
+    v4f64_w acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 0; q <= p; ++q) {
-        const double s = wave_sum(wrow[p] * wrow[q]);
-        if (lane == 0) a.gout[(size_t)blockIdx.x * KK + lidx(p, q)] = s;
-      }
+    for (int sidx = 0; sidx < WS_ROWS / 4; ++sidx) {
+      const double x = ii < K ? src[4 * sidx] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+    }
+    // element (row 4r + kk, col ii) sits in acc[r] of this lane; keep the lower triangle of the K x K corner
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * r + kk;
+      if (row < K && ii <= row) a.gout[(size_t)blockIdx.x * KK + lidx(row, ii)] = acc[r];
+    }
   }
 }
 
