@@ -381,7 +381,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     lds[W.S.rhs + tid] = fma(lds[W.S.rhs + tid], iv, zs[nl + nr + tid] * sqrt(iv));
   }
   __syncthreads();
-  if (wave == 0) banded_unit_backward(lds, W.S, ns, bw);       // (separator: dense, ns = bw: the window routine)
+  if (wave == 0) banded_unit_backward_auto<ROW16>(lds, W.S, ns, bw);   // (separator: one block of the blocked routine)
   __syncthreads();
   // known trailing unknowns of both halves
   if (tid < ns) {
