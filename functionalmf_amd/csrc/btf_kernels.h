@@ -1280,25 +1280,33 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
                                                       double nu2_a, double nu2_b, double sig_a, double sig_b, int which,
                                                       unsigned long long seed, double* __restrict__ hyp) {
   __shared__ double red[4];
+  __shared__ double stat[2];
+  // both reductions first (all threads), then the two draws side by side: thread 0 draws nu2 while thread 64
+  // (another wave) draws sigma2 - a Gamma draw with shape ~1e7 is ~2 us of dependent f64 work on one lane
   if (which & 1) {
     double acc = 0.0;
     for (int b = threadIdx.x; b < nb; b += 256) acc += bsum[b];
     const double sse = block_sum_fixed(acc, red) + ssw;
-    if (threadIdx.x == 0) {
-      CellRng g(seed, (unsigned long long)HYP_NU2);
-      hyp[HYP_SSE] = sse;
-      hyp[HYP_NU2] = (nu2_b + 0.5 * sse) / gamma_mt(nu2_a + 0.5 * nobs, g);
-    }
+    if (threadIdx.x == 0) stat[0] = sse;
   }
   if (which & 2) {
     double acc = 0.0;
     for (int e = threadIdx.x; e < N * K; e += 256) { const double w = W[e]; acc = fma(w, w, acc); }   // the structural zeros add 0
     const double wsq = block_sum_fixed(acc, red);
-    if (threadIdx.x == 0) {
-      CellRng g(seed, (unsigned long long)HYP_SIGMA2);
-      hyp[HYP_WSQ] = wsq;
-      hyp[HYP_SIGMA2] = (sig_b + 0.5 * wsq) / gamma_mt(sig_a + 0.5 * nfree, g);
-    }
+    if (threadIdx.x == 0) stat[1] = wsq;
+  }
+  __syncthreads();
+  if ((which & 1) && threadIdx.x == 0) {
+    const double sse = stat[0];
+    CellRng g(seed, (unsigned long long)HYP_NU2);
+    hyp[HYP_SSE] = sse;
+    hyp[HYP_NU2] = (nu2_b + 0.5 * sse) / gamma_mt(nu2_a + 0.5 * nobs, g);
+  }
+  if ((which & 2) && threadIdx.x == 64) {
+    const double wsq = stat[1];
+    CellRng g(seed, (unsigned long long)HYP_SIGMA2);
+    hyp[HYP_WSQ] = wsq;
+    hyp[HYP_SIGMA2] = (sig_b + 0.5 * wsq) / gamma_mt(sig_a + 0.5 * nfree, g);
   }
 }
 
