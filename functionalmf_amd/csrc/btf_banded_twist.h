@@ -185,22 +185,8 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   } else {
     reduce_gram(a.gpart, a.ngp, KK, a.sR, lds + W.L.band, Ql);
   }
-  // static zero regions of the three views: pads, scratch rows, dummy words (written out per view: an array of
-  // view pointers indexed in a loop put the layout structs into scratch memory - 5 k cycles for a few stores)
-  {
-    auto zero_view = [&](const VbLayout& V) {
-      if (tid < 64) {
-        lds[V.band + V.npad * R1 + tid] = 0.0;
-        lds[V.rhs + V.npad + tid] = 0.0;
-        lds[V.vsc + tid] = 0.0;
-      }
-      if (tid < V.FP) lds[V.rhs - V.FP + tid] = 0.0;       // FP = bw + 4 <= 256
-    };
-    zero_view(W.L);
-    zero_view(W.R);
-    zero_view(W.S);
-    for (int idx = tid; idx < 64 * 9 + 8; idx += VT_THREADS) lds[W.L.dummy + idx] = 0.0;
-  }
+  // (the static zero regions of the three views - pads, scratch rows, dummy words - are part of the one wide
+  //  zero fill at the top of the assembly below: the views and the dummy block are contiguous in LDS)
   __syncthreads();
   stamp[1] = __builtin_amdgcn_s_memtime();
 
@@ -228,9 +214,11 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     // are non-zero: clear both bands with wide stores, then write just those.  LS lanes per
     // column (lane = slot), VT_THREADS/LS columns per pass; no divisions inside the loops.
     {
-      double2* zb = reinterpret_cast<double2*>(lds + W.L.band);      // L and R bands (and what lies between) are contiguous
-      const int nz2 = (W.R.band + W.R.npad * R1 - W.L.band + 1) / 2;
+      double2* zb = reinterpret_cast<double2*>(lds + W.L.band);      // views L, R, S and the dummy block are contiguous
+      const int nzw = W.L.dummy + 64 * 9 + 8 - W.L.band;            // words; m0 follows directly: no overshoot
+      const int nz2 = nzw / 2;
       for (int idx = tid; idx < nz2; idx += VT_THREADS) zb[idx] = make_double2(0.0, 0.0);
+      if ((nzw & 1) && tid == 0) lds[W.L.band + nzw - 1] = 0.0;
     }
     __syncthreads();
     if (a.fill) {
