@@ -238,7 +238,7 @@ __device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, 
   return !bad;
 }
 
-// Panelised variant of banded_ldl_forward for bw == 15 (band stride 16 doubles): four pivots per panel,
+// Panelised variant of banded_ldl_forward for bw <= 15 stored with a band stride of 16 doubles: four pivots per panel,
 // the whole trailing update of a panel done by ONE v_mfma_f64_16x16x4.
 //   * the panel's four columns (16 entries each, replicated in all four lane groups) live in registers;
 //     pivot k updates the later panel columns with DPP row_shl lane shifts and a readlane multiplier,
@@ -263,8 +263,8 @@ __device__ __forceinline__ double row_shl_zero(double v) {       // lane i <- la
 }
 
 template <int NPL>
-__device__ inline bool banded_ldl_forward_p4(double* lds, const VbLayout L, int n, int n_elim) {
-  constexpr int bw = 15, R1 = 16;
+__device__ inline bool banded_ldl_forward_p4(double* lds, const VbLayout L, int n, int bw, int n_elim) {
+  constexpr int R1 = 16;             // band stride (L.R1 == 16): columns of bw + 1 <= 16 words, zero beyond
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, j = lane & 15;
   if (n_elim < 0) n_elim = n;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(VB_THREADS) void v_banded_fast_kernel(VBandArgs a, 
     stamp[2] = __builtin_amdgcn_s_memtime();
     if (wave == 0) {
       bool good;
-      if constexpr (ROW16) good = (a.panel4 && bw == 15) ? banded_ldl_forward_p4<NPL>(lds, L, n, n) : banded_ldl_forward<NPL, ROW16>(lds, L, n, bw);
+      if constexpr (ROW16) good = (a.panel4 && bw == 15) ? banded_ldl_forward_p4<NPL>(lds, L, n, bw, n) : banded_ldl_forward<NPL, ROW16>(lds, L, n, bw);
       else good = banded_ldl_forward<NPL, ROW16>(lds, L, n, bw);
       if (tid == 0) flag[0] = good ? 1.0 : 0.0;
     } else if (tried == 0) {

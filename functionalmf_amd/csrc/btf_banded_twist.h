@@ -37,7 +37,9 @@ __host__ __device__ inline bool twist_ok(int T, int K, int TF) {
 
 __host__ __device__ inline TwLayout tw_layout(int T, int K, int TF, int weighted) {
   TwLayout W;
-  const int n = T * K, S = TF + 1, bw = S * K, D1 = TF + 2, KK = tri(K), R1 = bw + 1;
+  // band stride: 16 words for every bw <= 15 (the unused tail of a column stays zero), so that the panelised
+  // MFMA factorisation - written for 16-word columns - serves all of them; bw + 1 beyond
+  const int n = T * K, S = TF + 1, bw = S * K, D1 = TF + 2, KK = tri(K), R1 = bw <= 15 ? 16 : bw + 1;
   W.ts = twist_ts(T, TF);
   W.ns = bw;
   W.nl = W.ts * K;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = blockIdx.x, jg = a.col0 + j;
-  const int KK = tri(K), T = a.T, n = T * K, D1 = a.TF + 2, bw = (a.TF + 1) * K, R1 = bw + 1;
+  const int KK = tri(K), T = a.T, n = T * K, D1 = a.TF + 2, bw = (a.TF + 1) * K, R1 = bw <= 15 ? 16 : bw + 1;   // = tw_layout's stride
   const int NV = a.weighted ? K + KK : K;
   const TwLayout W = tw_layout(T, K, a.TF, a.weighted);
   const int nl = W.nl, nr = W.nr, ns = W.ns, nL = W.nL, nR = W.nR;
@@ -301,12 +303,12 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     // ---- the two chains, concurrently -------------------------------------------------------
     if (wave == 0) {
       bool good;
-      if constexpr (ROW16) good = (a.panel4 && bw == 15) ? banded_ldl_forward_p4<NPL>(lds, W.L, nL, nl) : banded_ldl_forward<NPL, ROW16>(lds, W.L, nL, bw, nl);
+      if constexpr (ROW16) good = a.panel4 ? banded_ldl_forward_p4<NPL>(lds, W.L, nL, bw, nl) : banded_ldl_forward<NPL, ROW16>(lds, W.L, nL, bw, nl);
       else good = banded_ldl_forward<NPL, ROW16>(lds, W.L, nL, bw, nl);
       if (tid == 0) flag[0] = good ? 1.0 : 0.0;
     } else if (wave == 1) {
       bool good;
-      if constexpr (ROW16) good = (a.panel4 && bw == 15) ? banded_ldl_forward_p4<NPL>(lds, W.R, nR, nr) : banded_ldl_forward<NPL, ROW16>(lds, W.R, nR, bw, nr);
+      if constexpr (ROW16) good = a.panel4 ? banded_ldl_forward_p4<NPL>(lds, W.R, nR, bw, nr) : banded_ldl_forward<NPL, ROW16>(lds, W.R, nR, bw, nr);
       else good = banded_ldl_forward<NPL, ROW16>(lds, W.R, nR, bw, nr);
       if (tid == 64) flag[1] = good ? 1.0 : 0.0;
     } else if (tried == 0) {
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
       }
       if (wave == 0) {
         bool good;
-        if constexpr (ROW16) good = (a.panel4 && bw == 15) ? banded_ldl_forward_p4<NPL>(lds, W.S, ns, ns) : banded_ldl_forward<NPL, ROW16>(lds, W.S, ns, bw);
+        if constexpr (ROW16) good = a.panel4 ? banded_ldl_forward_p4<NPL>(lds, W.S, ns, bw, ns) : banded_ldl_forward<NPL, ROW16>(lds, W.S, ns, bw);
         else good = banded_ldl_forward<NPL, ROW16>(lds, W.S, ns, bw);
         if (tid == 0) flag[0] = good ? 1.0 : 0.0;
       } else {
