@@ -49,6 +49,7 @@ SIGNATURES = {
     "btf_set_nu2": (C.c_int, [_ctx, C.c_double]),
     "btf_set_omega": (C.c_int, [_ctx, _c_dp, _c_dp]),
     "btf_get_omega": (C.c_int, [_ctx, _c_dp]),
+    "btf_w_accum": (C.c_int, [_ctx, C.c_int]),
     "btf_resample_W": (C.c_int, [_ctx, _c_dp, C.c_uint64, C.c_int]),
     "btf_resample_V": (C.c_int, [_ctx, _c_dp, C.c_uint64, C.c_int, C.c_double, C.c_int]),
     "btf_get_V_attempts": (C.c_int, [_ctx, _c_ip]),

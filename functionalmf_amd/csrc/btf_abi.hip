@@ -52,7 +52,8 @@ struct btf_ctx {
   int* st_ptr = nullptr; int* st_row = nullptr; double* st_coef = nullptr;
   int* srcmap_w = nullptr; int* srcmap_v = nullptr;   // per-output source index of the cached weights
   bool stale_w = false, stale_v = false;
-  double ssw = 0.0, nobs = 0.0;
+  double ssw = 0.0, nobs = 0.0, sa2 = 0.0;      // within-cell SS, observation count, sum S1^2/cnt (Gaussian data)
+  bool w_part_valid = false; int w_part_mode = 0, w_part_nch = 0, w_part_rpb = 0; bool w_part_gv = false;   // W-step partials current?
   int rpb_w = 0, rpb_v = 0;
   bool force_generic_banded = false;
   int banded_variant = 2;   // 2: twisted two-chain kernel (default), 1: single chain, 0: wave-specialised pipeline (experimental)
@@ -527,9 +528,9 @@ int make_stats(btf_ctx* c, const double* hY, const double* hY2, int rows, int co
   int* dflag = c->status + 2;
   const int blocks = (int)std::min<size_t>(4096, (cells + 255) / 256);
   if (want_sums) {
-    if ((size_t)blocks * 2 > c->bsum_elems) {
-      if ((rc = dev_alloc(c, &c->bsum, (size_t)blocks * 2))) return rc;
-      c->bsum_elems = (size_t)blocks * 2;
+    if ((size_t)blocks * 3 > c->bsum_elems) {
+      if ((rc = dev_alloc(c, &c->bsum, (size_t)blocks * 3))) return rc;
+      c->bsum_elems = (size_t)blocks * 3;
     }
   }
   StatsArgs a{dY, dY2, rows, cols, R, ld, transposed ? 1 : 0, *A, *C, want_sums ? c->bsum : nullptr, dflag};
@@ -544,12 +545,13 @@ int make_stats(btf_ctx* c, const double* hY, const double* hY2, int rows, int co
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (want_sums) {
-    std::vector<double> h((size_t)blocks * 2);
+    std::vector<double> h((size_t)blocks * 3);
     HIPCHK(c, hipMemcpy(h.data(), c->bsum, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-    double ssw = 0.0, nobs = 0.0;
-    for (int b = 0; b < blocks; ++b) { ssw += h[2 * b]; nobs += h[2 * b + 1]; }
+    double ssw = 0.0, nobs = 0.0, sa2 = 0.0;
+    for (int b = 0; b < blocks; ++b) { ssw += h[3 * b]; nobs += h[3 * b + 1]; sa2 += h[3 * b + 2]; }
     c->ssw = ssw;
     c->nobs = nobs;
+    c->sa2 = sa2;
   }
   (void)hipFree(dY);
   if (dY2) (void)hipFree(dY2);
@@ -667,6 +669,7 @@ static int finish_data(btf_ctx* c) {
     (void)hipFree(c->C_v); c->C_v = nullptr;
   }
   c->have_data = true;
+  c->w_part_valid = false;
   return BTF_OK;
 }
 
@@ -760,6 +763,7 @@ int btf_set_V(btf_ctx* c, const double* V) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_V = true;
   c->nb_L_valid = false;
+  c->w_part_valid = false;
   c->ngp_v = 0;
   return BTF_OK;
 }
@@ -844,6 +848,7 @@ int btf_set_nu2(btf_ctx* c, double nu2) {
   return BTF_OK;
 }
 int btf_set_omega(btf_ctx* c, const double* omega_rows, const double* omega_cols) {
+  if (c) c->w_part_valid = false;   // the weights change
   if (!c || !omega_rows || !omega_cols) return BTF_EINVAL;
   if (!c->have_data || !c->binomial) return fail(c, BTF_ESTATE, "btf_set_omega needs binomial data");
   HIPCHK(c, hipSetDevice(c->dev));
@@ -873,10 +878,11 @@ int btf_get_omega(btf_ctx* c, double* omega_rows) {
 }
 
 // ---------------------------------------------------------------------------- W
-int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
-  if (!c) return BTF_EINVAL;
-  if (!c->have_data || !c->have_V || !c->have_W) return fail(c, BTF_ESTATE, "set data, W and V first");
-  HIPCHK(c, hipSetDevice(c->dev));
+namespace {
+// phase 1 of the W half-sweep: Gram / outer products of V and the streaming accumulation into c->part.
+// It depends on the data and on V only, so it can be queued ahead of the hyper-parameter draws
+// (btf_w_accum) and its partials also give the residual sum of squares (btf_draw_scalars, which & 4).
+int w_accum_phase(btf_ctx* c, int compat) {
   const int K = c->K, KK = c->KK, MT = c->M * c->T;
   const bool wt = c->weighted;
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_w && c->srcmap_w ? 2 : 1);
@@ -886,6 +892,38 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
   const int nch = (MT + rpb - 1) / rpb;
   int rc;
   if ((rc = ensure_part(c, (size_t)nch * NV * c->ldw))) return rc;
+  const bool whole = c->nl == c->N && c->ml == c->M;      // fused Grams cover all rows/columns only when unsharded
+  const bool use_gv = !wt && whole && c->fuse_gram && c->ngp_v > 0;
+  if (c->nl > 0) {
+    if (wt) { K_SWITCH(K, launch_products<KT>(c, c->V, MT, c->VV)); }
+    else if (!use_gv) { K_SWITCH(K, launch_gram<KT>(c, c->V, MT)); }
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->VV, c->srcmap_w, MT, c->ldw, rpb, nch));
+  }
+  HIPCHK(c, hipGetLastError());
+  c->w_part_valid = true; c->w_part_mode = mode; c->w_part_nch = nch; c->w_part_rpb = rpb; c->w_part_gv = use_gv;
+  return BTF_OK;
+}
+}  // namespace
+
+int btf_w_accum(btf_ctx* c, int compat) {
+  if (!c) return BTF_EINVAL;
+  if (!c->have_data || !c->have_V || !c->have_W) return fail(c, BTF_ESTATE, "set data, W and V first");
+  HIPCHK(c, hipSetDevice(c->dev));
+  return w_accum_phase(c, compat);
+}
+
+int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
+  if (!c) return BTF_EINVAL;
+  if (!c->have_data || !c->have_V || !c->have_W) return fail(c, BTF_ESTATE, "set data, W and V first");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const int K = c->K, KK = c->KK;
+  const bool wt = c->weighted;
+  const int want_mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_w && c->srcmap_w ? 2 : 1);
+  int rc;
+  if (!(c->w_part_valid && c->w_part_mode == want_mode)) { if ((rc = w_accum_phase(c, compat))) return rc; }
+  const int nch = c->w_part_nch;
+  const bool use_gv = c->w_part_gv;
+  c->w_part_valid = false;                                 // consumed: W changes below
   const double* dz = nullptr;
   if (z) {
     const size_t nz = (size_t)w_z_offset(c->N, K);
@@ -894,11 +932,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     dz = c->zbuf;
   }
   if (c->nl > 0) {
-    const bool whole = c->nl == c->N && c->ml == c->M;      // fused Grams cover all rows/columns only when unsharded
-    const bool use_gv = !wt && whole && c->fuse_gram && c->ngp_v > 0;
-    if (wt) { K_SWITCH(K, launch_products<KT>(c, c->V, MT, c->VV)); }
-    else if (!use_gv) { K_SWITCH(K, launch_gram<KT>(c, c->V, MT)); }
-    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->VV, c->srcmap_w, MT, c->ldw, rpb, nch));
+    const bool whole = c->nl == c->N && c->ml == c->M;
     WSolveArgs a{};
     a.part = c->part; a.nch = nch; a.ld = c->ldw; a.weighted = wt ? 1 : 0;
     a.gpart = use_gv ? c->gpart_v : c->gpart; a.ngp = use_gv ? c->ngp_v : GRAM_BLOCKS;
@@ -1018,6 +1052,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
   }
   c->sweep_v++;
   c->nb_L_valid = false;
+  c->w_part_valid = false;
   HIPCHK(c, hipGetLastError());
   return BTF_OK;
 }
@@ -1269,6 +1304,7 @@ int btf_nb_loglik(btf_ctx* c, const double* R, const double* cand, const int32_t
 
 int btf_nb_set_rate(btf_ctx* c, const double* R, const int32_t* shared) {
   if (!c || !R || !shared) return BTF_EINVAL;
+  c->w_part_valid = false;
   if (!c->counts) return fail(c, BTF_ESTATE, "btf_nb_set_rate follows btf_set_data_counts");
   HIPCHK(c, hipSetDevice(c->dev));
   int rc;
@@ -1474,13 +1510,37 @@ int btf_draw_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double 
   HIPCHK(c, hipSetDevice(c->dev));
   size_t nb = 0;
   int rc;
-  if (which & 1) { if ((rc = sse_launch(c, &nb))) return rc; }
+  double ssw = c->ssw;
+  if (which & 1) {
+    // which & 4: take the residual sum of squares from the W half-sweep's accumulation partials (btf_w_accum
+    // must have run for the current V; the stale-weight mode of compat="reference" has no such identity)
+    const bool from_part = (which & 4) && c->w_part_valid && c->w_part_mode != 2 && c->nl == c->N;
+    if (from_part) {
+      const int blocks = (c->nl + WS_ROWS - 1) / WS_ROWS;
+      if ((size_t)blocks > c->bsum_elems) { if ((rc = dev_alloc(c, &c->bsum, (size_t)blocks))) return rc; c->bsum_elems = (size_t)blocks; }
+      Prof p(c, BTF_K_SSE);
+      const double* gp = c->w_part_gv ? c->gpart_v : c->gpart;
+      const int ngp = c->w_part_gv ? c->ngp_v : GRAM_BLOCKS;
+      if (c->weighted) {
+        K_SWITCH(c->K, p.launch(sse_part_kernel<KT, true>, dim3(blocks), dim3(WS_ROWS * ws_split(KT)), 0, (const double*)c->part,
+                                c->w_part_nch, c->ldw, gp, ngp, (double)c->R, (const double*)c->W, c->row0, c->nl, c->bsum));
+      } else {
+        K_SWITCH(c->K, p.launch(sse_part_kernel<KT, false>, dim3(blocks), dim3(WS_ROWS * ws_split(KT)), 0, (const double*)c->part,
+                                c->w_part_nch, c->ldw, gp, ngp, (double)c->R, (const double*)c->W, c->row0, c->nl, c->bsum));
+      }
+      HIPCHK(c, hipGetLastError());
+      nb = (size_t)blocks;
+      ssw += c->sa2;
+    } else if ((rc = sse_launch(c, &nb))) {
+      return rc;
+    }
+  }
   const int h = std::min(c->K, c->N);
   const double nfree = (double)c->N * c->K - (double)h * (h - 1) / 2.0 - (double)(c->K - h) * c->N;   // factor.py:155-174
   {
     Prof p(c, BTF_K_PROD);
-    p.launch(scalars_kernel, dim3(1), dim3(256), 0, (const double*)c->bsum, (int)nb, c->ssw, c->nobs, (const double*)c->W,
-             c->N, c->K, nfree, nu2_a, nu2_b, sigma2_a, sigma2_b, which, (unsigned long long)seed, c->hyp);
+    p.launch(scalars_kernel, dim3(1), dim3(256), 0, (const double*)c->bsum, (int)nb, ssw, c->nobs, (const double*)c->W,
+             c->N, c->K, nfree, nu2_a, nu2_b, sigma2_a, sigma2_b, which & 3, (unsigned long long)seed, c->hyp);
   }
   HIPCHK(c, hipGetLastError());
   return BTF_OK;
@@ -1527,6 +1587,7 @@ int btf_sse(btf_ctx* c, double* sse, double* nobs) {
 
 int btf_pg_draw(btf_ctx* c, uint64_t seed) {
   if (!c) return BTF_EINVAL;
+  c->w_part_valid = false;          // the weights change
   if (!c->have_data || !c->binomial || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_pg_draw needs binomial data, W and V");
   HIPCHK(c, hipSetDevice(c->dev));
   const unsigned long long MT = (unsigned long long)c->M * c->T;

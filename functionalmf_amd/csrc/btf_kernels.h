@@ -764,14 +764,14 @@ struct StatsArgs {
   const double* Y; const double* Y2;  // Y2 = trials (binomial) or nullptr
   int rows, cols, R; int ld; int transposed;
   double* A; double* C;               // C may be nullptr (not kept)
-  double* bsum;                       // [gridDim][2] : ssw, nobs   (may be nullptr)
+  double* bsum;                       // [gridDim][3] : ssw, nobs, sum S1^2/cnt   (may be nullptr)
   int* incomplete;                    // set to 1 if any cell has cnt != R (Gaussian) / is missing (binomial)
 };
 
 __global__ __launch_bounds__(256) void stats_kernel(StatsArgs a) {
-  __shared__ double red[4][2];
+  __shared__ double red[4][3];
   const size_t cells = (size_t)a.rows * a.cols;
-  double ssw = 0.0, nobs = 0.0;
+  double ssw = 0.0, nobs = 0.0, sa2 = 0.0;
   bool inc = false;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < cells; idx += (size_t)gridDim.x * blockDim.x) {
     size_t row, col;
@@ -799,6 +799,7 @@ __global__ __launch_bounds__(256) void stats_kernel(StatsArgs a) {
         }
       }
       nobs += cnt;
+      if (cnt > 0) sa2 = fma(s1, s1 / cnt, sa2);
       inc |= (cnt != a.R);
       A = s1;
       C = (double)cnt;
@@ -818,12 +819,14 @@ __global__ __launch_bounds__(256) void stats_kernel(StatsArgs a) {
   if (a.bsum) {
     ssw = wave_sum(ssw);
     nobs = wave_sum(nobs);
+    sa2 = wave_sum(sa2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { red[wave][0] = ssw; red[wave][1] = nobs; }
+    if (lane == 0) { red[wave][0] = ssw; red[wave][1] = nobs; red[wave][2] = sa2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      a.bsum[2 * blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-      a.bsum[2 * blockIdx.x + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+      a.bsum[3 * blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+      a.bsum[3 * blockIdx.x + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+      a.bsum[3 * blockIdx.x + 2] = red[0][2] + red[1][2] + red[2][2] + red[3][2];
     }
   }
 }
@@ -1752,6 +1755,92 @@ __global__ __launch_bounds__(256) void posterior_summary_kernel(const double* __
     const double frac = pos - lo;
     q_out[((size_t)qi * N + i) * MT + jt0 + c] = row[lo] + frac * (row[hi] - row[lo]);
   }
+}
+
+// ============================================================================
+// Residual sum of squares from the W half-sweep's accumulation partials (rng="device" full sweep):
+//   sum_cells (S1 - cnt mu)^2 / cnt = sum S1^2/cnt - 2 sum_i w_i . m_i + sum_i w_i' Q_i w_i,
+//   m_i = sum_(j,t) S1 v_jt and Q_i = sum_(j,t) cnt v_jt v_jt' (= R V'V on complete data) being exactly
+//   what accum_kernel just produced for the W step with the CURRENT V - so nu2 | rest needs no pass of
+//   its own over the data (sse_kernel: 15 us at C3).  One lane per row, chunks split over the waves as in
+//   w_solve_kernel; bsum[block] = sum over the block's rows of  -2 w.m + w'Qw.
+// ============================================================================
+template <int K, bool WEIGHTED>
+__global__ __launch_bounds__(WS_ROWS * ws_split(K)) void sse_part_kernel(const double* __restrict__ part, int nch, int ld,
+                                                                        const double* __restrict__ gpart, int ngp, double Rrep,
+                                                                        const double* __restrict__ W, int row0, int nl,
+                                                                        double* __restrict__ bsum) {
+  constexpr int KK = tri(K);
+  constexpr int WS_SPLIT = ws_split(K);
+  constexpr int NV = WEIGHTED ? K + KK : K;
+  __shared__ double G[KK];
+  __shared__ double red[WS_SPLIT][K + KK][WS_ROWS];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  if constexpr (!WEIGHTED) reduce_gram(gpart, ngp, KK, Rrep, &red[0][0][0], G);
+  const int il = blockIdx.x * WS_ROWS + lane;
+  const bool live = il < nl;
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+  if (live) {
+    const size_t cst = (size_t)NV * ld;
+    int c = grp;
+    for (; c + 3 * WS_SPLIT < nch; c += 4 * WS_SPLIT) {          // four chunks' loads in flight, added in chunk order
+      const double* p = part + (size_t)c * cst + il;
+      double x[4][NV];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) x[u][v] = p[(size_t)u * WS_SPLIT * cst + (size_t)v * ld];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] += x[u][v];
+    }
+    for (; c < nch; c += WS_SPLIT) {
+      const double* p = part + (size_t)c * cst + il;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] += p[(size_t)v * ld];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) red[grp][v][lane] = acc[v];
+  __syncthreads();
+  if (grp != 0) return;
+  double s = 0.0;
+  if (live) {
+    double w[K], m[K], Q[KK];
+    const double* wr = W + (size_t)(row0 + il) * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      w[k] = wr[k];
+      double t = 0.0;
+#pragma unroll
+      for (int g = 0; g < WS_SPLIT; ++g) t += red[g][k][lane];
+      m[k] = t;
+    }
+#pragma unroll
+    for (int q = 0; q < KK; ++q) {
+      if constexpr (WEIGHTED) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < WS_SPLIT; ++g) t += red[g][K + q][lane];
+        Q[q] = t;
+      } else {
+        Q[q] = G[q];
+      }
+    }
+    double lin = 0.0, quad = 0.0;
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+      lin = fma(w[a], m[a], lin);
+#pragma unroll
+      for (int b = 0; b <= a; ++b) quad = fma((a == b ? 1.0 : 2.0) * w[a] * w[b], Q[lidx(a, b)], quad);
+    }
+    s = quad - 2.0 * lin;
+  }
+  s = wave_sum(s);
+  if (lane == 0) bsum[blockIdx.x] = s;
 }
 
 }  // namespace btf

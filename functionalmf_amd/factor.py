@@ -649,6 +649,12 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
             if getattr(self, "_in_sweep", False) and self.sample_sigma2:
                 which, self._sigma2_drawn = 3, True
             self._push_state()
+            if getattr(self, "_in_sweep", False) and self.sample_W:
+                # the W half-sweep's accumulation depends on the data and V only: queue it now and take the
+                # residual sum of squares from its partials (no pass of its own over the data); the W step
+                # later in this sweep goes straight to the solve
+                self._ctx.call("btf_w_accum", _native.COMPAT[self.compat])
+                which |= 4
             self._ctx.call("btf_draw_scalars", self._next_seed(), which, float(self.nu2_a), float(self.nu2_b),
                            float(self.sigma2_a), float(self.sigma2_b))
             self._sc_dev_new = True

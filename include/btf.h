@@ -166,6 +166,11 @@ int btf_get_omega(btf_ctx* ctx, double* omega_rows);     /* (nrows_local,M,T) */
  * z: host array of the sum_i min(i+1,K) standard normals of ALL rows in row
  * order (the legacy-RNG stream of factor.py:361), or NULL to draw them on the
  * device (Philox4x32-10 keyed by `seed`).                                     */
+/* btf_w_accum queues the first phase of btf_resample_W alone (the streaming accumulation, which
+ * depends on the data and on V only); the next btf_resample_W then goes straight to the solve.
+ * Between the two, btf_draw_scalars(which | 4) can take the residual sum of squares of nu2 | rest
+ * from the same partials instead of a pass of its own over the data.                          */
+int btf_w_accum(btf_ctx* ctx, int compat);
 int btf_resample_W(btf_ctx* ctx, const double* z, uint64_t seed, int compat);
 /* btf_resample_V replaces GaussianBTF._resample_V (factor.py:364-409) including
  * its call into sample_mvn_from_precision (fast_mvn.py:35-47, :62-68): for every

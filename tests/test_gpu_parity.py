@@ -867,3 +867,34 @@ def test_posterior_summary_rejects_bad_input_and_model_without_samples():
     m = GaussianBayesianTensorFiltering(3, 5, 6, nembeds=2, nu2_init=1.0, rng="device")
     with pytest.raises(RuntimeError):
         m.posterior_summary()
+
+
+@pytest.mark.parametrize("name,compat", [("g2_c2_complete.npz", "reference"), ("g1_c1_heldout.npz", "exact"),
+                                         ("g3_partial_reps.npz", "exact"), ("g1_c1_heldout.npz", "reference")])
+def test_in_sweep_sse_comes_from_the_w_partials(golden, name, compat):
+    """Inside a device-mode sweep nu2 | rest takes its residual sum of squares from the W half-sweep's
+    accumulation partials (btf_w_accum + btf_draw_scalars(which|4)); it must equal the direct reduction
+    (the stale-weight mode of compat='reference' with missing data falls back to the direct kernel), and the
+    W step that follows must be the same as without the early accumulation."""
+    from oracle import btf_oracle as orc
+    from functionalmf_amd import _native
+    g = golden(name)
+    Y = g["Y"]
+    model, st = gaussian_model(g, "s0_", rng="device", device_seed=17, compat=compat)
+    sse, nobs = orc.sse_and_count(st, Y)
+    model._in_sweep = True
+    model._resample_nu2(Y)
+    model._in_sweep = False
+    out = np.zeros(6)
+    model._ctx.call("btf_get_scalars", _native.dptr(out))
+    assert abs(out[4] - sse) < 1e-9 * sse, (out[4], sse)
+    # the W step after the early accumulation vs a fresh model that never called btf_w_accum
+    model.nu2, model.sigma2 = 0.7, 1.3
+    model.rng = "host"
+    np.random.seed(5)
+    model._resample_W(Y)
+    ref, _ = gaussian_model(g, "s0_", compat=compat)
+    ref.nu2, ref.sigma2 = 0.7, 1.3
+    np.random.seed(5)
+    ref._resample_W(Y)
+    assert relerr(model.W, ref.W) < 1e-12
