@@ -21,7 +21,10 @@ HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith("
 
 BTF_OK, BTF_EINVAL, BTF_EHIP, BTF_ENOTPD, BTF_ESTATE = 0, 1, 2, 3, 4
 COMPAT = {"reference": 0, "exact": 1}
-KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw", "nb_loglik"]
+KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw", "nb_loglik",
+                "prior_band", "gram_eig", "hyper"]
+OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM = 0, 1, 2
+SAMPLERS = {"banded": 0, "spectral": 1, "chain": 2, "generic": 3, "banded_nopanel": 4}
 
 # every symbol include/btf.h declares: (name, restype, argtypes)
 _c_dp = C.POINTER(C.c_double)
@@ -81,6 +84,9 @@ SIGNATURES = {
     "btf_set_profiling": (C.c_int, [_ctx, C.c_int]),
     "btf_kernel_times": (C.c_int, [_ctx, _c_dp, C.POINTER(C.c_int64)]),
     "btf_set_tuning": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "btf_set_option": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "btf_sym_eig": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, _c_dp]),
+    "btf_get_V_sampler": (C.c_int, [_ctx, _c_ip]),
 }
 
 

@@ -4,8 +4,8 @@
 #include "../../include/btf.h"
 #include "btf_kernels.h"
 #include "btf_banded_fast.h"
-#include "btf_banded_pipe.h"
 #include "btf_banded_twist.h"
+#include "btf_spectral.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -50,13 +50,14 @@ struct btf_ctx {
   int* status = nullptr;   // [0] flag [1] index
   int* tries = nullptr;
   int* st_ptr = nullptr; int* st_row = nullptr; double* st_coef = nullptr;
+  int* st_drow = nullptr; double* st_dcoef = nullptr; bool st_dense_ok = false;   // VS_MAXE slots per (t,d) (spectral sampler)
   int* srcmap_w = nullptr; int* srcmap_v = nullptr;   // per-output source index of the cached weights
   bool stale_w = false, stale_v = false;
   double ssw = 0.0, nobs = 0.0, sa2 = 0.0;      // within-cell SS, observation count, sum S1^2/cnt (Gaussian data)
   bool w_part_valid = false; int w_part_mode = 0, w_part_nch = 0, w_part_rpb = 0; bool w_part_gv = false;   // W-step partials current?
   int rpb_w = 0, rpb_v = 0;
-  bool force_generic_banded = false;
-  int banded_variant = 2;   // 2: twisted two-chain kernel (default), 1: single chain, 0: wave-specialised pipeline (experimental)
+  int sampler = BTF_SAMPLER_BANDED;   // BTF_OPT_SAMPLER
+  double* eig = nullptr;              // gram_eig_kernel output (spectral sampler): K eigenvalues, K*K vectors, sweeps
   long long* dbg = nullptr;
   double* pband = nullptr; bool pband_dirty = true;
   double* Ta = nullptr; double* Tb = nullptr; double* Tc = nullptr; double* lsum = nullptr;   // horseshoe+ chain (device mode)
@@ -77,8 +78,7 @@ struct btf_ctx {
   int* nb_optr = nullptr; double* nb_oval = nullptr; int nb_nout = 0;   // per-row outlier lists (CSR)
   bool nb_tabulable = false;        // every observed count is an integer in [0, NB_TAB)
   bool nb_L_valid = false;          // nb_L matches the current W, V
-  bool nb_no_hist = false;          // test hook: keep the full-tensor kernel
-  bool no_panel4 = false;           // test hook: twisted sampler without the panelised MFMA factorisation
+  bool nb_hist = true;              // BTF_OPT_NB_HISTOGRAMS
   // on-device sample collection (run_gibbs, rng="device"): [nsamp] slots of W, V, Tau2 and the scalars
   double* smp_W = nullptr; double* smp_V = nullptr; double* smp_T = nullptr; double* smp_s = nullptr; int smp_n = 0;
   double* hyp = nullptr;        // device-resident scalars [HYP_COUNT] (nu2, sigma2, lam2, lam2_a, ...)
@@ -138,8 +138,12 @@ struct Prof {
   }
   template <typename F, typename... Args>
   void launch(F kernel, dim3 grid, dim3 block, size_t lds, Args... args) {
-    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, c->stream, ev->a, ev->b, 0, args...);
-    else hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, c->stream, args...);
+    launch_on(c->stream, kernel, grid, block, lds, args...);
+  }
+  template <typename F, typename... Args>
+  void launch_on(hipStream_t st, F kernel, dim3 grid, dim3 block, size_t lds, Args... args) {
+    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, ev->a, ev->b, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, args...);
   }
 };
 
@@ -235,21 +239,36 @@ int build_stencil(btf_ctx* c) {
   HIPCHK(c, hipMemcpy(c->st_ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->st_row, row.data(), row.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->st_coef, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice));
+  {  // the same stencil with a fixed number of slots per (t,d): the spectral sampler fetches it in one round trip
+    const size_t ne = (size_t)T * D1;
+    std::vector<int> drow(ne * VS_MAXE, 0);
+    std::vector<double> dcoef(ne * VS_MAXE, 0.0);
+    c->st_dense_ok = true;
+    for (size_t e = 0; e < ne; ++e) {
+      const int cnt = ptr[e + 1] - ptr[e];
+      if (cnt > VS_MAXE) { c->st_dense_ok = false; break; }
+      for (int u = 0; u < cnt; ++u) { drow[e * VS_MAXE + u] = row[ptr[e] + u]; dcoef[e * VS_MAXE + u] = coef[ptr[e] + u]; }
+    }
+    if ((rc = dev_alloc(c, &c->st_drow, drow.size()))) return rc;
+    if ((rc = dev_alloc(c, &c->st_dcoef, dcoef.size()))) return rc;
+    HIPCHK(c, hipMemcpy(c->st_drow, drow.data(), drow.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->st_dcoef, dcoef.data(), dcoef.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   return BTF_OK;
 }
 
 // ---- templated launch tables -------------------------------------------------
 template <int K>
 void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const unsigned char* C8, const double* U,
-                  const double* UU, const int* srcmap, int Rdim, int ld, int rpb, int nch) {
+                  const double* UU, const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr}) {
   Prof p(c, kid);
-  dim3 grid(ld / ACC_TILE, nch);
+  dim3 grid(ld / ACC_TILE, nch + (side.out ? 1 : 0));      // (+ the side task's grid row)
   if (mode >= 1 && C8) {       // byte weights (Gaussian replicate counts)
-    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, UU, srcmap, c->part, Rdim, ld, rpb);
-    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, UU, srcmap, c->part, Rdim, ld, rpb);
-  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
-  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
-  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb);
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
+  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
+  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
+  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
 }
 template <int K>
 void launch_pg(btf_ctx* c, const double* B, double* out, const double* Lf, const double* Uf, int nl, int ld, int Rdim,
@@ -324,20 +343,6 @@ hipError_t dispatch_vbanded_fast(btf_ctx* c, const VBandArgs& a, int bw, size_t 
   *handled = false;
   return hipSuccess;
 }
-template <int NPLH, bool ROW16>
-hipError_t launch_vbanded_pipe(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)v_banded_pipe_kernel<NPLH, ROW16>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  Prof p(c, BTF_K_V_BANDED);
-  p.launch(v_banded_pipe_kernel<NPLH, ROW16>, dim3(a.ml), dim3(VP_THREADS), lds_bytes, a, c->K);
-  return hipSuccess;
-}
-bool pipe_nplh_ok(int bw);
 template <int NPL, bool ROW16>
 hipError_t launch_vbanded_twist(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
   static bool attr_set = false;
@@ -408,39 +413,26 @@ hipError_t dispatch_vbanded_twist(btf_ctx* c, const VBandArgs& a, int bw, size_t
   *handled = false;
   return hipSuccess;
 }
-// which sampler a V half-sweep of this context will use: 2 twisted, 1 single chain (LDS), 0 pipeline, -1 generic
+// which sampler a V half-sweep of this context will use: 3 spectral, 2 twisted, 1 single chain (LDS), -1 generic
 int banded_choice(const btf_ctx* c) {
   const int bw = (c->TF + 1) * c->K;
   const bool wt = c->weighted;
-  if (c->force_generic_banded || bw < 3) return -1;
-  if (c->banded_variant == 2 && twist_ok(c->T, c->K, c->TF) && tw_lds_bytes(c->T, c->K, c->TF, wt) <= 160 * 1024) return 2;
-  if (c->banded_variant == 0 && vp_lds_bytes(c->T, c->K, c->TF, wt) <= 158 * 1024 && pipe_nplh_ok(bw)) return 0;
+  if (c->sampler == BTF_SAMPLER_SPECTRAL && !wt && !c->binomial && c->st_dense_ok && vs_lds_bytes(c->T, c->K, c->TF, c->nD) <= 160 * 1024) return 3;
+  if (c->sampler == BTF_SAMPLER_GENERIC || bw < 3) return -1;
+  if (c->sampler != BTF_SAMPLER_CHAIN && twist_ok(c->T, c->K, c->TF) && tw_lds_bytes(c->T, c->K, c->TF, wt) <= 160 * 1024) return 2;
   if (vb_fast_lds_bytes(c->T, c->K, c->TF, wt) <= 158 * 1024) return 1;
   return -1;
 }
-// pairs per helper lane: the larger parity class of the diagonal-offset split
-int pipe_nplh(int bw);
-bool pipe_nplh_ok(int bw) { return pipe_nplh(bw) <= 4 && (bw > 15 || pipe_nplh(bw) == 1); }
-int pipe_nplh(int bw) {
-  int cnt[2] = {0, 0};
-  for (int d = 0; d <= bw - 3; ++d) cnt[d & 1] += bw - d - 2;
-  return std::max(1, (std::max(cnt[0], cnt[1]) + WAVE - 1) / WAVE);
-}
-hipError_t dispatch_vbanded_pipe(btf_ctx* c, const VBandArgs& a, int bw, size_t lds_bytes, bool* handled) {
-  const int nplh = pipe_nplh(bw);
-  *handled = true;
-  if (bw <= 15) {
-    if (nplh == 1) return launch_vbanded_pipe<1, true>(c, a, lds_bytes);
-  } else {
-    switch (nplh) {
-      case 1: return launch_vbanded_pipe<1, false>(c, a, lds_bytes);
-      case 2: return launch_vbanded_pipe<2, false>(c, a, lds_bytes);
-      case 3: return launch_vbanded_pipe<3, false>(c, a, lds_bytes);
-      case 4: return launch_vbanded_pipe<4, false>(c, a, lds_bytes);
-      default: break;
-    }
+template <int S>
+hipError_t launch_vspectral(btf_ctx* c, const VSpecArgs& a, size_t lds_bytes) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)v_spectral_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
   }
-  *handled = false;
+  Prof p(c, BTF_K_V_BANDED);
+  p.launch(v_spectral_kernel<S>, dim3(a.ml), dim3(VS_THREADS), lds_bytes, a);
   return hipSuccess;
 }
 template <int K>
@@ -620,7 +612,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->WW, c->VV, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->st_drow, c->st_dcoef, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
@@ -629,6 +621,7 @@ void btf_destroy(btf_ctx* c) {
     if (p) (void)hipFree(p);
   if (c->hyp) (void)hipFree(c->hyp);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -826,7 +819,7 @@ int btf_resample_Tau2(btf_ctx* c, uint64_t seed, double lam2, double stability, 
   if (!c->have_V || !c->have_hyper || !c->have_chain) return fail(c, BTF_ESTATE, "set V, Tau2 and the horseshoe+ chain first");
   HIPCHK(c, hipSetDevice(c->dev));
   {
-    Prof p(c, BTF_K_PROD);
+    Prof p(c, BTF_K_HYPER);
     p.launch(tau2_kernel, dim3(c->M), dim3(256), 0, (const double*)c->V, c->T, c->K, c->nD, (const int*)c->dr_ptr,
              (const int*)c->dr_col, (const double*)c->dr_val, lam2, stability, 1.0 / stability, c->Tau2, c->Ta, c->Tb,
              c->Tc, c->lsum, (unsigned long long)seed, (const double*)(c->dev_scalars ? c->hyp : nullptr));
@@ -985,7 +978,17 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     const bool use_gw = !wt && whole && c->fuse_gram && c->ngp_w > 0;
     if (wt) { K_SWITCH(K, launch_products<KT>(c, c->W, c->N, c->WW)); }
     else if (!use_gw) { K_SWITCH(K, launch_gram<KT>(c, c->W, c->N)); }
-    K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->WW, c->srcmap_v, c->N, c->ldv, rpb, nch));
+    const int choice = banded_choice(c);
+    EigSide side{nullptr, 0, 0, nullptr};
+    if (choice == 3) {
+      // spectral sampler: the eigen-system of the Gram W'W rides along in the accumulation launch (btf_eig.h)
+      if (!c->eig) {
+        if ((rc = dev_alloc(c, &c->eig, (size_t)K + K * K + 8))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->eig, 0, ((size_t)K + K * K + 8) * sizeof(double), c->stream));   // no previous solution
+      }
+      side = EigSide{use_gw ? c->gpart_w : c->gpart, use_gw ? c->ngp_w : GRAM_BLOCKS, K, c->eig};
+    }
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->WW, c->srcmap_v, c->N, c->ldv, rpb, nch, side));
     const int bw = (c->TF + 1) * K, R1 = bw + 1, D1 = c->TF + 2;
     size_t lds_fixed = (size_t)(3 * n + T * D1 + (wt ? T * KK : KK) + (bw * (bw + 1) / 2 + 3) / 4) * sizeof(double);
     size_t lds_band = (size_t)n * R1 * sizeof(double);
@@ -1006,20 +1009,52 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     a.sR = a.s * c->R;
     a.Tau2 = c->Tau2; a.lam2 = c->lam2; a.nD = c->nD;
     a.hyp = c->dev_scalars ? c->hyp : nullptr; a.Rrep = c->R; a.hyp_noise = c->binomial ? 0 : 1;
-    a.panel4 = c->no_panel4 ? 0 : 1;
+    a.panel4 = c->sampler == BTF_SAMPLER_BANDED_NOPANEL ? 0 : 1;
     a.st_ptr = c->st_ptr; a.st_row = c->st_row; a.st_coef = c->st_coef;
     a.T = T; a.TF = c->TF; a.col0 = c->col0; a.ml = c->ml;
     a.V = c->V; a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_v + 0x10001ULL;
     a.eps0 = eps0; a.attempts = attempts; a.status = c->status; a.tries = c->tries; a.dbg = c->dbg;
     hipError_t e = hipSuccess;
     bool handled = false;
-    const int choice = banded_choice(c);
     const bool fast = choice >= 0;
+    if (choice == 3) {
+      // spectral sampler (complete data): K scalar banded systems per column in the eigen-basis of the Gram
+      VSpecArgs sa{};
+      sa.part = c->part; sa.nch = nch; sa.ld = c->ldv; sa.eig = c->eig;
+      sa.s = a.s; sa.sR = a.sR; sa.Tau2 = c->Tau2; sa.lam2 = c->lam2; sa.nD = c->nD;
+      sa.st_ptr = c->st_ptr; sa.st_row = c->st_row; sa.st_coef = c->st_coef;
+      sa.st_drow = c->st_drow; sa.st_dcoef = c->st_dcoef;
+      sa.T = T; sa.TF = c->TF; sa.K = K; sa.col0 = c->col0; sa.ml = c->ml;
+      sa.V = c->V; sa.z = dz; sa.seed = seed; sa.stream = a.stream;
+      sa.eps0 = eps0; sa.attempts = attempts; sa.status = c->status; sa.tries = c->tries;
+      sa.hyp = a.hyp; sa.Rrep = a.Rrep; sa.hyp_noise = a.hyp_noise; sa.dbg = c->dbg;
+      const bool emit = whole && c->fuse_gram &&
+                        (size_t)c->ml * KK + 16 * KK <= (size_t)ws_split(K) * (K + KK) * WS_ROWS;   // w_solve's LDS stage
+      if (emit) {
+        if (!c->gpart_v) { if ((rc = dev_alloc(c, &c->gpart_v, (size_t)c->M * KK))) return rc; }
+        sa.gout = c->gpart_v;
+      }
+      c->ngp_v = emit ? c->ml : 0;
+      c->ngp_w = 0;
+      const size_t sl = vs_lds_bytes(T, K, c->TF, c->nD);
+      switch (c->TF + 1) {
+        case 1: e = launch_vspectral<1>(c, sa, sl); break;
+        case 2: e = launch_vspectral<2>(c, sa, sl); break;
+        case 3: e = launch_vspectral<3>(c, sa, sl); break;
+        default: e = launch_vspectral<4>(c, sa, sl); break;
+      }
+      HIPCHK(c, e);
+      c->sweep_v++;
+      c->nb_L_valid = false;
+      c->w_part_valid = false;
+      HIPCHK(c, hipGetLastError());
+      return BTF_OK;
+    }
     if (fast) {
       const int TD1 = T * D1;
       if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; c->pband_dirty = true; }
       if (c->pband_dirty) {
-        Prof p(c, BTF_K_PROD);
+        Prof p(c, BTF_K_PRIOR);
         p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
                  (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
                  (const double*)(c->dev_scalars ? c->hyp : nullptr));
@@ -1041,8 +1076,6 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       a.fill = c->fill_tab; a.nfill = c->fill_n;
       e = dispatch_vbanded_twist(c, a, bw, tw_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
     }
-    HIPCHK(c, e);
-    if (choice == 0) e = dispatch_vbanded_pipe(c, a, bw, vp_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
     HIPCHK(c, e);
     if (fast && !handled) e = dispatch_vbanded_fast(c, a, bw, vb_fast_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
     HIPCHK(c, e);
@@ -1238,7 +1271,7 @@ int btf_nb_loglik(btf_ctx* c, const double* R, const double* cand, const int32_t
   if ((rc = nb_upload_rate(c, R, cand, shared))) return rc;
   const int MT = c->M * c->T;
   const size_t nR = nb_rate_elems(c, shared);
-  if (shared[1] && shared[2] && c->nb_tabulable && !c->nb_no_hist) {   // rate constant along (j,t), integer counts: histogram form
+  if (shared[1] && shared[2] && c->nb_tabulable && c->nb_hist) {   // rate constant along (j,t), integer counts: histogram form
     if (!c->nb_L_valid) {
       const int lbx = std::max(1, std::min((MT + 255) / 256, std::max(1, 4096 / c->N)));
       if ((size_t)c->N * lbx > c->nb_tmp_elems) { if ((rc = dev_alloc(c, &c->nb_tmp, (size_t)c->N * lbx))) return rc; c->nb_tmp_elems = (size_t)c->N * lbx; }
@@ -1329,7 +1362,7 @@ int btf_nb_mh(btf_ctx* c, uint64_t seed, int nsteps, double rpropstdev, double r
               const double* R_in) {
   if (!c || !shared || nsteps < 0 || !(rpropstdev > 0.0) || !(rstdev > 0.0)) return fail(c, BTF_EINVAL, "bad MH arguments");
   if (!c->counts || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_nb_mh needs count data, W and V");
-  if (!(shared[1] && shared[2] && c->nb_tabulable && !c->nb_no_hist))
+  if (!(shared[1] && shared[2] && c->nb_tabulable && c->nb_hist))
     return fail(c, BTF_ESTATE, "device MH loop needs a rate shared along (cols, depth) and tabulable counts");
   HIPCHK(c, hipSetDevice(c->dev));
   int rc;
@@ -1538,7 +1571,7 @@ int btf_draw_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double 
   const int h = std::min(c->K, c->N);
   const double nfree = (double)c->N * c->K - (double)h * (h - 1) / 2.0 - (double)(c->K - h) * c->N;   // factor.py:155-174
   {
-    Prof p(c, BTF_K_PROD);
+    Prof p(c, BTF_K_HYPER);
     p.launch(scalars_kernel, dim3(1), dim3(256), 0, (const double*)c->bsum, (int)nb, ssw, c->nobs, (const double*)c->W,
              c->N, c->K, nfree, nu2_a, nu2_b, sigma2_a, sigma2_b, which & 3, (unsigned long long)seed, c->hyp);
   }
@@ -1552,7 +1585,7 @@ int btf_draw_lam2(btf_ctx* c, uint64_t seed, int compat) {
   HIPCHK(c, hipSetDevice(c->dev));
   const double shape = (double)c->nD * c->M * c->K + 1.0;
   {
-    Prof p(c, BTF_K_PROD);
+    Prof p(c, BTF_K_HYPER);
     p.launch(lam2_kernel, dim3(1), dim3(256), 0, (const double*)c->lsum, c->M, shape, compat == BTF_COMPAT_EXACT ? 1 : 0,
              (unsigned long long)seed, c->hyp);
   }
@@ -1683,6 +1716,27 @@ int btf_pg_batch(int device, int64_t n, const double* b, const double* psi, uint
   return BTF_OK;
 }
 
+int btf_sym_eig(int device, int K, int nparts, const double* parts, double* out) {
+  if (K < 1 || K > EIG_MAXK || nparts < 1 || !parts || !out) return fail(nullptr, BTF_EINVAL, "bad sym_eig arguments");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, BTF_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  const size_t np = (size_t)nparts * tri(K), no = (size_t)K + K * K + 2;
+  double *dp = nullptr, *dout = nullptr;
+  auto cleanup = [&]() { if (dp) (void)hipFree(dp); if (dout) (void)hipFree(dout); };
+#define SE(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return fail(nullptr, BTF_EHIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+  SE(hipMalloc((void**)&dp, np * sizeof(double)));
+  SE(hipMalloc((void**)&dout, no * sizeof(double)));
+  SE(hipMemset(dout, 0, no * sizeof(double)));
+  SE(hipMemcpy(dp, parts, np * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(gram_eig_kernel, dim3(1), dim3(WAVE), 0, 0, (const double*)dp, nparts, K, dout);
+  SE(hipGetLastError());
+  SE(hipDeviceSynchronize());
+  SE(hipMemcpy(out, dout, ((size_t)K + K * K + 1) * sizeof(double), hipMemcpyDeviceToHost));
+#undef SE
+  cleanup();
+  return BTF_OK;
+}
+
 int btf_sync(btf_ctx* c) {
   if (!c) return BTF_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
@@ -1784,16 +1838,36 @@ extern "C" int btf_debug_stamps(btf_ctx* c, long long* out) {
 }
 
 int btf_set_tuning(btf_ctx* c, int rows_per_block_w, int rows_per_block_v) {
+  if (!c || rows_per_block_w < 0 || rows_per_block_v < 0) return fail(c, BTF_EINVAL, "rows per workgroup must be >= 0 (0 = default)");
+  c->rpb_w = rows_per_block_w; c->rpb_v = rows_per_block_v;
+  return BTF_OK;
+}
+
+int btf_set_option(btf_ctx* c, int option, int value) {
   if (!c) return BTF_EINVAL;
-  // sampler selection hooks: rows_per_block_v == -1 generic (any-size) kernel, -2 single-chain LDS
-  // kernel, -3 wave-specialised pipeline; anything else the default (twisted where it applies)
-  // rows_per_block_w == -1: Negative-Binomial rate update always through the full-tensor kernel (no histograms)
-  c->nb_no_hist = rows_per_block_w == -1;
-  if (rows_per_block_w < 0) rows_per_block_w = 0;
-  c->no_panel4 = rows_per_block_v == -4;
-  c->force_generic_banded = rows_per_block_v == -1;
-  c->banded_variant = rows_per_block_v == -3 ? 0 : (rows_per_block_v == -2 ? 1 : 2);
-  c->rpb_w = rows_per_block_w; c->rpb_v = rows_per_block_v < 0 ? 0 : rows_per_block_v;
+  switch (option) {
+    case BTF_OPT_SAMPLER:
+      if (value < BTF_SAMPLER_BANDED || value > BTF_SAMPLER_BANDED_NOPANEL) return fail(c, BTF_EINVAL, "unknown sampler");
+      c->sampler = value;
+      c->ngp_v = 0;
+      return BTF_OK;
+    case BTF_OPT_NB_HISTOGRAMS:
+      c->nb_hist = value != 0;
+      return BTF_OK;
+    case BTF_OPT_FUSE_GRAM:
+      c->fuse_gram = value != 0;
+      c->ngp_v = c->ngp_w = 0;
+      return BTF_OK;
+    default:
+      return fail(c, BTF_EINVAL, "unknown option");
+  }
+}
+
+int btf_get_V_sampler(btf_ctx* c, int32_t* which) {
+  if (!c || !which) return BTF_EINVAL;
+  const int ch = banded_choice(c);
+  *which = ch == 3 ? BTF_SAMPLER_SPECTRAL : (ch == 2 ? (c->sampler == BTF_SAMPLER_BANDED_NOPANEL ? BTF_SAMPLER_BANDED_NOPANEL : BTF_SAMPLER_BANDED)
+                                                     : (ch == 1 ? BTF_SAMPLER_CHAIN : BTF_SAMPLER_GENERIC));
   return BTF_OK;
 }
 

@@ -12,6 +12,7 @@
 // l (one 16-byte global_load per row), and no cross-lane reduction is needed.
 #pragma once
 #include "btf_device.h"
+#include "btf_eig.h"
 
 namespace btf {
 
@@ -45,7 +46,7 @@ template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double>
 __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     const double* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const double* __restrict__ UU, const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
-    int rows_per_block) {
+    int rows_per_block, EigSide side) {
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
@@ -55,7 +56,16 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = blockIdx.x;
-  const int chunk = blockIdx.y;
+  int chunk = blockIdx.y;
+  if (side.out) {
+    // side task (spectral V sampler): the first grid row is dispatched first; one wave of it solves the K x K
+    // eigenproblem of the Gram beside the stream, the others leave at once
+    if (chunk == 0) {
+      if (tile == 0 && wave == 0) gram_eig_wave(side.gpart, side.ngp, side.K, side.out, &red[0][0][0]);
+      return;
+    }
+    --chunk;
+  }
   const size_t col = (size_t)tile * ACC_TILE + 2 * lane;
   const int r0 = chunk * rows_per_block;
   const int r1 = min(r0 + rows_per_block, Rdim);

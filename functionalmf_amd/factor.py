@@ -21,6 +21,17 @@ Extra keywords (all optional):
   device  HIP device ordinal;  stream: hipStream_t handle (int) or None.
   shard   (rank, world) to update only this rank's block of rows / columns
           (see functionalmf_amd/parallel.py); W and V stay replicated.
+  sampler square root used for the noise term of the V draw (fast_mvn.py:44 uses
+          CHOLMOD's P' L^-T; scikit-sparse is not part of the reference tree, so the
+          ordering is declared here - DESIGN.md section 2):
+          "banded"   block-banded LDL' in the declared elimination order
+                     (`v_order()`); default with rng="host";
+          "spectral" complete Gaussian data only: the K x K likelihood block is the
+                     same for every depth and column, its eigenvectors split each
+                     column into K scalar banded systems (include/btf.h,
+                     btf_get_V_sampler); default with rng="device", falls back to
+                     "banded" for data with missing cells / Binomial weights;
+          "auto"     (default) as described above.
 """
 import numpy as np
 
@@ -71,12 +82,15 @@ class BayesianTensorFiltering(_BayesianModel):
                  force_psd_eps=1e-6,
                  force_psd_attempts=4,
                  compat="reference", rng="host", device=0, stream=None, shard=None, device_seed=0,
+                 sampler="auto",
                  **kwargs):
         super().__init__(**kwargs)
         if compat not in _native.COMPAT:
             raise ValueError("compat must be 'reference' or 'exact'")
         if rng not in ("host", "device"):
             raise ValueError("rng must be 'host' or 'device'")
+        if sampler != "auto" and sampler not in _native.SAMPLERS:
+            raise ValueError("sampler must be 'auto' or one of %s" % sorted(_native.SAMPLERS))
         self.nrows, self.ncols, self.ndepth, self.nembeds = nrows, ncols, ndepth, nembeds
         self.tf_order = tf_order
         self.stability = stability
@@ -102,6 +116,9 @@ class BayesianTensorFiltering(_BayesianModel):
         self._exchange = Exchange(self._plan, self._ctx)
         if self._plan.world > 1:
             self._ctx.call("btf_set_shard", *self._plan.mine())
+        self.sampler = sampler
+        self._ctx.call("btf_set_option", _native.OPT_SAMPLER,
+                       _native.SAMPLERS[("spectral" if rng == "device" else "banded") if sampler == "auto" else sampler])
         self._data_key = None
         self._W_host_new = self._V_host_new = True      # host copy must be pushed before the next kernel
         self._W_dev_new = self._V_dev_new = False       # device copy is newer than the host mirror
@@ -559,6 +576,13 @@ class BayesianTensorFiltering(_BayesianModel):
         order = np.zeros(self.nembeds * self.ndepth, dtype=np.int32)
         self._ctx.call("btf_get_V_order", order.ctypes.data_as(_native._c_ip))
         return order
+
+    def v_sampler(self):
+        """Name of the sampler the next V half-sweep will run (known once the data is bound)."""
+        import ctypes
+        which = ctypes.c_int32()
+        self._ctx.call("btf_get_V_sampler", ctypes.byref(which))
+        return {v: k for k, v in _native.SAMPLERS.items()}[which.value]
 
     def sync(self):
         """Wait for the GPU; raises NotPositiveDefiniteError if a factorisation failed."""

@@ -59,7 +59,28 @@ enum {
   BTF_K_SSE = 7,     /* residual sum of squares for nu2                     */
   BTF_K_PG = 8,      /* Polya-Gamma draws                                   */
   BTF_K_NB = 9,      /* Negative-Binomial rate update: MH log-likelihood ratio */
-  BTF_K_COUNT = 10
+  BTF_K_PRIOR = 10,  /* prior band Delta' diag(1/(lam2 Tau2_j)) Delta of every column (factor.py:404-405) */
+  BTF_K_EIG = 11,    /* eigen-system of the K x K Gram (spectral sampler)   */
+  BTF_K_HYPER = 12,  /* device hyper-parameter draws: Tau2 chain, nu2/sigma2, lam2 */
+  BTF_K_COUNT = 13
+};
+
+/* btf_set_option keys / values */
+enum {
+  BTF_OPT_SAMPLER = 0,       /* V half-sweep sampler, BTF_SAMPLER_*                                   */
+  BTF_OPT_NB_HISTOGRAMS = 1, /* 1 (default): Negative-Binomial rate update from per-row count
+                                histograms where they apply; 0: always the full-tensor kernel          */
+  BTF_OPT_FUSE_GRAM = 2      /* 1 (default): W'W / V'V partials come out of the preceding solve kernel */
+};
+enum {
+  BTF_SAMPLER_BANDED = 0,   /* block-banded LDL' in the declared elimination order (btf_get_V_order):
+                               twisted two-chain kernel where it applies; default                     */
+  BTF_SAMPLER_SPECTRAL = 1, /* complete Gaussian data only: rotate by the eigenvectors of the shared
+                               K x K likelihood block, K scalar banded chains per column (falls back to
+                               BANDED for weighted data); square root documented at btf_resample_V     */
+  BTF_SAMPLER_CHAIN = 2,    /* single chain, depth-major order                                         */
+  BTF_SAMPLER_GENERIC = 3,  /* any-size kernel (band in LDS or HBM scratch), depth-major order         */
+  BTF_SAMPLER_BANDED_NOPANEL = 4 /* BANDED without the panelised MFMA factorisation (A/B aid)          */
 };
 
 /* ---- lifetime ------------------------------------------------------------
@@ -190,6 +211,21 @@ int btf_get_V_attempts(btf_ctx* ctx, int32_t* tries /* (ncols_local) */);
  * T-1..ts+tf+1 descending (k descending), then the separator depths ts..ts+tf.  z[j][i] is
  * the normal that multiplies pivot i (this is CHOLMOD's P() in fast_mvn.py:44).            */
 int btf_get_V_order(btf_ctx* ctx, int32_t* order /* (K*T) */);
+/* BTF_SAMPLER_SPECTRAL (complete Gaussian data: every depth of every column has the same K x K
+ * likelihood block G = (R/nu2) W'W, factor.py:396-398 with constant weights).  In the reference's own
+ * k-major ordering of the unknowns (factor.py:409) Q_j = G (x) I_T + I_K (x) P_j with P_j the prior
+ * precision of factor.py:404-405; with G = U diag(g) U' the draw is
+ *   V[j] = Q_j^-1 mu + (U (x) I_T) blockdiag_k(L_k^-T D_k^-1/2) z,   g_k I + P_j = L_k D_k L_k',
+ * z[j][k*T + t] multiplying pivot t of system k - a square root of Q_j^-1 like fast_mvn.py:44's
+ * P' L^-T, same mean term, same jitter schedule (the shift is added to every g_k).  U: eigenvectors in
+ * ascending order of eigenvalue, each with its largest-magnitude entry positive.
+ * btf_get_V_sampler reports the BTF_SAMPLER_* the next V half-sweep of this context will run.  */
+/* The eigen-solver the spectral sampler uses, stand-alone (one-wave cyclic Jacobi, K <= 10): sums `nparts`
+ * packed-lower K x K matrices parts[p][r(r+1)/2 + c], returns out[0..K-1] eigenvalues ascending,
+ * out[K + r*K + c] component r of eigenvector c (largest-magnitude entry positive), out[K+K*K] sweeps. */
+int btf_sym_eig(int device, int nembeds, int nparts, const double* parts, double* out);
+int btf_set_option(btf_ctx* ctx, int option, int value);
+int btf_get_V_sampler(btf_ctx* ctx, int32_t* which);
 
 /* Residual sum of squares and observation count over the LOCAL rows: the two
  * numbers GaussianBTF._resample_nu2 (factor.py:411-416, genlasso.py:157-160)
@@ -249,10 +285,7 @@ int btf_collect_summary(btf_ctx* ctx, int nsamples, int transform, const double*
  * BTF_K_* id (arrays of BTF_K_COUNT).                                         */
 int btf_set_profiling(btf_ctx* ctx, int on);
 int btf_kernel_times(btf_ctx* ctx, double* ms_total, int64_t* launches);
-/* Launch geometry of the streaming kernels (tuning knob; 0 = default).  Negative values are
- * test hooks: rows_per_block_v = -1 / -2 / -3 selects the generic / single-chain / pipelined
- * banded sampler, -4 the twisted sampler without the panelised MFMA factorisation, rows_per_block_w = -1 keeps the Negative-Binomial rate update on the
- * full-tensor kernel (no count histograms).                                   */
+/* Launch geometry of the streaming kernels: rows per workgroup (0 = default).   */
 int btf_set_tuning(btf_ctx* ctx, int rows_per_block_w, int rows_per_block_v);
 
 #ifdef __cplusplus

@@ -160,6 +160,78 @@ def mvn_from_precision(Q, mu_part=None, perm=None, z=None,
     return x
 
 
+def gram_eigensystem(G):
+    """Eigenvalues ascending, eigenvectors as columns, each vector's largest-magnitude entry
+    positive: the convention the build declares for its spectral V sampler (include/btf.h)."""
+    g, U = np.linalg.eigh(np.asarray(G, float))
+    big = np.argmax(np.abs(U), axis=0)
+    U = U * np.where(U[big, np.arange(U.shape[1])] < 0, -1.0, 1.0)[None, :]
+    return g, U
+
+
+def spectral_pivot_order(T, S):
+    """Depth of pivot i inside one system of the spectral sampler ("burn at both ends", include/btf.h):
+    depths 0..ts-1 ascending, depths T-1..ts+S descending, then the separator ts..ts+S-1, ts = (T-S)//2;
+    natural order when T < 2S+2."""
+    if T < 2 * S + 2:
+        return np.arange(T)
+    ts = (T - S) // 2
+    return np.concatenate([np.arange(ts), np.arange(T - 1, ts + S - 1, -1), np.arange(ts, ts + S)])
+
+
+def band_halfwidth(P):
+    """Half-bandwidth of a symmetric banded matrix (tf_order + 1 for the trend-filter prior)."""
+    r, c = np.nonzero(np.abs(P) > 0)
+    return int(np.max(np.abs(r - c))) if r.size else 0
+
+
+def kronecker_sum_parts(Q, K, T):
+    """Split a k-major precision of the form  G (x) I_T + I_K (x) P  (factor.py:396-405 with constant
+    likelihood weights) into a K x K matrix with G's eigenvectors and the T x T remainder:
+    Gs = G + P[0,0] I (entry (k T, k' T) of Q), Ps = P - P[0,0] I; raises if Q is not of that form."""
+    Q = np.asarray(Q, float)
+    idx = np.arange(K) * T
+    Gs = Q[np.ix_(idx, idx)].copy()
+    Ps = Q[:T, :T] - Gs[0, 0] * np.eye(T)
+    if np.abs(np.kron(Gs, np.eye(T)) + np.kron(np.eye(K), Ps) - Q).max() > 1e-9 * np.abs(Q).max():
+        raise ValueError("precision is not a Kronecker sum: the spectral sampler does not apply")
+    return Gs, Ps
+
+
+def mvn_from_precision_spectral(Q, K, T, mu_part=None, z=None, force_psd=True, eps0=1e-6, attempts=4, info=None, S=None):
+    """The square root the build's "spectral" V sampler declares in place of CHOLMOD's P' L^-T
+    (fast_mvn.py:35-47):  x = Q^-1 mu_part + (U (x) I_T) blockdiag_k(C_k^-T) z,  C_k C_k' = g_k I + P in
+    the pivot order o = spectral_pivot_order (C_k C_k' = (g_k I + P)[o, o]), Q = G (x) I_T + I_K (x) P
+    (k-major), G = U diag(g) U'.  z[k*T + i] multiplies pivot i of system k.  Jitter as fast_mvn.py:62-68: eps
+    added to the diagonal of Q cumulatively; z is drawn only after the factorisation succeeded."""
+    Gs, Ps = kronecker_sum_parts(Q, K, T)
+    g, U = gram_eigensystem(Gs)
+    o = spectral_pivot_order(T, band_halfwidth(Q[:T, :T]) if S is None else S)
+    Po = Ps[np.ix_(o, o)]
+    shift, eps, tried = 0.0, eps0, 0
+    while True:
+        try:
+            C = [np.linalg.cholesky(Po + (g[k] + shift) * np.eye(T)) for k in range(K)]
+            break
+        except np.linalg.LinAlgError:
+            if force_psd and tried < attempts:
+                shift += eps
+                eps *= 10.0
+                tried += 1
+            else:
+                raise NotPositiveDefinite("precision not PD after %d shifts" % tried)
+    if info is not None:
+        info["attempts"] = tried
+    if z is None:
+        z = np.random.normal(size=K * T)
+    zt = np.asarray(z, float).reshape(K, T)
+    mt = np.zeros((K, T)) if mu_part is None else U.T @ np.asarray(mu_part, float).reshape(K, T)
+    xt = np.empty((K, T))
+    for k in range(K):
+        xt[k, o] = sla.cho_solve((C[k], True), mt[k, o]) + sla.solve_triangular(C[k].T, zt[k], lower=False)
+    return (U @ xt).reshape(-1)
+
+
 # --------------------------------------------------------------------------
 # W half-sweep                       (factor.py:313-362)
 # --------------------------------------------------------------------------
@@ -263,12 +335,14 @@ def stale_column_sources(ybar):
 def v_step(st, Y, Delta, perm="depth", z=None, compat="reference",
            force_psd=True, eps0=1e-6, attempts=4, info=None, cols=None):
     """Column-by-column conjugate draw of V (factor.py:364-409 + fast_mvn).
-    perm: "depth" (declared ordering), "identity", or an explicit array.
+    perm: "depth" (declared ordering), "identity", "twist", an explicit array, or "spectral"
+    (mvn_from_precision_spectral: complete-data columns only).
     z: optional (M, K*T) normals, row j used for column j, indexed in the
     *permuted* order (as solve_Lt sees them, fast_mvn.py:44)."""
     V = st["V"]
     M, T, K = V.shape
     st["_cnt"], st["_ybar"] = replicate_stats(Y)
+    spectral = isinstance(perm, str) and perm == "spectral"
     if isinstance(perm, str):
         if perm == "twist":
             p = twisted_perm(K, T, (Delta.shape[0] + 1) // T - 1 if Delta.shape[0] != T else 0)
@@ -281,9 +355,13 @@ def v_step(st, Y, Delta, perm="depth", z=None, compat="reference",
     for j in (range(M) if cols is None else cols):
         Q, mu = v_step_system(st, Y, Delta, j, int(src[j]))
         inf = {}
-        x = mvn_from_precision(Q, mu_part=mu, perm=p,
-                               z=None if z is None else z[j],
-                               force_psd=force_psd, eps0=eps0, attempts=attempts, info=inf)
+        if spectral:
+            x = mvn_from_precision_spectral(Q, K, T, mu_part=mu, z=None if z is None else z[j], force_psd=force_psd,
+                                            eps0=eps0, attempts=attempts, info=inf, S=band_halfwidth(Delta.T @ Delta))
+        else:
+            x = mvn_from_precision(Q, mu_part=mu, perm=p,
+                                   z=None if z is None else z[j],
+                                   force_psd=force_psd, eps0=eps0, attempts=attempts, info=inf)
         tries[j] = inf.get("attempts", 0)
         V[j] = x.reshape(K, T).T
     if info is not None:
@@ -586,9 +664,20 @@ def hoisted_stats(Y):
     return int(cnt.flat[0]), ybar
 
 
-def w_step_strong(st, R, ybar, z=None):
+def w_step_strong(st, R, ybar, z=None, row0=0):
+    """(row0: global index of the first row when st["W"] / ybar hold a block of rows; z then holds
+    that block's normals only.)"""
     W, V = st["W"], st["V"]
     N, K = W.shape
+    if row0 >= K:                                                 # no triangular head in this block
+        Vf = V.reshape(-1, K)
+        s = R / st["nu2"]
+        L = np.linalg.cholesky(s * (Vf.T @ Vf) + np.eye(K) / st["sigma2"])
+        Mpart = s * (ybar.reshape(N, -1) @ Vf)
+        Z = (np.random.normal(size=N * K) if z is None else np.asarray(z)).reshape(N, K)
+        W[:] = sla.cho_solve((L, True), Mpart.T).T + sla.solve_triangular(L.T, Z.T, lower=False).T
+        return W
+    assert row0 == 0
     Vf = V.reshape(-1, K)
     s = R / st["nu2"]
     G = s * (Vf.T @ Vf)
@@ -609,8 +698,11 @@ def w_step_strong(st, R, ybar, z=None):
     return W
 
 
-def v_step_strong(st, R, ybar, Delta, z=None):
-    """Depth-major banded Cholesky per column (scipy.linalg.cholesky_banded)."""
+def v_step_strong(st, R, ybar, Delta, z=None, order=None):
+    """Depth-major banded Cholesky per column (scipy.linalg.cholesky_banded).
+    order: None (depth-major), an elimination order as depth-major indices (dense Cholesky of the
+    permuted precision: the twisted kernel's declared order), or "spectral"
+    (mvn_from_precision_spectral's square root, evaluated from G and the prior band directly)."""
     W, V = st["W"], st["V"]
     M, T, K = V.shape
     N = W.shape[0]
@@ -624,6 +716,26 @@ def v_step_strong(st, R, ybar, Delta, z=None):
         z = np.random.normal(size=(M, n))
     DtD = [Delta[:, :T - d] * Delta[:, d:] for d in range(tf1 + 1)]         # (nD, T-d) coefficient products
     kk = np.arange(K)
+    if isinstance(order, str) and order == "spectral":
+        g, U = gram_eigensystem(G)
+        mt = np.einsum("kl,mtk->mlt", U, mu)                      # (M,K,T) rotated right-hand sides
+        zt = np.asarray(z).reshape(M, K, T)
+        o = spectral_pivot_order(T, tf1)
+        for j in range(M):
+            lam = 1.0 / (st["lam2"] * st["Tau2"][j])
+            P1 = np.zeros((T, T))
+            for d in range(tf1 + 1):
+                pd = lam @ DtD[d]
+                P1[np.arange(d, T), np.arange(T - d)] = pd
+                P1[np.arange(T - d), np.arange(d, T)] = pd
+            Po = P1[np.ix_(o, o)]
+            xt = np.empty((K, T))
+            for k in range(K):
+                C = np.linalg.cholesky(Po + g[k] * np.eye(T))
+                xt[k, o] = sla.cho_solve((C, True), mt[j, k, o]) + sla.solve_triangular(C.T, zt[j, k], lower=False)
+            V[j] = (U @ xt).T
+        return V
+    pvt = None if order is None else np.asarray(order)
     for j in range(M):
         lam = 1.0 / (st["lam2"] * st["Tau2"][j])
         ab = np.zeros((bw + 1, n))                                # lower form: ab[i-j, j] = A[i, j]
@@ -634,6 +746,16 @@ def v_step_strong(st, R, ybar, Delta, z=None):
         for a in range(K):                                        # likelihood block on every depth
             for k in range(K - a):
                 ab[a, k::K] += G[k + a, k]
+        if pvt is not None:                                       # declared elimination order: dense, permuted
+            Qd = np.zeros((n, n))
+            for a in range(bw + 1):
+                Qd[np.arange(a, n), np.arange(n - a)] = ab[a, :n - a]
+            Qd = Qd + np.tril(Qd, -1).T
+            L = np.linalg.cholesky(Qd[np.ix_(pvt, pvt)])
+            x = np.empty(n)
+            x[pvt] = sla.cho_solve((L, True), mu[j].reshape(-1)[pvt]) + sla.solve_triangular(L.T, z[j], lower=False)
+            V[j] = x.reshape(T, K)
+            continue
         cb = sla.cholesky_banded(ab, lower=True)
         y = sla.cho_solve_banded((cb, True), mu[j].reshape(-1))
         # L' x = z  with L lower banded: L' is upper banded

@@ -17,16 +17,19 @@ Rr, ybar = orc.hoisted_stats(Y)
 st0 = dict(W=model.W.copy(), V=model.V.copy(), Tau2=np.array(model.Tau2, float).copy(), lam2=float(model.lam2), sigma2=float(model.sigma2), nu2=float(model.nu2))
 model._v_normals = lambda: np.zeros((M, K * T))
 outs = {}
-for var in (0, -4, -2, -1):
-    model._ctx.call("btf_set_tuning", 0, var)
+from functionalmf_amd import _native
+for var in ("banded", "banded_nopanel", "chain", "generic", "spectral"):
+    model._ctx.call("btf_set_option", _native.OPT_SAMPLER, _native.SAMPLERS[var])
     model.V = st0["V"].copy()
     model._resample_V(Y)
     outs[var] = model.V.copy()
 st = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st0.items()}
 orc.v_step_strong(st, Rr, ybar, Delta, z=np.zeros((M, K * T)))
 for var in outs:
-    print("variant %d vs cpu: %.3e" % (var, relerr(outs[var], st["V"])))
-print("p4 vs no-p4 %.3e ; twist-p4 vs generic %.3e ; no-p4 vs generic %.3e ; cpu vs generic %.3e" % (relerr(outs[0], outs[-4]), relerr(outs[0], outs[-1]), relerr(outs[-4], outs[-1]), relerr(st["V"], outs[-1])))
+    print("sampler %-15s vs cpu: %.3e" % (var, relerr(outs[var], st["V"])))
+print("p4 vs no-p4 %.3e ; twist-p4 vs generic %.3e ; spectral vs generic %.3e ; cpu vs generic %.3e" % (
+    relerr(outs["banded"], outs["banded_nopanel"]), relerr(outs["banded"], outs["generic"]), relerr(outs["spectral"], outs["generic"]),
+    relerr(st["V"], outs["generic"])))
 # per-column worst
-e = np.abs(outs[0] - st["V"]).reshape(M, -1).max(1) / np.abs(st["V"]).max()
+e = np.abs(outs["banded"] - st["V"]).reshape(M, -1).max(1) / np.abs(st["V"]).max()
 print("worst columns", np.argsort(e)[-3:], e[np.argsort(e)[-3:]], "lam2", st0["lam2"], "tau2 range", st0["Tau2"].min(), st0["Tau2"].max())

@@ -12,7 +12,8 @@ Y, _ = synth_rows(1, range(N), M, T, R, K, Vt)
 np.random.seed(1)
 m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, nu2_init=1.0, rng="device")
 import os
-m._ctx.call("btf_set_tuning", 0, int(os.environ.get("BTF_VARIANT", "0")))
+from functionalmf_amd import _native
+m._ctx.call("btf_set_option", _native.OPT_SAMPLER, _native.SAMPLERS[os.environ.get("BTF_SAMPLER", "spectral")])
 for _ in range(2):
     m.resample(Y)
 lib = m._ctx.lib
@@ -25,7 +26,7 @@ m.sync()
 lib.btf_debug_stamps(m._ctx.h, out.ctypes.data_as(C.POINTER(C.c_longlong)))
 d = np.diff(out, axis=1)
 import os
-print("variant", os.environ.get("BTF_VARIANT", "0"))
+print("sampler", os.environ.get("BTF_SAMPLER", "spectral"), m.v_sampler())
 names = ["setup(m0,gram,P)", "assemble", "factor(+z gen)", "w init", "backward"]
 print("median cycles per phase (shader clock):")
 for i, nme in enumerate(names):

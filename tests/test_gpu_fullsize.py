@@ -37,7 +37,8 @@ def snapshot(model):
 def test_full_size_half_sweeps_vs_cpu(c3):
     from oracle import btf_oracle as orc
     model, Y, Delta, Rr, ybar = c3
-    model._ctx.call("btf_set_tuning", 0, -2)            # depth-major single-chain kernel: same order as the CPU path
+    from functionalmf_amd import _native
+    model._ctx.call("btf_set_option", _native.OPT_SAMPLER, _native.SAMPLERS["chain"])   # depth-major single chain: the CPU path's order
     st = snapshot(model)
     np.random.seed(7)
     zw = np.random.normal(size=K * (K + 1) // 2 + (N - K) * K)
@@ -49,7 +50,7 @@ def test_full_size_half_sweeps_vs_cpu(c3):
     assert relerr(model.W, st["W"]) < 1e-10
     orc.v_step_strong(st, Rr, ybar, Delta, z=zv)
     assert relerr(model.V, st["V"]) < 1e-6
-    model._ctx.call("btf_set_tuning", 0, 0)
+    model._ctx.call("btf_set_option", _native.OPT_SAMPLER, _native.SAMPLERS["banded"])
 
 
 def test_full_size_mean_term_is_order_invariant_and_matches_cpu(c3, monkeypatch):
@@ -100,3 +101,132 @@ def test_full_size_sse_matches_cpu(c3):
     model._ctx.call("btf_sse", ctypes.byref(sse), ctypes.byref(nobs))
     ref, n = orc.sse_and_count(st, Y)
     assert abs(sse.value - ref) / ref < 1e-11 and nobs.value == n
+
+
+# ---- config C4: Binomial (512,256,64), 4 trials per cell, K=5 - PG draw + weighted half-sweeps at full size ----
+@pytest.fixture(scope="module")
+def c4():
+    from functionalmf_amd.factor import BinomialBayesianTensorFiltering
+    from bench import synth_rows, synth_V
+    Vt = synth_V(1, M, T, K)
+    _, Wt = synth_rows(1, range(N), M, T, 1, K, Vt, noise=0.0)
+    Mu = np.einsum("nk,mtk->nmt", Wt, Vt)
+    rs = np.random.RandomState(7)
+    Nt = np.full((N, M, T), 4.0)
+    Ys = rs.binomial(4, 1 / (1 + np.exp(-Mu))).astype(float)
+    return Ys, Nt
+
+
+@pytest.mark.parametrize("compat", ["reference", "exact"])
+def test_c4_binomial_full_size_pg_draw_and_weighted_half_sweeps(c4, compat):
+    """factor.py:437-460 at BASELINE config 4.  The device Polya-Gamma draw is checked against the closed-form
+    moments over all 8.4 M cells, then - GIVEN that omega (btf_get_omega) - the weighted W and V half-sweeps
+    against the oracle from identical state and normals (compat="reference": rows >= K reuse row K-1's weights
+    and every column reuses column 0's, quirks Q1/Q2; the oracle's W step always carries Q1)."""
+    from functionalmf_amd.factor import BinomialBayesianTensorFiltering
+    from oracle import btf_oracle as orc
+    Ys, Nt = c4
+    np.random.seed(3)
+    # (local scales of moderate size: under the raw horseshoe+ prior draw, Tau2 down to 1e-9, two correct fp64
+    #  factorisations in different orders agree only to cond * eps ~ 5e-6 - see the C3 mean-term test above)
+    tau0 = np.random.RandomState(4).gamma(2.0, 0.5, size=(M, 3 * T - 1))
+    model = BinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, compat=compat,
+                                            Tau2_init=tau0)
+    model.V = 0.5 * model.V                                    # keep |psi| moderate under the prior draw
+    W0, V0 = model.W.copy(), model.V.copy()
+    model._resample_nu2((Ys, Nt))
+    omega = 1.0 / model.nu2
+    psi = np.einsum("nk,mtk->nmt", W0, V0)
+    zs = (omega - orc.pg_mean(4.0, psi)) / np.sqrt(orc.pg_var(4.0, psi))
+    n = zs.size
+    assert abs(zs.mean()) < 5 / np.sqrt(n), zs.mean()
+    assert abs((zs ** 2).mean() - 1) < 1e-2, (zs ** 2).mean()
+    assert (omega > 0).all()
+    st = dict(W=W0.copy(), V=V0.copy(), Tau2=np.array(model.Tau2, float).copy(), lam2=float(model.lam2),
+              sigma2=float(model.sigma2), nu2=1.0 / omega)
+    Delta = orc.trend_penalty(T, 2)
+    np.random.seed(11)
+    zw = np.random.normal(size=K * (K + 1) // 2 + (N - K) * K)
+    zv = np.random.normal(size=(M, K * T))
+    np.random.seed(11)
+    model._resample_W((Ys, Nt))
+    if compat == "reference":
+        orc.binomial_w_step(st, Ys, Nt, z=zw)
+        assert relerr(model.W, st["W"]) < 1e-10
+    else:
+        st["W"] = model.W.copy()
+    model._resample_V((Ys, Nt))
+    assert model.v_sampler() == "banded"
+    orc.binomial_v_step(st, Ys, Nt, Delta, z=zv, compat=compat, perm=orc.perm_from_order(model.v_order(), K, T))
+    assert relerr(model.V, st["V"]) < 1e-6
+
+
+# ---- config C5: (4096,1024,64,4) K=8 row/column-sharded over 8 GPUs - one rank's slabs on one GPU ----
+C5 = dict(N=4096, M=1024, T=64, R=4, K=8, world=8)
+
+
+@pytest.mark.parametrize("rank", [0, 5])
+@pytest.mark.parametrize("sampler", ["banded", "spectral"])
+def test_c5_rank_slab_half_sweeps(rank, sampler):
+    """BASELINE config 5 as rank `rank` of 8 sees it: btf_set_shard with a 512-row slab (512,1024,64,4) for the W
+    half-sweep and a 128-column slab (4096,128,64,4) for the V half-sweep, through the C ABI, against
+    w_step_strong / v_step_strong on exactly those blocks from identical state and normals."""
+    import ctypes as C
+    from functionalmf_amd import _native
+    from oracle import btf_oracle as orc
+    from bench import synth_rows, synth_V
+    N_, M_, T_, R_, K_, world = (C5[k] for k in ("N", "M", "T", "R", "K", "world"))
+    nl, ml = N_ // world, M_ // world
+    row0, col0 = rank * nl, rank * ml
+    Vt = synth_V(1, M_, T_, K_)
+    rows, _ = synth_rows(1, range(row0, row0 + nl), M_, T_, R_, K_, Vt)                 # (nl, M, T, R)
+    cols, Wt = synth_rows(2, range(N_), ml, T_, R_, K_, Vt[col0:col0 + ml])             # (N, ml, T, R)
+    rs = np.random.RandomState(9)
+    W = Wt + 0.05 * rs.normal(size=Wt.shape)
+    W[np.triu_indices(K_, 1)] = 0
+    V = Vt + 0.05 * rs.normal(size=Vt.shape)
+    Delta = orc.trend_penalty(T_, 2)
+    nD = Delta.shape[0]
+    Tau2 = rs.gamma(2.0, 0.5, size=(M_, nD))
+    lam2, sigma2, nu2 = 0.1, 0.5, 0.3
+    ctx = _native.Context(N_, M_, T_, K_, 2)
+    ctx.call("btf_set_shard", row0, nl, col0, ml)
+    ctx.call("btf_set_option", _native.OPT_SAMPLER, _native.SAMPLERS[sampler])
+    ctx.call("btf_set_data_gaussian", _native.dptr(rows), _native.dptr(cols), R_)
+    ctx.call("btf_set_W", _native.dptr(W))
+    ctx.call("btf_set_V", _native.dptr(V))
+    ctx.call("btf_set_hyper", _native.dptr(Tau2), lam2, sigma2)
+    ctx.call("btf_set_nu2", nu2)
+    nzw = K_ * (K_ + 1) // 2 + (N_ - K_) * K_
+    zw = rs.normal(size=nzw)
+    zv = rs.normal(size=(M_, K_ * T_))
+    # ---- W half-sweep on the row slab
+    ctx.call("btf_resample_W", _native.dptr(zw), 1, _native.COMPAT["exact"])
+    Wg = np.empty_like(W)
+    ctx.call("btf_get_W", _native.dptr(Wg))
+    assert np.array_equal(np.delete(Wg, np.s_[row0:row0 + nl], axis=0), np.delete(W, np.s_[row0:row0 + nl], axis=0))
+    ybar_r = rows.mean(axis=3)
+    st = dict(W=W[row0:row0 + nl].copy(), V=V.copy(), nu2=nu2, sigma2=sigma2)
+    z0 = int(orc_w_offset(row0, K_))
+    orc.w_step_strong(st, R_, ybar_r, z=zw[z0:int(orc_w_offset(row0 + nl, K_))], row0=row0)
+    assert relerr(Wg[row0:row0 + nl], st["W"]) < 1e-10
+    # ---- V half-sweep on the column slab (from the ORIGINAL W: restore it)
+    ctx.call("btf_set_W", _native.dptr(W))
+    ctx.call("btf_resample_V", _native.dptr(zv), 2, _native.COMPAT["exact"], 1e-6, 4)
+    Vg = np.empty_like(V)
+    ctx.call("btf_get_V", _native.dptr(Vg))
+    assert np.array_equal(np.delete(Vg, np.s_[col0:col0 + ml], axis=0), np.delete(V, np.s_[col0:col0 + ml], axis=0))
+    which = C.c_int32()
+    ctx.call("btf_get_V_sampler", C.byref(which))
+    assert which.value == _native.SAMPLERS[sampler]
+    order = np.zeros(K_ * T_, dtype=np.int32)
+    ctx.call("btf_get_V_order", order.ctypes.data_as(_native._c_ip))
+    ybar_c = cols.mean(axis=3)
+    stv = dict(W=W.copy(), V=V[col0:col0 + ml].copy(), Tau2=Tau2[col0:col0 + ml], lam2=lam2, nu2=nu2)
+    orc.v_step_strong(stv, R_, ybar_c, Delta, z=zv[col0:col0 + ml], order="spectral" if sampler == "spectral" else order)
+    assert relerr(Vg[col0:col0 + ml], stv["V"]) < 1e-6
+    ctx.close()
+
+
+def orc_w_offset(i, K_):
+    return i * (i + 1) // 2 if i < K_ else K_ * (K_ + 1) // 2 + (i - K_) * K_

@@ -42,15 +42,13 @@ def test_w_step_vs_reference(golden, name, seed):
     assert relerr(model.W, g["W_after"]) < W_TOL
 
 
-@pytest.mark.parametrize("kernel", ["twist", "pipe", "fast", "generic"])
+@pytest.mark.parametrize("kernel", ["twist", "fast", "generic"])
 @pytest.mark.parametrize("name,seed", GAUSS)
 def test_v_step_vs_reference(golden, name, seed, kernel):
-    """All three samplers: the wave-specialised pipeline (default), the single-wave LDS
+    """The banded samplers: the twisted two-chain kernel (default), the single-chain LDS
     LDL' kernel and the any-size generic one."""
     g = golden(name)
-    model, _ = gaussian_model(g, "s0_")
-    if kernel != "twist":
-        model._ctx.call("btf_set_tuning", 0, {"generic": -1, "fast": -2, "pipe": -3}[kernel])
+    model, _ = gaussian_model(g, "s0_", sampler={"twist": "banded", "fast": "chain", "generic": "generic"}[kernel])
     model.W = g["W_after"]
     np.random.seed(seed + 1)
     model._resample_V(g["Y"])
@@ -88,8 +86,7 @@ def test_jitter_retry_matches_reference_schedule(golden):
     model._ctx.call("btf_get_V_attempts", tries.ctypes.data_as(C.POINTER(C.c_int32)))
     assert np.array_equal(tries, g["retry_tries_twist"])
     assert relerr(V, g["retry_V_after_twist"]) < 1e-5
-    model, _ = gaussian_model(g, "retry_s0_")
-    model._ctx.call("btf_set_tuning", 0, -2)            # single-chain kernel: depth-major fixture
+    model, _ = gaussian_model(g, "retry_s0_", sampler="chain")     # single-chain kernel: depth-major fixture
     np.random.seed(601)
     model._resample_V(g["Y"])
     model._ctx.call("btf_get_V_attempts", tries.ctypes.data_as(C.POINTER(C.c_int32)))
@@ -666,7 +663,7 @@ def test_negbinom_loglik_ratio_vs_oracle(golden, tag, hist):
     g = golden("g7_negbinom_%s.npz" % tag)
     model, st = negbinom_model(g)
     if not hist:                       # full-tensor kernel even where the count histograms apply
-        model._ctx.call("btf_set_tuning", -1, 0)
+        model._ctx.call("btf_set_option", _native.OPT_NB_HISTOGRAMS, 0)
     model._bind_data(g["data"])
     model._push_state()
     rs = np.random.RandomState(3)
@@ -898,3 +895,148 @@ def test_in_sweep_sse_comes_from_the_w_partials(golden, name, compat):
     np.random.seed(5)
     ref._resample_W(Y)
     assert relerr(model.W, ref.W) < 1e-12
+
+
+# ---- spectral V sampler (complete data; default with rng="device") -------------------------------------
+def _spectral_model(golden, tag, **kw):
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    from test_oracle_golden import _spectral_case
+    Y, st, (N, M, T, R, K, tf), z, Vref = _spectral_case(golden, tag)
+    model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                            nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"],
+                                            sampler="spectral", **kw)
+    return model, Y, st, (N, M, T, R, K, tf), z, Vref
+
+
+@pytest.mark.parametrize("tag", ["g2", "k5", "tf0", "tf1", "tf3", "short"])
+def test_spectral_v_step_vs_reference(golden, tag, monkeypatch):
+    """The spectral kernel against the fixture the reference's own _resample_V produced under the declared
+    spectral square root (tests/golden/make_golden_spectral.py), from the same state and normals."""
+    model, Y, st, dims, z, Vref = _spectral_model(golden, tag)
+    monkeypatch.setattr(model, "_v_normals", lambda: z)
+    model._resample_V(Y)
+    assert model.v_sampler() == "spectral"
+    assert relerr(model.V, Vref) < V_TOL
+
+
+def test_spectral_jitter_retry_matches_reference_schedule(golden):
+    import ctypes as C
+    g5, g8 = golden("g5_illcond.npz"), golden("g8_spectral.npz")
+    model, _ = gaussian_model(g5, "retry_s0_", sampler="spectral")
+    np.random.seed(601)
+    model._resample_V(g5["Y"])
+    V = model.V.copy()
+    tries = np.zeros(model.ncols, dtype=np.int32)
+    model._ctx.call("btf_get_V_attempts", tries.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert np.array_equal(tries, g8["g5_retry_tries_spectral"])
+    assert relerr(V, g8["g5_retry_V_after_spectral"]) < 1e-5
+
+
+def test_spectral_square_root_covariance_identity(golden, monkeypatch):
+    """Feed unit normals: the kernel's noise map S (column by column) must satisfy S S' Q = I for the
+    precision the reference assembles (oracle v_step_system) - the draw has exactly the conditional
+    covariance, whatever the normals."""
+    from oracle import btf_oracle as orc
+    model, Y, st, (N, M, T, R, K, tf), z, _ = _spectral_model(golden, "k5")
+    n = K * T
+    V0 = st["V"].copy()
+    monkeypatch.setattr(model, "_v_normals", lambda: np.zeros((M, n)))
+    model._resample_V(Y)
+    mean = model.V.copy()
+    S = np.zeros((M, n, n))                         # depth-major rows, pivot columns
+    for i in range(n):
+        e = np.zeros((M, n)); e[:, i] = 1.0
+        monkeypatch.setattr(model, "_v_normals", lambda e=e: e)
+        model.V = V0
+        model._resample_V(Y)
+        S[:, :, i] = (model.V - mean).reshape(M, n)
+    Delta = orc.trend_penalty(T, tf)
+    st["_cnt"], st["_ybar"] = orc.replicate_stats(Y)
+    pm = orc.depth_major_perm(K, T)
+    for j in range(M):
+        Q, _ = orc.v_step_system(st, Y, Delta, j, j)
+        Qd = Q[np.ix_(pm, pm)]
+        assert np.abs(S[j] @ S[j].T @ Qd - np.eye(n)).max() < 1e-8
+
+
+def test_device_rng_v_draw_is_white_under_the_conditional_precision(golden):
+    """rng="device" (the benchmarked mode; spectral sampler on complete data): for every column,
+    C' (x - Q^-1 mu) with C C' = Q must be standard normal.  Pooled over columns and repeats: mean, variance,
+    fourth moment, lag correlations and a KS test of the whitened residuals."""
+    from scipy import stats
+    from oracle import btf_oracle as orc
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    for sampler in ("spectral", "banded"):
+        _, Y, st, (N, M, T, R, K, tf), _, _ = _spectral_model(golden, "k5")
+        model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                                nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"],
+                                                rng="device", sampler=sampler, device_seed=5)
+        Delta = orc.trend_penalty(T, tf)
+        n = K * T
+        pm = orc.depth_major_perm(K, T)
+        st["_cnt"], st["_ybar"] = orc.replicate_stats(Y)
+        Cs, means = [], []
+        for j in range(M):
+            Q, mu = orc.v_step_system(st, Y, Delta, j, j)
+            Qd = Q[np.ix_(pm, pm)]
+            Cs.append(np.linalg.cholesky(Qd))
+            means.append(np.linalg.solve(Qd, mu[pm]))
+        reps = 400
+        res = np.empty((reps, M, n))
+        for r in range(reps):
+            model._resample_V(Y)
+            Vd = model.V.reshape(M, n)
+            for j in range(M):
+                res[r, j] = Cs[j].T @ (Vd[j] - means[j])
+        assert model.v_sampler() == sampler
+        x = res.reshape(-1)
+        assert abs(x.mean()) < 5 / np.sqrt(x.size)
+        assert abs(x.var() - 1) < 5 * np.sqrt(2 / x.size)
+        assert abs((x ** 4).mean() - 3) < 5 * np.sqrt(96 / x.size)
+        assert stats.kstest(x[::7], "norm").pvalue > 1e-3
+        # no correlation between unknowns of a column, nor between columns, nor between consecutive draws
+        c1 = np.mean(res[:, :, :-1] * res[:, :, 1:])
+        c2 = np.mean(res[:, :-1, :] * res[:, 1:, :])
+        c3 = np.mean(res[:-1] * res[1:])
+        assert max(abs(c1), abs(c2), abs(c3)) < 5 / np.sqrt(x.size)
+        # per-coordinate variances (a wrong factor entry shows up in a few coordinates only)
+        v = res.var(axis=0)
+        assert np.abs(v - 1).max() < 6 * np.sqrt(2 / reps)
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+def test_sym_eig_matches_lapack(K):
+    """btf_sym_eig (the one-wave Jacobi the spectral sampler runs beside the V accumulation) against numpy
+    eigh under the declared conventions: ascending eigenvalues, largest-magnitude entry of each vector positive.
+    Matrices: random Grams (well separated), a nearly diagonal one, and one with a tiny eigenvalue."""
+    from functionalmf_amd import _native
+    from oracle import btf_oracle as orc
+    lib = _native.load()
+    rs = np.random.RandomState(K)
+    KK = K * (K + 1) // 2
+    tril = np.tril_indices(K)
+    mats = []
+    X = rs.normal(size=(300, K)) * (1 + np.arange(K))
+    parts = np.stack([(X[b::4].T @ X[b::4])[tril] for b in range(4)])       # four partial Grams
+    mats.append(parts)
+    D = np.diag(1.0 + np.arange(K)) + 1e-9 * rs.normal(size=(K, K))
+    mats.append(((D + D.T) / 2)[tril][None, :])
+    Y = rs.normal(size=(K + 3, K))
+    Y[:, -1] *= 1e-7
+    mats.append((Y.T @ Y)[tril][None, :])
+    for parts in mats:
+        parts = np.ascontiguousarray(parts)
+        out = np.zeros(K + K * K + 1)
+        rc = lib.btf_sym_eig(0, K, parts.shape[0], _native.dptr(parts), _native.dptr(out))
+        assert rc == 0
+        G = np.zeros((K, K))
+        G[tril] = parts.sum(axis=0)
+        G = G + np.tril(G, -1).T
+        g, U = orc.gram_eigensystem(G)
+        lam, Ud = out[:K], out[K:K + K * K].reshape(K, K)
+        assert np.abs(lam - g).max() <= 1e-13 * np.abs(g).max()
+        assert np.abs(Ud.T @ Ud - np.eye(K)).max() < 1e-14
+        assert np.abs(Ud.T @ G @ Ud - np.diag(lam)).max() <= 1e-13 * np.abs(g).max()
+        gap = np.min(np.diff(g)) / np.abs(g).max() if K > 1 else 1.0
+        assert np.abs(Ud - U).max() < 1e-13 / max(gap, 1e-12)
+        assert out[-1] <= 12

@@ -54,7 +54,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, -2, -3, -4])
+@pytest.mark.parametrize("variant", ["banded", "chain", "banded_nopanel", "spectral"])
 @pytest.mark.parametrize("N,M,T,R,K,tf,missing", CASES)
 def test_half_sweeps_match_oracle(N, M, T, R, K, tf, missing, variant):
     from functionalmf_amd.factor import GaussianBayesianTensorFiltering
@@ -62,9 +62,8 @@ def test_half_sweeps_match_oracle(N, M, T, R, K, tf, missing, variant):
     Y, st = make_case(N, M, T, R, K, tf, missing, seed=N * 131 + K * 7 + tf)
     model = GaussianBayesianTensorFiltering(
         N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
-        W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"])
+        W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], sampler=variant)
     assert model.Delta.shape[0] == st["Tau2"].shape[1]
-    model._ctx.call("btf_set_tuning", 0, variant)      # 0: default (twisted), -2: single chain, -3: wave-specialised pipeline
     Delta = orc.trend_penalty(T, tf)
     nzw = sum(min(i + 1, K) for i in range(N))
     np.random.seed(5)
@@ -76,7 +75,9 @@ def test_half_sweeps_match_oracle(N, M, T, R, K, tf, missing, variant):
     model._resample_V(Y)
     orc.w_step(ost, Y, z=zw)
     assert relerr(model.W, ost["W"]) < 1e-10
-    orc.v_step(ost, Y, Delta, z=zv, perm=orc.perm_from_order(model.v_order(), K, T))
+    spectral = model.v_sampler() == "spectral"
+    assert spectral == (variant == "spectral" and not missing)      # weighted data falls back to the banded sampler
+    orc.v_step(ost, Y, Delta, z=zv, perm="spectral" if spectral else orc.perm_from_order(model.v_order(), K, T))
     assert relerr(model.V, ost["V"]) < 1e-8
     # nu2 statistics on the new state
     np.random.seed(6)
@@ -141,7 +142,7 @@ def test_posterior_summary_matches_numpy(S, N, M, T, K, transform):
     assert np.max(np.abs(quant - ref)) < 1e-12 * max(1.0, np.abs(Mu).max())
 
 
-@pytest.mark.parametrize("variant", [0, -4, -2])
+@pytest.mark.parametrize("variant", ["banded", "banded_nopanel", "chain", "spectral"])
 def test_bw15_indefinite_column_is_reported_and_jitter_recovers(variant):
     """K = 5, tf = 2 (bw = 15: the panelised MFMA factorisation records a bad pivot instead of branching on
     it): a grossly indefinite column must still end in NotPositiveDefiniteError with its index, and a
@@ -152,8 +153,8 @@ def test_bw15_indefinite_column_is_reported_and_jitter_recovers(variant):
     Y, st = make_case(N, M, T, R, K, 2, False, seed=5)
     def build():
         m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
-                                            nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"].copy())
-        m._ctx.call("btf_set_tuning", 0, variant)
+                                            nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"].copy(),
+                                            sampler=variant)
         return m
     m = build()
     m.Tau2[3, 9] = -1e-3
@@ -167,11 +168,12 @@ def test_bw15_indefinite_column_is_reported_and_jitter_recovers(variant):
     np.random.seed(0)
     m._resample_V(Y)
     m.sync()
+    from functionalmf_amd import _native
     ref = build()
-    ref._ctx.call("btf_set_tuning", 0, -1)          # generic kernel
+    ref._ctx.call("btf_set_option", _native.OPT_SAMPLER, _native.SAMPLERS["generic"])
     np.random.seed(0)
     ref._resample_V(Y)
-    order_dependent = variant != -2                  # twisted order differs from depth-major in the noise term
+    order_dependent = variant != "chain"             # other square roots differ from depth-major in the noise term
     if not order_dependent:
         assert relerr(m.V, ref.V) < 1e-8
     assert np.isfinite(m.V).all()

@@ -231,3 +231,58 @@ def test_negbinom_full_sweep_given_omega(golden, tag):
     orc.binomial_v_step(st, Y, Ntr, Delta, perm="twist")
     for k, tol in (("sigma2", 1e-12), ("lam2", 1e-12), ("Tau2", 1e-10), ("W", 1e-10), ("V", 1e-8)):
         assert relerr(st[k], g["full_" + k]) < tol, k
+
+
+# ---- spectral V sampler: reference code under the spectral square-root shim (make_golden_spectral.py) ----
+def _spectral_case(golden, tag):
+    g8 = golden("g8_spectral.npz")
+    if tag == "g2":
+        g2 = golden("g2_c2_complete.npz")
+        st = state_from(g2, "s0_")
+        st["W"] = g2["W_after"].copy()
+        return g2["Y"], st, [int(x) for x in g2["dims"]], g2["z_V"], g8["g2_V_after_spectral"]
+    st = {k: (float(g8["%s_s0_%s" % (tag, k)]) if k in ("lam2", "sigma2", "nu2") else g8["%s_s0_%s" % (tag, k)].copy())
+          for k in ("W", "V", "Tau2", "lam2", "sigma2", "nu2")}
+    return g8[tag + "_Y"], st, [int(x) for x in g8[tag + "_dims"]], g8[tag + "_z_V"], g8[tag + "_V_after_spectral"]
+
+
+@pytest.mark.parametrize("tag", ["g2", "k5", "tf0", "tf1", "tf3", "short"])
+def test_v_step_spectral_square_root_vs_reference(golden, tag):
+    """factor.py:364-409 + fast_mvn.py:35-47 run by the reference itself with the spectral shim: the
+    oracle's restatement (faithful per-column assembly and the vectorised strong path) must reproduce it,
+    and its mean term must be the order-invariant Q^-1 mu of the depth-major draw."""
+    Y, st, (N, M, T, R, K, tf), z, Vref = _spectral_case(golden, tag)
+    Delta = orc.trend_penalty(T, tf)
+    a = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    tol = 1e-6 if tag == "g2" else 1e-9        # g2: lam2 on its floor after two sweeps, cond(Q) ~ 1e9 (cond * eps)
+    orc.v_step(a, Y, Delta, perm="spectral", z=z)
+    assert relerr(a["V"], Vref) < tol
+    b = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    Rr, ybar = orc.hoisted_stats(Y)
+    orc.v_step_strong(b, Rr, ybar, Delta, z=z, order="spectral")
+    assert relerr(b["V"], Vref) < tol
+    c = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    d = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    orc.v_step(c, Y, Delta, perm="spectral", z=0 * z)
+    orc.v_step(d, Y, Delta, perm="depth", z=0 * z)
+    assert relerr(c["V"], d["V"]) < tol
+
+
+def test_spectral_square_root_has_the_right_covariance(golden):
+    """S S' = Q^-1 for the spectral square root (unit normals pick out the columns of S)."""
+    Y, st, (N, M, T, R, K, tf), z, _ = _spectral_case(golden, "k5")
+    Delta = orc.trend_penalty(T, tf)
+    st["_cnt"], st["_ybar"] = orc.replicate_stats(Y)
+    Q, mu = orc.v_step_system(st, Y, Delta, 1, 1)
+    S = np.stack([orc.mvn_from_precision_spectral(Q, K, T, z=e) for e in np.eye(K * T)], axis=1)
+    assert np.abs(S @ S.T @ Q - np.eye(K * T)).max() < 1e-10
+
+
+def test_spectral_jitter_retry_matches_reference_schedule(golden):
+    g5, g8 = golden("g5_illcond.npz"), golden("g8_spectral.npz")
+    N, M, T, R, K, tf = [int(x) for x in g5["dims"]]
+    st = state_from(g5, "retry_s0_")
+    info = {}
+    orc.v_step(st, g5["Y"], orc.trend_penalty(T, tf), perm="spectral", z=g5["retry_z_V"], info=info)
+    assert np.array_equal(info["attempts"], g8["g5_retry_tries_spectral"])
+    assert relerr(st["V"], g8["g5_retry_V_after_spectral"]) < 1e-5
