@@ -3,26 +3,29 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one W half-sweep + one V half-sweep (model._resample_W then
-model._resample_V through the C ABI) on synthetic Gaussian data that is already
-resident in HBM, with the normals drawn on the device (rng="device": nothing but
-scalars crosses PCIe inside the timed region).
+One "step" = one W half-sweep + one V half-sweep (model._resample_W then model._resample_V through
+the C ABI) on synthetic data that is already resident in HBM, with the normals drawn on the device
+(rng="device": nothing but scalars crosses PCIe inside the timed region).  The prior precision
+Delta' diag(1/(lam2 Tau2_j)) Delta of every column is rebuilt in every step, as factor.py:404-405 does.
 
-N = 1   workload C3 of BASELINE.json: (512,256,64,4), nembeds=5, tf_order=2, complete data.
-N > 1   weak scaling over rows: global tensor (512*N,256,64,4); every rank streams one
-        (512,256,64,4)-sized slab per half-sweep (its rows in the W step, its 256/N
-        columns of all rows in the V step); W and V blocks are all-gathered over
-        RCCL after each half-sweep.  value = N * (global sweeps/s) = C3-sized slab
-        updates per second over the whole job.
-Use --strong to shard a fixed tensor instead, --config c5 for (4096,1024,64,4) K=8.
+N = 1   workload C3 of BASELINE.json: Gaussian (512,256,64,4), nembeds=5, tf_order=2, complete data
+        (--variant / --config select the other single-GPU workloads; C4 = --variant binomial).
+N > 1   workload C5 of BASELINE.json, STRONG scaling: the fixed tensor (4096,1024,64,4) nembeds=8 is
+        row-sharded (W half-sweep) and column-sharded (V half-sweep) over the N ranks; the freshly drawn
+        block of W resp. V is all-gathered over RCCL after each half-sweep.  value = sweeps/s of that one
+        global tensor.  (--weak: every rank streams one C3-sized slab, value = N x global sweeps/s.)
+        `python bench.py --gpus N` launches its own ranks (one child `python -m torch.distributed.run`);
+        under torchrun (WORLD_SIZE set) it is a rank.
 
-Besides the contract fields the JSON line carries `roofline` (streaming accumulation
-kernel: algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak) and, at N=1,
-`cpu_baseline` (the numpy oracle's reference-faithful W+V update on the host cores).
+Besides the contract fields the JSON line carries `roofline` (the streaming accumulation kernel:
+algorithmic bytes / HIP-event time of exactly that dispatch against the 8 TB/s HBM peak, plus the
+whole-step fraction and a measured device-copy ceiling) and, at N=1, `cpu_baseline` (the numpy
+oracle's reference-faithful W+V update on the host cores, all BLAS threads and one thread).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,7 +40,8 @@ CONFIGS = {
     "c5": dict(N=4096, M=1024, T=64, R=4, K=8),
     "c3k8": dict(N=512, M=256, T=64, R=4, K=8),      # tuning aid: C3 cells with C5's embedding size
 }
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+METRIC = "Gibbs sweeps/sec (full W+V update) at (512,256,64) K=5; % HBM roofline"
 
 
 def synth_rows(seed, rows, M, T, R, K, Vt, noise=0.5):
@@ -60,47 +64,81 @@ def synth_V(seed, M, T, K):
     return 0.1 * np.cumsum(rs.normal(0, 1, size=(M, T, K)), axis=1)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--strong", action="store_true", help="fixed global tensor instead of weak scaling")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: c3 at --gpus 1, c5 beyond")
+    ap.add_argument("--weak", action="store_true", help="N>1: weak scaling over rows (one C3-sized slab per rank) instead of the fixed C5 tensor")
+    ap.add_argument("--strong", action="store_true", help="(default for N>1; kept for compatibility)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--rpb", type=int, nargs=2, default=[0, 0], help="rows per workgroup (W, V) tuning override")
     ap.add_argument("--variant", default="complete", choices=["complete", "heldout", "missing5", "binomial", "negbinom"],
                     help="complete: headline; heldout: Y[:3,:3]=NaN; missing5: 5%% curves + 5%% single replicates NaN; "
                          "binomial: 4 trials per cell, device Polya-Gamma draw included in the step (config C4); "
                          "negbinom: NB(4, p) counts, step = 30 MH steps on the rate R + PG draw + W + V (SURVEY 8(f) rank 2)")
-    ap.add_argument("--burn", type=int, default=3, help="full Gibbs sweeps before timing (leave the initial state)")
-    args = ap.parse_args()
+    ap.add_argument("--sampler", default="auto", help="V sampler: auto (spectral on complete data, banded otherwise), banded, spectral, chain")
+    ap.add_argument("--burn", type=int, default=10, help="full Gibbs sweeps before timing (leave the initial state)")
+    ap.add_argument("--master-port", type=int, default=29533)
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def self_launch(args):
+    """python bench.py --gpus N (N>1) outside torchrun: start the ranks as a CHILD process (never exec: nothing here
+    has touched the GPU yet, and the child is an ordinary subprocess), relay its one JSON line and its exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    return proc.returncode if proc.returncode != 0 or lines else 1
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0 and args.gpus > 1:
+        sys.exit(self_launch(args))
+    world = max(world, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("BTF_FORCE_DEVICE") is not None:      # rehearsal aid: several ranks on one GPU
         local_rank = int(os.environ["BTF_FORCE_DEVICE"])
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
+    dry = os.environ.get("BTF_BENCH_DRY", "0") == "1"       # CPU rehearsal of the launch / timing / reporting plumbing
+    if args.config is None:
+        args.config = "c3" if (world == 1 or args.weak) else "c5"
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
     exercise = os.environ.get("BTF_EXERCISE_EXCHANGE", "0") == "1"
+    backend = None
+    if not dry:
+        torch.cuda.set_device(local_rank)
     if world > 1 or exercise:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
+        backend = "gloo" if dry or os.environ.get("BTF_BACKEND") == "gloo" else "nccl"
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    if dry:
+        return dry_run(args, world, rank, dist, backend)
 
+    from functionalmf_amd import _native
     from functionalmf_amd.factor import (GaussianBayesianTensorFiltering, BinomialBayesianTensorFiltering,
                                          NegativeBinomialBayesianTensorFiltering)
     from functionalmf_amd.parallel import ShardPlan
 
     cfg = dict(CONFIGS[args.config])
-    weak = world > 1 and not args.strong
+    weak = world > 1 and args.weak
     if weak:
         cfg["N"] *= world
     N, M, T, R, K = cfg["N"], cfg["M"], cfg["T"], cfg["R"], cfg["K"]
@@ -108,7 +146,6 @@ def main():
     # ---- synthetic data: only this rank's two slabs are ever materialised -------------
     Vt = synth_V(1, M, T, K)
     plan = ShardPlan(N, M, rank, world)
-    t0 = time.time()
     if world == 1:
         Y, _ = synth_rows(1, range(N), M, T, R, K, Vt)
         slabs = None
@@ -120,11 +157,10 @@ def main():
             cols[i0:i0 + blk.shape[0]] = blk[:, plan.col0:plan.col0 + plan.ml]
         slabs = (rows, cols)
         Y = None
-    t_data = time.time() - t0
 
     if args.variant != "complete":
         if world > 1:
-            sys.exit("--variant other than complete is single-GPU only in this round")
+            sys.exit("--variant other than complete is single-GPU only")
         rs = np.random.RandomState(7)
         if args.variant == "heldout":
             Y[:3, :3] = np.nan
@@ -143,7 +179,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream or None     # null stream -> the ctx's own / a dedicated torch stream
     common = dict(nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, rng="device",
                   compat="reference" if world == 1 else "exact", device=local_rank, stream=stream,
-                  shard=(rank, world) if world > 1 else None, device_seed=1)
+                  shard=(rank, world) if world > 1 else None, device_seed=1, sampler=args.sampler)
     if args.variant == "binomial":
         model = BinomialBayesianTensorFiltering(N, M, T, **common)
     elif args.variant == "negbinom":
@@ -157,7 +193,7 @@ def main():
     else:
         data = _SlabData(slabs, (N, M, T, R))
         model._upload = lambda d, _m=model: _upload_slabs(_m, d)
-    # leave the prior draw: a few full sweeps (nu2, sigma2, Tau2, lam2, W, V)
+    # leave the prior draw: full sweeps (nu2, sigma2, Tau2, lam2, W, V)
     for _ in range(args.burn):
         model.resample(data)
     model.sync()
@@ -197,17 +233,31 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # ---- per-step GPU time by events between the steps (median of >= 50: BASELINE.md section 4) ----
+    nmed = max(50, min(args.steps, 200))
+    tstream = torch.cuda.ExternalStream(model._ctx.stream_handle, device=local_rank) if model._ctx.stream_handle else torch.cuda.current_stream()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nmed + 1)]
+    evs[0].record(tstream)
+    for i in range(nmed):
+        step()
+        evs[i + 1].record(tstream)
+    fence()
+    per_step_ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(nmed)])
+
     # ---- per-kernel HIP-event timing of the same steps (separate pass: events perturb) ----
     model._ctx.call("btf_set_profiling", 1)
     model._ctx.kernel_times()
     nprof = min(args.steps, 200)
+    model._exchange.timing = True
     for _ in range(nprof):
         step()
     fence()
     kt = model._ctx.kernel_times()
+    coll = model._exchange.collective_us()
+    model._exchange.timing = False
     model._ctx.call("btf_set_profiling", 0)
 
-    # full Gibbs sweep (nu2, sigma2, Tau2, lam2, W, V) - device Tau2 chain, host scalar draws
+    # full Gibbs sweep (nu2, sigma2, Tau2, lam2, W, V), everything drawn on the device
     nfull = max(10, min(args.steps, 100))
     for _ in range(3):
         model.resample(data)
@@ -222,26 +272,28 @@ def main():
     units = world if weak else 1
     value = sweeps_per_s * units
 
-    # algorithmic bytes of one accumulation launch: the local slab of the linear
-    # statistic once (8 B/cell, complete data) + the small operands / partials it touches
+    # algorithmic bytes: the local slab of the linear statistic once per accumulation launch
+    # (8 B/cell complete data; + a byte of replicate count with missing data; + f64 weights for Binomial)
     cells_local = (N // world if world > 1 else N) * M * T
+    cells_local_v = N * (M // world if world > 1 else M) * T
+    bpc = {"complete": 8.0, "heldout": 9.0, "missing5": 9.0}.get(args.variant, 16.0)
     acc_ms = kt["w_accum"][0] + kt["v_accum"][0]
     acc_n = kt["w_accum"][1] + kt["v_accum"][1]
     acc_us = 1e3 * acc_ms / max(acc_n, 1)
-    # complete data: the linear statistic only; missing data: + a byte of replicate count; Binomial: + f64 weights
-    alg_bytes = {"complete": 8.0, "heldout": 9.0, "missing5": 9.0}.get(args.variant, 16.0) * cells_local
+    alg_bytes = bpc * 0.5 * (cells_local + cells_local_v)
     achieved = alg_bytes / (acc_us * 1e-6) / 1e9 if acc_us > 0 else 0.0
+    b_wv = bpc * (cells_local + cells_local_v)                     # B_WV of SURVEY 8(d), per GPU
+    ms_step = 1e3 * dt / args.steps
     kernels_us = {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in kt.items() if v[1] > 0}
-    traffic = pmc_traffic("accum_kernel") if (world == 1 and args.config == "c3") else None
-
+    sampler = model.v_sampler()
     out = {
-        "metric": "Gibbs sweeps/sec (full W+V update) at (512,256,64) K=5; % HBM roofline",
+        "metric": METRIC,
         "value": round(value, 2),
         "unit": "sweeps/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "ms_per_step": round(ms_step, 4),
         "higher_is_better": True,
         "scaling": "weak" if (weak or world == 1) else "strong",
         "vs_baseline": None,
@@ -251,15 +303,27 @@ def main():
                                % ({"binomial": "binomial", "negbinom": "negbinom"}.get(args.variant, "gaussian"), args.config, N, M, T, R, K, args.variant,
                                   "; %d-way row/column shards, RCCL all-gather of W and V" % world if world > 1 else ""),
                    "global_sweeps_per_s": round(sweeps_per_s, 2), "units_per_sweep": units,
+                   "median_ms_per_step": round(float(np.median(per_step_ms)), 4), "median_over_steps": int(nmed),
+                   "burn_in_sweeps": args.burn,
                    "full_resample_sweeps_per_s": round(full_per_s, 2),
+                   "v_sampler": sampler,
                    "parallelism": "rows(W)/cols(V) x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "accum_kernel (w_accum + v_accum launches)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(acc_us, 2)},
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": pmc_traffic(args.config, args.variant) if world == 1 else None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(acc_us, 2),
+                     "timing": "hipExtLaunchKernelGGL start/stop events of each accumulation dispatch, %d steps" % nprof,
+                     "whole_step_bytes": b_wv,
+                     "whole_step_frac": round(b_wv / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "copy_ceiling_GBs": copy_ceiling(torch)},
         "kernels_us": kernels_us,
     }
-
+    if args.variant in ("binomial", "negbinom"):
+        out["config"]["pg_sampler"] = getattr(model, "pg_sampler", "series")
+    if world > 1 or exercise:
+        out["config"].update({"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                              "collective_us": coll})
     if world == 1 and not args.no_cpu and args.variant not in ("binomial", "negbinom"):
         out["cpu_baseline"] = cpu_baseline(Y, model, cfg)
 
@@ -270,17 +334,75 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the streaming kernel from the committed rocprofv3 PMC passes
-    (profiles/r*_pmc_summary.json: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
-    MI355X_MICROARCH.md applied); None if no profile of this workload is committed."""
+def dry_run(args, world, rank, dist, backend):
+    """BTF_BENCH_DRY=1: no GPU.  Exercises what the driver depends on - rank launch, barriers, max-over-ranks
+    timing, one JSON line from rank 0 - with a host all-gather standing in for a step (tests/test_host_logic.py)."""
+    import torch
+    x = torch.zeros(64, dtype=torch.float64)
+    def step():
+        if world > 1:
+            outs = [torch.empty_like(x) for _ in range(world)]
+            dist.all_gather(outs, x + rank)
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    out = {"metric": METRIC, "value": round(args.steps / dt, 2), "unit": "sweeps/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+           "scaling": "weak" if (args.weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f64", "data": "dry-run (no GPU work)",
+           "config": {"workload": "DRY RUN %s x%d" % (args.config, world), "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                      "backend": backend}}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def copy_ceiling(torch):
+    """Measured device-to-device copy rate on this GPU (read + write bytes per second, 1 GiB buffers: past the
+    256 MiB Infinity Cache) - the achievable ceiling next to the 8 TB/s spec peak."""
+    try:
+        n = 1 << 27
+        a = torch.empty(n, dtype=torch.float64, device="cuda")
+        b = torch.empty_like(a)
+        a.fill_(1.0)
+        for _ in range(3):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        del a, b
+        return round(2 * n * 8 / (ms * 1e-3) / 1e9, 1)
+    except Exception:
+        return None
+
+
+def pmc_traffic(config, variant):
+    """HBM bytes per accumulation launch from a committed rocprofv3 PMC pass OF THIS WORKLOAD
+    (profiles/r*_pmc_<config>_<variant>.json: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+    MI355X_MICROARCH.md applied); None if no such profile is committed (never another workload's figure)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_%s.json" % (config, variant))))
     if not files:
         return None
     try:
         d = json.load(open(files[-1]))
-        vals = [v["hbm_bytes_per_launch_corrected"] for k, v in d.items() if kernel_substr in k]
+        vals = [v["hbm_bytes_per_launch_corrected"] for k, v in d.items() if "accum_kernel" in k]
         return round(max(vals), 1) if vals else None
     except Exception:
         return None
@@ -302,32 +424,51 @@ def _upload_slabs(model, d):
                     _native.dptr(np.ascontiguousarray(d.cols)), int(d.shape[3]))
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(Y, model, cfg):
-    """The oracle's reference-faithful W+V update (per-row / per-column loops, the
-    sufficient statistics re-reduced from the 4-D tensor on every half-sweep as
-    factor.py:329-330/:374-375 do, dense LAPACK in place of CHOLMOD) on the host cores,
-    from the GPU chain's current state; bounded to roughly 10-30 s."""
+    """The oracle's reference-faithful W+V update (per-row / per-column loops, the sufficient statistics
+    re-reduced from the 4-D tensor on every half-sweep as factor.py:329-330/:374-375 do, dense LAPACK in
+    place of CHOLMOD) on the host cores, from the GPU chain's current state: with all BLAS threads and with
+    one thread; bounded to roughly 30 s in all."""
     from oracle import btf_oracle as orc
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
+        threadpool_limits = None
         cores = os.cpu_count() or 1
     st = dict(W=model.W.copy(), V=model.V.copy(), Tau2=np.array(model.Tau2, dtype=float).copy(),
               lam2=float(model.lam2), sigma2=float(model.sigma2), nu2=float(np.asarray(model.nu2).reshape(-1)[0]))
     Delta = orc.trend_penalty(cfg["T"], 2)
-    np.random.seed(123)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        orc.w_step(st, Y)
-        orc.v_step(st, Y, Delta)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > 12.0 or n >= 50:
-            break
-    out = {"value": round(n / el, 4), "unit": "sweeps/s", "cores": int(cores), "kind": "port",
+
+    def faithful(budget, nmax):
+        np.random.seed(123)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            orc.w_step(st, Y)
+            orc.v_step(st, Y, Delta)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget or n >= nmax:
+                return n, el
+    n, el = faithful(10.0, 50)
+    out = {"value": round(n / el, 4), "unit": "sweeps/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model(),
            "sample": "%d full W+V updates of the same (%d,%d,%d,%d) K=%d tensor by oracle/btf_oracle.py "
                      "(numpy/LAPACK, BLAS threads=%d)" % (n, cfg["N"], cfg["M"], cfg["T"], cfg["R"], cfg["K"], cores)}
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            n1, el1 = faithful(8.0, 20)
+        out["single_thread_value"] = round(n1 / el1, 4)
+        out["single_thread_sample"] = "%d W+V updates, same code, BLAS / OpenMP limited to 1 thread" % n1
     # second CPU number (BASELINE.md 4b): statistics hoisted, BLAS + banded LAPACK ("strong CPU")
     try:
         Rr, ybar = orc.hoisted_stats(Y)
@@ -337,7 +478,7 @@ def cpu_baseline(Y, model, cfg):
             orc.v_step_strong(st, Rr, ybar, Delta)
             n2 += 1
             el2 = time.perf_counter() - t0
-            if el2 > 8.0 or n2 >= 200:
+            if el2 > 6.0 or n2 >= 200:
                 break
         out["strong_cpu_value"] = round(n2 / el2, 3)
         out["strong_cpu_sample"] = "%d W+V updates, hoisted statistics + BLAS + scipy banded Cholesky" % n2

@@ -36,6 +36,7 @@ SIGNATURES = {
     "btf_last_error": (C.c_char_p, [_ctx]),
     "btf_fail_index": (C.c_int, [_ctx]),
     "btf_set_shard": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "btf_stream": (C.c_void_p, [_ctx]),
     "btf_dev_W": (C.c_void_p, [_ctx]),
     "btf_dev_V": (C.c_void_p, [_ctx]),
     "btf_set_data_gaussian": (C.c_int, [_ctx, _c_dp, _c_dp, C.c_int]),
@@ -163,6 +164,8 @@ class Context:
         if rc != BTF_OK:
             raise BTFError(rc, self.lib.btf_last_error(None).decode())
         self.dims = (nrows, ncols, ndepth, nembeds, tf_order)
+        self.device = device
+        self.stream_handle = self.lib.btf_stream(self.h)      # hipStream_t the step functions enqueue on
 
     def close(self):
         if getattr(self, "h", None):

@@ -59,7 +59,7 @@ struct btf_ctx {
   int sampler = BTF_SAMPLER_BANDED;   // BTF_OPT_SAMPLER
   double* eig = nullptr;              // gram_eig_kernel output (spectral sampler): K eigenvalues, K*K vectors, sweeps
   long long* dbg = nullptr;
-  double* pband = nullptr; bool pband_dirty = true;
+  double* pband = nullptr;
   double* Ta = nullptr; double* Tb = nullptr; double* Tc = nullptr; double* lsum = nullptr;   // horseshoe+ chain (device mode)
   int* dr_ptr = nullptr; int* dr_col = nullptr; double* dr_val = nullptr;                   // Delta, CSR by row
   bool have_chain = false;
@@ -501,16 +501,23 @@ int pick_rpb(int Rdim, int tiles, int user) {
 }
 
 // upload a host slab and turn it into the padded device layouts
+// `keep`: device copies of the uploaded slab(s) from the previous call on the same host arrays (the unsharded
+// case hands in one array as both the row and the column slab): uploaded once, freed by the second call.
+struct Uploaded { const double* h = nullptr; const double* h2 = nullptr; double* d = nullptr; double* d2 = nullptr; };
 int make_stats(btf_ctx* c, const double* hY, const double* hY2, int rows, int cols, int R, bool transposed,
-               double** A, double** C, double** B, int ld, size_t out_rows, bool want_sums) {
+               double** A, double** C, double** B, int ld, size_t out_rows, bool want_sums, Uploaded* keep, bool last) {
   const size_t cells = (size_t)rows * cols;
   double* dY = nullptr; double* dY2 = nullptr;
   int rc;
-  if ((rc = dev_alloc(c, &dY, cells * R))) return rc;
-  HIPCHK(c, hipMemcpy(dY, hY, cells * R * sizeof(double), hipMemcpyHostToDevice));
-  if (hY2) {
-    if ((rc = dev_alloc(c, &dY2, cells))) return rc;
-    HIPCHK(c, hipMemcpy(dY2, hY2, cells * sizeof(double), hipMemcpyHostToDevice));
+  const bool reuse = keep && keep->d && keep->h == hY && keep->h2 == hY2;
+  if (reuse) { dY = keep->d; dY2 = keep->d2; }
+  else {
+    if ((rc = dev_alloc(c, &dY, cells * R))) return rc;
+    HIPCHK(c, hipMemcpy(dY, hY, cells * R * sizeof(double), hipMemcpyHostToDevice));
+    if (hY2) {
+      if ((rc = dev_alloc(c, &dY2, cells))) return rc;
+      HIPCHK(c, hipMemcpy(dY2, hY2, cells * sizeof(double), hipMemcpyHostToDevice));
+    }
   }
   const size_t out_elems = out_rows * (size_t)ld;
   if ((rc = dev_alloc(c, A, out_elems))) return rc;
@@ -545,8 +552,12 @@ int make_stats(btf_ctx* c, const double* hY, const double* hY2, int rows, int co
     c->nobs = nobs;
     c->sa2 = sa2;
   }
-  (void)hipFree(dY);
-  if (dY2) (void)hipFree(dY2);
+  if (keep && !last) { keep->h = hY; keep->h2 = hY2; keep->d = dY; keep->d2 = dY2; }
+  else {
+    (void)hipFree(dY);
+    if (dY2) (void)hipFree(dY2);
+    if (keep) *keep = Uploaded{};
+  }
   return BTF_OK;
 }
 
@@ -637,6 +648,7 @@ int btf_set_shard(btf_ctx* c, int row0, int nrows_local, int col0, int ncols_loc
   c->row0 = row0; c->nl = nrows_local; c->col0 = col0; c->ml = ncols_local;
   return BTF_OK;
 }
+void* btf_stream(btf_ctx* c) { return c ? (void*)c->stream : nullptr; }
 void* btf_dev_W(btf_ctx* c) { return c ? c->W : nullptr; }
 void* btf_dev_V(btf_ctx* c) { return c ? c->V : nullptr; }
 
@@ -677,9 +689,14 @@ int btf_set_data_gaussian(btf_ctx* c, const double* y_rows, const double* y_cols
   HIPCHK(c, hipMemcpy(c->status + 2, &zero, sizeof(int), hipMemcpyHostToDevice));
   int rc;
   // row slab -> transposed layout A_wT[MT][ldw] (W half-sweep); carries the global sums
-  if ((rc = make_stats(c, y_rows, nullptr, c->nl, MT, nreps, true, &c->A_wT, &c->C_wT, nullptr, c->ldw, MT, true))) return rc;
+  Uploaded up;
+  const bool same = y_rows == y_cols && c->nl == c->N && c->ml == c->M;     // unsharded: one upload serves both layouts
+  if ((rc = make_stats(c, y_rows, nullptr, c->nl, MT, nreps, true, &c->A_wT, &c->C_wT, nullptr, c->ldw, MT, true, same ? &up : nullptr, false))) return rc;
   // column slab -> A_v[N][ldv] (V half-sweep, SSE)
-  if ((rc = make_stats(c, y_cols, nullptr, c->N, c->ml * c->T, nreps, false, &c->A_v, &c->C_v, nullptr, c->ldv, c->N, false))) return rc;
+  if ((rc = make_stats(c, y_cols, nullptr, c->N, c->ml * c->T, nreps, false, &c->A_v, &c->C_v, nullptr, c->ldv, c->N, false, same ? &up : nullptr, true))) {
+    if (up.d) (void)hipFree(up.d);
+    return rc;
+  }
   return finish_data(c);
 }
 
@@ -694,8 +711,14 @@ int btf_set_data_binomial(btf_ctx* c, const double* succ_rows, const double* tri
   int zero = 0;
   HIPCHK(c, hipMemcpy(c->status + 2, &zero, sizeof(int), hipMemcpyHostToDevice));
   int rc;
-  if ((rc = make_stats(c, succ_rows, trials_rows, c->nl, MT, 1, true, &c->A_wT, &c->C_wT, &c->B_wT, c->ldw, MT, true))) return rc;
-  if ((rc = make_stats(c, succ_cols, trials_cols, c->N, c->ml * c->T, 1, false, &c->A_v, &c->C_v, &c->B_v, c->ldv, c->N, false))) return rc;
+  Uploaded up;
+  const bool same = succ_rows == succ_cols && trials_rows == trials_cols && c->nl == c->N && c->ml == c->M;
+  if ((rc = make_stats(c, succ_rows, trials_rows, c->nl, MT, 1, true, &c->A_wT, &c->C_wT, &c->B_wT, c->ldw, MT, true, same ? &up : nullptr, false))) return rc;
+  if ((rc = make_stats(c, succ_cols, trials_cols, c->N, c->ml * c->T, 1, false, &c->A_v, &c->C_v, &c->B_v, c->ldv, c->N, false, same ? &up : nullptr, true))) {
+    if (up.d) (void)hipFree(up.d);
+    if (up.d2) (void)hipFree(up.d2);
+    return rc;
+  }
   // until the first PG draw / set_omega the weights are zero
   HIPCHK(c, hipMemset(c->C_wT, 0, (size_t)MT * c->ldw * sizeof(double)));
   HIPCHK(c, hipMemset(c->C_v, 0, (size_t)c->N * c->ldv * sizeof(double)));
@@ -773,9 +796,7 @@ int btf_set_hyper(btf_ctx* c, const double* Tau2, double lam2, double sigma2) {
     HIPCHK(c, hipMemcpyAsync(c->Tau2, Tau2, (size_t)c->M * c->nD * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_hyper = true;
-    c->pband_dirty = true;
   }
-  if (lam2 != c->lam2) c->pband_dirty = true;
   c->lam2 = lam2; c->sigma2 = sigma2;
   return BTF_OK;
 }
@@ -825,7 +846,6 @@ int btf_resample_Tau2(btf_ctx* c, uint64_t seed, double lam2, double stability, 
              c->Tc, c->lsum, (unsigned long long)seed, (const double*)(c->dev_scalars ? c->hyp : nullptr));
   }
   HIPCHK(c, hipGetLastError());
-  c->pband_dirty = true;
   if (lsum_out) {   // through pinned memory: a pageable destination makes the small copy several times slower
     if (!c->pin_lsum) HIPCHK(c, hipHostMalloc((void**)&c->pin_lsum, (size_t)c->M * sizeof(double), hipHostMallocDefault));
     HIPCHK(c, hipMemcpyAsync(c->pin_lsum, c->lsum, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1052,13 +1072,12 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     }
     if (fast) {
       const int TD1 = T * D1;
-      if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; c->pband_dirty = true; }
-      if (c->pband_dirty) {
+      if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; }
+      {   // rebuilt on every call, as the reference rebuilds Q_prior per column (factor.py:404-405)
         Prof p(c, BTF_K_PRIOR);
         p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
                  (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
                  (const double*)(c->dev_scalars ? c->hyp : nullptr));
-        c->pband_dirty = false;
       }
       a.pband = c->pband;
     }
@@ -1507,7 +1526,6 @@ int btf_device_scalars(btf_ctx* c, int enable) {
     if ((rc = ensure_hyp(c))) return rc;
   }
   c->dev_scalars = enable != 0;
-  c->pband_dirty = true;
   return BTF_OK;
 }
 
@@ -1517,11 +1535,9 @@ int btf_set_scalars(btf_ctx* c, double nu2, double sigma2, double lam2, double l
   int rc;
   if ((rc = ensure_hyp(c))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));      // the staging word may still be in flight
-  if (lam2 != c->lam2) c->pband_dirty = true;
   c->nu2 = nu2; c->sigma2 = sigma2; c->lam2 = lam2;
   c->pin_hyp[HYP_NU2] = nu2; c->pin_hyp[HYP_SIGMA2] = sigma2; c->pin_hyp[HYP_LAM2] = lam2; c->pin_hyp[HYP_LAM2A] = lam2_a;
   HIPCHK(c, hipMemcpyAsync(c->hyp, c->pin_hyp, 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  c->pband_dirty = true;
   return BTF_OK;
 }
 
@@ -1590,7 +1606,6 @@ int btf_draw_lam2(btf_ctx* c, uint64_t seed, int compat) {
              (unsigned long long)seed, c->hyp);
   }
   HIPCHK(c, hipGetLastError());
-  c->pband_dirty = true;
   return BTF_OK;
 }
 

@@ -47,6 +47,15 @@ def _scalar(x):
     return float(np.asarray(x, dtype=float).reshape(-1)[0])
 
 
+def _fingerprint(a):
+    """Cheap content check of an observation array (see set_data): sum and NaN count of 64 strided entries."""
+    flat = a.reshape(-1) if isinstance(a, np.ndarray) and a.flags.c_contiguous else None
+    if flat is None or flat.size == 0:
+        return None
+    s = flat[::max(1, flat.size // 61)][:64]
+    return float(np.nansum(s)), int(np.isnan(s).sum())
+
+
 def stale_row_sources(nrows, nembeds, any_nan):
     """Quirk Q1 (factor.py:320,349): without any NaN in the data the per-row design
     cache is refreshed only for rows < K, so rows >= K reuse row K-1's weights."""
@@ -100,16 +109,10 @@ class BayesianTensorFiltering(_BayesianModel):
         self._device_seed = int(device_seed)
         self._draws = 0
 
-        # Sharded runs exchange W / V through torch.distributed: kernels and collectives must
-        # share one (non-null) stream so that the all-gather is ordered after the draw and the
-        # next half-sweep after the all-gather.
+        # Sharded runs exchange W / V through torch.distributed on the ctx's own stream (parallel.Exchange wraps it
+        # in a torch.cuda.ExternalStream and issues the collectives under it): the all-gather is ordered after
+        # the draw and the next half-sweep after the all-gather without touching torch's current stream.
         import os
-        sharded = (shard is not None and shard[1] > 1) or os.environ.get("BTF_EXERCISE_EXCHANGE", "0") == "1"
-        if sharded and not stream:
-            import torch
-            self._torch_stream = torch.cuda.Stream(device=device)
-            torch.cuda.set_stream(self._torch_stream)
-            stream = self._torch_stream.cuda_stream
         # device context first: without the HIP library / a GPU nothing below can run
         self._ctx = _native.Context(nrows, ncols, ndepth, nembeds, tf_order, device=device, stream=stream)
         self._plan = ShardPlan(nrows, ncols, *(shard if shard is not None else (0, 1)))
@@ -310,7 +313,7 @@ class BayesianTensorFiltering(_BayesianModel):
         """Upload the observations once and hoist their sufficient statistics (what
         factor.py:329-330 / :374-375 recompute on every half-sweep)."""
         arrays = data if isinstance(data, (tuple, list)) else (data,)
-        key = tuple((id(a), a.shape) for a in arrays)
+        key = tuple((id(a), a.shape, _fingerprint(a)) for a in arrays)
         if key == self._data_key:
             return
         self._upload(data)
@@ -318,7 +321,10 @@ class BayesianTensorFiltering(_BayesianModel):
         self._data_key = key
 
     def set_data(self, data):
-        """Force a re-upload (e.g. after mutating the observation array in place)."""
+        """Force a re-upload.  The reference re-reads the observation array on every half-sweep
+        (factor.py:329-330, :374-375); here it is uploaded once and recognised again by identity, shape and
+        a 64-point fingerprint, which catches wholesale in-place edits (imputation, rescaling) but NOT a few
+        changed cells: after mutating the array in place, call set_data()."""
         self._data_key = None
         self._bind_data(data)
 

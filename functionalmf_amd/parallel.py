@@ -23,9 +23,13 @@ def _block(n, rank, world):
 
 
 class ShardPlan:
+    MAX_WORLD = 64      # the context pads W / V by 64 rows / columns for the in-place all-gather (btf_create)
+
     def __init__(self, nrows, ncols, rank=0, world=1):
         if not (0 <= rank < world):
             raise ValueError("rank %d outside world of %d" % (rank, world))
+        if world > self.MAX_WORLD:
+            raise ValueError("at most %d shards (the device buffers are padded for that many)" % self.MAX_WORLD)
         self.nrows, self.ncols, self.rank, self.world = nrows, ncols, rank, world
         self.row0, self.nl, self.row_chunk = _block(nrows, rank, world)
         self.col0, self.ml, self.col_chunk = _block(ncols, rank, world)
@@ -64,6 +68,8 @@ class Exchange:
     def __init__(self, plan, ctx=None, group=None):
         self.plan, self.ctx, self.group = plan, ctx, group
         self._Wt = self._Vt = None
+        self._tstream = None
+        self.timing, self._events = False, {"all_gather_W": [], "all_gather_V": []}
         # BTF_EXERCISE_EXCHANGE=1: issue the collectives even in a 1-rank group (lets a 1-GPU box
         # run the exact RCCL call sequence of the sharded path)
         import os
@@ -76,12 +82,44 @@ class Exchange:
                 raise RuntimeError("shard does not match the process group")
 
     # -- device path (RCCL) ----------------------------------------------------------
+    def _stream(self):
+        """The ctx's HIP stream as a torch stream: the collectives are issued under it, so that RCCL orders
+        them after the draw kernel and the next half-sweep after them - whichever stream is torch's current one."""
+        import torch
+        if self._tstream is None:
+            self._tstream = torch.cuda.ExternalStream(self.ctx.stream_handle, device=torch.device("cuda", self.ctx.device))
+        return self._tstream
+
+    def _timed(self, name, fn):
+        import torch
+        with torch.cuda.stream(self._stream()):
+            if self.timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                self._events[name].append((e0, e1))
+            else:
+                fn()
+
+    def collective_us(self):
+        """Mean microseconds per collective since timing was switched on (synchronises)."""
+        import torch
+        out = {}
+        if any(self._events.values()):
+            torch.cuda.synchronize()
+        for k, evs in self._events.items():
+            if evs:
+                out[k] = round(1e3 * sum(a.elapsed_time(b) for a, b in evs) / len(evs), 2)
+            self._events[k] = []
+        return out
+
     def _views(self):
         import torch
         p, (N, M, T, K, _) = self.plan, self.ctx.dims
         if self._Wt is None:
             lib = self.ctx.lib
-            dev = torch.device("cuda", torch.cuda.current_device())
+            dev = torch.device("cuda", self.ctx.device)
             # the context over-allocates W / V by 64 rows / columns, so world*chunk fits
             self._Wt = torch.as_tensor(_DevView(lib.btf_dev_W(self.ctx.h), (p.world * p.row_chunk * K,)), device=dev)
             self._Vt = torch.as_tensor(_DevView(lib.btf_dev_V(self.ctx.h), (p.world * p.col_chunk * T * K,)), device=dev)
@@ -111,7 +149,7 @@ class Exchange:
         Wt, _ = self._views()
         K = self.ctx.dims[3]
         n = self.plan.row_chunk * K
-        dist.all_gather_into_tensor(Wt, Wt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group)
+        self._timed("all_gather_W", lambda: dist.all_gather_into_tensor(Wt, Wt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group))
 
     def after_V(self):
         if not self.active:
@@ -123,7 +161,7 @@ class Exchange:
         _, Vt = self._views()
         _, _, T, K, _ = self.ctx.dims
         n = self.plan.col_chunk * T * K
-        dist.all_gather_into_tensor(Vt, Vt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group)
+        self._timed("all_gather_V", lambda: dist.all_gather_into_tensor(Vt, Vt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group))
 
     def sum_scalars(self, *vals):
         if not self.active:

@@ -99,6 +99,9 @@ int btf_fail_index(const btf_ctx* ctx);
  * Default: everything.  W and V are replicated: after each half-sweep the host
  * all-gathers the updated block (device pointers via btf_dev_W / btf_dev_V). */
 int btf_set_shard(btf_ctx* ctx, int row0, int nrows_local, int col0, int ncols_local);
+void* btf_stream(btf_ctx* ctx); /* the hipStream_t every step function of this ctx enqueues on (the one passed
+                                  to btf_create, or the private one): collectives on the ctx's buffers and event
+                                  timing must be ordered against it */
 void* btf_dev_W(btf_ctx* ctx); /* device double[N][K]    */
 void* btf_dev_V(btf_ctx* ctx); /* device double[M][T][K] */
 

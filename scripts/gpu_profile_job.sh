@@ -1,13 +1,17 @@
 #!/bin/bash
-# Round profile job (run through gpurun): tests, bench, rocprofv3 kernel stats and the two
-# PMC passes (FETCH_SIZE / WRITE_SIZE need separate passes on gfx950: TCC slots).
+# Profile job (run through gpurun):  scripts/gpu_profile_job.sh <tag> <config> <variant> [steps]
+# rocprofv3 kernel stats and the two PMC passes (FETCH_SIZE / WRITE_SIZE need separate passes on gfx950: TCC
+# slots) of `bench.py --config <config> --variant <variant>`; then scripts/summarize_profiles.py <tag> <config> <variant>.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r01}
-cd $R
-timeout -k 10 600 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; tail -3 gpurun_out/pytest_gpu.log
-timeout -k 10 400 python bench.py > gpurun_out/bench_$TAG.log 2>&1; tail -1 gpurun_out/bench_$TAG.log
+TAG=${1:-r02}; CFG=${2:-c3}; VAR=${3:-complete}; STEPS=${4:-100}
+NAME=${TAG}_${CFG}_${VAR}
+export PYTHONUNBUFFERED=1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o $TAG --output-format csv -- python $R/bench.py --steps 100 --warmup 10 --no-cpu > $R/gpurun_out/prof_$TAG.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch_$TAG -o $TAG --output-format csv -- python $R/bench.py --steps 20 --warmup 2 --no-cpu > $R/gpurun_out/pmc_fetch_$TAG.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write_$TAG -o $TAG --output-format csv -- python $R/bench.py --steps 20 --warmup 2 --no-cpu > $R/gpurun_out/pmc_write_$TAG.log 2>&1
-ls $R/gpurun_out/prof_$TAG $R/gpurun_out/pmc_fetch_$TAG $R/gpurun_out/pmc_write_$TAG
+ARGS="--config $CFG --variant $VAR --no-cpu"
+timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$NAME -o $NAME --output-format csv -- python3 $R/bench.py $ARGS --steps $STEPS --warmup 10 > $R/gpurun_out/prof_$NAME.log 2>&1 || exit 1
+echo "stats pass done"
+timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch_$NAME -o $NAME --output-format csv -- python3 $R/bench.py $ARGS --steps 20 --warmup 2 --burn 2 > $R/gpurun_out/pmc_fetch_$NAME.log 2>&1 || exit 1
+echo "fetch pass done"
+timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write_$NAME -o $NAME --output-format csv -- python3 $R/bench.py $ARGS --steps 20 --warmup 2 --burn 2 > $R/gpurun_out/pmc_write_$NAME.log 2>&1 || exit 1
+echo "write pass done"
+tail -1 $R/gpurun_out/prof_$NAME.log

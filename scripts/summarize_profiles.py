@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/{prof,pmc_fetch,pmc_write}_<tag> into profiles/<tag>_*.  Usage:
-   python scripts/summarize_profiles.py r01"""
+"""Condense gpurun_out/{prof,pmc_fetch,pmc_write}_<tag>_<config>_<variant> into profiles/.  Usage:
+   python scripts/summarize_profiles.py r02 c3 complete"""
 import collections, csv, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag, cfg, var = (sys.argv[1:4] + ["r02", "c3", "complete"][len(sys.argv) - 1:])[:3]
+name = "%s_%s_%s" % (tag, cfg, var)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
-shutil.copy(os.path.join(root, "gpurun_out", "prof_%s" % tag, "%s_kernel_stats.csv" % tag),
-            os.path.join(out, "%s_kernel_stats.csv" % tag))
+shutil.copy(os.path.join(root, "gpurun_out", "prof_%s" % name, "%s_kernel_stats.csv" % name),
+            os.path.join(out, "%s_kernel_stats.csv" % name))
+log = open(os.path.join(root, "gpurun_out", "prof_%s.log" % name)).read().splitlines()
+line = [ln for ln in log if ln.startswith("{") and '"metric"' in ln]
+if line:
+    open(os.path.join(out, "%s_bench.json" % name), "w").write(line[-1] + "\n")
 pmc = {}
 for nm, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    rows = list(csv.DictReader(open(os.path.join(root, "gpurun_out", "pmc_%s_%s" % (nm, tag), "%s_counter_collection.csv" % tag))))
+    rows = list(csv.DictReader(open(os.path.join(root, "gpurun_out", "pmc_%s_%s" % (nm, name), "%s_counter_collection.csv" % name))))
     agg = collections.defaultdict(list)
     for r in rows:
         if r["Counter_Name"] == ctr:
@@ -22,6 +27,6 @@ for nm, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 for k, d in pmc.items():
     f, w = d.get("FETCH_SIZE_KB_avg", 0.0), d.get("WRITE_SIZE_KB_avg", 0.0)
     d["hbm_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0
-json.dump(pmc, open(os.path.join(out, "%s_pmc_summary.json" % tag), "w"), indent=1, sort_keys=True)
+json.dump(pmc, open(os.path.join(out, "%s_pmc_%s_%s.json" % (tag, cfg, var)), "w"), indent=1, sort_keys=True)
 for k, d in sorted(pmc.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"])[:6]:
     print("%-60s %10.2f MB/launch" % (k[:60], d["hbm_bytes_per_launch_corrected"] / 1e6))

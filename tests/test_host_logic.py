@@ -142,3 +142,35 @@ def test_sharded_half_sweeps_equal_unsharded_gloo_world2():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count("DIST_OK") == 2, out.stdout[-2000:]
+
+
+@pytest.mark.timeout(300)
+def test_bench_launches_its_own_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2` outside torchrun must start its two ranks as a child process (the way the
+    driver starts the 1-GPU run) and relay exactly one JSON line with n_gpus = 2, strong scaling on config C5.
+    BTF_BENCH_DRY=1: the launch / barrier / max-over-ranks / reporting plumbing on CPU over gloo, no GPU work."""
+    import json
+    env = dict(os.environ, BTF_BENCH_DRY="1", PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                          "--master-port", "29577"], env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["backend"] == "gloo" and "c5" in d["config"]["workload"]
+    # the same entry point under torchrun (the driver's N>1 form) is a rank, not a launcher
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29578", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_shard_plan_rejects_more_shards_than_the_padding_allows():
+    from functionalmf_amd.parallel import ShardPlan
+    with pytest.raises(ValueError):
+        ShardPlan(1000, 1000, 0, 65)
