@@ -79,6 +79,7 @@ def parse_args(argv=None):
                          "binomial: 4 trials per cell, device Polya-Gamma draw included in the step (config C4); "
                          "negbinom: NB(4, p) counts, step = 30 MH steps on the rate R + PG draw + W + V (SURVEY 8(f) rank 2)")
     ap.add_argument("--sampler", default="auto", help="V sampler: auto (spectral on complete data, banded otherwise), banded, spectral, chain")
+    ap.add_argument("--pg-exact", action="store_true", help="binomial / negbinom: Devroye's exact Polya-Gamma sampler for every count")
     ap.add_argument("--burn", type=int, default=10, help="full Gibbs sweeps before timing (leave the initial state)")
     ap.add_argument("--master-port", type=int, default=29533)
     return ap.parse_args(argv)
@@ -181,9 +182,9 @@ def main():
                   compat="reference" if world == 1 else "exact", device=local_rank, stream=stream,
                   shard=(rank, world) if world > 1 else None, device_seed=1, sampler=args.sampler)
     if args.variant == "binomial":
-        model = BinomialBayesianTensorFiltering(N, M, T, **common)
+        model = BinomialBayesianTensorFiltering(N, M, T, pg_exact=args.pg_exact, **common)
     elif args.variant == "negbinom":
-        model = NegativeBinomialBayesianTensorFiltering(N, M, T, **common)
+        model = NegativeBinomialBayesianTensorFiltering(N, M, T, pg_exact=args.pg_exact, **common)
     else:
         model = GaussianBayesianTensorFiltering(N, M, T, nu2_init=1.0, **common)
     if args.rpb != [0, 0]:
@@ -283,6 +284,8 @@ def main():
     alg_bytes = bpc * 0.5 * (cells_local + cells_local_v)
     achieved = alg_bytes / (acc_us * 1e-6) / 1e9 if acc_us > 0 else 0.0
     b_wv = bpc * (cells_local + cells_local_v)                     # B_WV of SURVEY 8(d), per GPU
+    if args.variant in ("binomial", "negbinom"):                   # + the PG draw: trials in, omega out (48 B/cell in all)
+        b_wv += 16.0 * cells_local
     ms_step = 1e3 * dt / args.steps
     kernels_us = {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in kt.items() if v[1] > 0}
     sampler = model.v_sampler()
@@ -300,7 +303,8 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%s_btf %s (%d,%d,%d,%d) nembeds=%d tf_order=2 %s data, W+V update, rng=device%s"
-                               % ({"binomial": "binomial", "negbinom": "negbinom"}.get(args.variant, "gaussian"), args.config, N, M, T, R, K, args.variant,
+                               % ({"binomial": "binomial", "negbinom": "negbinom"}.get(args.variant, "gaussian"), args.config, N, M, T,
+                                  {"binomial": 1}.get(args.variant, R), K, args.variant + (" (4 trials per cell)" if args.variant == "binomial" else ""),
                                   "; %d-way row/column shards, RCCL all-gather of W and V" % world if world > 1 else ""),
                    "global_sweeps_per_s": round(sweeps_per_s, 2), "units_per_sweep": units,
                    "median_ms_per_step": round(float(np.median(per_step_ms)), 4), "median_over_steps": int(nmed),

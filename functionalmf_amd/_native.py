@@ -23,7 +23,7 @@ BTF_OK, BTF_EINVAL, BTF_EHIP, BTF_ENOTPD, BTF_ESTATE = 0, 1, 2, 3, 4
 COMPAT = {"reference": 0, "exact": 1}
 KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw", "nb_loglik",
                 "prior_band", "gram_eig", "hyper"]
-OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM = 0, 1, 2
+OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT = 0, 1, 2, 3
 SAMPLERS = {"banded": 0, "spectral": 1, "chain": 2, "generic": 3, "banded_nopanel": 4}
 
 # every symbol include/btf.h declares: (name, restype, argtypes)
@@ -73,6 +73,7 @@ SIGNATURES = {
     "btf_sse_end": (C.c_int, [_ctx, _c_dp, _c_dp, _c_dp]),
     "btf_pg_draw": (C.c_int, [_ctx, C.c_uint64]),
     "btf_pg_batch": (C.c_int, [C.c_int, C.c_int64, _c_dp, _c_dp, C.c_uint64, _c_dp]),
+    "btf_pg_batch_mode": (C.c_int, [C.c_int, C.c_int64, _c_dp, _c_dp, C.c_uint64, C.c_int, _c_dp]),
     "btf_posterior_summary": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, C.c_int, _c_dp,
                                         C.c_int, _c_dp, _c_dp]),
     "btf_collect_begin": (C.c_int, [_ctx, C.c_int]),

@@ -79,6 +79,8 @@ struct btf_ctx {
   bool nb_tabulable = false;        // every observed count is an integer in [0, NB_TAB)
   bool nb_L_valid = false;          // nb_L matches the current W, V
   bool nb_hist = true;              // BTF_OPT_NB_HISTOGRAMS
+  bool pg_exact = false;            // BTF_OPT_PG_EXACT
+  bool pg_has_small = true, pg_has_big = true;   // trial counts: any integer 1..PG_DEVROYE_MAX / anything else below the normal range
   // on-device sample collection (run_gibbs, rng="device"): [nsamp] slots of W, V, Tau2 and the scalars
   double* smp_W = nullptr; double* smp_V = nullptr; double* smp_T = nullptr; double* smp_s = nullptr; int smp_n = 0;
   double* hyp = nullptr;        // device-resident scalars [HYP_COUNT] (nu2, sigma2, lam2, lam2_a, ...)
@@ -270,15 +272,30 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
   else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
   else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
 }
+// which Polya-Gamma passes a draw needs: exact mode - the exact sampler alone; otherwise the series for every cell
+// that is not an integer count of 1 or 2, and the exact sampler for those (each launch only if such cells exist)
+void pg_passes(const btf_ctx* c, bool* series, bool* exact) {
+  *exact = c->pg_exact || c->pg_has_small;
+  *series = !c->pg_exact && (c->pg_has_big || !c->pg_has_small);
+}
 template <int K>
 void launch_pg(btf_ctx* c, const double* B, double* out, const double* Lf, const double* Uf, int nl, int ld, int Rdim,
                unsigned long long base, unsigned long long stride_r, unsigned long long stride_l, unsigned long long seed) {
-  Prof p(c, BTF_K_PG);
   const int gx = (nl + PG_THREADS - 1) / PG_THREADS;
   int nrb = std::max(1, std::min(Rdim, 4096 / std::max(1, gx)));
   const int rpb = (Rdim + nrb - 1) / nrb;
   nrb = (Rdim + rpb - 1) / rpb;
-  p.launch(pg_kernel<K>, dim3(gx, nrb), dim3(PG_THREADS), 0, B, out, Lf, Uf, nl, ld, Rdim, rpb, base, stride_r, stride_l, seed);
+  bool series, exact;
+  pg_passes(c, &series, &exact);
+  if (series) {
+    Prof p(c, BTF_K_PG);
+    p.launch(pg_kernel<K, PG_PATH_SERIES>, dim3(gx, nrb), dim3(PG_THREADS), 0, B, out, Lf, Uf, nl, ld, Rdim, rpb, base, stride_r, stride_l, seed, 0, 1);
+  }
+  if (exact) {
+    Prof p(c, BTF_K_PG);
+    p.launch(pg_kernel<K, PG_PATH_EXACT>, dim3(gx, nrb), dim3(PG_THREADS), 0, B, out, Lf, Uf, nl, ld, Rdim, rpb, base, stride_r, stride_l, seed,
+             c->pg_exact ? 1 : 0, series ? 0 : 1);
+  }
 }
 template <int K>
 void launch_gram(btf_ctx* c, const double* U, int Rdim) {
@@ -718,6 +735,19 @@ int btf_set_data_binomial(btf_ctx* c, const double* succ_rows, const double* tri
     if (up.d) (void)hipFree(up.d);
     if (up.d2) (void)hipFree(up.d2);
     return rc;
+  }
+  {   // which samplers the trial counts need (see pg_passes); both slabs hold every class a rank can meet
+    bool small = false, big = false;
+    auto scan = [&](const double* t, size_t n) {
+      for (size_t i = 0; i < n && !(small && big); ++i) {
+        const double b = t[i];
+        if (!(b > 0.0) || b >= (double)PG_NORMAL_B) continue;
+        if (b <= (double)PG_DEVROYE_MAX && b == std::floor(b)) small = true; else big = true;
+      }
+    };
+    scan(trials_cols, (size_t)c->N * c->ml * c->T);
+    scan(trials_rows, (size_t)c->nl * MT);
+    c->pg_has_small = small; c->pg_has_big = big;
   }
   // until the first PG draw / set_omega the weights are zero
   HIPCHK(c, hipMemset(c->C_wT, 0, (size_t)MT * c->ldw * sizeof(double)));
@@ -1216,6 +1246,7 @@ int btf_set_data_counts(btf_ctx* c, const double* counts, int nreps) {
   const int MT = c->M * c->T;
   const size_t cells = (size_t)c->N * MT;
   c->R = 1; c->binomial = true; c->counts = true; c->nb_Rr = nreps;
+  c->pg_has_small = c->pg_has_big = true;      // pseudo-trial counts change with the rate: both passes
   if (c->C8_wT) { (void)hipFree(c->C8_wT); c->C8_wT = nullptr; }
   if (c->C8_v) { (void)hipFree(c->C8_v); c->C8_v = nullptr; }
   c->ldw = round_up(c->N, ACC_TILE);
@@ -1639,12 +1670,22 @@ int btf_pg_draw(btf_ctx* c, uint64_t seed) {
   if (!c->have_data || !c->binomial || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_pg_draw needs binomial data, W and V");
   HIPCHK(c, hipSetDevice(c->dev));
   const unsigned long long MT = (unsigned long long)c->M * c->T;
-  if (c->nl == c->N && c->ml == c->M) {   // unsharded: one pass, both layouts (LDS tile transpose)
-    Prof p(c, BTF_K_PG);
+  if (c->nl == c->N && c->ml == c->M) {   // unsharded: every cell once, both layouts (LDS tile transpose)
     dim3 grid((unsigned)((MT + 63) / 64), (unsigned)((c->N + 63) / 64));
-    K_SWITCH(c->K, p.launch(pg_tile_kernel<KT>, grid, dim3(256), 0, (const double*)c->B_v, c->C_v, c->C_wT,
-                            (const double*)c->W, (const double*)c->V, c->N, (int)MT, c->ldv, c->ldw,
-                            (unsigned long long)seed));
+    bool series, exact;
+    pg_passes(c, &series, &exact);
+    if (series) {
+      Prof p(c, BTF_K_PG);
+      K_SWITCH(c->K, p.launch(pg_tile_kernel<KT, PG_PATH_SERIES>, grid, dim3(256), 0, (const double*)c->B_v, c->C_v, c->C_wT,
+                              (const double*)c->W, (const double*)c->V, c->N, (int)MT, c->ldv, c->ldw,
+                              (unsigned long long)seed, 0, 1));
+    }
+    if (exact) {
+      Prof p(c, BTF_K_PG);
+      K_SWITCH(c->K, p.launch(pg_tile_kernel<KT, PG_PATH_EXACT>, grid, dim3(256), 0, (const double*)c->B_v, c->C_v, c->C_wT,
+                              (const double*)c->W, (const double*)c->V, c->N, (int)MT, c->ldv, c->ldw,
+                              (unsigned long long)seed, c->pg_exact ? 1 : 0, series ? 0 : 1));
+    }
     HIPCHK(c, hipGetLastError());
     return BTF_OK;
   }
@@ -1711,6 +1752,10 @@ int btf_posterior_summary(int device, int nsamples, int nrows, int ncols, int nd
 }
 
 int btf_pg_batch(int device, int64_t n, const double* b, const double* psi, uint64_t seed, double* out) {
+  return btf_pg_batch_mode(device, n, b, psi, seed, 0, out);
+}
+
+int btf_pg_batch_mode(int device, int64_t n, const double* b, const double* psi, uint64_t seed, int exact, double* out) {
   if (n < 1 || !b || !psi || !out) return fail(nullptr, BTF_EINVAL, "bad pg_batch arguments");
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return fail(nullptr, BTF_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
@@ -1722,7 +1767,7 @@ int btf_pg_batch(int device, int64_t n, const double* b, const double* psi, uint
   PB(hipMalloc((void**)&dout, n * sizeof(double)));
   PB(hipMemcpy(db, b, n * sizeof(double), hipMemcpyHostToDevice));
   PB(hipMemcpy(dp, psi, n * sizeof(double), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(pg_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, db, dp, dout, (long long)n, seed);
+  hipLaunchKernelGGL(pg_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, db, dp, dout, (long long)n, seed, exact);
   PB(hipGetLastError());
   PB(hipDeviceSynchronize());
   PB(hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1868,6 +1913,9 @@ int btf_set_option(btf_ctx* c, int option, int value) {
       return BTF_OK;
     case BTF_OPT_NB_HISTOGRAMS:
       c->nb_hist = value != 0;
+      return BTF_OK;
+    case BTF_OPT_PG_EXACT:
+      c->pg_exact = value != 0;
       return BTF_OK;
     case BTF_OPT_FUSE_GRAM:
       c->fuse_gram = value != 0;

@@ -25,6 +25,12 @@ namespace btf {
 #ifndef BTF_ACC_UNR
 #define BTF_ACC_UNR 2
 #endif
+#ifndef BTF_ACC_PF_WT
+#define BTF_ACC_PF_WT 0   // weighted modes: software-pipelined accumulation loop (A/B aid; measured slower, see below)
+#endif
+#ifndef BTF_ACC_WAVES_WT
+#define BTF_ACC_WAVES_WT 16   // weighted modes, K <= 5: waves per workgroup
+#endif
 constexpr int ACC_WAVES = BTF_ACC_WAVES;   // waves per workgroup
 constexpr int ACC_THREADS = ACC_WAVES * WAVE;
 constexpr int ACC_TILE = 2 * WAVE;      // outputs per workgroup along the lane axis
@@ -37,8 +43,13 @@ constexpr int ACC_RG = (ACC_THREADS / ACC_TILE) < 4 ? (ACC_THREADS / ACC_TILE) :
 //         same row and the linear statistic is rescaled by C_src/C_own - the reference's
 //         stale cached weights (factor.py:349 and :394-401)
 // waves per workgroup: 16 wherever the accumulators fit 128 VGPRs (1024-thread launch bound);
-// the weighted modes of K >= 6 would spill there and run with 8 waves (256-VGPR budget)
-__host__ __device__ constexpr int acc_waves(int K, int MODE) { return (MODE >= 1 && K >= 6) ? 8 : ACC_WAVES; }
+// the weighted modes of K >= 6 would spill there and run with 8 waves (256-VGPR budget).
+// Measured (round 2, C3, profiles/README.md): the weighted modes are bound by the number of vector-memory
+// INSTRUCTIONS per row, not by occupancy or by the fused multiply-adds - one 1-KiB load per row runs at 11.5 us
+// (complete data), two loads per row (statistic + byte counts / f64 weights) at 20-23 us, four (stale-weight
+// gathers) at 28-35 us.  A software-pipelined loop (BTF_ACC_PF_WT=1), 12 or 8 waves per workgroup for a larger
+// register budget: all equal or slower.
+__host__ __device__ constexpr int acc_waves(int K, int MODE) { return MODE >= 1 ? (K >= 6 ? 8 : BTF_ACC_WAVES_WT) : ACC_WAVES; }
 
 // CT: storage type of the weights C: double (Binomial: the Polya-Gamma draws) or unsigned char (Gaussian data with
 // missing replicates: C is the replicate count 0..R, 1 byte instead of 8 per cell: 9 instead of 16 B/cell)
@@ -79,52 +90,76 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     s1 = srcmap[col + 1];
   }
 
-  for (int rb = r0 + wave; rb < r1; rb += ACC_WAVES * ACC_UNR) {
-    double2 x[ACC_UNR];
-    double2 c[MODE >= 1 ? ACC_UNR : 1];
+  struct Rows { double2 x[ACC_UNR]; double2 c[MODE >= 1 ? ACC_UNR : 1]; double2 cs[MODE == 2 ? ACC_UNR : 1]; };
+  auto load_rows = [&](int rb, Rows& R) {
 #pragma unroll
     for (int u = 0; u < ACC_UNR; ++u) {
       const int r = rb + u * ACC_WAVES;  // wave-uniform
       if (r < r1) {
-        x[u] = *reinterpret_cast<const double2*>(X + (size_t)r * ld + col);
+        R.x[u] = *reinterpret_cast<const double2*>(X + (size_t)r * ld + col);
         if constexpr (MODE >= 1) {
           if constexpr (sizeof(CT) == 1) {
             const uchar2 cc = *reinterpret_cast<const uchar2*>(Cx + (size_t)r * ld + col);
-            c[u] = make_double2((double)cc.x, (double)cc.y);
+            R.c[u] = make_double2((double)cc.x, (double)cc.y);
           } else {
-            c[u] = *reinterpret_cast<const double2*>(Cx + (size_t)r * ld + col);
+            R.c[u] = *reinterpret_cast<const double2*>(Cx + (size_t)r * ld + col);
           }
         }
-        if constexpr (MODE == 2) {
-          const double cs0 = (double)Cx[(size_t)r * ld + s0], cs1 = (double)Cx[(size_t)r * ld + s1];
-          if (s0 != (int)col) x[u].x = c[u].x != 0.0 ? x[u].x * cs0 / c[u].x : 0.0;
-          if (s1 != (int)col + 1) x[u].y = c[u].y != 0.0 ? x[u].y * cs1 / c[u].y : 0.0;
-          c[u] = make_double2(cs0, cs1);
-        }
+        if constexpr (MODE == 2) R.cs[u] = make_double2((double)Cx[(size_t)r * ld + s0], (double)Cx[(size_t)r * ld + s1]);
       } else {
-        x[u] = make_double2(0.0, 0.0);
-        if constexpr (MODE >= 1) c[u] = make_double2(0.0, 0.0);
+        R.x[u] = make_double2(0.0, 0.0);
+        if constexpr (MODE >= 1) R.c[u] = make_double2(0.0, 0.0);
+        if constexpr (MODE == 2) R.cs[u] = make_double2(0.0, 0.0);
       }
     }
+  };
+  auto compute = [&](int rb, Rows& R) {
 #pragma unroll
     for (int u = 0; u < ACC_UNR; ++u) {
+      if constexpr (MODE == 2) {           // stale cached weights: the source output's weight, the statistic rescaled
+        if (s0 != (int)col) R.x[u].x = R.c[u].x != 0.0 ? R.x[u].x * R.cs[u].x / R.c[u].x : 0.0;
+        if (s1 != (int)col + 1) R.x[u].y = R.c[u].y != 0.0 ? R.x[u].y * R.cs[u].y / R.c[u].y : 0.0;
+        R.c[u] = R.cs[u];
+      }
       const int r = min(rb + u * ACC_WAVES, r1 - 1);  // clamp: x/c are zero beyond r1
       const double* __restrict__ up = U + (size_t)r * K;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const double uk = up[k];
-        acc[k][0] = fma(x[u].x, uk, acc[k][0]);
-        acc[k][1] = fma(x[u].y, uk, acc[k][1]);
+        acc[k][0] = fma(R.x[u].x, uk, acc[k][0]);
+        acc[k][1] = fma(R.x[u].y, uk, acc[k][1]);
       }
       if constexpr (MODE >= 1) {
         const double* __restrict__ uup = UU + (size_t)r * KK;
 #pragma unroll
         for (int q = 0; q < KK; ++q) {
           const double uq = uup[q];
-          acc[K + q][0] = fma(c[u].x, uq, acc[K + q][0]);
-          acc[K + q][1] = fma(c[u].y, uq, acc[K + q][1]);
+          acc[K + q][0] = fma(R.c[u].x, uq, acc[K + q][0]);
+          acc[K + q][1] = fma(R.c[u].y, uq, acc[K + q][1]);
         }
       }
+    }
+  };
+  constexpr int STEP = ACC_WAVES * ACC_UNR;
+  constexpr bool PIPELINED = MODE >= 1 && BTF_ACC_PF_WT;      // (complete data: 5 FMAs per load, nothing to hide)
+  if constexpr (PIPELINED) {
+    Rows A, B;
+    int rb = r0 + wave;
+    if (rb < r1) load_rows(rb, A);
+    while (rb < r1) {
+      if (rb + STEP < r1) load_rows(rb + STEP, B);
+      compute(rb, A);
+      rb += STEP;
+      if (rb >= r1) break;
+      if (rb + STEP < r1) load_rows(rb + STEP, A);
+      compute(rb, B);
+      rb += STEP;
+    }
+  } else {
+    for (int rb = r0 + wave; rb < r1; rb += STEP) {
+      Rows A;
+      load_rows(rb, A);
+      compute(rb, A);
     }
   }
 
@@ -1082,22 +1117,42 @@ __device__ __forceinline__ double gamma_mt(double shape, CellRng& g) {
   }
 }
 
-__device__ __forceinline__ double pg_draw(double b, double psi, CellRng& g) {
-  if (!(b > 0.0)) return 0.0;
-  if (b >= PG_NORMAL_B) {
-    const double m = pg_mean_dev(b, psi), sd = sqrt(pg_var_dev(b, psi));
-    double x;
-    do { x = m + sd * g.normal(); } while (x <= 0.0);
-    return x;
-  }
+// ---- the two samplers -------------------------------------------------------------------------------------
+// PATH_SERIES (fast, approximate): sum-of-gammas series with a normal remainder, any 0 < b < PG_NORMAL_B.
+// PATH_EXACT:  Devroye's alternating-series sampler (Polson, Scott & Windle 2013, the algorithm of
+//              pypolyagamma's PyPolyaGamma.pgdrawv for integer b: factor.py:459) summed floor(b) times - exact;
+//              a fractional part of b is added as a 128-term series of exact f64 Gamma(frac) draws with the mean of
+//              the remainder (truncation: < 1e-6 of that part's variance).
+// b >= PG_NORMAL_B: moment-matched normal in both (pypolyagamma switches to a normal approximation at b > 170).
+enum { PG_PATH_SERIES = 0, PG_PATH_EXACT = 1 };
+
+__device__ __forceinline__ double pg_draw_normal(double b, double psi, CellRng& g) {
+  const double m = pg_mean_dev(b, psi), sd = sqrt(pg_var_dev(b, psi));
+  double x;
+  do { x = m + sd * g.normal(); } while (x <= 0.0);
+  return x;
+}
+
+__device__ __forceinline__ double pg_draw_exact(double b, double psi, CellRng& g) {
   const double fl = floor(b);
-  if (b == fl && b <= (double)PG_DEVROYE_MAX) {     // small integer b: sum of exact PG(1, psi) draws
-    const double z = 0.5 * fabs(psi);
-    const double p_exp = pg_mass_texpon(z);
-    double sum = 0.0;
-    for (int i = 0; i < (int)fl; ++i) sum += pg_one(z, p_exp, g);
-    return sum;
+  const double z = 0.5 * fabs(psi);
+  const double p_exp = pg_mass_texpon(z);
+  double sum = 0.0;
+  for (int i = 0; i < (int)fl; ++i) sum += pg_one(z, p_exp, g);
+  const double fr = b - fl;
+  if (fr > 0.0) {
+    const double c2 = psi * psi / (4.0 * PG_PI * PG_PI);
+    const double sc = sqrt(c2);
+    const int NT = 128 + (int)(2.0 * sc);
+    double sfr = 0.0;
+    for (int k = 1; k <= NT; ++k) sfr += gamma_mt<false>(fr, g) / ((k - 0.5) * (k - 0.5) + c2);
+    const double tmean = sc > 1e-4 * NT ? atan(sc / NT) / sc : 1.0 / NT;      // int_NT^inf dx / (x^2 + c2)
+    sum += (sfr + fr * tmean) / (2.0 * PG_PI * PG_PI);
   }
+  return sum;
+}
+
+__device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& g) {
   // any other b: PG(b, psi) = 1/(2 pi^2) sum_k g_k / ((k-1/2)^2 + c2), g_k ~ Gamma(b, 1), c2 = psi^2/(4 pi^2).
   // The first NT terms are drawn; the remainder - a sum of many comparably small independent terms -
   // enters through a normal with its exact mean  b int_NT^inf dx/(x^2+c2)  and variance
@@ -1150,15 +1205,43 @@ __device__ __forceinline__ double pg_draw(double b, double psi, CellRng& g) {
   return fmax(x, 1e-300) / (2.0 * PG_PI * PG_PI);
 }
 
+// which sampler a cell goes through.  exact_mode: every b below the normal range; otherwise the exact sampler
+// keeps the integer counts 1 and 2 (Bernoulli / two-trial data stay exact at one or two Devroye draws per cell)
+// and everything else takes the series.
+__device__ __forceinline__ int pg_path_of(double b, bool exact_mode) {
+  return (exact_mode || (b <= (double)PG_DEVROYE_MAX && b == floor(b))) ? PG_PATH_EXACT : PG_PATH_SERIES;
+}
+
+// one-call form (validation entry point, small problems): per-lane choice of the path
+__device__ __forceinline__ double pg_draw(double b, double psi, CellRng& g, bool exact_mode = false) {
+  if (!(b > 0.0)) return 0.0;
+  if (b >= PG_NORMAL_B) return pg_draw_normal(b, psi, g);
+  return pg_path_of(b, exact_mode) == PG_PATH_EXACT ? pg_draw_exact(b, psi, g) : pg_draw_series(b, psi, g);
+}
+
+
 constexpr int PG_THREADS = 256;
 
 // out[r][l] = PG(B[r][l], L[l0+l] . U[r]);  global cell id = base + r*stride_r + l*stride_l
-template <int K>
+// A launch handles the cells of ONE path (PATH) - the other path's cells are left to its own launch (the host
+// skips a launch no cell needs): each kernel carries one sampler's registers, not both.  `fill`: this launch also
+// writes the zeros of the cells without an observation and the normal-range draws (b >= PG_NORMAL_B).
+template <int PATH>
+__device__ __forceinline__ bool pg_cell(double b, double psi, bool exact_mode, bool fill, CellRng& g, double& om) {
+  if (!(b > 0.0)) { om = 0.0; return fill; }
+  if (b >= PG_NORMAL_B) { if (fill) om = pg_draw_normal(b, psi, g); return fill; }
+  if (pg_path_of(b, exact_mode) != PATH) return false;
+  om = PATH == PG_PATH_EXACT ? pg_draw_exact(b, psi, g) : pg_draw_series(b, psi, g);
+  return true;
+}
+
+template <int K, int PATH>
 __global__ __launch_bounds__(PG_THREADS, 2) void pg_kernel(const double* __restrict__ B, double* __restrict__ out,
                                                         const double* __restrict__ Lf, const double* __restrict__ Uf,
                                                         int nl, int ld, int Rdim, int rows_per_block,
                                                         unsigned long long base, unsigned long long stride_r,
-                                                        unsigned long long stride_l, unsigned long long seed) {
+                                                        unsigned long long stride_l, unsigned long long seed,
+                                                        int exact_mode, int fill) {
   const int l = blockIdx.x * PG_THREADS + threadIdx.x;
   if (l >= nl) return;
   double f[K];
@@ -1172,18 +1255,19 @@ __global__ __launch_bounds__(PG_THREADS, 2) void pg_kernel(const double* __restr
     for (int k = 0; k < K; ++k) psi = fma(f[k], u[k], psi);
     const double b = B[(size_t)r * ld + l];
     CellRng g(seed, base + (unsigned long long)r * stride_r + (unsigned long long)l * stride_l);
-    out[(size_t)r * ld + l] = pg_draw(b, psi, g);
+    double om;
+    if (pg_cell<PATH>(b, psi, exact_mode != 0, fill != 0, g, om)) out[(size_t)r * ld + l] = om;
   }
 }
 
 // One-pass variant for an unsharded context: every cell is drawn once (lanes along (j,t)),
 // written to the V-layout array directly and to the W-layout array through an LDS tile
 // transpose.  Same (seed, cell) streams as pg_kernel, hence identical draws.
-template <int K>
+template <int K, int PATH>
 __global__ __launch_bounds__(256, 2) void pg_tile_kernel(const double* __restrict__ Bv, double* __restrict__ Cv,
                                                      double* __restrict__ CwT, const double* __restrict__ W,
                                                      const double* __restrict__ V, int N, int MT, int ldv, int ldw,
-                                                     unsigned long long seed) {
+                                                     unsigned long long seed, int exact_mode, int fill) {
   __shared__ double tile[64][65];
   const int col = threadIdx.x & 63;
   const int rgrp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1195,16 +1279,19 @@ __global__ __launch_bounds__(256, 2) void pg_tile_kernel(const double* __restric
   for (int k = 0; k < K; ++k) v[k] = vc ? V[(size_t)jt * K + k] : 0.0;
   for (int q = 0; q < 16; ++q) {
     const int r = rgrp + 4 * q, i = i0 + r;               // wave-uniform
-    double om = 0.0;
-    if (i < N) {
+    double om = -1.0;                                      // < 0: not this launch's cell
+    if (i < N && vc) {
       const double* __restrict__ w = W + (size_t)i * K;
       double psi = 0.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) psi = fma(w[k], v[k], psi);
-      const double b = vc ? Bv[(size_t)i * ldv + jt] : 0.0;
+      const double b = Bv[(size_t)i * ldv + jt];
       CellRng g(seed, (unsigned long long)i * MT + jt);
-      om = pg_draw(b, psi, g);
-      if (vc) Cv[(size_t)i * ldv + jt] = om;
+      double x;
+      if (pg_cell<PATH>(b, psi, exact_mode != 0, fill != 0, g, x)) {
+        om = x;
+        Cv[(size_t)i * ldv + jt] = om;
+      }
     }
     tile[r][col] = om;
   }
@@ -1212,16 +1299,18 @@ __global__ __launch_bounds__(256, 2) void pg_tile_kernel(const double* __restric
   const int i = i0 + col;                                  // now lanes run along the rows
   for (int q = 0; q < 16; ++q) {
     const int c = rgrp + 4 * q, jj = jt0 + c;
-    if (jj < MT && i < N) CwT[(size_t)jj * ldw + i] = tile[col][c];
+    const double om = tile[col][c];
+    if (jj < MT && i < N && om >= 0.0) CwT[(size_t)jj * ldw + i] = om;
   }
 }
 
 // stand-alone batch of PG draws (validation entry point)
-__global__ void pg_batch_kernel(const double* b, const double* psi, double* out, long long n, unsigned long long seed) {
+__global__ void pg_batch_kernel(const double* b, const double* psi, double* out, long long n, unsigned long long seed,
+                                int exact_mode) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   CellRng g(seed, (unsigned long long)i);
-  out[i] = pg_draw(b[i], psi[i], g);
+  out[i] = pg_draw(b[i], psi[i], g, exact_mode != 0);
 }
 
 // ============================================================================

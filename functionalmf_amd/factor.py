@@ -715,9 +715,15 @@ class BinomialBayesianTensorFiltering(GaussianBayesianTensorFiltering):
     _queue_sse = False     # nu2 here is the tensor 1/omega (PG draw), not a variance to update from residuals
     _scalar_noise = False
 
-    def __init__(self, nrows, ncols, ndepth, pg_seed=42, **kwargs):
+    def __init__(self, nrows, ncols, ndepth, pg_seed=42, pg_exact=False, **kwargs):
+        """pg_exact: draw every omega ~ PG(N, psi) with Devroye's exact sampler summed N times (what pypolyagamma
+        does for integer N, factor.py:459); default False: exact for N in {1, 2}, the validated sum-of-gammas
+        series with a normal remainder for larger N (include/btf.h, BTF_OPT_PG_EXACT)."""
         super().__init__(nrows, ncols, ndepth, **kwargs)
         self.pg_seed = pg_seed
+        self.pg_exact = bool(pg_exact)
+        self.pg_sampler = "devroye-exact" if pg_exact else "devroye(N<=2)+gamma-series"
+        self._ctx.call("btf_set_option", _native.OPT_PG_EXACT, 1 if pg_exact else 0)
         self._pg_calls = 0
         self._nu2 = np.zeros((nrows, ncols, ndepth))
         self._omega_dev_new = False

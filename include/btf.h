@@ -70,7 +70,13 @@ enum {
   BTF_OPT_SAMPLER = 0,       /* V half-sweep sampler, BTF_SAMPLER_*                                   */
   BTF_OPT_NB_HISTOGRAMS = 1, /* 1 (default): Negative-Binomial rate update from per-row count
                                 histograms where they apply; 0: always the full-tensor kernel          */
-  BTF_OPT_FUSE_GRAM = 2      /* 1 (default): W'W / V'V partials come out of the preceding solve kernel */
+  BTF_OPT_FUSE_GRAM = 2,     /* 1 (default): W'W / V'V partials come out of the preceding solve kernel */
+  BTF_OPT_PG_EXACT = 3       /* Polya-Gamma sampler of btf_pg_draw.  0 (default): integer trial counts 1 and 2 by
+                                Devroye's exact alternating-series sampler, every other count by the sum-of-gammas
+                                series with a normal remainder (approximate; validated against the exact sampler).
+                                1: the exact sampler for every count below 200 - floor(b) Devroye draws, as
+                                pypolyagamma does for integer b (factor.py:459) - plus a 128-term series for a
+                                fractional part.  Counts >= 200: moment-matched normal in both modes.           */
 };
 enum {
   BTF_SAMPLER_BANDED = 0,   /* block-banded LDL' in the declared elimination order (btf_get_V_order):
@@ -246,6 +252,8 @@ int btf_pg_draw(btf_ctx* ctx, uint64_t seed);
 /* Stand-alone batch of PG(b_i, psi_i) draws from the same device sampler (used to
  * validate its distribution; element i uses the Philox stream (seed, i)).      */
 int btf_pg_batch(int device, int64_t n, const double* b, const double* psi, uint64_t seed, double* out);
+/* the same with the sampler of BTF_OPT_PG_EXACT chosen by `exact` (0 / 1) */
+int btf_pg_batch_mode(int device, int64_t n, const double* b, const double* psi, uint64_t seed, int exact, double* out);
 
 int btf_sync(btf_ctx* ctx); /* waits; returns BTF_ENOTPD if a step failed since the last sync */
 

@@ -117,8 +117,8 @@ def c4():
     return Ys, Nt
 
 
-@pytest.mark.parametrize("compat", ["reference", "exact"])
-def test_c4_binomial_full_size_pg_draw_and_weighted_half_sweeps(c4, compat):
+@pytest.mark.parametrize("compat,pg_exact", [("reference", False), ("exact", False), ("exact", True)])
+def test_c4_binomial_full_size_pg_draw_and_weighted_half_sweeps(c4, compat, pg_exact):
     """factor.py:437-460 at BASELINE config 4.  The device Polya-Gamma draw is checked against the closed-form
     moments over all 8.4 M cells, then - GIVEN that omega (btf_get_omega) - the weighted W and V half-sweeps
     against the oracle from identical state and normals (compat="reference": rows >= K reuse row K-1's weights
@@ -131,7 +131,7 @@ def test_c4_binomial_full_size_pg_draw_and_weighted_half_sweeps(c4, compat):
     #  factorisations in different orders agree only to cond * eps ~ 5e-6 - see the C3 mean-term test above)
     tau0 = np.random.RandomState(4).gamma(2.0, 0.5, size=(M, 3 * T - 1))
     model = BinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, compat=compat,
-                                            Tau2_init=tau0)
+                                            Tau2_init=tau0, pg_exact=pg_exact)
     model.V = 0.5 * model.V                                    # keep |psi| moderate under the prior draw
     W0, V0 = model.W.copy(), model.V.copy()
     model._resample_nu2((Ys, Nt))

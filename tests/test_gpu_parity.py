@@ -252,16 +252,63 @@ def test_binomial_exact_mode_differs_from_reference_quirk(golden):
     assert relerr(model.W, g["W_after"]) > 1e-3
 
 
-def pg_batch(b, psi, seed):
+def pg_batch(b, psi, seed, exact=False):
     import ctypes as C
     from functionalmf_amd import _native
     lib = _native.load()
     b = _native.as_f64(b)
     psi = _native.as_f64(psi)
     out = np.empty_like(b)
-    rc = lib.btf_pg_batch(0, b.size, _native.dptr(b), _native.dptr(psi), C.c_uint64(seed), _native.dptr(out))
+    rc = lib.btf_pg_batch_mode(0, b.size, _native.dptr(b), _native.dptr(psi), C.c_uint64(seed), 1 if exact else 0, _native.dptr(out))
     assert rc == 0, lib.btf_last_error(None)
     return out
+
+
+def _cumulants3(x):
+    m = x.mean()
+    d = x - m
+    return m, (d * d).mean(), (d * d * d).mean()
+
+
+@pytest.mark.parametrize("b", [3, 4, 8, 4.3])
+@pytest.mark.parametrize("c", [0.0, 1.0, 5.0, 20.0])
+def test_pg_series_sampler_against_exact_sampler(b, c):
+    """A/B of the two device samplers (BTF_OPT_PG_EXACT): the default sum-of-gammas series (4 drawn Gamma(b)
+    terms + 2|psi|/2pi, f32-transcendental variates, normal remainder) against Devroye's exact sampler summed
+    floor(b) times (+ a 128-term f64 series for a fractional part) - the algorithm pypolyagamma runs for
+    integer b (factor.py:459).  b = 4 is config C4's trial count.  2e6 draws each: two-sample KS and
+    Anderson-Darling (tail-weighted), and the first three cumulants - the exact sampler's against the closed
+    forms, the series sampler's against the exact sampler's within Monte-Carlo error."""
+    from scipy.stats import ks_2samp, anderson_ksamp
+    from oracle import btf_oracle as orc
+    n = 2000000 if b == int(b) else 400000
+    x = pg_batch(np.full(n, float(b)), np.full(n, c), seed=9000 + int(10 * b) + int(c))
+    y = pg_batch(np.full(n, float(b)), np.full(n, c), seed=19000 + int(10 * b) + int(c), exact=True)
+    assert np.all(x > 0) and np.all(y > 0)
+    assert ks_2samp(x, y).pvalue > 1e-3
+    ad = anderson_ksamp([x[:400000], y[:400000]])
+    assert ad.statistic < ad.critical_values[-1], (ad.statistic, ad.critical_values)      # 0.1 % level
+    m, v = float(orc.pg_mean(b, c)), float(orc.pg_var(b, c))
+    mx, vx, tx = _cumulants3(x)
+    my, vy, ty = _cumulants3(y)
+    se = np.sqrt(v / n)
+    assert abs(my - m) < 5 * se and abs(mx - m) < 5 * se, (mx, my, m)
+    k4 = ((y - my) ** 4).mean()
+    sev = np.sqrt((k4 - v * v) / n)
+    assert abs(vy - v) < 6 * sev and abs(vx - v) < 6 * sev + 2e-3 * v, (vx, vy, v)
+    se3 = np.sqrt(((y - my) ** 6).mean() / n) * 1.5
+    assert abs(tx - ty) < 6 * se3 + 0.02 * abs(ty), (tx, ty)
+
+
+@pytest.mark.parametrize("b,c", [(1, 0.0), (2, 3.0), (4, 1.0), (7, 0.5), (2.5, 2.0), (0.4, 1.0)])
+def test_pg_exact_sampler_ks_against_definition(b, c):
+    """The exact device sampler against the oracle's 256-term definition-based sampler."""
+    from scipy.stats import ks_2samp
+    from oracle import btf_oracle as orc
+    n = 100000
+    x = pg_batch(np.full(n, float(b)), np.full(n, c), seed=31, exact=True)
+    y = orc.pg_draw_series(b, c, n, np.random.default_rng(5))
+    assert ks_2samp(x, y).pvalue > 1e-3
 
 
 @pytest.mark.parametrize("b", [1, 2, 4, 10, 1.3, 7.5, 13, 40, 33.7, 100.5, 300])

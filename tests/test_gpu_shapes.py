@@ -177,3 +177,24 @@ def test_bw15_indefinite_column_is_reported_and_jitter_recovers(variant):
     if not order_dependent:
         assert relerr(m.V, ref.V) < 1e-8
     assert np.isfinite(m.V).all()
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_long_depth_axis_band_in_hbm_scratch(weighted):
+    """K*T = 3700 (the size of the reference's flu-trends application: flutrends/, 370 weeks x 10 embeddings):
+    the block-banded factor does not fit the 160 KB of LDS, so the any-size kernel keeps the band in HBM scratch
+    and only the vectors on chip.  One column block against the oracle from identical state and normals."""
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    from oracle import btf_oracle as orc
+    N, M, T, R, K, tf = 12, 2, 370, 2, 10, 2
+    Y, st = make_case(N, M, T, R, K, tf, weighted, seed=77)
+    model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                            nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], sampler="banded")
+    np.random.seed(5)
+    zv = np.random.normal(size=(M, K * T))
+    np.random.seed(5)
+    model._resample_V(Y)
+    assert model.v_sampler() == "generic"
+    ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    orc.v_step(ost, Y, orc.trend_penalty(T, tf), z=zv, perm=orc.perm_from_order(model.v_order(), K, T))
+    assert relerr(model.V, ost["V"]) < 1e-8
