@@ -22,7 +22,7 @@ HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith("
 BTF_OK, BTF_EINVAL, BTF_EHIP, BTF_ENOTPD, BTF_ESTATE = 0, 1, 2, 3, 4
 COMPAT = {"reference": 0, "exact": 1}
 KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw", "nb_loglik",
-                "prior_band", "gram_eig", "hyper"]
+                "prior_band", "gram_eig", "hyper", "ess"]
 OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT = 0, 1, 2, 3
 SAMPLERS = {"banded": 0, "spectral": 1, "chain": 2, "generic": 3, "banded_nopanel": 4}
 
@@ -81,6 +81,10 @@ SIGNATURES = {
     "btf_collect_end": (C.c_int, [_ctx, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
     "btf_collect_summary": (C.c_int, [_ctx, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp]),
     "btf_sync": (C.c_int, [_ctx]),
+    "btf_ess_begin": (C.c_int, [_ctx, C.c_int, _c_dp, C.c_uint64, C.c_double, C.c_int]),
+    "btf_ess_eval": (C.c_int, [_ctx, C.c_int, C.c_double, C.c_int, C.c_int, _c_dp]),
+    "btf_ess_run": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _c_dp, C.c_uint64, C.c_int, C.c_double, C.c_int]),
+    "btf_ess_info": (C.c_int, [_ctx, _c_ip, _c_dp]),
     "btf_mvn_banded": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_uint64,
                                  C.c_double, C.c_int, _c_dp, _c_ip]),
     "btf_set_profiling": (C.c_int, [_ctx, C.c_int]),

@@ -6,6 +6,7 @@
 #include "btf_banded_fast.h"
 #include "btf_banded_twist.h"
 #include "btf_spectral.h"
+#include "btf_ess.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -58,6 +59,9 @@ struct btf_ctx {
   int rpb_w = 0, rpb_v = 0;
   int sampler = BTF_SAMPLER_BANDED;   // BTF_OPT_SAMPLER
   double* eig = nullptr;              // gram_eig_kernel output (spectral sampler): K eigenvalues, K*K vectors, sweeps
+  // elliptical slice sampling (btf_ess_*): current state, prior draw, per-chain {hh, lo, hi, theta, ll}, partial sums
+  double* essX0 = nullptr; double* essNu = nullptr; double* ess_st = nullptr; double* ess_theta = nullptr; int* ess_done = nullptr;
+  double* ess_part = nullptr; size_t ess_part_elems = 0; int ess_last_chains = 0;
   long long* dbg = nullptr;
   double* pband = nullptr;
   double* Ta = nullptr; double* Tb = nullptr; double* Tc = nullptr; double* lsum = nullptr;   // horseshoe+ chain (device mode)
@@ -431,10 +435,10 @@ hipError_t dispatch_vbanded_twist(btf_ctx* c, const VBandArgs& a, int bw, size_t
   return hipSuccess;
 }
 // which sampler a V half-sweep of this context will use: 3 spectral, 2 twisted, 1 single chain (LDS), -1 generic
-int banded_choice(const btf_ctx* c) {
+int banded_choice(const btf_ctx* c, bool allow_spectral = true) {
   const int bw = (c->TF + 1) * c->K;
   const bool wt = c->weighted;
-  if (c->sampler == BTF_SAMPLER_SPECTRAL && !wt && !c->binomial && c->st_dense_ok && vs_lds_bytes(c->T, c->K, c->TF, c->nD) <= 160 * 1024) return 3;
+  if (allow_spectral && c->sampler == BTF_SAMPLER_SPECTRAL && !wt && !c->binomial && c->st_dense_ok && vs_lds_bytes(c->T, c->K, c->TF, c->nD) <= 160 * 1024) return 3;
   if (c->sampler == BTF_SAMPLER_GENERIC || bw < 3) return -1;
   if (c->sampler != BTF_SAMPLER_CHAIN && twist_ok(c->T, c->K, c->TF) && tw_lds_bytes(c->T, c->K, c->TF, wt) <= 160 * 1024) return 2;
   if (vb_fast_lds_bytes(c->T, c->K, c->TF, wt) <= 158 * 1024) return 1;
@@ -460,6 +464,34 @@ void launch_sse(btf_ctx* c, const double* A, const double* C, double Rc, int nco
                         (const double*)c->V, c->N, ncols, ld, rpb, (size_t)c->col0 * c->T, c->bsum);
   else p.launch(sse_kernel<K>, grid, dim3(SSE_THREADS), 0, A, C, Rc, (const double*)c->W, (const double*)c->V, c->N, ncols, ld, rpb,
                 (size_t)c->col0 * c->T, c->bsum);
+}
+
+// log-likelihood partials of the current W, V: rows layout (joint chains and per-row chains) or columns layout
+template <int K>
+void launch_ess_ll(btf_ctx* c, int what, int mode, int link, int nbx) {
+  Prof p(c, BTF_K_ESS);
+  const double Rc = (double)c->R;
+  const unsigned char* c8v = c->C8_v; const unsigned char* c8w = c->C8_wT;
+  if (what == 1 && mode == 1) {      // per-column chains: W layout
+    dim3 grid(nbx, c->M);
+#define ESS_COLS(LINK_)                                                                                                   \
+    if (c8w) p.launch(poisson_ll_cols_kernel<K, LINK_, unsigned char>, grid, dim3(ESS_THREADS), 0, (const double*)c->A_wT, c8w, Rc, \
+                      (const double*)c->W, (const double*)c->V, 0, c->N, c->ldw, 0, c->T, (const int*)c->ess_done, c->ess_part);   \
+    else p.launch(poisson_ll_cols_kernel<K, LINK_, double>, grid, dim3(ESS_THREADS), 0, (const double*)c->A_wT, (const double*)c->C_wT, Rc, \
+                  (const double*)c->W, (const double*)c->V, 0, c->N, c->ldw, 0, c->T, (const int*)c->ess_done, c->ess_part);
+    if (link == ESS_LINK_LOG) { ESS_COLS(ESS_LINK_LOG) } else { ESS_COLS(ESS_LINK_IDENTITY) }
+#undef ESS_COLS
+  } else {
+    dim3 grid(nbx, c->N);
+    const int per_row = (what == 0 && mode == 1) ? 1 : 0;
+#define ESS_ROWS(LINK_)                                                                                                   \
+    if (c8v) p.launch(poisson_ll_rows_kernel<K, LINK_, unsigned char>, grid, dim3(ESS_THREADS), 0, (const double*)c->A_v, c8v, Rc,  \
+                      (const double*)c->W, (const double*)c->V, 0, c->M * c->T, c->ldv, (size_t)0, (const int*)c->ess_done, per_row, c->ess_part); \
+    else p.launch(poisson_ll_rows_kernel<K, LINK_, double>, grid, dim3(ESS_THREADS), 0, (const double*)c->A_v, (const double*)c->C_v, Rc, \
+                  (const double*)c->W, (const double*)c->V, 0, c->M * c->T, c->ldv, (size_t)0, (const int*)c->ess_done, per_row, c->ess_part);
+    if (link == ESS_LINK_LOG) { ESS_ROWS(ESS_LINK_LOG) } else { ESS_ROWS(ESS_LINK_IDENTITY) }
+#undef ESS_ROWS
+  }
 }
 
 #define K_SWITCH(K, CALL)                                          \
@@ -640,7 +672,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->WW, c->VV, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->st_drow, c->st_dcoef, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
@@ -1002,6 +1034,78 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
 }
 
 // ---------------------------------------------------------------------------- V
+// The banded samplers of the V half-sweep (twisted / single chain / any-size), writing the draw of every local
+// column to `out`.  prior_only: the likelihood part is switched off (no partials, no Gram) - a draw from the
+// prior N(0, (I_K (x) Delta' Lambda_j Delta)^-1) in the same declared order (elliptical slice sampling, btf_ess_*).
+static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t seed, int nch, bool use_gw, double eps0,
+                             int attempts, double* out, bool prior_only) {
+  const int K = c->K, KK = c->KK, T = c->T, n = T * K;
+  const bool wt = c->weighted;
+  const bool whole = c->nl == c->N && c->ml == c->M;
+  int rc;
+  const int bw = (c->TF + 1) * K, R1 = bw + 1, D1 = c->TF + 2;
+  size_t lds_fixed = (size_t)(3 * n + T * D1 + (wt ? T * KK : KK) + (bw * (bw + 1) / 2 + 3) / 4) * sizeof(double);
+  size_t lds_band = (size_t)n * R1 * sizeof(double);
+  size_t lds_bytes = lds_fixed + lds_band;
+  VBandArgs a{};
+  if (lds_bytes > 150 * 1024) {  // band lives in HBM scratch, only vectors on chip
+    if (lds_fixed > 150 * 1024) return fail(c, BTF_EINVAL, "ndepth*nembeds too large for the on-chip vectors");
+    if (!c->gband || c->gband_stride != (size_t)n * R1) {
+      if ((rc = dev_alloc(c, &c->gband, (size_t)c->ml * n * R1))) return rc;
+      c->gband_stride = (size_t)n * R1;
+    }
+    a.gband = c->gband; a.gband_stride = c->gband_stride;
+    lds_bytes = lds_fixed;
+  }
+  a.part = c->part; a.nch = nch; a.ld = c->ldv; a.weighted = wt ? 1 : 0;
+  a.gpart = use_gw ? c->gpart_w : c->gpart; a.ngp = use_gw ? c->ngp_w : GRAM_BLOCKS;
+  a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
+  a.sR = a.s * c->R;
+  a.Tau2 = c->Tau2; a.lam2 = c->lam2; a.nD = c->nD;
+  a.hyp = c->dev_scalars ? c->hyp : nullptr; a.Rrep = c->R; a.hyp_noise = c->binomial ? 0 : 1;
+  a.panel4 = c->sampler == BTF_SAMPLER_BANDED_NOPANEL ? 0 : 1;
+  a.st_ptr = c->st_ptr; a.st_row = c->st_row; a.st_coef = c->st_coef;
+  a.T = T; a.TF = c->TF; a.col0 = c->col0; a.ml = c->ml;
+  a.V = c->V; a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_v + 0x10001ULL;
+  a.eps0 = eps0; a.attempts = attempts; a.status = c->status; a.tries = c->tries; a.dbg = c->dbg;
+  if (prior_only) { a.nch = 0; a.ngp = 0; a.s = 0.0; a.sR = 0.0; a.hyp_noise = 0; }
+  a.V = out;
+  hipError_t e = hipSuccess;
+  bool handled = false;
+  const bool fast = choice >= 0;
+  if (fast) {
+    const int TD1 = T * D1;
+    if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; }
+    {   // rebuilt on every call, as the reference rebuilds Q_prior per column (factor.py:404-405)
+      Prof p(c, BTF_K_PRIOR);
+      p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
+               (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
+               (const double*)(c->dev_scalars ? c->hyp : nullptr));
+    }
+    a.pband = c->pband;
+  }
+  // V'V partials for the next W half-sweep (one KK block per column; bounded by the consumer's LDS stage)
+  const bool emit_gv = !prior_only && fast && whole && c->fuse_gram && !wt &&
+                       (size_t)c->ml * KK + 16 * KK <= (size_t)ws_split(K) * (K + KK) * WS_ROWS;   // w_solve's LDS stage
+  if (emit_gv) {
+    if (!c->gpart_v) { if ((rc = dev_alloc(c, &c->gpart_v, (size_t)c->M * KK))) return rc; }
+    a.gout = c->gpart_v;
+  }
+  if (!prior_only) { c->ngp_v = emit_gv ? c->ml : 0; c->ngp_w = 0; }
+  if (choice == 2) {
+    if ((rc = make_fill_table(c, wt))) return rc;
+    a.fill = c->fill_tab; a.nfill = c->fill_n;
+    e = dispatch_vbanded_twist(c, a, bw, tw_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
+  }
+  HIPCHK(c, e);
+  if (fast && !handled) e = dispatch_vbanded_fast(c, a, bw, vb_fast_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
+  HIPCHK(c, e);
+  if (!handled) { a.gout = nullptr; if (!prior_only) c->ngp_v = 0; }
+  if (!handled) { K_SWITCH(K, e = launch_vbanded<KT>(c, a, lds_bytes)); }
+  HIPCHK(c, e);
+  return BTF_OK;
+}
+
 int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, double eps0, int attempts) {
   if (!c) return BTF_EINVAL;
   if (!c->have_data || !c->have_V || !c->have_W || !c->have_hyper) return fail(c, BTF_ESTATE, "set data, W, V and hyper-parameters first");
@@ -1039,45 +1143,19 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       side = EigSide{use_gw ? c->gpart_w : c->gpart, use_gw ? c->ngp_w : GRAM_BLOCKS, K, c->eig};
     }
     K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->WW, c->srcmap_v, c->N, c->ldv, rpb, nch, side));
-    const int bw = (c->TF + 1) * K, R1 = bw + 1, D1 = c->TF + 2;
-    size_t lds_fixed = (size_t)(3 * n + T * D1 + (wt ? T * KK : KK) + (bw * (bw + 1) / 2 + 3) / 4) * sizeof(double);
-    size_t lds_band = (size_t)n * R1 * sizeof(double);
-    size_t lds_bytes = lds_fixed + lds_band;
-    VBandArgs a{};
-    if (lds_bytes > 150 * 1024) {  // band lives in HBM scratch, only vectors on chip
-      if (lds_fixed > 150 * 1024) return fail(c, BTF_EINVAL, "ndepth*nembeds too large for the on-chip vectors");
-      if (!c->gband || c->gband_stride != (size_t)n * R1) {
-        if ((rc = dev_alloc(c, &c->gband, (size_t)c->ml * n * R1))) return rc;
-        c->gband_stride = (size_t)n * R1;
-      }
-      a.gband = c->gband; a.gband_stride = c->gband_stride;
-      lds_bytes = lds_fixed;
-    }
-    a.part = c->part; a.nch = nch; a.ld = c->ldv; a.weighted = wt ? 1 : 0;
-    a.gpart = use_gw ? c->gpart_w : c->gpart; a.ngp = use_gw ? c->ngp_w : GRAM_BLOCKS;
-    a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
-    a.sR = a.s * c->R;
-    a.Tau2 = c->Tau2; a.lam2 = c->lam2; a.nD = c->nD;
-    a.hyp = c->dev_scalars ? c->hyp : nullptr; a.Rrep = c->R; a.hyp_noise = c->binomial ? 0 : 1;
-    a.panel4 = c->sampler == BTF_SAMPLER_BANDED_NOPANEL ? 0 : 1;
-    a.st_ptr = c->st_ptr; a.st_row = c->st_row; a.st_coef = c->st_coef;
-    a.T = T; a.TF = c->TF; a.col0 = c->col0; a.ml = c->ml;
-    a.V = c->V; a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_v + 0x10001ULL;
-    a.eps0 = eps0; a.attempts = attempts; a.status = c->status; a.tries = c->tries; a.dbg = c->dbg;
     hipError_t e = hipSuccess;
-    bool handled = false;
-    const bool fast = choice >= 0;
     if (choice == 3) {
       // spectral sampler (complete data): K scalar banded systems per column in the eigen-basis of the Gram
       VSpecArgs sa{};
       sa.part = c->part; sa.nch = nch; sa.ld = c->ldv; sa.eig = c->eig;
-      sa.s = a.s; sa.sR = a.sR; sa.Tau2 = c->Tau2; sa.lam2 = c->lam2; sa.nD = c->nD;
+      sa.s = c->binomial ? 1.0 : 1.0 / c->nu2; sa.sR = sa.s * c->R;
+      sa.Tau2 = c->Tau2; sa.lam2 = c->lam2; sa.nD = c->nD;
       sa.st_ptr = c->st_ptr; sa.st_row = c->st_row; sa.st_coef = c->st_coef;
       sa.st_drow = c->st_drow; sa.st_dcoef = c->st_dcoef;
       sa.T = T; sa.TF = c->TF; sa.K = K; sa.col0 = c->col0; sa.ml = c->ml;
-      sa.V = c->V; sa.z = dz; sa.seed = seed; sa.stream = a.stream;
+      sa.V = c->V; sa.z = dz; sa.seed = seed; sa.stream = 2 * c->sweep_v + 0x10001ULL;
       sa.eps0 = eps0; sa.attempts = attempts; sa.status = c->status; sa.tries = c->tries;
-      sa.hyp = a.hyp; sa.Rrep = a.Rrep; sa.hyp_noise = a.hyp_noise; sa.dbg = c->dbg;
+      sa.hyp = c->dev_scalars ? c->hyp : nullptr; sa.Rrep = c->R; sa.hyp_noise = c->binomial ? 0 : 1; sa.dbg = c->dbg;
       const bool emit = whole && c->fuse_gram &&
                         (size_t)c->ml * KK + 16 * KK <= (size_t)ws_split(K) * (K + KK) * WS_ROWS;   // w_solve's LDS stage
       if (emit) {
@@ -1100,43 +1178,196 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       HIPCHK(c, hipGetLastError());
       return BTF_OK;
     }
-    if (fast) {
-      const int TD1 = T * D1;
-      if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; }
-      {   // rebuilt on every call, as the reference rebuilds Q_prior per column (factor.py:404-405)
-        Prof p(c, BTF_K_PRIOR);
-        p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
-                 (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
-                 (const double*)(c->dev_scalars ? c->hyp : nullptr));
-      }
-      a.pband = c->pband;
-    }
-    // V'V partials for the next W half-sweep (one KK block per column; bounded by the consumer's LDS stage)
-    const bool emit_gv = fast && whole && c->fuse_gram && !wt &&
-                         (size_t)c->ml * KK + 16 * KK <= (size_t)ws_split(K) * (K + KK) * WS_ROWS;   // w_solve's LDS stage
-    if (emit_gv) {
-      if (!c->gpart_v) { if ((rc = dev_alloc(c, &c->gpart_v, (size_t)c->M * KK))) return rc; }
-      a.gout = c->gpart_v;
-    }
-    c->ngp_v = emit_gv ? c->ml : 0;
-    c->ngp_w = 0;
-    if (choice == 2) {
-      if ((rc = make_fill_table(c, wt))) return rc;
-      a.fill = c->fill_tab; a.nfill = c->fill_n;
-      e = dispatch_vbanded_twist(c, a, bw, tw_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
-    }
-    HIPCHK(c, e);
-    if (fast && !handled) e = dispatch_vbanded_fast(c, a, bw, vb_fast_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
-    HIPCHK(c, e);
-    if (!handled) { a.gout = nullptr; c->ngp_v = 0; }
-    if (!handled) { K_SWITCH(K, e = launch_vbanded<KT>(c, a, lds_bytes)); }
-    HIPCHK(c, e);
+    if ((rc = v_banded_dispatch(c, choice, dz, seed, nch, use_gw, eps0, attempts, c->V, false))) return rc;
   }
   c->sweep_v++;
   c->nb_L_valid = false;
   c->w_part_valid = false;
   HIPCHK(c, hipGetLastError());
   return BTF_OK;
+}
+
+// ------------------------------------------------------------------ elliptical slice sampling
+namespace {
+struct EssDims { int nchains, per, nbx, nsum; long long n; };
+int ess_alloc(btf_ctx* c) {
+  if (c->essX0) return BTF_OK;
+  const size_t nx = std::max((size_t)c->N * c->K, (size_t)c->M * c->T * c->K);
+  const size_t nc = (size_t)std::max(std::max(c->N, c->M), 1);
+  int rc;
+  if ((rc = dev_alloc(c, &c->essX0, nx))) return rc;
+  if ((rc = dev_alloc(c, &c->essNu, nx))) return rc;
+  if ((rc = dev_alloc(c, &c->ess_st, nc * 5))) return rc;
+  if ((rc = dev_alloc(c, &c->ess_theta, nc))) return rc;
+  if ((rc = dev_alloc(c, &c->ess_done, nc))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->ess_done, 0, nc * sizeof(int), c->stream));
+  return BTF_OK;
+}
+int ess_check(btf_ctx* c, int what, int link) {
+  if (what < 0 || what > 1 || link < 0 || link > 1) return fail(c, BTF_EINVAL, "bad elliptical-slice arguments");
+  if (!c->have_data || c->binomial || !c->have_W || !c->have_V || !c->have_hyper)
+    return fail(c, BTF_ESTATE, "elliptical slice sampling needs count data (btf_set_data_gaussian statistics), W, V and hyper-parameters");
+  if (c->nl != c->N || c->ml != c->M) return fail(c, BTF_ESTATE, "elliptical slice sampling needs an unsharded context");
+  return BTF_OK;
+}
+EssDims ess_dims(const btf_ctx* c, int what, int mode) {
+  EssDims d;
+  d.n = what == 0 ? (long long)c->N * c->K : (long long)c->M * c->T * c->K;
+  if (mode == 0) {                                   // joint: one chain over everything, rows-layout partials
+    d.nchains = 1; d.per = 0;
+    d.nbx = std::max(1, std::min((c->M * c->T + ESS_THREADS - 1) / ESS_THREADS, std::max(1, 2048 / std::max(c->N, 1))));
+    d.nsum = c->N * d.nbx;
+  } else if (what == 0) {                            // a chain per row
+    d.nchains = c->N; d.per = c->K;
+    d.nbx = std::max(1, std::min((c->M * c->T + ESS_THREADS - 1) / ESS_THREADS, std::max(1, 2048 / std::max(c->N, 1))));
+    d.nsum = d.nbx;
+  } else {                                           // a chain per column
+    d.nchains = c->M; d.per = c->T * c->K;
+    d.nbx = std::max(1, std::min((c->N + ESS_THREADS - 1) / ESS_THREADS, std::max(1, 2048 / std::max(c->M, 1))));
+    d.nsum = d.nbx;
+  }
+  return d;
+}
+int ess_ensure_part(btf_ctx* c, const EssDims& d) {
+  const size_t need = (size_t)std::max(c->N, c->M) * d.nbx;
+  if (need > c->ess_part_elems) {
+    int rc = dev_alloc(c, &c->ess_part, need);
+    if (rc) return rc;
+    c->ess_part_elems = need;
+  }
+  return BTF_OK;
+}
+// X0 <- current state, Nu <- prior draw (W: sigma z on the free entries; V: the banded sampler with the likelihood off)
+int ess_begin(btf_ctx* c, int what, const double* z, uint64_t seed, double eps0, int attempts) {
+  int rc;
+  if ((rc = ess_alloc(c))) return rc;
+  const int K = c->K, n = c->T * K;
+  if (what == 0) {
+    const size_t nw = (size_t)c->N * K;
+    HIPCHK(c, hipMemcpyAsync(c->essX0, c->W, nw * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    const double* dz = nullptr;
+    if (z) {
+      const size_t nz = (size_t)w_z_offset(c->N, K);
+      if ((rc = ensure_z(c, nz))) return rc;
+      HIPCHK(c, hipMemcpyAsync(c->zbuf, z, nz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      dz = c->zbuf;
+    }
+    Prof p(c, BTF_K_ESS);
+    p.launch(ess_w_prior_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, c->essNu, c->N, K, c->sigma2,
+             (const double*)(c->dev_scalars ? c->hyp : nullptr), dz, (unsigned long long)seed, 2 * c->sweep_w + 0x20000ULL);
+    c->sweep_w++;
+  } else {
+    const size_t nv = (size_t)c->M * n;
+    HIPCHK(c, hipMemcpyAsync(c->essX0, c->V, nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    const double* dz = nullptr;
+    if (z) {
+      if ((rc = ensure_z(c, nv))) return rc;
+      HIPCHK(c, hipMemcpyAsync(c->zbuf, z, nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      dz = c->zbuf;
+    }
+    if ((rc = ensure_part(c, 1))) return rc;
+    if ((rc = v_banded_dispatch(c, banded_choice(c, false), dz, seed, 0, false, eps0, attempts, c->essNu, true))) return rc;
+    c->sweep_v++;
+  }
+  HIPCHK(c, hipGetLastError());
+  return BTF_OK;
+}
+}  // namespace
+
+int btf_ess_begin(btf_ctx* c, int what, const double* z, uint64_t seed, double eps0, int attempts) {
+  if (!c) return BTF_EINVAL;
+  int rc;
+  if ((rc = ess_check(c, what, 0))) return rc;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if ((rc = ess_begin(c, what, z, seed, eps0, attempts < 0 ? 0 : attempts))) return rc;
+  // one joint chain: not done
+  HIPCHK(c, hipMemsetAsync(c->ess_done, 0, sizeof(int), c->stream));
+  return BTF_OK;
+}
+
+int btf_ess_eval(btf_ctx* c, int what, double theta, int current, int link, double* ll) {
+  if (!c || !ll) return BTF_EINVAL;
+  int rc;
+  if ((rc = ess_check(c, what, link))) return rc;
+  if (!c->essX0) return fail(c, BTF_ESTATE, "btf_ess_eval follows btf_ess_begin");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const EssDims d = ess_dims(c, what, 0);
+  if ((rc = ess_ensure_part(c, d))) return rc;
+  if (!current) {
+    HIPCHK(c, hipMemcpyAsync(c->ess_theta, &theta, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // theta is a host temporary
+    Prof p(c, BTF_K_ESS);
+    p.launch(ess_combine_kernel, dim3((unsigned)((d.n + 255) / 256)), dim3(256), 0, (const double*)c->essX0, (const double*)c->essNu,
+             what == 0 ? c->W : c->V, d.n, 0, (const double*)c->ess_theta, (const int*)c->ess_done, 0);
+    if (what == 0) { c->ngp_w = 0; c->w_part_valid = false; } else { c->ngp_v = 0; c->w_part_valid = false; }
+    c->nb_L_valid = false;
+  }
+  K_SWITCH(c->K, launch_ess_ll<KT>(c, what, 0, link, d.nbx));
+  HIPCHK(c, hipGetLastError());
+  std::vector<double> h((size_t)d.nsum);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->ess_part, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double s = 0.0;
+  for (double v : h) s += v;            // fixed order
+  *ll = s;
+  return check_status(c);
+}
+
+int btf_ess_run(btf_ctx* c, int what, int link, int mode, const double* z, uint64_t seed, int max_rounds, double eps0, int attempts) {
+  if (!c) return BTF_EINVAL;
+  int rc;
+  if ((rc = ess_check(c, what, link))) return rc;
+  if (mode < 0 || mode > 1 || max_rounds < 1) return fail(c, BTF_EINVAL, "bad elliptical-slice arguments");
+  HIPCHK(c, hipSetDevice(c->dev));
+  if ((rc = ess_begin(c, what, z, seed, eps0, attempts < 0 ? 0 : attempts))) return rc;
+  const EssDims d = ess_dims(c, what, mode);
+  if ((rc = ess_ensure_part(c, d))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->ess_done, 0, (size_t)d.nchains * sizeof(int), c->stream));
+  double* X = what == 0 ? c->W : c->V;
+  const unsigned long long dseed = seed * 0x9E3779B97F4A7C15ULL + 0x5851F42D4C957F2DULL;
+  auto decide = [&](int round) {
+    Prof p(c, BTF_K_ESS);
+    p.launch(ess_decide_kernel, dim3(d.nchains), dim3(ESS_THREADS), 0, (const double*)c->ess_part, d.nsum, d.nchains, c->ess_st,
+             c->ess_theta, c->ess_done, round, dseed);
+  };
+  K_SWITCH(c->K, launch_ess_ll<KT>(c, what, mode, link, d.nbx));      // ll of the current state
+  decide(-1);
+  for (int r = 0; r < max_rounds; ++r) {
+    {
+      Prof p(c, BTF_K_ESS);
+      p.launch(ess_combine_kernel, dim3((unsigned)((d.n + 255) / 256)), dim3(256), 0, (const double*)c->essX0, (const double*)c->essNu, X,
+               d.n, d.per, (const double*)c->ess_theta, (const int*)c->ess_done, 0);
+    }
+    K_SWITCH(c->K, launch_ess_ll<KT>(c, what, mode, link, d.nbx));
+    decide(r);
+  }
+  {   // chains that used up the rounds keep the current state (never observed: the bracket halves every round)
+    Prof p(c, BTF_K_ESS);
+    p.launch(ess_combine_kernel, dim3((unsigned)((d.n + 255) / 256)), dim3(256), 0, (const double*)c->essX0, (const double*)c->essNu, X,
+             d.n, d.per, (const double*)c->ess_theta, (const int*)c->ess_done, 1);
+  }
+  HIPCHK(c, hipGetLastError());
+  c->ess_last_chains = d.nchains;
+  if (what == 0) c->ngp_w = 0; else c->ngp_v = 0;
+  c->w_part_valid = false;
+  c->nb_L_valid = false;
+  return BTF_OK;
+}
+
+int btf_ess_info(btf_ctx* c, int32_t* unfinished, double* ll_first) {
+  if (!c || !unfinished) return BTF_EINVAL;
+  if (!c->essX0 || c->ess_last_chains < 1) return fail(c, BTF_ESTATE, "no elliptical-slice run yet");
+  HIPCHK(c, hipSetDevice(c->dev));
+  std::vector<int> dn((size_t)c->ess_last_chains);
+  double st[5];
+  HIPCHK(c, hipMemcpyAsync(dn.data(), c->ess_done, dn.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(st, c->ess_st, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int u = 0;
+  for (int v : dn) u += v ? 0 : 1;
+  *unfinished = u;
+  if (ll_first) *ll_first = st[4];
+  return check_status(c);
 }
 
 int btf_get_V_order(btf_ctx* c, int32_t* order) {

@@ -924,3 +924,121 @@ class NegativeBinomialBayesianTensorFiltering(BinomialBayesianTensorFiltering):
     def _inferred_variables(self, var_map):
         super()._inferred_variables(var_map)
         var_map['R'] = np.copy(self.R)
+
+
+class NonconjugateBayesianTensorFiltering(BayesianTensorFiltering):
+    """Non-conjugate likelihoods by elliptical slice sampling (factor.py:567-612): the prior draw and the slice
+    loop of `_resample_W` / `_resample_V` run on the GPU (include/btf.h, btf_ess_*).
+
+    The reference takes a Python callback `loglikelihood(W, V, data)` and evaluates it on the whole tensor for
+    every proposal.  Here the likelihood is evaluated by a device kernel, so `loglikelihood` names one of
+    the built-in families instead (a callable raises NotImplementedError: no host evaluation path exists):
+        "poisson" / "poisson_log"   counts y ~ Poisson(exp(w.v))
+        "poisson_identity"          counts y ~ Poisson(w.v), zero likelihood where w.v <= 0
+                                    (the likelihood of examples/poisson_tensor_filtering.py:26-37)
+    data: counts (N,M,T) or (N,M,T,R), NaN = missing.
+
+    ess = "joint" (default): ONE slice over all of W, then one over all of V, as the reference; with rng="host" the
+          normals and uniforms come from the global legacy numpy generator in the reference's order, so a seeded
+          chain walks the reference's path (tests/golden/g9_ess.npz).
+    ess = "rows" (rng="device" only): one slice per row of W / per column of V - conditionally independent given
+          the other factor, as in the reference's constrained model (factor.py:665-720) - all brackets shrinking
+          in lockstep on the device; mixes faster than the joint slice, whose step shrinks with the dimension."""
+
+    LINKS = {"poisson": 0, "poisson_log": 0, "poisson_identity": 1}
+
+    def __init__(self, nrows, ncols, ndepth, loglikelihood, ess="joint", ess_max_rounds=40, **kwargs):
+        if callable(loglikelihood) or loglikelihood not in self.LINKS:
+            raise NotImplementedError("loglikelihood must name a device likelihood %s: the slice loop evaluates it on "
+                                      "the GPU, there is no host path for a Python callback" % sorted(self.LINKS))
+        if ess not in ("joint", "rows"):
+            raise ValueError("ess must be 'joint' or 'rows'")
+        super().__init__(nrows, ncols, ndepth, **kwargs)
+        if self._plan.world > 1:
+            raise NotImplementedError("NonconjugateBayesianTensorFiltering: unsharded runs only")
+        if ess == "rows" and self.rng != "device":
+            raise ValueError("ess='rows' draws its uniforms on the device: use rng='device'")
+        self.loglikelihood = loglikelihood
+        self._link = self.LINKS[loglikelihood]
+        self.ess, self.ess_max_rounds = ess, int(ess_max_rounds)
+        self.ess_evaluations = 0          # likelihood evaluations of the last host-driven slice (diagnostic)
+        self._ll_const = 0.0
+
+    def _upload(self, Y):
+        if Y.ndim not in (3, 4):
+            raise AssertionError('Observations must be 3- or 4-tensor.')
+        Y4 = Y[..., None] if Y.ndim == 3 else Y
+        if Y4.shape[:3] != (self.nrows, self.ncols, self.ndepth):
+            raise ValueError("data shape %r does not match the model" % (Y.shape,))
+        from scipy.special import gammaln
+        rows, cols = self._plan.slabs(Y4)
+        self._ctx.call("btf_set_data_gaussian", _native.dptr(rows), _native.dptr(cols), int(Y4.shape[3]))
+        obs = ~np.isnan(Y4)
+        self._ll_const = -float(gammaln(np.where(obs, Y4, 0.0) + 1.0)[obs].sum())     # - sum lgamma(y+1): state-independent
+
+    def log_likelihood(self, data):
+        """Poisson log-likelihood of the current state (what the reference's callback returns)."""
+        import ctypes
+        self._bind_data(data)
+        self._push_state()
+        if not getattr(self, "_ess_ready", False):
+            self._ctx.call("btf_ess_begin", 0, None, 0, 1e-6, 0)
+            self._ess_ready = True
+        ll = ctypes.c_double()
+        self._ctx.call("btf_ess_eval", 0, 0.0, 1, self._link, ctypes.byref(ll))
+        return ll.value + self._ll_const
+
+    def _ess_step(self, what, data):
+        import ctypes
+        self._bind_data(data)
+        self._push_state()
+        o = self.linalg_opts
+        eps, att = float(o["force_psd_eps"]), int(o["force_psd_attempts"]) if o["force_psd"] else 0
+        if self.rng == "device":
+            self._ctx.call("btf_ess_run", what, self._link, 0 if self.ess == "joint" else 1, None, self._next_seed(),
+                           self.ess_max_rounds, eps, att)
+        else:
+            # elliptical_slice.py:59-124 with the reference's draws: normals of the prior sample
+            # (fast_mvn.py:41), log-uniform slice height, uniform angle, one uniform per shrink
+            z = self._w_normals() if what == 0 else self._v_normals()
+            self._keep_z = z
+            self._ctx.call("btf_ess_begin", what, _native.dptr(_native.as_f64(z)), self._next_seed(), eps, att)
+            ll = ctypes.c_double()
+            self._ctx.call("btf_ess_eval", what, 0.0, 1, self._link, ctypes.byref(ll))
+            hh = np.log(np.random.rand()) + ll.value
+            phi = np.random.rand() * 2 * np.pi
+            phi_min, phi_max = phi - 2 * np.pi, phi
+            nev = 0
+            while True:
+                self._ctx.call("btf_ess_eval", what, float(phi), 0, self._link, ctypes.byref(ll))
+                nev += 1
+                if ll.value >= hh:
+                    break
+                if phi > 0:
+                    phi_max = phi
+                elif phi < 0:
+                    phi_min = phi
+                else:
+                    break
+                phi = np.random.rand() * (phi_max - phi_min) + phi_min
+            self.ess_evaluations = nev
+        self._ess_ready = True
+        if what == 0:
+            self._W_dev_new = True
+        else:
+            self._V_dev_new = True
+            self._lsum_valid = False
+            self._lsum_on_device = False
+
+    def _resample_W(self, data):
+        self._ess_step(0, data)
+
+    def _resample_V(self, data):
+        self._ess_step(1, data)
+
+    def ess_unfinished(self):
+        """Chains of the last device-driven slice that used up ess_max_rounds (they keep their current state)."""
+        import ctypes
+        u = ctypes.c_int32()
+        self._ctx.call("btf_ess_info", ctypes.byref(u), None)
+        return u.value

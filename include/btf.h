@@ -62,7 +62,8 @@ enum {
   BTF_K_PRIOR = 10,  /* prior band Delta' diag(1/(lam2 Tau2_j)) Delta of every column (factor.py:404-405) */
   BTF_K_EIG = 11,    /* eigen-system of the K x K Gram (spectral sampler)   */
   BTF_K_HYPER = 12,  /* device hyper-parameter draws: Tau2 chain, nu2/sigma2, lam2 */
-  BTF_K_COUNT = 13
+  BTF_K_ESS = 13,    /* elliptical slice sampling: prior draws, proposals, likelihood passes, decisions */
+  BTF_K_COUNT = 14
 };
 
 /* btf_set_option keys / values */
@@ -266,6 +267,34 @@ int btf_sync(btf_ctx* ctx); /* waits; returns BTF_ENOTPD if a step failed since 
 int btf_mvn_banded(int device, int batch, int n, int bw, const double* band,
                    const double* mu_part, const double* z, uint64_t seed,
                    double eps0, int attempts, double* x_out, int32_t* tries_out);
+
+/* ---- elliptical slice sampling for non-conjugate likelihoods -----------------
+ * Replaces NonconjugateBayesianTensorFiltering._resample_W / _resample_V (factor.py:567-590): a prior draw nu
+ * (sample_mvn_from_precision on the packed prior precision of factor.py:155-195 - for V the banded sampler with
+ * the likelihood switched off, same declared order as btf_resample_V with BTF_SAMPLER_BANDED) and the slice loop
+ * of elliptical_slice_ (elliptical_slice.py:59-124).  The likelihood callback of the reference becomes a device
+ * likelihood over the statistics btf_set_data_gaussian hoisted (counts y, NaN = missing):
+ *   link 0  Poisson, log link:       sum_cells  S1 (w.v) - cnt exp(w.v)
+ *   link 1  Poisson, identity link:  sum_cells  S1 log(w.v) - cnt (w.v),  -inf where w.v <= 0
+ * (the state-independent term - sum lgamma(y+1) is left to the caller).  what: 0 = W, 1 = V.  Unsharded contexts.
+ *
+ * Host-driven form (rng="host": the uniforms come from the caller's generator, so a seeded chain walks the
+ * reference's path): btf_ess_begin saves the current state x0 and draws nu (z: the normals of
+ * sample_mvn_from_precision, W: sum_i min(i+1,K), V: (M, K*T) in the declared order; NULL = device Philox);
+ * btf_ess_eval(theta, current=0) sets the state to x0 cos(theta) + nu sin(theta) and returns its log-likelihood
+ * (current=1: of the state as it stands); when the caller stops, the state holds the last proposal, exactly what
+ * elliptical_slice_ returns.  Synchronises.
+ *
+ * Device-driven form: btf_ess_run = begin + at most max_rounds proposal / likelihood / decision rounds queued on the
+ * stream, uniforms from Philox, nothing read back.  mode 0: one slice over all of W (resp. V), as the reference;
+ * mode 1: one slice per row of W (resp. per column of V) - the rows are conditionally independent given V - all
+ * brackets shrinking in lockstep, one proposal per row per round.  btf_ess_info (synchronises): chains that used up
+ * max_rounds (they keep the current state) and the log-likelihood the first chain ended on.                      */
+int btf_ess_begin(btf_ctx* ctx, int what, const double* z, uint64_t seed, double eps0, int attempts);
+int btf_ess_eval(btf_ctx* ctx, int what, double theta, int current, int link, double* ll);
+int btf_ess_run(btf_ctx* ctx, int what, int link, int mode, const double* z, uint64_t seed, int max_rounds,
+                double eps0, int attempts);
+int btf_ess_info(btf_ctx* ctx, int32_t* unfinished, double* ll_first);
 
 /* ---- posterior summaries (stateless) --------------------------------
  * Mean and percentiles over the kept samples of f(w_s[i] . v_s[j,t]) for every cell: what the

@@ -765,3 +765,229 @@ def v_step_strong(st, R, ybar, Delta, z=None, order=None):
         x = sla.solve_banded((0, bw), up, z[j])
         V[j] = (y + x).reshape(T, K)
     return V
+
+
+# --------------------------------------------------------------------------
+# fast_mvn: the dense branches and the dispatcher   (fast_mvn.py:49-60, :77-179)
+# --------------------------------------------------------------------------
+
+def sample_mvn_dense(Q, mu=None, mu_part=None, precision=False, chol_factor=False, z=None):
+    """The `sparse=False` branches of sample_mvn_from_precision (fast_mvn.py:49-60) and
+    sample_mvn_from_covariance (:126-142), reached through sample_mvn (:145-179; a scalar or vector Q means Q*I).
+    precision: x = Lt^-1 z (+ Q^-1 mu_part | + mu), Lt = chol(Q)' (chol_factor: Q is the lower factor);
+    covariance: x = L z (+ Q mu_part | + mu), L = chol(Q) (chol_factor: Q IS that factor)."""
+    if not chol_factor and (np.isscalar(Q) or np.ndim(Q) == 1):
+        dim = len(mu) if mu is not None else len(mu_part)
+        Q = np.eye(dim) * Q
+    Q = np.asarray(Q, float)
+    n = Q.shape[0]
+    if z is None:
+        z = np.random.normal(size=n)
+    if precision:
+        Lt = np.linalg.cholesky(Q).T if not chol_factor else Q.T
+        x = sla.solve_triangular(Lt, z, lower=False)
+        if mu_part is not None:
+            x = x + sla.cho_solve((Lt, False), mu_part)
+        elif mu is not None:
+            x = x + mu
+        return x
+    if chol_factor:
+        L = Q
+        Q = L @ L.T
+    else:
+        L = np.linalg.cholesky(Q)
+    x = L @ z
+    if mu_part is not None:
+        x = x + Q @ mu_part
+    elif mu is not None:
+        x = x + mu
+    return x
+
+
+# --------------------------------------------------------------------------
+# elliptical slice sampling          (elliptical_slice.py:59-124)
+# --------------------------------------------------------------------------
+
+def elliptical_slice(xx, prior, log_like_fn, cur_log_like=None, angle_range=0, ll_args=None, mu=None, info=None):
+    """One elliptical-slice update.  prior: a prior sample (size D) or chol(Sigma, lower) (D x D: nu = L randn).
+    Legacy global RNG in the reference's order: [randn] - rand (slice height) - rand (first angle; two when
+    angle_range > 0) - one rand per shrink.  Returns (proposal on the slice, its log-likelihood)."""
+    xx = np.array(xx, dtype=float)
+    D = xx.size
+    prior = np.asarray(prior, float)
+    if prior.size == D:
+        nu = prior.reshape(D)
+    else:
+        if prior.shape != (D, D):
+            raise ValueError("prior must be a D-element sample or a D x D lower Cholesky factor")
+        nu = (prior @ np.random.randn(D, 1)).T.reshape(xx.shape)
+    mu = np.zeros(D) if mu is None else np.asarray(mu, float)
+    if cur_log_like is None:
+        cur_log_like = log_like_fn(xx, ll_args)
+    hh = np.log(np.random.rand()) + cur_log_like
+    if angle_range <= 0:
+        phi = np.random.rand() * 2 * np.pi
+        phi_min, phi_max = phi - 2 * np.pi, phi
+    else:
+        phi_min = -angle_range * np.random.rand()
+        phi_max = phi_min + angle_range
+        phi = np.random.rand() * (phi_max - phi_min) + phi_min
+    nev = 0
+    while True:
+        prop = (xx - mu) * np.cos(phi) + nu * np.sin(phi) + mu
+        cur_log_like = log_like_fn(prop, ll_args)
+        nev += 1
+        if cur_log_like >= hh:
+            break
+        if phi > 0:
+            phi_max = phi
+        elif phi < 0:
+            phi_min = phi
+        else:
+            break                       # shrunk to the current position and still rejected (:112-116)
+        phi = np.random.rand() * (phi_max - phi_min) + phi_min
+    if info is not None:
+        info["evaluations"] = nev
+        info["phi"] = phi
+    return prop, cur_log_like
+
+
+# --------------------------------------------------------------------------
+# generalized analytic slice sampling   (gass.py:13-130)
+# --------------------------------------------------------------------------
+
+def gass(x, v, loglikelihood, Constraints, cur_ll=None, mu=None, ll_args=None, ngrid=100, info=None):
+    """One GASS update of x under the linear constraints  Constraints[:, :-1] x >= Constraints[:, -1].
+    v: the proposal the reference draws with sample_mvn (gass.py:24) - passed in, because which fast_mvn branch
+    draws it is the caller's choice (sample_mvn_dense / mvn_from_precision above).  RNG order after v:
+    rand (slice height, drawn BEFORE v in the reference: the caller draws v after calling np.random.random
+    once - see tests), [choice(grid, ngrid) if the valid grid is longer than ngrid], choice(#accepted)."""
+    x = np.asarray(x, float)
+    if cur_ll is None:
+        cur_ll = loglikelihood(x, ll_args)
+    ll = cur_ll + np.log(np.random.random())
+    v = v() if callable(v) else np.asarray(v, float)
+    mu = np.zeros_like(x) if mu is None else np.asarray(mu, float)
+    A, cvec = Constraints[:, :-1], Constraints[:, -1]
+    if not np.all(A @ x >= cvec):
+        raise ValueError("invalid starting point")
+    x0 = x - mu
+    a, b, c = A @ x0, A @ v, cvec - A @ mu
+    sqrt_term = a ** 2 + b ** 2 - c ** 2
+    eps = 1e-6
+    concerning = (sqrt_term >= 0) & (a != -c)
+    if np.any(concerning):
+        denom = a + c
+        rt = np.sqrt(sqrt_term[concerning])
+        theta1 = 2 * np.arctan((b[concerning] + rt) / denom[concerning])
+        theta2 = 2 * np.arctan((b[concerning] - rt) / denom[concerning])
+        comp = a[concerning] ** 2 < c[concerning] ** 2
+        grid = np.linspace(-np.pi, np.pi, 10000)
+        for t1, t2 in zip(theta1[comp], theta2[comp]):          # convex: outside [min, max]
+            grid = grid[(grid <= min(t1, t2)) | (grid >= max(t1, t2))]
+        if np.any(~comp):                                       # concave: inside every [min, max]
+            t1i, t2i = theta1[~comp], theta2[~comp]
+            lo = np.minimum(t1i, t2i).max() + eps
+            hi = np.maximum(t1i, t2i).min() - eps
+            grid = grid[(grid >= lo) & (grid <= hi)]
+    else:
+        grid = np.linspace(-np.pi, np.pi, ngrid)
+    if len(grid) == 0:
+        options, opt_ll = [], []
+    else:
+        if len(grid) > ngrid:
+            grid = np.random.choice(grid, size=ngrid, replace=False)
+        options = x0[None] * np.cos(grid[:, None]) + v[None] * np.sin(grid[:, None]) + mu[None]
+        opt_ll = loglikelihood(options, ll_args)
+        keep = opt_ll >= ll
+        options, opt_ll = options[keep], opt_ll[keep]
+    if info is not None:
+        info["grid"] = len(grid)
+        info["accepted"] = len(options)
+    if len(options) > 0:
+        sel = np.random.choice(len(options))
+        return options[sel], opt_ll[sel]
+    return x, cur_ll
+
+
+# --------------------------------------------------------------------------
+# non-conjugate model: joint elliptical-slice updates of W and V   (factor.py:155-228, :567-590)
+# --------------------------------------------------------------------------
+
+def pack_W(W):
+    """Free entries of W: lower triangle of the leading square block, then the rows below (factor.py:155-174)."""
+    N, K = W.shape
+    h = min(K, N)
+    return np.concatenate([W[np.tril_indices(h)], W[h:].reshape(-1)])
+
+
+def unpack_W(vec, W):
+    N, K = W.shape
+    h = min(K, N)
+    nt = h * (h + 1) // 2
+    W[np.tril_indices(h)] = vec[:nt]
+    W[h:] = vec[nt:].reshape(N - h, K)
+    return W
+
+
+def poisson_loglik(W, V, Y, link="log"):
+    """sum over observed cells / replicates of log Poisson(y | lambda), lambda = exp(w.v) or w.v
+    (the likelihood of examples/poisson_tensor_filtering.py:26-37, scipy.stats.poisson.logpmf + nansum)."""
+    from scipy.special import gammaln
+    eta = np.einsum("nk,mtk->nmt", W, V)
+    Y4 = Y[..., None] if Y.ndim == 3 else Y
+    obs = ~np.isnan(Y4)
+    y = np.where(obs, Y4, 0.0)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        if link == "log":
+            term = y * eta[..., None] - np.exp(eta)[..., None]
+        else:
+            term = np.where(eta[..., None] > 0, y * np.log(np.where(eta > 0, eta, 1.0))[..., None] - eta[..., None], -np.inf)
+    term = np.where(obs, term - gammaln(y + 1.0), 0.0)
+    return float(term.sum())
+
+
+def nonconjugate_w_step(st, Y, link="log", z=None, info=None):
+    """factor.py:572-581: prior sample of the packed W (precision I/sigma2: nu = sqrt(sigma2) z), one elliptical
+    slice over all of it with the full-tensor likelihood."""
+    W, V = st["W"], st["V"]
+    cur = pack_W(W)
+    if z is None:
+        z = np.random.normal(size=cur.size)
+    nu = np.sqrt(st["sigma2"]) * np.asarray(z)
+
+    def ll(vec, _):
+        return poisson_loglik(unpack_W(vec, np.zeros_like(W)), V, Y, link)
+    new, _ = elliptical_slice(cur, nu, ll, info=info)
+    unpack_W(new, W)
+    return W
+
+
+def nonconjugate_v_step(st, Y, Delta, link="log", perm="depth", z=None, info=None):
+    """factor.py:583-590: prior sample of the packed V (block-diagonal precision I_K (x) Delta' Lambda_j Delta per
+    column, k-major, factor.py:176-195; drawn column by column in the declared order `perm`), one elliptical
+    slice over all of V."""
+    W, V = st["W"], st["V"]
+    M, T, K = V.shape
+    n = K * T
+    if isinstance(perm, str):
+        p = twisted_perm(K, T, band_halfwidth(Delta.T @ Delta) - 1) if perm == "twist" else \
+            (depth_major_perm(K, T) if perm == "depth" else np.arange(n))
+    else:
+        p = np.asarray(perm)
+    if z is None:
+        z = np.random.normal(size=M * n)
+    z = np.asarray(z).reshape(M, n)
+    nu = np.empty(M * n)
+    for j in range(M):
+        Q = np.kron(np.eye(K), prior_precision_1d(Delta, st["lam2"], st["Tau2"][j]))
+        nu[j * n:(j + 1) * n] = mvn_from_precision(Q, perm=p, z=z[j])
+    cur = np.concatenate([V[j].T.reshape(-1) for j in range(M)])
+
+    def ll(vec, _):
+        Vp = np.stack([vec[j * n:(j + 1) * n].reshape(K, T).T for j in range(M)])
+        return poisson_loglik(W, Vp, Y, link)
+    new, _ = elliptical_slice(cur, nu, ll, info=info)
+    for j in range(M):
+        V[j] = new[j * n:(j + 1) * n].reshape(K, T).T
+    return V

@@ -286,3 +286,85 @@ def test_spectral_jitter_retry_matches_reference_schedule(golden):
     orc.v_step(st, g5["Y"], orc.trend_penalty(T, tf), perm="spectral", z=g5["retry_z_V"], info=info)
     assert np.array_equal(info["attempts"], g8["g5_retry_tries_spectral"])
     assert relerr(st["V"], g8["g5_retry_V_after_spectral"]) < 1e-5
+
+
+# ---- slice samplers and dense fast_mvn branches: fixtures from the reference itself (make_golden_ess.py) ----
+def test_elliptical_slice_vs_reference(golden):
+    g = golden("g9_ess.npz")
+    Sigma, target = g["ess_Sigma"], g["ess_target"]
+    L = np.linalg.cholesky(Sigma)
+    D = target.size
+
+    def bump(x, args):
+        return -0.5 * np.sum((x - args) ** 2) / 0.3
+    x = g["ess_x0"].copy()
+    for rep in range(6):
+        np.random.seed(700 + rep)
+        prior = L if rep % 2 == 0 else L @ np.random.normal(size=D)
+        np.random.seed(800 + rep)
+        info = {}
+        x, ll = orc.elliptical_slice(x, prior, bump, ll_args=target, mu=None if rep < 4 else 0.2 * target,
+                                     angle_range=0 if rep != 3 else 1.5, info=info)
+        assert relerr(x, g["ess_out"][rep]) < 1e-12 and abs(ll - g["ess_ll"][rep]) < 1e-10
+        assert info["evaluations"] == g["ess_nev"][rep]
+
+
+def test_dense_mvn_branches_vs_reference(golden):
+    g = golden("g9_ess.npz")
+    S, mu = g["mvn_S"], g["mvn_mu"]
+    kws = (dict(precision=True), dict(precision=True, mu_part=mu), dict(precision=True, mu=mu), dict(precision=False),
+           dict(precision=False, mu=mu), dict(precision=False, mu_part=mu), dict(precision=False, chol_factor=True),
+           dict(precision=True, chol_factor=True, mu_part=mu))
+    for i, kw in enumerate(kws):
+        Q = np.linalg.cholesky(S) if kw.get("chol_factor") else S
+        np.random.seed(900 + i)
+        assert relerr(orc.sample_mvn_dense(Q, **kw), g["mvn_out"][i]) < 1e-12, kw
+    np.random.seed(950)
+    assert relerr(orc.sample_mvn_dense(0.7, mu=mu), g["mvn_out"][8]) < 1e-12
+    np.random.seed(951)
+    assert relerr(orc.sample_mvn_dense(np.full(mu.size, 2.5), mu_part=mu, precision=True), g["mvn_out"][9]) < 1e-12
+
+
+def test_gass_vs_reference(golden):
+    g = golden("g9_ess.npz")
+    Sig, C, tgt = g["gass_Sigma"], g["gass_C"], g["gass_target"]
+
+    def gll(x, args):
+        x = np.atleast_2d(x)
+        r = -0.5 * np.sum((x - args) ** 2, axis=1) / 0.5
+        return r if r.shape[0] > 1 else r[0]
+    x = g["gass_x"][0].copy()
+    for rep in range(6):
+        np.random.seed(1000 + rep)
+        if rep % 2 == 0:
+            x, ll = orc.gass(x, lambda: orc.sample_mvn_dense(Sig, mu=np.zeros_like(x)), gll, C, ll_args=tgt, ngrid=50)
+        else:
+            x, ll = orc.gass(x, lambda: orc.sample_mvn_dense(np.linalg.inv(Sig), mu=np.zeros_like(x), precision=True), gll, C,
+                             ll_args=tgt, mu=0.1 * tgt, ngrid=50)
+        assert relerr(x, g["gass_x"][rep + 1]) < 1e-10 and abs(ll - g["gass_ll"][rep]) < 1e-9
+        assert np.all(C[:, :-1] @ x >= C[:, -1] - 1e-12)
+
+
+def _nc_case(golden, link):
+    g = golden("g9_ess.npz")
+    tag = "nc_%s_" % link
+    st = {k: (float(g[tag + "s0_" + k]) if k in ("lam2", "sigma2") else g[tag + "s0_" + k].copy())
+          for k in ("W", "V", "Tau2", "lam2", "sigma2")}
+    return g, tag, st, [int(x) for x in g[tag + "dims"]]
+
+
+@pytest.mark.parametrize("link", ["log", "identity"])
+def test_nonconjugate_joint_slice_steps_vs_reference(golden, link):
+    """NonconjugateBayesianTensorFiltering._resample_W / _resample_V (factor.py:567-590) run by the reference with
+    a Poisson likelihood callback: the oracle's restatement must land on the same states after the same number
+    of likelihood evaluations, from the same legacy-RNG seeds."""
+    g, tag, st, (N, M, T, R, K, tf) = _nc_case(golden, link)
+    Y = g[tag + "Y"]
+    Delta = orc.trend_penalty(T, tf)
+    info = {}
+    np.random.seed(1100)
+    orc.nonconjugate_w_step(st, Y, link=link, info=info)
+    assert relerr(st["W"], g[tag + "W_after"]) < 1e-12 and info["evaluations"] == int(g[tag + "W_nev"])
+    np.random.seed(1200)
+    orc.nonconjugate_v_step(st, Y, Delta, link=link, perm="twist", info=info)
+    assert relerr(st["V"], g[tag + "V_after"]) < 1e-9 and info["evaluations"] == int(g[tag + "V_nev"])
