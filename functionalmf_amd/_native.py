@@ -65,6 +65,9 @@ SIGNATURES = {
     "btf_nb_set_rate": (C.c_int, [_ctx, _c_dp, _c_ip]),
     "btf_nb_mh": (C.c_int, [_ctx, C.c_uint64, C.c_int, C.c_double, C.c_double, _c_ip, _c_dp]),
     "btf_nb_get_rate": (C.c_int, [_ctx, _c_dp, _c_ip]),
+    "btf_dev_hyp": (C.c_void_p, [_ctx]),
+    "btf_set_global_nobs": (C.c_int, [_ctx, C.c_double]),
+    "btf_set_scalar_slot": (C.c_int, [_ctx, C.c_int, C.c_double]),
     "btf_device_scalars": (C.c_int, [_ctx, C.c_int]),
     "btf_set_scalars": (C.c_int, [_ctx, C.c_double, C.c_double, C.c_double, C.c_double]),
     "btf_get_scalars": (C.c_int, [_ctx, _c_dp]),

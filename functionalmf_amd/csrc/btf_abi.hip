@@ -44,7 +44,7 @@ struct btf_ctx {
   double lam2 = 1.0, sigma2 = 1.0, nu2 = 1.0;
   bool have_W = false, have_V = false, have_hyper = false;
   double* part = nullptr; size_t part_elems = 0;
-  double* gpart = nullptr;
+  double* gpart = nullptr; int ngp_gram = 16;      // partial Grams of the last gram_kernel launch
   double* zbuf = nullptr; size_t z_elems = 0;
   double* bsum = nullptr; size_t bsum_elems = 0;
   double* gband = nullptr; size_t gband_stride = 0;
@@ -55,6 +55,7 @@ struct btf_ctx {
   int* srcmap_w = nullptr; int* srcmap_v = nullptr;   // per-output source index of the cached weights
   bool stale_w = false, stale_v = false;
   double ssw = 0.0, nobs = 0.0, sa2 = 0.0;      // within-cell SS, observation count, sum S1^2/cnt (Gaussian data)
+  double nobs_global = -1.0;                    // sharded runs: observation count over all ranks (btf_set_global_nobs)
   bool w_part_valid = false; int w_part_mode = 0, w_part_nch = 0, w_part_rpb = 0; bool w_part_gv = false;   // W-step partials current?
   int rpb_w = 0, rpb_v = 0;
   int sampler = BTF_SAMPLER_BANDED;   // BTF_OPT_SAMPLER
@@ -304,7 +305,8 @@ void launch_pg(btf_ctx* c, const double* B, double* out, const double* Lf, const
 template <int K>
 void launch_gram(btf_ctx* c, const double* U, int Rdim) {
   Prof p(c, BTF_K_GRAM);
-  p.launch(gram_kernel<K>, dim3(GRAM_BLOCKS), dim3(GRAM_THREADS), 0, U, Rdim, c->gpart);
+  c->ngp_gram = gram_blocks(Rdim);      // 16 partial Grams, up to 64 for long factors (4 MB of V at C5: 16 us -> 5 us)
+  p.launch(gram_kernel<K>, dim3(c->ngp_gram), dim3(GRAM_THREADS), 0, U, Rdim, c->gpart);
 }
 template <int K>
 void launch_products(btf_ctx* c, const double* U, int Rdim, double* UU) {
@@ -1010,7 +1012,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     const bool whole = c->nl == c->N && c->ml == c->M;
     WSolveArgs a{};
     a.part = c->part; a.nch = nch; a.ld = c->ldw; a.weighted = wt ? 1 : 0;
-    a.gpart = use_gv ? c->gpart_v : c->gpart; a.ngp = use_gv ? c->ngp_v : GRAM_BLOCKS;
+    a.gpart = use_gv ? c->gpart_v : c->gpart; a.ngp = use_gv ? c->ngp_v : c->ngp_gram;
     const int wblocks = (c->nl + WS_ROWS - 1) / WS_ROWS;
     if (whole && c->fuse_gram) {
       if (!c->gpart_w) { if ((rc = dev_alloc(c, &c->gpart_w, (size_t)((c->N + WS_ROWS - 1) / WS_ROWS) * KK))) return rc; }
@@ -1045,7 +1047,7 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
   int rc;
   const int bw = (c->TF + 1) * K, R1 = bw + 1, D1 = c->TF + 2;
   size_t lds_fixed = (size_t)(3 * n + T * D1 + (wt ? T * KK : KK) + (bw * (bw + 1) / 2 + 3) / 4) * sizeof(double);
-  size_t lds_band = (size_t)n * R1 * sizeof(double);
+  size_t lds_band = std::max((size_t)n * R1, (size_t)(GRAM_BLOCKS + 16) * KK) * sizeof(double);   // (also the Gram staging area)
   size_t lds_bytes = lds_fixed + lds_band;
   VBandArgs a{};
   if (lds_bytes > 150 * 1024) {  // band lives in HBM scratch, only vectors on chip
@@ -1058,7 +1060,7 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
     lds_bytes = lds_fixed;
   }
   a.part = c->part; a.nch = nch; a.ld = c->ldv; a.weighted = wt ? 1 : 0;
-  a.gpart = use_gw ? c->gpart_w : c->gpart; a.ngp = use_gw ? c->ngp_w : GRAM_BLOCKS;
+  a.gpart = use_gw ? c->gpart_w : c->gpart; a.ngp = use_gw ? c->ngp_w : c->ngp_gram;
   a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
   a.sR = a.s * c->R;
   a.Tau2 = c->Tau2; a.lam2 = c->lam2; a.nD = c->nD;
@@ -1140,7 +1142,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
         if ((rc = dev_alloc(c, &c->eig, (size_t)K + K * K + 8))) return rc;
         HIPCHK(c, hipMemsetAsync(c->eig, 0, ((size_t)K + K * K + 8) * sizeof(double), c->stream));   // no previous solution
       }
-      side = EigSide{use_gw ? c->gpart_w : c->gpart, use_gw ? c->ngp_w : GRAM_BLOCKS, K, c->eig};
+      side = EigSide{use_gw ? c->gpart_w : c->gpart, use_gw ? c->ngp_w : c->ngp_gram, K, c->eig};
     }
     K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->WW, c->srcmap_v, c->N, c->ldv, rpb, nch, side));
     hipError_t e = hipSuccess;
@@ -1783,7 +1785,6 @@ int btf_device_scalars(btf_ctx* c, int enable) {
   if (!c) return BTF_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
   if (enable) {
-    if (c->nl != c->N || c->ml != c->M) return fail(c, BTF_ESTATE, "device-resident scalars need an unsharded context");
     int rc;
     if ((rc = ensure_hyp(c))) return rc;
   }
@@ -1814,8 +1815,29 @@ int btf_get_scalars(btf_ctx* c, double* out) {
   return BTF_OK;
 }
 
+void* btf_dev_hyp(btf_ctx* c) { return c ? (void*)c->hyp : nullptr; }
+
+int btf_set_scalar_slot(btf_ctx* c, int slot, double value) {
+  if (!c || slot < 0 || slot >= HYP_COUNT) return BTF_EINVAL;
+  if (!c->hyp) return fail(c, BTF_ESTATE, "no device-resident scalars yet");
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->pin_hyp[slot] = value;
+  HIPCHK(c, hipMemcpyAsync(c->hyp + slot, c->pin_hyp + slot, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return BTF_OK;
+}
+
+int btf_set_global_nobs(btf_ctx* c, double nobs) {
+  if (!c || !(nobs >= 0.0)) return BTF_EINVAL;
+  c->nobs_global = nobs;
+  return BTF_OK;
+}
+
 int btf_draw_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double nu2_b, double sigma2_a, double sigma2_b) {
   if (!c || !c->dev_scalars) return fail(c, BTF_ESTATE, "enable device-resident scalars first");
+  // which & 8 / & 16: the two halves of a sharded nu2 draw (see scalars_kernel): 8 = reduce this rank's residual sum
+  // of squares into the device scalar HYP_SSE and stop; 16 = draw from HYP_SSE (all-reduced by the caller in between)
+  const int phase = (which & 8) ? 1 : ((which & 16) ? 2 : 0);
   if ((which & 1) && (!c->have_data || c->binomial)) return fail(c, BTF_ESTATE, "the scalar nu2 draw needs Gaussian data");
   if (!c->have_W || ((which & 1) && !c->have_V)) return fail(c, BTF_ESTATE, "set W and V first");
   HIPCHK(c, hipSetDevice(c->dev));
@@ -1825,13 +1847,13 @@ int btf_draw_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double 
   if (which & 1) {
     // which & 4: take the residual sum of squares from the W half-sweep's accumulation partials (btf_w_accum
     // must have run for the current V; the stale-weight mode of compat="reference" has no such identity)
-    const bool from_part = (which & 4) && c->w_part_valid && c->w_part_mode != 2 && c->nl == c->N;
+    const bool from_part = phase != 2 && (which & 4) && c->w_part_valid && c->w_part_mode != 2;
     if (from_part) {
       const int blocks = (c->nl + WS_ROWS - 1) / WS_ROWS;
       if ((size_t)blocks > c->bsum_elems) { if ((rc = dev_alloc(c, &c->bsum, (size_t)blocks))) return rc; c->bsum_elems = (size_t)blocks; }
       Prof p(c, BTF_K_SSE);
       const double* gp = c->w_part_gv ? c->gpart_v : c->gpart;
-      const int ngp = c->w_part_gv ? c->ngp_v : GRAM_BLOCKS;
+      const int ngp = c->w_part_gv ? c->ngp_v : c->ngp_gram;
       if (c->weighted) {
         K_SWITCH(c->K, p.launch(sse_part_kernel<KT, true>, dim3(blocks), dim3(WS_ROWS * ws_split(KT)), 0, (const double*)c->part,
                                 c->w_part_nch, c->ldw, gp, ngp, (double)c->R, (const double*)c->W, c->row0, c->nl, c->bsum));
@@ -1842,7 +1864,7 @@ int btf_draw_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double 
       HIPCHK(c, hipGetLastError());
       nb = (size_t)blocks;
       ssw += c->sa2;
-    } else if ((rc = sse_launch(c, &nb))) {
+    } else if (phase != 2 && (rc = sse_launch(c, &nb))) {
       return rc;
     }
   }
@@ -1850,8 +1872,9 @@ int btf_draw_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double 
   const double nfree = (double)c->N * c->K - (double)h * (h - 1) / 2.0 - (double)(c->K - h) * c->N;   // factor.py:155-174
   {
     Prof p(c, BTF_K_HYPER);
-    p.launch(scalars_kernel, dim3(1), dim3(256), 0, (const double*)c->bsum, (int)nb, ssw, c->nobs, (const double*)c->W,
-             c->N, c->K, nfree, nu2_a, nu2_b, sigma2_a, sigma2_b, which & 3, (unsigned long long)seed, c->hyp);
+    p.launch(scalars_kernel, dim3(1), dim3(256), 0, (const double*)c->bsum, (int)nb, ssw,
+             c->nobs_global >= 0.0 ? c->nobs_global : c->nobs, (const double*)c->W,
+             c->N, c->K, nfree, nu2_a, nu2_b, sigma2_a, sigma2_b, which & 3, (unsigned long long)seed, c->hyp, phase);
   }
   HIPCHK(c, hipGetLastError());
   return BTF_OK;

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
 // ============================================================================
 // small helpers: Gram of the fixed factor, per-row outer products
 // ============================================================================
-constexpr int GRAM_BLOCKS = 16;
+constexpr int GRAM_BLOCKS = 64;          // at most (gpart is sized for it); gram_blocks() picks the launch
+__host__ inline int gram_blocks(int Rdim) { int b = Rdim / 1024; return b < 16 ? 16 : (b > GRAM_BLOCKS ? GRAM_BLOCKS : b); }
 constexpr int GRAM_THREADS = 256;
 
 template <int K>
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const double* __rest
   double acc[KK];
 #pragma unroll
   for (int q = 0; q < KK; ++q) acc[q] = 0.0;
-  for (int r = blockIdx.x * GRAM_THREADS + threadIdx.x; r < Rdim; r += GRAM_BLOCKS * GRAM_THREADS) {
+  for (int r = blockIdx.x * GRAM_THREADS + threadIdx.x; r < Rdim; r += gridDim.x * GRAM_THREADS) {
     double u[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) u[k] = U[(size_t)r * K + k];
@@ -1377,20 +1378,29 @@ __device__ inline double block_sum_fixed(double x, double* red) {   // all 256 t
 }
 
 // which: bit 0 = nu2 (needs the SSE block partials), bit 1 = sigma2
+// phase 0: reduce and draw (one GPU).  Sharded runs split the nu2 part around an all-reduce of the rank-local sum:
+// phase 1 = reduce only, hyp[HYP_SSE] <- this rank's residual sum of squares; phase 2 = draw from hyp[HYP_SSE]
+// as it stands (the collective has summed it over the ranks in between; every rank then draws the same value).
 __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__ bsum, int nb, double ssw, double nobs,
                                                       const double* __restrict__ W, int N, int K, double nfree,
                                                       double nu2_a, double nu2_b, double sig_a, double sig_b, int which,
-                                                      unsigned long long seed, double* __restrict__ hyp) {
+                                                      unsigned long long seed, double* __restrict__ hyp, int phase) {
   __shared__ double red[4];
   __shared__ double stat[2];
   // both reductions first (all threads), then the two draws side by side: thread 0 draws nu2 while thread 64
   // (another wave) draws sigma2 - a Gamma draw with shape ~1e7 is ~2 us of dependent f64 work on one lane
-  if (which & 1) {
+  if ((which & 1) && phase != 2) {
     double acc = 0.0;
     for (int b = threadIdx.x; b < nb; b += 256) acc += bsum[b];
     const double sse = block_sum_fixed(acc, red) + ssw;
     if (threadIdx.x == 0) stat[0] = sse;
   }
+  if (phase == 1) {
+    __syncthreads();
+    if ((which & 1) && threadIdx.x == 0) hyp[HYP_SSE] = stat[0];
+    return;
+  }
+  if ((which & 1) && phase == 2 && threadIdx.x == 0) stat[0] = hyp[HYP_SSE];
   if (which & 2) {
     double acc = 0.0;
     for (int e = threadIdx.x; e < N * K; e += 256) { const double w = W[e]; acc = fma(w, w, acc); }   // the structural zeros add 0

@@ -130,7 +130,9 @@ class BayesianTensorFiltering(_BayesianModel):
         # scalar hyper-parameters: host values, or (rng="device", unsharded) device-resident
         self._sc = {"nu2": 1.0, "sigma2": 1.0, "lam2": 1.0, "lam2_a": 1.0}
         self._sc_host_new, self._sc_dev_new = False, False
-        self._dev_scalars = rng == "device" and self._plan.world == 1 and not self._exchange.active
+        # rng="device": nu2, sigma2, lam2, lam2_a live on the GPU.  Sharded runs keep them there too: W and V are
+        # replicated, so only the residual sum of squares of nu2 | rest needs an exchange (one all-reduced double)
+        self._dev_scalars = rng == "device"
         if self._dev_scalars:
             self._ctx.call("btf_device_scalars", 1)
 
@@ -317,8 +319,19 @@ class BayesianTensorFiltering(_BayesianModel):
         if key == self._data_key:
             return
         self._upload(data)
+        if self._exchange.active:      # observation count over all ranks (a constant of the data set)
+            (tot,) = self._exchange.sum_scalars(float(self._local_nobs(data)))
+            self._ctx.call("btf_set_global_nobs", float(tot))
         self._data_ref = data          # keep alive so ids are not recycled
         self._data_key = key
+
+    def _local_nobs(self, data):
+        """Observed entries of this rank's row slab."""
+        rows = getattr(data, "rows", None)
+        if rows is None:
+            a = data[0] if isinstance(data, (tuple, list)) else data
+            rows = a[self._plan.row0:self._plan.row0 + self._plan.nl]
+        return int(np.count_nonzero(~np.isnan(rows)))
 
     def set_data(self, data):
         """Force a re-upload.  The reference re-reads the observation array on every half-sweep
@@ -330,6 +343,16 @@ class BayesianTensorFiltering(_BayesianModel):
 
     def _upload(self, data):
         raise NotImplementedError
+
+    def _set_stale_sources(self, any_nan, missing):
+        """Quirks Q1/Q2 are reproduced only under compat="reference"; "exact" uses every output's own weights (and a
+        sharded run could not reach a source row / column outside its slabs)."""
+        if self.compat != "reference":
+            self._ctx.call("btf_set_stale_sources", None, None)
+            return
+        self._ctx.call("btf_set_stale_sources",
+                       stale_row_sources(self.nrows, self.nembeds, any_nan).ctypes.data_as(_native._c_ip),
+                       stale_col_sources(missing).ctypes.data_as(_native._c_ip))
 
     # ---- construction draws ------------------------------------------------------
     def _init_sigma2(self):
@@ -497,7 +520,8 @@ class BayesianTensorFiltering(_BayesianModel):
 
     # ---- sample collection ------------------------------------------------------------
     def _collects_on_device(self):
-        return self._dev_scalars and getattr(self, "_scalar_noise", False)
+        return self._dev_scalars and getattr(self, "_scalar_noise", False) and self._plan.world == 1 \
+            and not self._exchange.active
 
     def run_gibbs(self, data, nburn=1000, nthin=1, nsamples=1000, verbose=True, print_freq=100,
                   callback=None, **kwargs):
@@ -633,9 +657,7 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
         rows, cols = self._plan.slabs(Y4)
         self._ctx.call("btf_set_data_gaussian", _native.dptr(rows), _native.dptr(cols), int(Y4.shape[3]))
         miss = np.isnan(Y4)
-        self._ctx.call("btf_set_stale_sources",
-                       stale_row_sources(self.nrows, self.nembeds, bool(miss.any())).ctypes.data_as(_native._c_ip),
-                       stale_col_sources(miss.all(axis=3)).ctypes.data_as(_native._c_ip))
+        self._set_stale_sources(bool(miss.any()), miss.all(axis=3))
 
     def resample(self, data):
         self._in_sweep = True
@@ -685,7 +707,13 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
                 # later in this sweep goes straight to the solve
                 self._ctx.call("btf_w_accum", _native.COMPAT[self.compat])
                 which |= 4
-            self._ctx.call("btf_draw_scalars", self._next_seed(), which, float(self.nu2_a), float(self.nu2_b),
+            seed = self._next_seed()
+            if self._exchange.active:      # this rank's share -> all-reduce of one device double -> identical draws
+                self._ctx.call("btf_draw_scalars", seed, (which & 5) | 8, float(self.nu2_a), float(self.nu2_b),
+                               float(self.sigma2_a), float(self.sigma2_b))
+                self._exchange.all_reduce_sse()
+                which = (which & 3) | 16
+            self._ctx.call("btf_draw_scalars", seed, which, float(self.nu2_a), float(self.nu2_b),
                            float(self.sigma2_a), float(self.sigma2_b))
             self._sc_dev_new = True
             return
@@ -755,9 +783,7 @@ class BinomialBayesianTensorFiltering(GaussianBayesianTensorFiltering):
         nr, nc = self._plan.slabs(N[..., None])
         self._ctx.call("btf_set_data_binomial", _native.dptr(yr), _native.dptr(nr), _native.dptr(yc), _native.dptr(nc))
         miss = np.isnan(Y) | np.isnan(N)
-        self._ctx.call("btf_set_stale_sources",
-                       stale_row_sources(self.nrows, self.nembeds, bool(miss.any())).ctypes.data_as(_native._c_ip),
-                       stale_col_sources(miss).ctypes.data_as(_native._c_ip))
+        self._set_stale_sources(bool(miss.any()), miss)
         self._omega_host_new = True
 
     def _set_noise(self):
@@ -852,9 +878,7 @@ class NegativeBinomialBayesianTensorFiltering(BinomialBayesianTensorFiltering):
             raise ValueError("data shape %r does not match the model" % (data.shape,))
         self._ctx.call("btf_set_data_counts", _native.dptr(d4), int(d4.shape[3]))
         miss = np.all(np.isnan(d4), axis=-1)
-        self._ctx.call("btf_set_stale_sources",
-                       stale_row_sources(self.nrows, self.nembeds, bool(miss.any())).ctypes.data_as(_native._c_ip),
-                       stale_col_sources(miss).ctypes.data_as(_native._c_ip))
+        self._set_stale_sources(bool(miss.any()), miss)
         self._nb_sum = np.nansum(d4, axis=-1)
         self._nb_cnt = (~np.isnan(d4)).sum(axis=-1).astype(float)
         self._rate_key = None

@@ -69,7 +69,7 @@ class Exchange:
         self.plan, self.ctx, self.group = plan, ctx, group
         self._Wt = self._Vt = None
         self._tstream = None
-        self.timing, self._events = False, {"all_gather_W": [], "all_gather_V": []}
+        self.timing, self._events = False, {"all_gather_W": [], "all_gather_V": [], "all_reduce_sse": []}
         # BTF_EXERCISE_EXCHANGE=1: issue the collectives even in a 1-rank group (lets a 1-GPU box
         # run the exact RCCL call sequence of the sharded path)
         import os
@@ -162,6 +162,24 @@ class Exchange:
         _, _, T, K, _ = self.ctx.dims
         n = self.plan.col_chunk * T * K
         self._timed("all_gather_V", lambda: dist.all_gather_into_tensor(Vt, Vt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group))
+
+    def all_reduce_sse(self):
+        """Sum the rank-local residual sum of squares (device scalar slot 4, btf_dev_hyp) over the ranks, in place,
+        on the ctx's stream: the one exchange of a sharded nu2 draw (include/btf.h, btf_draw_scalars which | 8 / | 16)."""
+        if not self.active:
+            return
+        import torch.distributed as dist
+        if self._staged():
+            out = np.zeros(6)
+            self.ctx.call("btf_get_scalars", out.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double)))
+            (tot,) = self.sum_scalars(float(out[4]))
+            self.ctx.call("btf_set_scalar_slot", 4, float(tot))
+            return
+        import torch
+        if getattr(self, "_sse_t", None) is None:
+            ptr = self.ctx.lib.btf_dev_hyp(self.ctx.h)
+            self._sse_t = torch.as_tensor(_DevView(ptr + 4 * 8, (1,)), device=torch.device("cuda", self.ctx.device))
+        self._timed("all_reduce_sse", lambda: dist.all_reduce(self._sse_t, group=self.group))
 
     def sum_scalars(self, *vals):
         if not self.active:

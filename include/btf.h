@@ -181,6 +181,14 @@ int btf_set_nu2(btf_ctx* ctx, double nu2);               /* Gaussian scalar nois
  * draw them there from Philox streams, so that a full Gibbs sweep queues without a host round
  * trip.  btf_set_scalars uploads values, btf_get_scalars (synchronises) returns
  * {nu2, sigma2, lam2, lam2_a, SSE of the last nu2 draw, sum W^2 of the last sigma2 draw}.      */
+/* Sharded contexts: the residual sum of squares of nu2 | rest is a sum over the ranks' row slabs.  btf_draw_scalars
+ * with which | 8 only reduces this rank's share into the device scalar out6[4] (btf_dev_hyp() + 4 doubles); the caller
+ * all-reduces that one double over the ranks (RCCL, on btf_stream) and calls btf_draw_scalars with which | 16, which
+ * draws from it - every rank the same value (same seed).  btf_set_global_nobs: the observation count over all
+ * ranks (a constant of the data set).  sigma2, Tau2, lam2 need no exchange: W and V are replicated.            */
+void* btf_dev_hyp(btf_ctx* ctx);
+int btf_set_global_nobs(btf_ctx* ctx, double nobs);
+int btf_set_scalar_slot(btf_ctx* ctx, int slot, double value);  /* one entry of the btf_get_scalars array (staged exchanges) */
 int btf_device_scalars(btf_ctx* ctx, int enable);
 int btf_set_scalars(btf_ctx* ctx, double nu2, double sigma2, double lam2, double lam2_a);
 int btf_get_scalars(btf_ctx* ctx, double* out6);

@@ -46,6 +46,49 @@ def main():
         np.random.seed(50)
         ref = 1.0 / np.random.gamma(0.1 + n / 2.0, 1.0 / (0.1 + sse / 2.0))
         assert abs(model.nu2 - ref) / ref < 1e-10, (model.nu2, ref)
+    # ---- rng="device": whole sweeps with every scalar drawn on the GPU.  The Philox streams are keyed by global row /
+    # column / cell indices and the residual sum of squares is all-reduced on the device, so the sharded chain must
+    # reproduce the unsharded one (up to the rounding of differently grouped sums).
+    from functionalmf_amd.factor import BinomialBayesianTensorFiltering
+    for name in ("g2_c2_complete.npz", "g1_c1_heldout.npz"):
+        g = load_golden(name)
+        N, M, T, R, K, tf = [int(x) for x in g["dims"]]
+        st = state_from(g, "s0_")
+        chains = []
+        for shard in ((rank, world), None):
+            np.random.seed(7)
+            m = GaussianBayesianTensorFiltering(
+                N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
+                W_init=st["W"], V_init=st["V"], compat="exact", shard=shard, device=0, rng="device", device_seed=9,
+                # (held-out cells: a rank whose slabs happen to be complete would pick the spectral sampler where the
+                #  unsharded run - one weighted tensor - uses the banded one: same distribution, another square root)
+                sampler="auto" if name.startswith("g2") else "banded")
+            assert m._dev_scalars and (m._exchange.active == (shard is not None))
+            for _ in range(3):
+                m.resample(g["Y"])
+            chains.append((m.W.copy(), m.V.copy(), float(m.nu2), float(m.sigma2), float(m.lam2), np.array(m.Tau2).copy()))
+            del m
+        a, b = chains
+        assert np.abs(a[0] - b[0]).max() / np.abs(b[0]).max() < 1e-7, name
+        assert np.abs(a[1] - b[1]).max() / np.abs(b[1]).max() < 1e-5, name
+        assert abs(a[2] - b[2]) / b[2] < 1e-9 and abs(a[3] - b[3]) / b[3] < 1e-9 and abs(a[4] - b[4]) / b[4] < 1e-7, (name, a[2:5], b[2:5])
+        assert np.abs(a[5] - b[5]).max() / np.abs(b[5]).max() < 1e-5, name
+    g = load_golden("g4_binomial_full.npz")
+    N, M, T, R, K, tf = [int(x) for x in g["dims"]]
+    st = state_from(g, "s0_")
+    chains = []
+    for shard in ((rank, world), None):
+        np.random.seed(7)
+        m = BinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                            W_init=st["W"], V_init=st["V"], compat="exact", shard=shard, device=0, rng="device",
+                                            device_seed=9)
+        for _ in range(2):
+            m.resample((g["Ysucc"], g["Ntrials"]))
+        chains.append((m.W.copy(), m.V.copy(), np.array(m.nu2).copy()))
+        del m
+    a, b = chains
+    assert np.abs(a[2] - b[2]).max() / np.abs(b[2]).max() < 1e-12          # the same Polya-Gamma draws, cell by cell
+    assert np.abs(a[0] - b[0]).max() / np.abs(b[0]).max() < 1e-7 and np.abs(a[1] - b[1]).max() / np.abs(b[1]).max() < 1e-5
     print("SHARD_GPU_OK rank", rank, flush=True)
     dist.barrier()
     dist.destroy_process_group()
