@@ -94,7 +94,7 @@ SIGNATURES = {
     "btf_kernel_times": (C.c_int, [_ctx, _c_dp, C.POINTER(C.c_int64)]),
     "btf_set_tuning": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "btf_set_option": (C.c_int, [_ctx, C.c_int, C.c_int]),
-    "btf_sym_eig": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, _c_dp]),
+    "btf_sym_eig": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp]),
     "btf_get_V_sampler": (C.c_int, [_ctx, _c_ip]),
 }
 

@@ -269,7 +269,7 @@ template <int K>
 void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const unsigned char* C8, const double* U,
                   const double* UU, const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr}) {
   Prof p(c, kid);
-  dim3 grid(ld / ACC_TILE, nch + (side.out ? 1 : 0));      // (+ the side task's grid row)
+  dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 : 0));   // (+ the side task's workgroup)
   if (mode >= 1 && C8) {       // byte weights (Gaussian replicate counts)
     if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
     else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
@@ -316,8 +316,8 @@ void launch_products(btf_ctx* c, const double* U, int Rdim, double* UU) {
 template <int K>
 void launch_wsolve(btf_ctx* c, const WSolveArgs& a) {
   Prof p(c, BTF_K_W_SOLVE);
-  if (a.weighted) p.launch(w_solve_kernel<K, true>, dim3((a.nl + WS_ROWS - 1) / WS_ROWS), dim3(WS_ROWS * ws_split(K)), 0, a);
-  else p.launch(w_solve_kernel<K, false>, dim3((a.nl + WS_ROWS - 1) / WS_ROWS), dim3(WS_ROWS * ws_split(K)), 0, a);
+  if (a.weighted) p.launch(w_solve_kernel<K, true>, dim3((a.nl + WS_ROWS - 1) / WS_ROWS), dim3(WS_ROWS * ws_split_of(K, true)), 0, a);
+  else p.launch(w_solve_kernel<K, false>, dim3((a.nl + WS_ROWS - 1) / WS_ROWS), dim3(WS_ROWS * ws_split_of(K, false)), 0, a);
 }
 template <int K>
 hipError_t launch_vbanded(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
@@ -1050,11 +1050,13 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
   size_t lds_band = std::max((size_t)n * R1, (size_t)(GRAM_BLOCKS + 16) * KK) * sizeof(double);   // (also the Gram staging area)
   size_t lds_bytes = lds_fixed + lds_band;
   VBandArgs a{};
-  if (lds_bytes > 150 * 1024) {  // band lives in HBM scratch, only vectors on chip
+  if (lds_bytes > 150 * 1024) {  // band (and the weighted case's per-depth likelihood blocks) in HBM scratch, only vectors on chip
+    if (wt) lds_fixed -= (size_t)T * KK * sizeof(double);
     if (lds_fixed > 150 * 1024) return fail(c, BTF_EINVAL, "ndepth*nembeds too large for the on-chip vectors");
-    if (!c->gband || c->gband_stride != (size_t)n * R1) {
-      if ((rc = dev_alloc(c, &c->gband, (size_t)c->ml * n * R1))) return rc;
-      c->gband_stride = (size_t)n * R1;
+    const size_t stride = (size_t)n * R1 + (wt ? (size_t)T * KK : 0);
+    if (!c->gband || c->gband_stride != stride) {
+      if ((rc = dev_alloc(c, &c->gband, (size_t)c->ml * stride))) return rc;
+      c->gband_stride = stride;
     }
     a.gband = c->gband; a.gband_stride = c->gband_stride;
     lds_bytes = lds_fixed;
@@ -1088,7 +1090,7 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
   }
   // V'V partials for the next W half-sweep (one KK block per column; bounded by the consumer's LDS stage)
   const bool emit_gv = !prior_only && fast && whole && c->fuse_gram && !wt &&
-                       (size_t)c->ml * KK + 16 * KK <= (size_t)ws_split(K) * (K + KK) * WS_ROWS;   // w_solve's LDS stage
+                       (size_t)c->ml * KK + 16 * KK <= ws_gram_stage(K, false);   // w_solve's LDS stage
   if (emit_gv) {
     if (!c->gpart_v) { if ((rc = dev_alloc(c, &c->gpart_v, (size_t)c->M * KK))) return rc; }
     a.gout = c->gpart_v;
@@ -1159,7 +1161,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       sa.eps0 = eps0; sa.attempts = attempts; sa.status = c->status; sa.tries = c->tries;
       sa.hyp = c->dev_scalars ? c->hyp : nullptr; sa.Rrep = c->R; sa.hyp_noise = c->binomial ? 0 : 1; sa.dbg = c->dbg;
       const bool emit = whole && c->fuse_gram &&
-                        (size_t)c->ml * KK + 16 * KK <= (size_t)ws_split(K) * (K + KK) * WS_ROWS;   // w_solve's LDS stage
+                        (size_t)c->ml * KK + 16 * KK <= ws_gram_stage(K, false);   // w_solve's LDS stage
       if (emit) {
         if (!c->gpart_v) { if ((rc = dev_alloc(c, &c->gpart_v, (size_t)c->M * KK))) return rc; }
         sa.gout = c->gpart_v;
@@ -2030,7 +2032,7 @@ int btf_pg_batch_mode(int device, int64_t n, const double* b, const double* psi,
   return BTF_OK;
 }
 
-int btf_sym_eig(int device, int K, int nparts, const double* parts, double* out) {
+int btf_sym_eig(int device, int K, int nparts, const double* parts, double* out, const double* warm_from) {
   if (K < 1 || K > EIG_MAXK || nparts < 1 || !parts || !out) return fail(nullptr, BTF_EINVAL, "bad sym_eig arguments");
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return fail(nullptr, BTF_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
@@ -2041,8 +2043,14 @@ int btf_sym_eig(int device, int K, int nparts, const double* parts, double* out)
   SE(hipMalloc((void**)&dp, np * sizeof(double)));
   SE(hipMalloc((void**)&dout, no * sizeof(double)));
   SE(hipMemset(dout, 0, no * sizeof(double)));
+  if (warm_from) {      // a previous solution to refine: eigenvalues, vectors, (sweeps), then the "valid" word
+    std::vector<double> w(no, 0.0);
+    std::memcpy(w.data(), warm_from, ((size_t)K + K * K) * sizeof(double));
+    w[(size_t)K + K * K + 1] = 1.0;
+    SE(hipMemcpy(dout, w.data(), no * sizeof(double), hipMemcpyHostToDevice));
+  }
   SE(hipMemcpy(dp, parts, np * sizeof(double), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(gram_eig_kernel, dim3(1), dim3(WAVE), 0, 0, (const double*)dp, nparts, K, dout);
+  hipLaunchKernelGGL(gram_eig_kernel, dim3(1), dim3(WAVE), 0, 0, (const double*)dp, nparts, K, dout, warm_from ? 1 : 0);
   SE(hipGetLastError());
   SE(hipDeviceSynchronize());
   SE(hipMemcpy(out, dout, ((size_t)K + K * K + 1) * sizeof(double), hipMemcpyDeviceToHost));

@@ -8,10 +8,9 @@
 // out[K + K*K]     number of sweeps used (diagnostic)
 // out[K + K*K + 1] warm-start counter (see below); 0 = `out` holds no previous solution
 //
-// Warm start: between two Gibbs sweeps the Gram moves little, so the previous eigenvectors nearly diagonalise
-// the new matrix: the iteration starts from A0 = U_prev' G U_prev, U0 = U_prev (two K^3 products) and needs two
-// or three sweeps instead of six.  Rounding lets U0 drift from orthogonality by ~1e-16 per call, so every 16th
-// call starts cold from U0 = I.  The result is the eigen-system of G to rounding either way.
+// Warm start: between two Gibbs sweeps the Gram moves little, so the previous eigenvectors (left in `out`) are
+// refined instead of recomputed (Ogita-Aishima iteration, below): two or three iterations of four K^3 products.
+// First call, or no convergence: cold cyclic Jacobi.  The result is the eigen-system of G to rounding either way.
 //
 // A lone wave issues one f64 instruction per ~8 cycles, so a round is written for instruction count: every
 // index computes its own rotation (no serial section), the angle comes from the hardware rsq / rcp
@@ -74,31 +73,77 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
   const bool h0 = e0 < K2, h1 = e1 < K2;
   const int r0 = h0 ? e0 / K : 0, c0 = h0 ? e0 - r0 * K : 0;
   const int r1 = h1 ? e1 / K : 0, c1 = h1 ? e1 - r1 * K : 0;
+  // ---- warm path: refine the previous eigenvectors (Ogita & Aishima 2018, "Iterative refinement for symmetric
+  //      eigenvalue decomposition"): with X ~ eigenvectors,  R = I - X'X,  S = X'GX,  lambda_i = s_ii / (1 - r_ii),
+  //      e_ij = (s_ij + lambda_j r_ij) / (lambda_j - lambda_i)  (r_ij / 2 on the diagonal and inside a cluster),
+  //      X <- X + X E.  Four K^3 products per iteration, quadratic convergence, and the R term pulls X back to
+  //      orthogonality, so nothing drifts from call to call.  Between two Gibbs sweeps the Gram moves by ~1e-3, so
+  //      two or three iterations reach 1e-15.  Anything else (first call, no convergence) takes the Jacobi path.
   const double wcount = out[K + K2 + 1];
-  const bool warm = warm_ok && wcount >= 1.0 && wcount < 16.0;
-  if (h0) Ub0[e0] = warm ? out[K + e0] : (r0 == c0 ? 1.0 : 0.0);
-  if (h1) Ub0[e1] = warm ? out[K + e1] : (r1 == c1 ? 1.0 : 0.0);
-  wave_lds_sync();
-  if (warm) {                           // A0 = U0' G U0 through Ab1 = G U0
-    for (int h = 0; h < 2; ++h) {
-      const bool on = h ? h1 : h0;
-      const int e = h ? e1 : e0, r = h ? r1 : r0, c = h ? c1 : c0;
-      if (on) {
-        double s = 0.0;
-        for (int k = 0; k < K; ++k) s = fma(Ab0[r * K + k], Ub0[k * K + c], s);
-        Ab1[e] = s;
+  const bool warm = warm_ok && wcount >= 1.0 && K > 1;
+  double* lamv = reinterpret_cast<double*>(csg);                   // K eigenvalue estimates (csg is idle here)
+  bool refined = false;
+  int xcur = 0;
+  if (warm) {
+    if (h0) Ub0[e0] = out[K + e0];
+    if (h1) Ub0[e1] = out[K + e1];
+    wave_lds_sync();
+    float prev_err = 3.0e38f;
+    for (int it = 0; it < 8; ++it) {
+      const double* X = xcur ? Ub1 : Ub0;
+      double* Xn = xcur ? Ub0 : Ub1;
+      // T = G X (-> Ab1), R = I - X'X (registers)
+      double R0 = 0.0, R1 = 0.0;
+      {
+        double t0 = 0.0, t1 = 0.0, q0 = 0.0, q1 = 0.0;
+        if (h0) for (int k = 0; k < K; ++k) { const double xc = X[k * K + c0]; t0 = fma(Ab0[r0 * K + k], xc, t0); q0 = fma(X[k * K + r0], xc, q0); }
+        if (h1) for (int k = 0; k < K; ++k) { const double xc = X[k * K + c1]; t1 = fma(Ab0[r1 * K + k], xc, t1); q1 = fma(X[k * K + r1], xc, q1); }
+        if (h0) { Ab1[e0] = t0; R0 = (r0 == c0 ? 1.0 : 0.0) - q0; }
+        if (h1) { Ab1[e1] = t1; R1 = (r1 == c1 ? 1.0 : 0.0) - q1; }
       }
+      wave_lds_sync();
+      // S = X'T (registers); eigenvalue estimates from the diagonal
+      double S0 = 0.0, S1 = 0.0;
+      if (h0) for (int k = 0; k < K; ++k) S0 = fma(X[k * K + r0], Ab1[k * K + c0], S0);
+      if (h1) for (int k = 0; k < K; ++k) S1 = fma(X[k * K + r1], Ab1[k * K + c1], S1);
+      if (h0 && r0 == c0) lamv[r0] = S0 / (1.0 - R0);
+      if (h1 && r1 == c1) lamv[r1] = S1 / (1.0 - R1);
+      wave_lds_sync();
+      double lmax = 0.0;
+      for (int k = 0; k < K; ++k) lmax = fmax(lmax, fabs(lamv[k]));
+      // error of this iterate: off-diagonal of S and all of R, relative to the largest eigenvalue
+      float err = 0.0f;
+      if (h0) err = fmaxf(err, (float)fmax(r0 == c0 ? 0.0 : fabs(S0), lmax * fabs(R0)));
+      if (h1) err = fmaxf(err, (float)fmax(r1 == c1 ? 0.0 : fabs(S1), lmax * fabs(R1)));
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) err = fmaxf(err, __shfl_xor(err, off, WAVE));
+      const float rel = err / (float)lmax;
+      if (rel <= 2e-15f) { refined = true; break; }
+      if (!(rel < 0.05f) || !(err < 0.5f * prev_err) || it == 7) break;      // too far, or not contracting: Jacobi
+      prev_err = err;
+      const bool last = rel <= 1e-8f;      // quadratic convergence: this update lands at ~rel^2, no further check needed
+      const double delta = 2.0 * K * (double)err;                            // cluster threshold (bounds ||S - D|| + ||G|| ||R||)
+      if (h0) {
+        const double gap = lamv[c0] - lamv[r0];
+        Ab1[e0] = (r0 == c0 || !(fabs(gap) > delta)) ? 0.5 * R0 : (S0 + lamv[c0] * R0) / gap;
+      }
+      if (h1) {
+        const double gap = lamv[c1] - lamv[r1];
+        Ab1[e1] = (r1 == c1 || !(fabs(gap) > delta)) ? 0.5 * R1 : (S1 + lamv[c1] * R1) / gap;
+      }
+      wave_lds_sync();
+      // X <- X + X E
+      if (h0) { double x = X[e0]; for (int k = 0; k < K; ++k) x = fma(X[r0 * K + k], Ab1[k * K + c0], x); Xn[e0] = x; }
+      if (h1) { double x = X[e1]; for (int k = 0; k < K; ++k) x = fma(X[r1 * K + k], Ab1[k * K + c1], x); Xn[e1] = x; }
+      xcur ^= 1;
+      wave_lds_sync();
+      if (last) { refined = true; break; }
     }
+  }
+  if (!refined) {
+    if (h0) Ub0[e0] = r0 == c0 ? 1.0 : 0.0;
+    if (h1) Ub0[e1] = r1 == c1 ? 1.0 : 0.0;
     wave_lds_sync();
-    double t0 = 0.0, t1 = 0.0;
-    if (h0) for (int k = 0; k < K; ++k) t0 = fma(Ub0[k * K + r0], Ab1[k * K + c0], t0);
-    if (h1) for (int k = 0; k < K; ++k) t1 = fma(Ub0[k * K + r1], Ab1[k * K + c1], t1);
-    wave_lds_sync();
-    if (h0) Ab0[e0] = t0;
-    if (h1) Ab0[e1] = t1;
-    wave_lds_sync();
-    // (A0 is symmetric up to rounding; the rotations read its upper triangle for a pair (p < q) and both triangles
-    //  in the update, exactly as for a cold start)
   }
   const int Ke = K + (K & 1);            // players of the round-robin tournament (a phantom one if K is odd)
   const int Km = Ke - 1;
@@ -113,7 +158,7 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
   }
   wave_lds_sync();
   int cur = 0, sweeps = 0;
-  for (; sweeps < 20 && K > 1; ++sweeps) {
+  for (; !refined && sweeps < 20 && K > 1; ++sweeps) {
     bool big = false;
     for (int round = 0; round < Km; ++round) {
       const double* A = cur ? Ab1 : Ab0;
@@ -179,12 +224,16 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
   }
   // ---- sort ascending, fix the signs, write
   const double* A = cur ? Ab1 : Ab0;
-  const double* U = cur ? Ub1 : Ub0;
+  const double* U = refined ? (xcur ? Ub1 : Ub0) : (cur ? Ub1 : Ub0);
+  if (!refined) {
+    if (lane < K) lamv[lane] = A[lane * K + lane];
+    wave_lds_sync();
+  }
   if (lane < K) {
-    const double lam = A[lane * K + lane];
+    const double lam = lamv[lane];
     int rank = 0;
     for (int i = 0; i < K; ++i) {
-      const double li = A[i * K + i];
+      const double li = lamv[i];
       if (li < lam || (li == lam && i < lane)) ++rank;
     }
     int bigr = 0;
@@ -198,8 +247,8 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
     for (int r = 0; r < K; ++r) out[K + r * K + rank] = sgn * U[r * K + lane];
   }
   if (lane == 0) {
-    out[K + K * K] = (double)sweeps;
-    out[K + K * K + 1] = warm ? wcount + 1.0 : 1.0;
+    out[K + K * K] = (double)sweeps;           // Jacobi sweeps (0: the refinement path converged)
+    out[K + K * K + 1] = 1.0;                  // `out` now holds a solution to start the next call from
   }
   __builtin_amdgcn_s_setprio(0);
 }
@@ -208,9 +257,9 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
 struct EigSide { const double* gpart; int ngp; int K; double* out; };
 
 __global__ __launch_bounds__(WAVE) void gram_eig_kernel(const double* __restrict__ gpart, int ngp, int K,
-                                                        double* __restrict__ out) {
+                                                        double* __restrict__ out, int warm) {
   __shared__ __attribute__((aligned(16))) double scratch[EIG_LDS_DOUBLES];
-  gram_eig_wave(gpart, ngp, K, out, scratch, false);
+  gram_eig_wave(gpart, ngp, K, out, scratch, warm != 0);
 }
 
 }  // namespace btf

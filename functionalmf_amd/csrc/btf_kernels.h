@@ -66,17 +66,21 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = blockIdx.x;
-  int chunk = blockIdx.y;
+  // grid: one workgroup per (tile, chunk), linear; with a side task one more in front of them
+  int b = blockIdx.x;
   if (side.out) {
-    // side task (spectral V sampler): the first grid row is dispatched first; one wave of it solves the K x K
-    // eigenproblem of the Gram beside the stream, the others leave at once
-    if (chunk == 0) {
-      if (tile == 0 && wave == 0) gram_eig_wave(side.gpart, side.ngp, side.K, side.out, &red[0][0][0]);
+    // side task (spectral V sampler): the first workgroup is dispatched first; one wave of it solves the K x K
+    // eigenproblem of the Gram beside the stream, its other waves leave at once
+    if (b == 0) {
+#ifndef BTF_EIG_NOP      // (timing aid: BTF_EIG_NOP builds skip the side task - results are wrong, only the clock is read)
+      if (wave == 0) gram_eig_wave(side.gpart, side.ngp, side.K, side.out, &red[0][0][0]);
+#endif
       return;
     }
-    --chunk;
+    --b;
   }
+  const int ntiles = ld / ACC_TILE;
+  const int chunk = b / ntiles, tile = b - chunk * ntiles;
   const size_t col = (size_t)tile * ACC_TILE + 2 * lane;
   const int r0 = chunk * rows_per_block;
   const int r1 = min(r0 + rows_per_block, Rdim);
@@ -350,23 +354,41 @@ enum { HYP_NU2 = 0, HYP_SIGMA2 = 1, HYP_LAM2 = 2, HYP_LAM2A = 3, HYP_SSE = 4, HY
 constexpr int WS_ROWS = 64;   // rows per workgroup (one per lane)
 // waves per workgroup: the chunk partials are summed WS_SPLIT-way in parallel (LDS-bounded)
 __host__ __device__ constexpr int ws_split(int K) { return K <= 6 ? 8 : (K <= 8 ? 4 : 2); }
+// (complete data, 16 waves so that the 64 chunks of a C3 row come in with one batch of loads per wave: measured
+//  10.2 us against 8.2 us for 8 waves - the 1024-thread workgroup costs more than the second batch)
+#ifndef BTF_WS_SPLIT_U
+#define BTF_WS_SPLIT_U 8
+#endif
+__host__ __device__ constexpr int ws_split_of(int K, bool weighted) { return weighted ? ws_split(K) : (K <= 6 ? BTF_WS_SPLIT_U : ws_split(K)); }
+// doubles of LDS the Gram partials may use as their staging area in w_solve (see reduce_gram)
+__host__ __device__ constexpr size_t ws_gram_stage(int K, bool weighted) {
+  return (size_t)ws_split_of(K, weighted) * (K + tri(K)) * WS_ROWS;
+}
 
 template <int K, bool WEIGHTED>
-__global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveArgs a) {
+__global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_kernel(WSolveArgs a) {
   constexpr int KK = tri(K);
-  constexpr int WS_SPLIT = ws_split(K);
+  constexpr int WS_SPLIT = ws_split_of(K, WEIGHTED);
   constexpr int NVMAX = WEIGHTED ? K + KK : K;
   constexpr int NV = NVMAX;
   constexpr int UNR = WEIGHTED ? 2 : 4;                  // chunks whose loads are in flight together
   __shared__ double G[KK];
-  __shared__ double red[WS_SPLIT][K + KK][WS_ROWS];   // also the staging area of reduce_gram
+  __shared__ double red[WS_SPLIT][K + KK][WS_ROWS];   // also the staging area of the Gram partials
   __shared__ double zsh[K][WS_ROWS];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   if (a.hyp) {
     if (a.hyp_noise) { a.s = 1.0 / a.hyp[HYP_NU2]; a.sR = a.s * a.Rrep; }
     a.inv_sigma2 = 1.0 / a.hyp[HYP_SIGMA2];
   }
-  if constexpr (!WEIGHTED) reduce_gram(a.gpart, a.ngp, KK, a.sR, &red[0][0][0], G);
+  // Gram partials of the fixed factor: fetched NOW, together with the first batch of chunk loads below (one
+  // global round trip for both), summed after the chunk sums have left for LDS
+  double gx[8];
+  bool g_early = false;
+  if constexpr (!WEIGHTED) {
+    g_early = a.ngp * KK <= 8 * (int)(WS_ROWS * WS_SPLIT);
+    if (g_early) reduce_gram_fetch(a.gpart, a.ngp, KK, gx);
+    else reduce_gram(a.gpart, a.ngp, KK, a.sR, &red[0][0][0], G);
+  }
   const int il = blockIdx.x * WS_ROWS + lane;
   // stage 1: wave `grp` sums chunks grp, grp+WS_SPLIT, ... (fixed order => deterministic).  The first
   // batch of loads is issued BEFORE the Philox normals of the row are computed (component k by wave
@@ -419,6 +441,10 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void w_solve_kernel(WSolveAr
 #pragma unroll
         for (int v = 0; v < NV; ++v) part[v] += p[(size_t)v * a.ld];
       }
+    }
+    // (the staging area of the Gram partials is `red` itself: this wave's sums wait in registers meanwhile)
+    if constexpr (!WEIGHTED) {
+      if (g_early) reduce_gram_finish(gx, a.ngp, KK, a.sR, &red[0][0][0], G);     // ends with a barrier
     }
 #pragma unroll
     for (int v = 0; v < NVMAX; ++v) red[grp][v][lane] = part[v];
@@ -674,8 +700,11 @@ __global__ __launch_bounds__(WAVE) void v_banded_kernel(VBandArgs a) {
   double* m0 = rhs + n;             // n
   double* invd = m0 + n;            // n
   double* P = invd + n;             // T*D1 prior band  P[t][d] = (Delta' Lambda Delta)[t+d, t]
-  double* Ql = P + T * D1;          // weighted: T*KK ; else KK
-  double* Qe = Ql + (a.weighted ? T * KK : KK);
+  // likelihood blocks: weighted T*KK, else KK.  With the band in HBM scratch (long depth axes) the per-depth blocks
+  // of the weighted case go there too, behind the band: only the vectors stay on chip
+  const bool ql_hbm = a.gband != nullptr && a.weighted;
+  double* Ql = ql_hbm ? a.gband + (size_t)j * a.gband_stride + (size_t)n * R1 : P + T * D1;
+  double* Qe = P + T * D1 + (ql_hbm ? 0 : (a.weighted ? T * KK : KK));
   unsigned short* ptab = reinterpret_cast<unsigned short*>(Qe);   // bw(bw+1)/2 entries, padded to doubles
   double* Bl = Qe + (bw * (bw + 1) / 2 + 3) / 4;
   double* Bc = a.gband ? a.gband + (size_t)j * a.gband_stride : Bl;

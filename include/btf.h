@@ -241,7 +241,9 @@ int btf_get_V_order(btf_ctx* ctx, int32_t* order /* (K*T) */);
 /* The eigen-solver the spectral sampler uses, stand-alone (one-wave cyclic Jacobi, K <= 10): sums `nparts`
  * packed-lower K x K matrices parts[p][r(r+1)/2 + c], returns out[0..K-1] eigenvalues ascending,
  * out[K + r*K + c] component r of eigenvector c (largest-magnitude entry positive), out[K+K*K] sweeps. */
-int btf_sym_eig(int device, int nembeds, int nparts, const double* parts, double* out);
+int btf_sym_eig(int device, int nembeds, int nparts, const double* parts, double* out, const double* warm_from);
+/* warm_from: NULL (cyclic Jacobi from the identity) or the `out` of a nearby matrix, refined by the
+ * Ogita-Aishima iteration (the path the sampler takes from the second sweep on; out[K+K*K] = 0 then). */
 int btf_set_option(btf_ctx* ctx, int option, int value);
 int btf_get_V_sampler(btf_ctx* ctx, int32_t* which);
 

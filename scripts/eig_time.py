@@ -11,8 +11,8 @@ for K in (3, 5, 8, 10):
     tril = np.tril_indices(K)
     parts = np.ascontiguousarray(np.stack([(X[b::8].T @ X[b::8])[tril] for b in range(8)]))
     out = np.zeros(K + K * K + 1)
-    lib.btf_sym_eig(0, K, 8, _native.dptr(parts), _native.dptr(out))
+    lib.btf_sym_eig(0, K, 8, _native.dptr(parts), _native.dptr(out), None)
     t0 = time.perf_counter()
     for _ in range(20):
-        lib.btf_sym_eig(0, K, 8, _native.dptr(parts), _native.dptr(out))
+        lib.btf_sym_eig(0, K, 8, _native.dptr(parts), _native.dptr(out), None)
     print("K=%d sweeps=%d  (host wall per call incl. malloc/copies: %.1f us)" % (K, out[-1], 1e6 * (time.perf_counter() - t0) / 20))
