@@ -995,6 +995,8 @@ struct CellRng {
   bool has32;
   double spare;        // second Box-Muller variate
   bool has_spare;
+  float sparef = 0.0f; // ... of the single-precision pair
+  bool has_sparef = false;
   __device__ CellRng(uint64_t s, uint64_t c)
       : seed(s), cell(c), ctr(0), b0(0), b1(0), b2(0), b3(0), have(0), w32(0), has32(false), spare(0.0), has_spare(false) {}
   __device__ __forceinline__ void half(uint32_t& lo, uint32_t& hi) {
@@ -1034,6 +1036,24 @@ struct CellRng {
     spare = (double)(r * __builtin_amdgcn_sinf(u2));
     has_spare = true;
     return (double)(r * __builtin_amdgcn_cosf(u2));
+  }
+  // the same pair kept in single precision (the flat Gamma loop of the Polya-Gamma series works in f32 throughout)
+  __device__ __forceinline__ float normal32f() {
+    if (has_sparef) { has_sparef = false; return sparef; }
+    uint32_t lo, hi;
+    half(lo, hi);
+    const float u1 = ((float)(lo >> 1) + 0.5f) * (1.0f / 2147483648.0f);
+    const float u2 = (float)(hi >> 8) * (1.0f / 16777216.0f);
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    sparef = r * __builtin_amdgcn_sinf(u2);
+    has_sparef = true;
+    return r * __builtin_amdgcn_cosf(u2);
+  }
+  __device__ __forceinline__ float uniform32f() {               // (0,1), 24-bit resolution: accept / reject only
+    uint32_t w;
+    if (has32) { w = w32; has32 = false; }
+    else { uint32_t hi; half(w, hi); w32 = hi; has32 = true; }
+    return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f);
   }
   __device__ __forceinline__ double normal() {                  // Box-Muller, both variates used
     if (has_spare) { has_spare = false; return spare; }
@@ -1199,39 +1219,51 @@ __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& 
     // if it is accepted, adds it to its current term - a wave runs ~NT + 3 trips instead of NT rejection
     // loops that each last as long as the unluckiest lane.  Candidate normal and the acceptance test use
     // the f32 hardware log (threshold good to ~1e-6: the bias is far below the Monte-Carlo noise).
-    const double d = b - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
-    const float df = (float)d;
+    // The candidate lives in f32 end to end (variates good to ~1e-7 relative); only the accepted term is widened
+    // for the f64 sum, and the weights 1/((k-1/2)^2 + c2) come from v_rcp_f64 + one Newton step, not a division.
+    const double d = b - 1.0 / 3.0;
+    const float df = (float)d, ccf = __builtin_amdgcn_rsqf(9.0f * df);
+    auto weight = [&](int kk) -> double {
+      const double q = fma(kk - 0.5, kk - 0.5, c2);
+      const double r = __builtin_amdgcn_rcp(q);
+      return r * fma(-q, r, 2.0);
+    };
     int k = 1;
-    double wk = 1.0 / (0.25 + c2);
+    double wk = weight(1);
     while (k <= NT) {
-      const double x = g.normal32();
-      const double v1 = 1.0 + cc * x;
-      const double v = v1 * v1 * v1;
-      const float xf = (float)x, vf = (float)v;
-      const float lnu = 0.69314718f * __builtin_amdgcn_logf((float)g.uniform32());
+      const float xf = g.normal32f();
+      const float v1 = fmaf(ccf, xf, 1.0f);
+      const float vf = v1 * v1 * v1;
+      const float lnu = 0.69314718f * __builtin_amdgcn_logf(g.uniform32f());
       const float rhs = 0.5f * xf * xf + df * (1.0f - vf + 0.69314718f * __builtin_amdgcn_logf(vf));
-      if (v1 > 0.0 && lnu < rhs) {
-        s = fma(d * v, wk, s);
+      if (v1 > 0.0f && lnu < rhs) {
+        s = fma(d * (double)vf, wk, s);
         ++k;
-        wk = 1.0 / ((k - 0.5) * (k - 0.5) + c2);
+        wk = weight(k);
       }
     }
   }
-  double tmean, tvar;
-  if (sc > 1e-4 * NT) {
-    const double phi = atan(sc / NT);                       // = pi/2 - atan(NT/sc)
-    tmean = phi / sc;
-    tvar = (phi - 0.5 * sin(2.0 * phi)) / (2.0 * c2 * sc);
+  // Remainder in single precision: it carries a few per cent of the mean and 3e-4 of the variance, so f32's 1e-7
+  // is far inside the Monte-Carlo noise - and the f64 atan / sin / Box-Muller it replaces were ~700 of the ~1000
+  // instructions of a draw.  u = sc / NT: int_NT^inf dx/(x^2+c2) = atan(u)/sc, int dx/(x^2+c2)^2 =
+  // (atan u - u/(1+u^2)) / (2 sc^3); small u by series (the closed forms cancel there).
+  const float NTf = (float)NT, scf = (float)sc, u = scf / NTf, u2 = u * u;
+  float tmean, tvar;
+  if (u < 0.3f) {
+    tmean = (1.0f - u2 * (1.0f / 3.0f - u2 * (0.2f - u2 * (1.0f / 7.0f)))) / NTf;
+    tvar = (1.0f - u2 * (1.2f - u2 * (9.0f / 7.0f - u2 * (4.0f / 3.0f)))) / (3.0f * NTf * NTf * NTf);
   } else {
-    tmean = 1.0 / NT;
-    tvar = 1.0 / (3.0 * (double)NT * NT * NT);
+    const float phi = atanf(u);
+    tmean = phi / scf;
+    tvar = (phi - u / (1.0f + u2)) / (2.0f * scf * scf * scf);
   }
   {   // first Euler-Maclaurin term of the midpoint sums: sum_{k>NT} f(k-1/2) = int_NT^inf f dx + f'(NT)/24 + ...
-    const double q2 = (double)NT * NT + c2;
-    tmean -= (double)NT / (12.0 * q2 * q2);
-    tvar -= (double)NT / (6.0 * q2 * q2 * q2);
+    const float q2 = NTf * NTf + scf * scf;
+    tmean -= NTf / (12.0f * q2 * q2);
+    tvar -= NTf / (6.0f * q2 * q2 * q2);
   }
-  const double x = s + b * tmean + sqrt(b * tvar) * g.normal();
+  const float bf = (float)b;
+  const double x = s + (double)(bf * tmean + __builtin_amdgcn_sqrtf(bf * tvar) * g.normal32f());
   return fmax(x, 1e-300) / (2.0 * PG_PI * PG_PI);
 }
 
