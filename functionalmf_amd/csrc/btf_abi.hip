@@ -39,7 +39,7 @@ struct btf_ctx {
   double* A_wT = nullptr; double* C_wT = nullptr; double* A_v = nullptr; double* C_v = nullptr;
   double* B_wT = nullptr; double* B_v = nullptr;   // binomial: trials (0 where missing)
   unsigned char* C8_wT = nullptr; unsigned char* C8_v = nullptr;   // Gaussian data with missing replicates: counts as bytes (C_* freed)
-  double* W = nullptr; double* V = nullptr; double* WW = nullptr; double* VV = nullptr;
+  double* W = nullptr; double* V = nullptr;
   double* Tau2 = nullptr;
   double lam2 = 1.0, sigma2 = 1.0, nu2 = 1.0;
   bool have_W = false, have_V = false, have_hyper = false;
@@ -267,15 +267,15 @@ int build_stencil(btf_ctx* c) {
 // ---- templated launch tables -------------------------------------------------
 template <int K>
 void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const unsigned char* C8, const double* U,
-                  const double* UU, const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr}) {
+                  const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr}) {
   Prof p(c, kid);
   dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 : 0));   // (+ the side task's workgroup)
   if (mode >= 1 && C8) {       // byte weights (Gaussian replicate counts)
-    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
-    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
-  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
-  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
-  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, UU, srcmap, c->part, Rdim, ld, rpb, side);
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side);
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side);
+  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side);
+  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side);
+  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side);
 }
 // which Polya-Gamma passes a draw needs: exact mode - the exact sampler alone; otherwise the series for every cell
 // that is not an integer count of 1 or 2, and the exact sampler for those (each launch only if such cells exist)
@@ -309,15 +309,15 @@ void launch_gram(btf_ctx* c, const double* U, int Rdim) {
   p.launch(gram_kernel<K>, dim3(c->ngp_gram), dim3(GRAM_THREADS), 0, U, Rdim, c->gpart);
 }
 template <int K>
-void launch_products(btf_ctx* c, const double* U, int Rdim, double* UU) {
-  Prof p(c, BTF_K_PROD);
-  p.launch(products_kernel<K>, dim3((Rdim + 255) / 256), dim3(256), 0, U, Rdim, UU);
-}
-template <int K>
 void launch_wsolve(btf_ctx* c, const WSolveArgs& a) {
   Prof p(c, BTF_K_W_SOLVE);
-  if (a.weighted) p.launch(w_solve_kernel<K, true>, dim3((a.nl + WS_ROWS - 1) / WS_ROWS), dim3(WS_ROWS * ws_split_of(K, true)), 0, a);
-  else p.launch(w_solve_kernel<K, false>, dim3((a.nl + WS_ROWS - 1) / WS_ROWS), dim3(WS_ROWS * ws_split_of(K, false)), 0, a);
+  const int rw = ws_rows_for(a.nl);
+  const dim3 grid((a.nl + rw - 1) / rw);
+#define WS_LAUNCH(WT, RWV) p.launch(w_solve_kernel<K, WT, RWV>, grid, dim3(WS_ROWS * ws_split_of(K, WT)), 0, a)
+#define WS_PICK(WT) do { if (rw == 8) WS_LAUNCH(WT, 8); else if (rw == 16) WS_LAUNCH(WT, 16); else if (rw == 32) WS_LAUNCH(WT, 32); else WS_LAUNCH(WT, 64); } while (0)
+  if (a.weighted) WS_PICK(true); else WS_PICK(false);
+#undef WS_PICK
+#undef WS_LAUNCH
 }
 template <int K>
 hipError_t launch_vbanded(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
@@ -542,13 +542,17 @@ int ensure_z(btf_ctx* c, size_t elems) {
   return BTF_OK;
 }
 
-int pick_rpb(int Rdim, int tiles, int user) {
-  // rows per workgroup: a multiple of ACC_WAVES*ACC_UNR (=64) sized so that the
-  // grid has >= ~1024 workgroups when the problem allows, partials stay small
+int pick_rpb(int Rdim, int tiles, int user, bool weighted) {
+  // rows per workgroup (a multiple of 64): enough workgroups to fill the chip twice over when the problem is that
+  // large, but never fewer rows than pay for a workgroup's prologue and its share of the partials - measured at
+  // C3 (scripts/ab_rpb.sh): complete data 512 rows (128 workgroups: W 11.5 us, V 12.8 -> 11.2 us, and w_solve
+  // sums half as many chunks), weighted data 256 rows (V 19.4 -> 15.5 us; 512 is slower there)
   if (user > 0) return std::max(64, round_up(user, 64));
-  int want_chunks = std::max(1, (tiles >= 32 ? 512 : 256) / std::max(1, tiles));
-  int rpb = round_up((Rdim + want_chunks - 1) / want_chunks, 64);
-  return std::max(rpb, 128);
+  const long long want_wgs = tiles >= 32 ? 512 : 256;
+  long long rpb = ((long long)Rdim * tiles + want_wgs - 1) / want_wgs;
+  rpb = std::max<long long>(rpb, weighted ? 256 : 512);
+  rpb = std::min<long long>(rpb, std::max(Rdim, 1));
+  return std::max(128, round_up((int)rpb, 64));
 }
 
 // upload a host slab and turn it into the padded device layouts
@@ -652,8 +656,6 @@ int btf_create(btf_ctx** out, int nrows, int ncols, int ndepth, int nembeds, int
   auto A = [&](int r) { if (rc == BTF_OK) rc = r; };
   A(dev_alloc(c, &c->W, (size_t)(nrows + 64) * nembeds));        // +64: room for a padded all-gather
   A(dev_alloc(c, &c->V, (size_t)(ncols + 64) * ndepth * nembeds));
-  A(dev_alloc(c, &c->WW, (size_t)nrows * c->KK));
-  A(dev_alloc(c, &c->VV, (size_t)ncols * ndepth * c->KK));
   A(dev_alloc(c, &c->gpart, (size_t)GRAM_BLOCKS * c->KK));
   A(dev_alloc(c, &c->status, 4));
   if (rc == BTF_OK) {
@@ -672,7 +674,7 @@ void btf_destroy(btf_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->dev);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->WW, c->VV, c->Tau2, c->part,
+  void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
                   c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -965,16 +967,15 @@ int w_accum_phase(btf_ctx* c, int compat) {
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_w && c->srcmap_w ? 2 : 1);
   const int NV = wt ? K + KK : K;
   const int tiles = c->ldw / ACC_TILE;
-  const int rpb = pick_rpb(MT, tiles, c->rpb_w);
+  const int rpb = pick_rpb(MT, tiles, c->rpb_w, wt);
   const int nch = (MT + rpb - 1) / rpb;
   int rc;
   if ((rc = ensure_part(c, (size_t)nch * NV * c->ldw))) return rc;
   const bool whole = c->nl == c->N && c->ml == c->M;      // fused Grams cover all rows/columns only when unsharded
   const bool use_gv = !wt && whole && c->fuse_gram && c->ngp_v > 0;
   if (c->nl > 0) {
-    if (wt) { K_SWITCH(K, launch_products<KT>(c, c->V, MT, c->VV)); }
-    else if (!use_gv) { K_SWITCH(K, launch_gram<KT>(c, c->V, MT)); }
-    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->VV, c->srcmap_w, MT, c->ldw, rpb, nch));
+    if (!wt && !use_gv) { K_SWITCH(K, launch_gram<KT>(c, c->V, MT)); }
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, rpb, nch));
   }
   HIPCHK(c, hipGetLastError());
   c->w_part_valid = true; c->w_part_mode = mode; c->w_part_nch = nch; c->w_part_rpb = rpb; c->w_part_gv = use_gv;
@@ -1013,9 +1014,10 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     WSolveArgs a{};
     a.part = c->part; a.nch = nch; a.ld = c->ldw; a.weighted = wt ? 1 : 0;
     a.gpart = use_gv ? c->gpart_v : c->gpart; a.ngp = use_gv ? c->ngp_v : c->ngp_gram;
-    const int wblocks = (c->nl + WS_ROWS - 1) / WS_ROWS;
+    const int wrows = ws_rows_for(c->nl);
+    const int wblocks = (c->nl + wrows - 1) / wrows;
     if (whole && c->fuse_gram) {
-      if (!c->gpart_w) { if ((rc = dev_alloc(c, &c->gpart_w, (size_t)((c->N + WS_ROWS - 1) / WS_ROWS) * KK))) return rc; }
+      if (!c->gpart_w) { if ((rc = dev_alloc(c, &c->gpart_w, (size_t)std::max(64, (c->N + WS_ROWS - 1) / WS_ROWS) * KK))) return rc; }
       a.gout = c->gpart_w;
     }
     a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
@@ -1088,9 +1090,9 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
     }
     a.pband = c->pband;
   }
-  // V'V partials for the next W half-sweep (one KK block per column; bounded by the consumer's LDS stage)
+  // V'V partials for the next W half-sweep (one KK block per column; bounded: every w_solve workgroup sums all of them)
   const bool emit_gv = !prior_only && fast && whole && c->fuse_gram && !wt &&
-                       (size_t)c->ml * KK + 16 * KK <= ws_gram_stage(K, false);   // w_solve's LDS stage
+                       (size_t)c->ml * KK + 16 * KK <= ws_gram_stage(K, false);
   if (emit_gv) {
     if (!c->gpart_v) { if ((rc = dev_alloc(c, &c->gpart_v, (size_t)c->M * KK))) return rc; }
     a.gout = c->gpart_v;
@@ -1120,7 +1122,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_v && c->srcmap_v ? 2 : 1);
   const int NV = wt ? K + KK : K;
   const int tiles = c->ldv / ACC_TILE;
-  const int rpb = pick_rpb(c->N, tiles, c->rpb_v);
+  const int rpb = pick_rpb(c->N, tiles, c->rpb_v, wt);
   const int nch = (c->N + rpb - 1) / rpb;
   int rc;
   if ((rc = ensure_part(c, (size_t)nch * NV * c->ldv))) return rc;
@@ -1134,8 +1136,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
   if (c->ml > 0) {
     const bool whole = c->nl == c->N && c->ml == c->M;
     const bool use_gw = !wt && whole && c->fuse_gram && c->ngp_w > 0;
-    if (wt) { K_SWITCH(K, launch_products<KT>(c, c->W, c->N, c->WW)); }
-    else if (!use_gw) { K_SWITCH(K, launch_gram<KT>(c, c->W, c->N)); }
+    if (!wt && !use_gw) { K_SWITCH(K, launch_gram<KT>(c, c->W, c->N)); }
     const int choice = banded_choice(c);
     EigSide side{nullptr, 0, 0, nullptr};
     if (choice == 3) {
@@ -1146,7 +1147,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       }
       side = EigSide{use_gw ? c->gpart_w : c->gpart, use_gw ? c->ngp_w : c->ngp_gram, K, c->eig};
     }
-    K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->WW, c->srcmap_v, c->N, c->ldv, rpb, nch, side));
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb, nch, side));
     hipError_t e = hipSuccess;
     if (choice == 3) {
       // spectral sampler (complete data): K scalar banded systems per column in the eigen-basis of the Gram
@@ -1161,7 +1162,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       sa.eps0 = eps0; sa.attempts = attempts; sa.status = c->status; sa.tries = c->tries;
       sa.hyp = c->dev_scalars ? c->hyp : nullptr; sa.Rrep = c->R; sa.hyp_noise = c->binomial ? 0 : 1; sa.dbg = c->dbg;
       const bool emit = whole && c->fuse_gram &&
-                        (size_t)c->ml * KK + 16 * KK <= ws_gram_stage(K, false);   // w_solve's LDS stage
+                        (size_t)c->ml * KK + 16 * KK <= ws_gram_stage(K, false);
       if (emit) {
         if (!c->gpart_v) { if ((rc = dev_alloc(c, &c->gpart_v, (size_t)c->M * KK))) return rc; }
         sa.gout = c->gpart_v;

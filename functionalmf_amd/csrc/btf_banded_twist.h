@@ -133,7 +133,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     }
   }
   double gx[8];
-  const bool g_early = !a.weighted && a.ngp * KK <= 8 * VT_THREADS;     // Gram partials: fetched now, summed below
+  const bool g_early = !a.weighted && gram_early_ok(a.ngp, KK);     // Gram partials: fetched now, summed below
   if (g_early) reduce_gram_fetch(a.gpart, a.ngp, KK, gx);
   if (n <= 2 * VT_THREADS) {   // both elements of a thread at once: one round of global-load latency, not two
     // element e = k*T + t: consecutive lanes read consecutive depths t of one factor row k (coalesced 8-B

@@ -11,6 +11,7 @@
 // and used as the SGPR operand of v_fma_f64, every lane owns two adjacent outputs
 // l (one 16-byte global_load per row), and no cross-lane reduction is needed.
 #pragma once
+#include <type_traits>
 #include "btf_device.h"
 #include "btf_eig.h"
 
@@ -28,14 +29,19 @@ namespace btf {
 #ifndef BTF_ACC_PF_WT
 #define BTF_ACC_PF_WT 0   // weighted modes: software-pipelined accumulation loop (A/B aid; measured slower, see below)
 #endif
+#ifndef BTF_ACC_UNR_WT
+#define BTF_ACC_UNR_WT 2     // weighted modes: rows in flight per wave (and per buffer of the pipelined loop)
+#endif
 #ifndef BTF_ACC_WAVES_WT
-#define BTF_ACC_WAVES_WT 16   // weighted modes, K <= 5: waves per workgroup
+#define BTF_ACC_WAVES_WT 12   // weighted modes, K <= 5: waves per workgroup
 #endif
 constexpr int ACC_WAVES = BTF_ACC_WAVES;   // waves per workgroup
 constexpr int ACC_THREADS = ACC_WAVES * WAVE;
 constexpr int ACC_TILE = 2 * WAVE;      // outputs per workgroup along the lane axis
 constexpr int ACC_UNR = BTF_ACC_UNR;       // rows in flight per wave
 constexpr int ACC_RG = (ACC_THREADS / ACC_TILE) < 4 ? (ACC_THREADS / ACC_TILE) : 4;   // values reduced per LDS round
+
+__device__ inline void reduce_gram(const double* __restrict__ gpart, int ngp, int KK, double scale, double* scratch, double* G);
 
 // MODE 0: X only (complete data)
 // MODE 1: X, C and the outer products UU
@@ -56,11 +62,12 @@ __host__ __device__ constexpr int acc_waves(int K, int MODE) { return MODE >= 1 
 template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double>
 __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     const double* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
-    const double* __restrict__ UU, const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
+    const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
     int rows_per_block, EigSide side) {
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
+  constexpr int ACC_UNR = MODE >= 1 ? BTF_ACC_UNR_WT : BTF_ACC_UNR;
   constexpr int ACC_RG = (WAVES * WAVE / ACC_TILE) < 4 ? (WAVES * WAVE / ACC_TILE) : 4;
   __shared__ double red[ACC_WAVES][ACC_RG][ACC_TILE];
 
@@ -73,7 +80,12 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     // eigenproblem of the Gram beside the stream, its other waves leave at once
     if (b == 0) {
 #ifndef BTF_EIG_NOP      // (timing aid: BTF_EIG_NOP builds skip the side task - results are wrong, only the clock is read)
-      if (wave == 0) gram_eig_wave(side.gpart, side.ngp, side.K, side.out, &red[0][0][0]);
+      // the whole workgroup sums the Gram partials (one round of loads, whatever their number), wave 0 goes on
+      double* sc = &red[0][0][0];
+      double* gsum = sc + EIG_LDS_DOUBLES + ACC_WAVES * WAVE;
+      static_assert(EIG_LDS_DOUBLES + ACC_WAVES * WAVE + tri(EIG_MAXK) <= ACC_WAVES * ACC_RG * ACC_TILE, "side task scratch");
+      reduce_gram(side.gpart, side.ngp, tri(side.K), 1.0, sc + EIG_LDS_DOUBLES, gsum);
+      if (wave == 0) gram_eig_wave(gsum, 1, side.K, side.out, sc);
 #endif
       return;
     }
@@ -94,12 +106,20 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     s1 = srcmap[col + 1];
   }
 
-  struct Rows { double2 x[ACC_UNR]; double2 c[MODE >= 1 ? ACC_UNR : 1]; double2 cs[MODE == 2 ? ACC_UNR : 1]; };
-  auto load_rows = [&](int rb, Rows& R) {
+  // (uk: the wave-uniform factor row - scalar loads issued WITH the vector loads, one wait for all of them)
+  // FULL: every row of the group exists - no guards, one basic block (the guarded form is the tail's)
+  struct Rows { double2 x[ACC_UNR]; double2 c[MODE >= 1 ? ACC_UNR : 1]; double2 cs[MODE == 2 ? ACC_UNR : 1]; double uk[ACC_UNR][K]; };
+  auto load_rows = [&](int rb, Rows& R, auto full) {
+    constexpr bool FULL = decltype(full)::value;
 #pragma unroll
     for (int u = 0; u < ACC_UNR; ++u) {
       const int r = rb + u * ACC_WAVES;  // wave-uniform
-      if (r < r1) {
+      {
+        const double* __restrict__ up = U + (size_t)(FULL ? r : min(r, r1 - 1)) * K;      // clamp: x/c are zero beyond r1
+#pragma unroll
+        for (int k = 0; k < K; ++k) R.uk[u][k] = up[k];
+      }
+      if (FULL || r < r1) {
         R.x[u] = *reinterpret_cast<const double2*>(X + (size_t)r * ld + col);
         if constexpr (MODE >= 1) {
           if constexpr (sizeof(CT) == 1) {
@@ -125,8 +145,7 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
         if (s1 != (int)col + 1) R.x[u].y = R.c[u].y != 0.0 ? R.x[u].y * R.cs[u].y / R.c[u].y : 0.0;
         R.c[u] = R.cs[u];
       }
-      const int r = min(rb + u * ACC_WAVES, r1 - 1);  // clamp: x/c are zero beyond r1
-      const double* __restrict__ up = U + (size_t)r * K;
+      const double* up = R.uk[u];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const double uk = up[k];
@@ -134,37 +153,51 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
         acc[k][1] = fma(R.x[u].y, uk, acc[k][1]);
       }
       if constexpr (MODE >= 1) {
-        const double* __restrict__ uup = UU + (size_t)r * KK;
+        // outer products on the fly: (c u_p) u_q, K more multiplies per output instead of KK more scalar operands
+        // per row - the scalar loads of a precomputed table (KK doubles per row, more than the SGPR file holds for
+        // the rows in flight) were issued just in time and stalled every wave four times per row
 #pragma unroll
-        for (int q = 0; q < KK; ++q) {
-          const double uq = uup[q];
-          acc[K + q][0] = fma(R.c[u].x, uq, acc[K + q][0]);
-          acc[K + q][1] = fma(R.c[u].y, uq, acc[K + q][1]);
+        for (int p = 0; p < K; ++p) {
+          const double cx = R.c[u].x * up[p], cy = R.c[u].y * up[p];
+#pragma unroll
+          for (int q = 0; q <= p; ++q) {
+            acc[K + lidx(p, q)][0] = fma(cx, up[q], acc[K + lidx(p, q)][0]);
+            acc[K + lidx(p, q)][1] = fma(cy, up[q], acc[K + lidx(p, q)][1]);
+          }
         }
       }
     }
   };
   constexpr int STEP = ACC_WAVES * ACC_UNR;
   constexpr bool PIPELINED = MODE >= 1 && BTF_ACC_PF_WT;      // (complete data: 5 FMAs per load, nothing to hide)
+  const int full_end = r1 - (ACC_UNR - 1) * ACC_WAVES;        // groups starting below it have all their rows
+  int rb = r0 + wave;
   if constexpr (PIPELINED) {
     Rows A, B;
-    int rb = r0 + wave;
-    if (rb < r1) load_rows(rb, A);
-    while (rb < r1) {
-      if (rb + STEP < r1) load_rows(rb + STEP, B);
+    bool more = rb < full_end;
+    if (more) load_rows(rb, A, std::true_type{});
+    while (more) {
+      const bool nextB = rb + STEP < full_end;
+      if (nextB) load_rows(rb + STEP, B, std::true_type{});
       compute(rb, A);
       rb += STEP;
-      if (rb >= r1) break;
-      if (rb + STEP < r1) load_rows(rb + STEP, A);
+      if (!nextB) break;
+      more = rb + STEP < full_end;
+      if (more) load_rows(rb + STEP, A, std::true_type{});
       compute(rb, B);
       rb += STEP;
     }
   } else {
-    for (int rb = r0 + wave; rb < r1; rb += STEP) {
+    for (; rb < full_end; rb += STEP) {
       Rows A;
-      load_rows(rb, A);
+      load_rows(rb, A, std::true_type{});
       compute(rb, A);
     }
+  }
+  if (rb < r1) {
+    Rows A;
+    load_rows(rb, A, std::false_type{});
+    compute(rb, A);
   }
 
   // cross-wave reduction through LDS, ACC_RG values per round, fixed order
@@ -226,104 +259,57 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(const double* __rest
   }
 }
 
-// Sum the GRAM_BLOCKS partial Grams into G[KK] (LDS) with one global-load latency:
-// every thread fetches at most a few partial entries, then KK threads add them up in a
-// fixed order.  `stage` is LDS scratch of ngp*KK doubles.  Ends with a barrier.
+// Sum the ngp partial Grams into G[KK] (LDS), fixed order, one or two global-load latencies: thread
+// (l = tid / KK, q = tid % KK), l < lanes, adds the partials b = l, l + lanes, ... of entry q (eight loads in
+// flight), then KK threads add the `lanes` sums.  `scratch`: lanes*KK <= blockDim.x doubles of LDS, whatever ngp
+// is - the partials are never staged.  Ends with a barrier.
+__device__ __forceinline__ int gram_lanes(int KK) {
+  const int l = (int)blockDim.x / KK;
+  return l > 32 ? 32 : (l < 1 ? 1 : l);
+}
+__device__ __forceinline__ void reduce_gram_tail(double s, int KK, double scale, double* scratch, double* G) {
+  const int lanes = gram_lanes(KK);
+  const int l = threadIdx.x / KK, q = threadIdx.x - l * KK;
+  if (l < lanes) scratch[l * KK + q] = s;
+  __syncthreads();
+  if ((int)threadIdx.x < KK) {
+    double t = 0.0;
+    for (int b = 0; b < lanes; ++b) t += scratch[b * KK + threadIdx.x];
+    G[threadIdx.x] = t * scale;
+  }
+  __syncthreads();
+}
 __device__ inline void reduce_gram(const double* __restrict__ gpart, int ngp, int KK, double scale,
-                                   double* stage, double* G) {
-  const int nthr = blockDim.x;
-  {   // all global loads of a thread are issued before the first LDS store (one memory latency, not one per element)
-    const int tot = ngp * KK;
-    int i = threadIdx.x;
-    for (; i + 7 * nthr < tot; i += 8 * nthr) {
+                                   double* scratch, double* G) {
+  const int lanes = gram_lanes(KK);
+  const int l = threadIdx.x / KK, q = threadIdx.x - l * KK;
+  double s = 0.0;
+  if (l < lanes) {
+    for (int b0 = l; b0 < ngp; b0 += 8 * lanes) {
       double x[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = gpart[i + u * nthr];
+      for (int u = 0; u < 8; ++u) x[u] = b0 + u * lanes < ngp ? gpart[(size_t)(b0 + u * lanes) * KK + q] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) stage[i + u * nthr] = x[u];
+      for (int u = 0; u < 8; ++u) s += x[u];
     }
-    double x[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) x[u] = (i + u * nthr < tot) ? gpart[i + u * nthr] : 0.0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) if (i + u * nthr < tot) stage[i + u * nthr] = x[u];
   }
-  __syncthreads();
-  // two levels, fixed order: `lanes` threads per Gram entry each add a strided share, then one adds those
-  int lanes = nthr / KK;
-  if (lanes > 16) lanes = 16;
-  if (lanes < 1) lanes = 1;
-  double* lvl = stage + ngp * KK;          // lanes*KK doubles of scratch after the staged partials
-  const int q = threadIdx.x % KK, l = threadIdx.x / KK;
-  if (l < lanes) {
-    double s = 0.0;
-    for (int b = l; b < ngp; b += lanes) s += stage[b * KK + q];
-    lvl[l * KK + q] = s;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < KK) {
-    double s = 0.0;
-    for (int b = 0; b < lanes; ++b) s += lvl[b * KK + threadIdx.x];
-    G[threadIdx.x] = s * scale;
-  }
-  __syncthreads();
+  reduce_gram_tail(s, KK, scale, scratch, G);
 }
 
-// reduce_gram in two halves for callers that want the global loads in flight early: the partials of a
-// thread (ngp*KK <= 8*blockDim.x) are fetched by reduce_gram_fetch and staged / summed later.
+// reduce_gram in two halves for callers that want the global loads in flight early (gram_early_ok: at most eight
+// partials per thread): reduce_gram_fetch issues them, reduce_gram_finish adds them up later.
+__device__ __forceinline__ bool gram_early_ok(int ngp, int KK) { return ngp <= 8 * gram_lanes(KK); }
 __device__ __forceinline__ void reduce_gram_fetch(const double* __restrict__ gpart, int ngp, int KK, double (&x)[8]) {
-  const int tot = ngp * KK, nthr = blockDim.x;
+  const int lanes = gram_lanes(KK);
+  const int l = threadIdx.x / KK, q = threadIdx.x - l * KK;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) x[u] = ((int)threadIdx.x + u * nthr < tot) ? gpart[threadIdx.x + u * nthr] : 0.0;
+  for (int u = 0; u < 8; ++u) x[u] = (l < lanes && l + u * lanes < ngp) ? gpart[(size_t)(l + u * lanes) * KK + q] : 0.0;
 }
-__device__ inline void reduce_gram_finish(const double (&x)[8], int ngp, int KK, double scale, double* stage, double* G) {
-  const int tot = ngp * KK, nthr = blockDim.x;
-  if (tot <= nthr) {      // one partial per thread (the usual case: N/64 or M blocks of KK): stage, sum in block order
-    if ((int)threadIdx.x < tot) stage[threadIdx.x] = x[0];
-    __syncthreads();
-    if ((int)threadIdx.x < KK) {
-      double s = 0.0;
-      for (int b = 0; b < ngp; ++b) s += stage[b * KK + threadIdx.x];
-      G[threadIdx.x] = s * scale;
-    }
-    __syncthreads();
-    return;
-  }
+__device__ inline void reduce_gram_finish(const double (&x)[8], int ngp, int KK, double scale, double* scratch, double* G) {
+  double s = 0.0;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) if ((int)threadIdx.x + u * nthr < tot) stage[threadIdx.x + u * nthr] = x[u];
-  __syncthreads();
-  // two levels, fixed order: `lanes` threads per Gram entry each add a strided share, then one adds those
-  int lanes = nthr / KK;
-  if (lanes > 16) lanes = 16;
-  if (lanes < 1) lanes = 1;
-  double* lvl = stage + ngp * KK;          // lanes*KK doubles of scratch after the staged partials
-  const int q = threadIdx.x % KK, l = threadIdx.x / KK;
-  if (l < lanes) {
-    double s = 0.0;
-    for (int b = l; b < ngp; b += lanes) s += stage[b * KK + q];
-    lvl[l * KK + q] = s;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < KK) {
-    double s = 0.0;
-    for (int b = 0; b < lanes; ++b) s += lvl[b * KK + threadIdx.x];
-    G[threadIdx.x] = s * scale;
-  }
-  __syncthreads();
-}
-
-template <int K>
-__global__ void products_kernel(const double* __restrict__ U, int Rdim, double* __restrict__ UU) {
-  constexpr int KK = tri(K);
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= Rdim) return;
-  double u[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) u[k] = U[(size_t)r * K + k];
-#pragma unroll
-  for (int a = 0; a < K; ++a)
-#pragma unroll
-    for (int b = 0; b <= a; ++b) UU[(size_t)r * KK + lidx(a, b)] = u[a] * u[b];
+  for (int u = 0; u < 8; ++u) s += x[u];
+  reduce_gram_tail(s, KK, scale, scratch, G);
 }
 
 // ============================================================================
@@ -360,14 +346,21 @@ __host__ __device__ constexpr int ws_split(int K) { return K <= 6 ? 8 : (K <= 8 
 #define BTF_WS_SPLIT_U 8
 #endif
 __host__ __device__ constexpr int ws_split_of(int K, bool weighted) { return weighted ? ws_split(K) : (K <= 6 ? BTF_WS_SPLIT_U : ws_split(K)); }
-// doubles of LDS the Gram partials may use as their staging area in w_solve (see reduce_gram)
+// bound on the doubles of fused Gram partials a V half-sweep hands to w_solve (historically its LDS staging area)
 __host__ __device__ constexpr size_t ws_gram_stage(int K, bool weighted) {
   return (size_t)ws_split_of(K, weighted) * (K + tri(K)) * WS_ROWS;
 }
 
-template <int K, bool WEIGHTED>
+// RW rows per workgroup (8..64): lane = (row rr = lane % RW, chunk subgroup sub = lane / RW).  A factor of N rows
+// gives only N/64 workgroups with a lane per row - 8 at C3, every one summing 64 chunks of partials in a few
+// dependent batches of loads; with RW = 8 there are 64 workgroups and the 8 x 64/RW (wave, subgroup) pairs of a
+// row take ONE chunk each.  The solve itself is a per-lane latency chain whatever the number of live lanes.
+__host__ __device__ constexpr int ws_rows_for(int nl) { return nl > 2048 ? 64 : (nl > 1024 ? 32 : (nl > 512 ? 16 : 8)); }
+
+template <int K, bool WEIGHTED, int RW = WS_ROWS>
 __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_kernel(WSolveArgs a) {
   constexpr int KK = tri(K);
+  constexpr int SUB = WS_ROWS / RW;
   constexpr int WS_SPLIT = ws_split_of(K, WEIGHTED);
   constexpr int NVMAX = WEIGHTED ? K + KK : K;
   constexpr int NV = NVMAX;
@@ -385,12 +378,14 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
   double gx[8];
   bool g_early = false;
   if constexpr (!WEIGHTED) {
-    g_early = a.ngp * KK <= 8 * (int)(WS_ROWS * WS_SPLIT);
+    g_early = gram_early_ok(a.ngp, KK);
     if (g_early) reduce_gram_fetch(a.gpart, a.ngp, KK, gx);
     else reduce_gram(a.gpart, a.ngp, KK, a.sR, &red[0][0][0], G);
   }
-  const int il = blockIdx.x * WS_ROWS + lane;
-  // stage 1: wave `grp` sums chunks grp, grp+WS_SPLIT, ... (fixed order => deterministic).  The first
+  const int rr = lane % RW, sub = lane / RW;
+  const int il = blockIdx.x * RW + rr;
+  constexpr int CS = WS_SPLIT * SUB;                     // chunk stride of one (wave, subgroup) pair
+  // stage 1: pair (grp, sub) sums chunks grp*SUB+sub, +CS, ... (fixed order => deterministic).  The first
   // batch of loads is issued BEFORE the Philox normals of the row are computed (component k by wave
   // k % WS_SPLIT), so the transcendental work hides under the memory latency.
   {
@@ -399,44 +394,44 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     for (int v = 0; v < NVMAX; ++v) part[v] = 0.0;
     const size_t cst = (size_t)NV * a.ld;               // chunk stride
     const bool live1 = il < a.nl;
-    int c = grp;
+    int c = grp * SUB + sub;
     double x0[UNR][NV];
-    const bool first = live1 && c + (UNR - 1) * WS_SPLIT < a.nch;
+    const bool first = live1 && c + (UNR - 1) * CS < a.nch;
     if (first) {
       const double* p = a.part + (size_t)c * cst + il;
 #pragma unroll
       for (int u = 0; u < UNR; ++u)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) x0[u][v] = p[(size_t)u * WS_SPLIT * cst + (size_t)v * a.ld];
+        for (int v = 0; v < NV; ++v) x0[u][v] = p[(size_t)u * CS * cst + (size_t)v * a.ld];
     }
     if (live1) {
       const int i = a.row0 + il;
       const long long zoff = w_z_offset(i, K);
       const int d = i + 1 < K ? i + 1 : K;
-      for (int k = grp; k < K; k += WS_SPLIT)
-        zsh[k][lane] = k < d ? (a.z ? a.z[zoff + k] : philox_normal(a.seed, a.stream, (unsigned long long)(zoff + k))) : 0.0;
+      for (int k = grp * SUB + sub; k < K; k += CS)
+        zsh[k][rr] = k < d ? (a.z ? a.z[zoff + k] : philox_normal(a.seed, a.stream, (unsigned long long)(zoff + k))) : 0.0;
     }
     if (first) {
 #pragma unroll
       for (int u = 0; u < UNR; ++u)
 #pragma unroll
         for (int v = 0; v < NV; ++v) part[v] += x0[u][v];
-      c += UNR * WS_SPLIT;
+      c += UNR * CS;
     }
     if (live1) {
-      for (; c + (UNR - 1) * WS_SPLIT < a.nch; c += UNR * WS_SPLIT) {   // UNR chunks' loads in flight, added in order
+      for (; c + (UNR - 1) * CS < a.nch; c += UNR * CS) {   // UNR chunks' loads in flight, added in order
         const double* p = a.part + (size_t)c * cst + il;
         double x[UNR][NV];
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
-          for (int v = 0; v < NV; ++v) x[u][v] = p[(size_t)u * WS_SPLIT * cst + (size_t)v * a.ld];
+          for (int v = 0; v < NV; ++v) x[u][v] = p[(size_t)u * CS * cst + (size_t)v * a.ld];
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
           for (int v = 0; v < NV; ++v) part[v] += x[u][v];
       }
-      for (; c < a.nch; c += WS_SPLIT) {
+      for (; c < a.nch; c += CS) {
         const double* p = a.part + (size_t)c * cst + il;
 #pragma unroll
         for (int v = 0; v < NV; ++v) part[v] += p[(size_t)v * a.ld];
@@ -446,12 +441,18 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     if constexpr (!WEIGHTED) {
       if (g_early) reduce_gram_finish(gx, a.ngp, KK, a.sR, &red[0][0][0], G);     // ends with a barrier
     }
+    // the SUB subgroups of a wave hold shares of the same rows: butterfly over the lane bits above RW (fixed
+    // order), so that one value per (wave, row) goes to LDS
+#pragma unroll
+    for (int st = RW; st < WS_ROWS; st <<= 1)
+#pragma unroll
+      for (int v = 0; v < NVMAX; ++v) part[v] += __shfl_xor(part[v], st);
 #pragma unroll
     for (int v = 0; v < NVMAX; ++v) red[grp][v][lane] = part[v];
   }
   __syncthreads();
   if (grp != 0) return;                      // wave 0 finishes: one lane per row
-  const bool live = il < a.nl;
+  const bool live = lane < RW && il < a.nl;
   const int i = a.row0 + (live ? il : 0);
   const int d = i + 1 < K ? i + 1 : K;
   double m[K], Q[KK];
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
   for (int k = 0; k < K; ++k) {
     double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < WS_SPLIT; ++w) s += red[w][k][lane];
+    for (int w = 0; w < WS_SPLIT; ++w) s += red[w][k][rr];
     m[k] = s * a.s;
   }
 #pragma unroll
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     if constexpr (WEIGHTED) {
       double s = 0.0;
 #pragma unroll
-      for (int w = 0; w < WS_SPLIT; ++w) s += red[w][K + q][lane];
+      for (int w = 0; w < WS_SPLIT; ++w) s += red[w][K + q][rr];
       Q[q] = s * a.s;
     } else {
       Q[q] = G[q];
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
   }
 #pragma unroll
   for (int r = 0; r < K; ++r)
-    if (r < d) y[r] += zsh[r][lane];
+    if (r < d) y[r] += zsh[r][rr];
 #pragma unroll
   for (int r = K - 1; r >= 0; --r) {
     double v = y[r];

@@ -55,7 +55,8 @@ enum {
   BTF_K_V_ACCUM = 3, /* streaming Gram/mean accumulation, V half-sweep      */
   BTF_K_V_BANDED = 4,/* block-banded Cholesky sampler per column (fast_mvn) */
   BTF_K_GRAM = 5,    /* K x K Gram of the fixed factor (complete-data path) */
-  BTF_K_PROD = 6,    /* per-row outer products u u' (weighted path)         */
+  BTF_K_PROD = 6,    /* small reductions (NB log-likelihood partials); the per-row outer products of the weighted
+                        path are formed inside the accumulation since round 2 */
   BTF_K_SSE = 7,     /* residual sum of squares for nu2                     */
   BTF_K_PG = 8,      /* Polya-Gamma draws                                   */
   BTF_K_NB = 9,      /* Negative-Binomial rate update: MH log-likelihood ratio */

@@ -1,4 +1,5 @@
-"""Diagnostic: where does the fast banded kernel spend its cycles (phase stamps)."""
+"""Diagnostic: where does the fast banded kernel spend its cycles (phase stamps).
+BTF_SAMPLER=banded|spectral|chain, BTF_HELDOUT=1 (weighted data)."""
 import ctypes as C
 import sys, os
 import numpy as np
@@ -9,6 +10,8 @@ from bench import synth_rows, synth_V
 N, M, T, R, K = 512, 256, 64, 4, 5
 Vt = synth_V(1, M, T, K)
 Y, _ = synth_rows(1, range(N), M, T, R, K, Vt)
+if os.environ.get("BTF_HELDOUT"):
+    Y[:3, :3] = np.nan
 np.random.seed(1)
 m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, nu2_init=1.0, rng="device")
 import os
