@@ -277,7 +277,8 @@ def main():
     # (8 B/cell complete data; + a byte of replicate count with missing data; + f64 weights for Binomial)
     cells_local = (N // world if world > 1 else N) * M * T
     cells_local_v = N * (M // world if world > 1 else M) * T
-    bpc = {"complete": 8.0, "heldout": 9.0, "missing5": 9.0}.get(args.variant, 16.0)
+    form = model.likelihood_form()     # "curve_counts": held-out whole curves run the complete-data stream (no counts read)
+    bpc = 8.0 if form in ("complete", "curve_counts") else ({"heldout": 9.0, "missing5": 9.0}.get(args.variant, 16.0))
     acc_ms = kt["w_accum"][0] + kt["v_accum"][0]
     acc_n = kt["w_accum"][1] + kt["v_accum"][1]
     acc_us = 1e3 * acc_ms / max(acc_n, 1)
@@ -310,7 +311,7 @@ def main():
                    "median_ms_per_step": round(float(np.median(per_step_ms)), 4), "median_over_steps": int(nmed),
                    "burn_in_sweeps": args.burn,
                    "full_resample_sweeps_per_s": round(full_per_s, 2),
-                   "v_sampler": sampler,
+                   "v_sampler": sampler, "likelihood_form": form,
                    "parallelism": "rows(W)/cols(V) x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "accum_kernel (w_accum + v_accum launches)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -320,7 +321,7 @@ def main():
                      "timing": "hipExtLaunchKernelGGL start/stop events of each accumulation dispatch, %d steps" % nprof,
                      "whole_step_bytes": b_wv,
                      "whole_step_frac": round(b_wv / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "copy_ceiling_GBs": copy_ceiling(torch)},
+                     "copy_ceiling_GBs": copy_ceiling(torch), "read_ceiling_GBs": read_ceiling(local_rank)},
         "kernels_us": kernels_us,
     }
     if args.variant in ("binomial", "negbinom"):
@@ -371,6 +372,19 @@ def dry_run(args, world, rank, dist, backend):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def read_ceiling(device):
+    """Measured rate of a plain streaming read on this GPU (1 GiB, past the Infinity Cache; btf_read_probe): what a
+    read-only kernel like the accumulation can reach at best, next to the 8 TB/s spec peak."""
+    try:
+        import ctypes as C
+        from functionalmf_amd import _native
+        out = C.c_double()
+        rc = _native.load().btf_read_probe(int(device), 1 << 30, 10, C.byref(out))
+        return round(out.value, 1) if rc == 0 else None
+    except Exception:
+        return None
 
 
 def copy_ceiling(torch):

@@ -23,7 +23,7 @@ BTF_OK, BTF_EINVAL, BTF_EHIP, BTF_ENOTPD, BTF_ESTATE = 0, 1, 2, 3, 4
 COMPAT = {"reference": 0, "exact": 1}
 KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw", "nb_loglik",
                 "prior_band", "gram_eig", "hyper", "ess"]
-OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT = 0, 1, 2, 3
+OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT, OPT_CURVE_COUNTS = 0, 1, 2, 3, 4
 SAMPLERS = {"banded": 0, "spectral": 1, "chain": 2, "generic": 3, "banded_nopanel": 4}
 
 # every symbol include/btf.h declares: (name, restype, argtypes)
@@ -95,6 +95,8 @@ SIGNATURES = {
     "btf_set_tuning": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "btf_set_option": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "btf_sym_eig": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp]),
+    "btf_read_probe": (C.c_int, [C.c_int, C.c_size_t, C.c_int, _c_dp]),
+    "btf_get_likelihood_form": (C.c_int, [_ctx, _c_ip]),
     "btf_get_V_sampler": (C.c_int, [_ctx, _c_ip]),
 }
 

@@ -94,6 +94,14 @@ struct btf_ctx {
   double* gpart_w = nullptr; int ngp_w = 0;   // W'W partials written by w_solve (valid until W changes otherwise)
   double* gpart_v = nullptr; int ngp_v = 0;   // V'V partials written by the fast banded sampler
   bool fuse_gram = true;
+  // curve-structured replicate counts (btf_kernels.h, CurveLists): counts constant along the depth axis
+  bool curve = false, curve_opt = true;
+  std::vector<unsigned char> cv_cij;                                  // host copy of c_ij [N][M] (stale-source test)
+  int* cv_cptr = nullptr; int* cv_crow = nullptr; double* cv_cdef = nullptr;   // by column: deficient rows
+  int* cv_rptr = nullptr; int* cv_rcol = nullptr; double* cv_rdef = nullptr;   // by row: deficient columns
+  double* eig_cols = nullptr;                                         // [M][K + K*K + 8] per-column eigen-systems
+  int* cv_dcols = nullptr; int cv_ndef = 0;                           // the columns that have deficient rows
+  bool w_part_curve = false;                                          // the W-step partials were made in curve mode
   unsigned long long sweep_w = 0, sweep_v = 0;
   bool profiling = false;
   std::vector<EvPair> ev_pool;
@@ -267,15 +275,16 @@ int build_stencil(btf_ctx* c) {
 // ---- templated launch tables -------------------------------------------------
 template <int K>
 void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const unsigned char* C8, const double* U,
-                  const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr}) {
+                  const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr},
+                  EigSideCols sidec = EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}) {
   Prof p(c, kid);
-  dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 : 0));   // (+ the side task's workgroup)
+  dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 + sidec.ncols : 0));   // (+ the side tasks' workgroups)
   if (mode >= 1 && C8) {       // byte weights (Gaussian replicate counts)
-    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side);
-    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side);
-  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side);
-  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side);
-  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side);
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec);
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec);
+  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec);
+  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec);
+  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec);
 }
 // which Polya-Gamma passes a draw needs: exact mode - the exact sampler alone; otherwise the series for every cell
 // that is not an integer count of 1 or 2, and the exact sampler for those (each launch only if such cells exist)
@@ -437,15 +446,25 @@ hipError_t dispatch_vbanded_twist(btf_ctx* c, const VBandArgs& a, int bw, size_t
   return hipSuccess;
 }
 // which sampler a V half-sweep of this context will use: 3 spectral, 2 twisted, 1 single chain (LDS), -1 generic
-int banded_choice(const btf_ctx* c, bool allow_spectral = true) {
+int banded_choice_for(const btf_ctx* c, bool wt, bool allow_spectral) {
   const int bw = (c->TF + 1) * c->K;
-  const bool wt = c->weighted;
   if (allow_spectral && c->sampler == BTF_SAMPLER_SPECTRAL && !wt && !c->binomial && c->st_dense_ok && vs_lds_bytes(c->T, c->K, c->TF, c->nD) <= 160 * 1024) return 3;
   if (c->sampler == BTF_SAMPLER_GENERIC || bw < 3) return -1;
   if (c->sampler != BTF_SAMPLER_CHAIN && twist_ok(c->T, c->K, c->TF) && tw_lds_bytes(c->T, c->K, c->TF, wt) <= 160 * 1024) return 2;
   if (vb_fast_lds_bytes(c->T, c->K, c->TF, wt) <= 158 * 1024) return 1;
   return -1;
 }
+// curve-structured counts are handled as complete data plus corrections when nothing is stale, the per-column
+// Grams of V fit w_solve's budget and the sampler is one that knows the per-column Gram (spectral, twisted)
+bool curve_on(const btf_ctx* c) {
+  if (!c->curve || !c->curve_opt || c->binomial || !c->weighted || c->stale_w || c->stale_v) return false;
+  if (c->nl != c->N || c->ml != c->M) return false;
+  if ((size_t)c->ml * c->KK + 16 * c->KK > ws_gram_stage(c->K, false)) return false;
+  return banded_choice_for(c, false, true) >= 2;
+}
+// does the likelihood part run its weighted form (per-cell weights streamed, per-depth Gram blocks)?
+bool lik_weighted(const btf_ctx* c) { return c->weighted && !curve_on(c); }
+int banded_choice(const btf_ctx* c, bool allow_spectral = true) { return banded_choice_for(c, lik_weighted(c), allow_spectral); }
 template <int S>
 hipError_t launch_vspectral(btf_ctx* c, const VSpecArgs& a, size_t lds_bytes) {
   static bool attr_set = false;
@@ -676,7 +695,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
@@ -705,10 +724,71 @@ void* btf_stream(btf_ctx* c) { return c ? (void*)c->stream : nullptr; }
 void* btf_dev_W(btf_ctx* c) { return c ? c->W : nullptr; }
 void* btf_dev_V(btf_ctx* c) { return c ? c->V : nullptr; }
 
+// Are the replicate counts constant along the depth axis (whole curves missing or thinned)?  Then keep c_ij and
+// the lists of deficient partners (see CurveLists).  Unsharded contexts only.
+static int detect_curve_counts(btf_ctx* c) {
+  c->curve = false;
+  c->cv_cij.clear();
+  if (!c->C8_v || c->nl != c->N || c->ml != c->M) return BTF_OK;
+  const int N = c->N, M = c->M, T = c->T;
+  std::vector<unsigned char> h((size_t)N * c->ldv);
+  HIPCHK(c, hipMemcpy(h.data(), c->C8_v, h.size(), hipMemcpyDeviceToHost));
+  std::vector<unsigned char> cij((size_t)N * M);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < M; ++j) {
+      const unsigned char* p = h.data() + (size_t)i * c->ldv + (size_t)j * T;
+      const unsigned char v = p[0];
+      for (int t = 1; t < T; ++t) if (p[t] != v) return BTF_OK;          // varies with depth: the general weighted path
+      cij[(size_t)i * M + j] = v;
+    }
+  std::vector<int> cptr(M + 1, 0), rptr(N + 1, 0);
+  size_t nnz = 0;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < M; ++j) if (cij[(size_t)i * M + j] < c->R) { ++cptr[j + 1]; ++rptr[i + 1]; ++nnz; }
+  if (nnz == 0 || nnz > (size_t)N * M / 4) return BTF_OK;                 // (many deficient curves: the corrections stop being cheap)
+  for (int j = 0; j < M; ++j) cptr[j + 1] += cptr[j];
+  for (int i = 0; i < N; ++i) rptr[i + 1] += rptr[i];
+  std::vector<int> crow(nnz), rcol(nnz), cfill(cptr.begin(), cptr.end() - 1), rfill(rptr.begin(), rptr.end() - 1);
+  std::vector<double> cdef(nnz), rdef(nnz);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < M; ++j) {
+      const int v = cij[(size_t)i * M + j];
+      if (v >= c->R) continue;
+      const double d = (double)(c->R - v);
+      crow[cfill[j]] = i; cdef[cfill[j]++] = d;
+      rcol[rfill[i]] = j; rdef[rfill[i]++] = d;
+    }
+  int rc;
+  if ((rc = dev_alloc(c, &c->cv_cptr, cptr.size()))) return rc;
+  if ((rc = dev_alloc(c, &c->cv_crow, nnz))) return rc;
+  if ((rc = dev_alloc(c, &c->cv_cdef, nnz))) return rc;
+  if ((rc = dev_alloc(c, &c->cv_rptr, rptr.size()))) return rc;
+  if ((rc = dev_alloc(c, &c->cv_rcol, nnz))) return rc;
+  if ((rc = dev_alloc(c, &c->cv_rdef, nnz))) return rc;
+  HIPCHK(c, hipMemcpy(c->cv_cptr, cptr.data(), cptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->cv_crow, crow.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->cv_cdef, cdef.data(), nnz * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->cv_rptr, rptr.data(), rptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->cv_rcol, rcol.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->cv_rdef, rdef.data(), nnz * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<int> dcols;
+  for (int j = 0; j < M; ++j) if (cptr[j + 1] > cptr[j]) dcols.push_back(j);
+  if ((rc = dev_alloc(c, &c->cv_dcols, dcols.size()))) return rc;
+  HIPCHK(c, hipMemcpy(c->cv_dcols, dcols.data(), dcols.size() * sizeof(int), hipMemcpyHostToDevice));
+  c->cv_ndef = (int)dcols.size();
+  const size_t ne = (size_t)M * (c->K + c->K * c->K + 8);
+  if ((rc = dev_alloc(c, &c->eig_cols, ne))) return rc;
+  HIPCHK(c, hipMemset(c->eig_cols, 0, ne * sizeof(double)));               // no previous solutions
+  c->cv_cij.swap(cij);
+  c->curve = true;
+  return BTF_OK;
+}
+
 static int finish_data(btf_ctx* c) {
   int flag = 0;
   HIPCHK(c, hipMemcpy(&flag, c->status + 2, sizeof(int), hipMemcpyDeviceToHost));
   c->weighted = c->binomial || flag != 0;
+  c->curve = false; c->cv_cij.clear();
   if (c->C8_wT) { (void)hipFree(c->C8_wT); c->C8_wT = nullptr; }
   if (c->C8_v) { (void)hipFree(c->C8_v); c->C8_v = nullptr; }
   if (!c->weighted) {  // complete Gaussian data: counts are the constant R, drop them
@@ -725,6 +805,8 @@ static int finish_data(btf_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->C_wT); c->C_wT = nullptr;
     (void)hipFree(c->C_v); c->C_v = nullptr;
+    int rc2 = detect_curve_counts(c);
+    if (rc2) return rc2;
   }
   c->have_data = true;
   c->w_part_valid = false;
@@ -805,6 +887,7 @@ int btf_set_stale_sources(btf_ctx* c, const int32_t* src_row, const int32_t* src
     for (int il = 0; il < c->nl; ++il) {
       const int s = src_row[c->row0 + il] - c->row0;
       if (s < 0 || s >= c->nl) return fail(c, BTF_EINVAL, "stale weight source row outside this shard (use compat=exact when sharding)");
+      if (s != il && c->curve && !std::memcmp(&c->cv_cij[(size_t)il * c->M], &c->cv_cij[(size_t)s * c->M], (size_t)c->M)) continue;   // same counts: nothing stale
       mw[il] = s;
       c->stale_w |= (s != il);
     }
@@ -812,6 +895,11 @@ int btf_set_stale_sources(btf_ctx* c, const int32_t* src_row, const int32_t* src
     for (int jl = 0; jl < c->ml; ++jl) {
       const int s = src_col[c->col0 + jl] - c->col0;
       if (s < 0 || s >= c->ml) return fail(c, BTF_EINVAL, "stale weight source column outside this shard (use compat=exact when sharding)");
+      if (s != jl && c->curve) {
+        bool same = true;
+        for (int i = 0; i < c->N && same; ++i) same = c->cv_cij[(size_t)i * c->M + jl] == c->cv_cij[(size_t)i * c->M + s];
+        if (same) continue;                                              // same counts: nothing stale
+      }
       for (int t = 0; t < c->T; ++t) mv[jl * c->T + t] = s * c->T + t;
       c->stale_v |= (s != jl);
     }
@@ -963,7 +1051,7 @@ namespace {
 // (btf_w_accum) and its partials also give the residual sum of squares (btf_draw_scalars, which & 4).
 int w_accum_phase(btf_ctx* c, int compat) {
   const int K = c->K, KK = c->KK, MT = c->M * c->T;
-  const bool wt = c->weighted;
+  const bool wt = lik_weighted(c), cv = c->weighted && !wt;
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_w && c->srcmap_w ? 2 : 1);
   const int NV = wt ? K + KK : K;
   const int tiles = c->ldw / ACC_TILE;
@@ -972,13 +1060,23 @@ int w_accum_phase(btf_ctx* c, int compat) {
   int rc;
   if ((rc = ensure_part(c, (size_t)nch * NV * c->ldw))) return rc;
   const bool whole = c->nl == c->N && c->ml == c->M;      // fused Grams cover all rows/columns only when unsharded
-  const bool use_gv = !wt && whole && c->fuse_gram && c->ngp_v > 0;
+  bool use_gv = !wt && whole && c->fuse_gram && c->ngp_v > 0;
+  if (cv && c->nl > 0) {                      // the per-column Grams V_j'V_j: from the sampler that drew V, or computed here
+    if (c->ngp_v != c->ml) {
+      if (!c->gpart_v) { if ((rc = dev_alloc(c, &c->gpart_v, (size_t)c->M * KK))) return rc; }
+      Prof p(c, BTF_K_GRAM);
+      K_SWITCH(K, p.launch(colgram_kernel<KT>, dim3(c->ml), dim3(WAVE), 0, (const double*)c->V, c->T, c->ml, c->gpart_v));
+      c->ngp_v = c->ml;
+    }
+    use_gv = true;
+  }
   if (c->nl > 0) {
     if (!wt && !use_gv) { K_SWITCH(K, launch_gram<KT>(c, c->V, MT)); }
     K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, rpb, nch));
   }
   HIPCHK(c, hipGetLastError());
   c->w_part_valid = true; c->w_part_mode = mode; c->w_part_nch = nch; c->w_part_rpb = rpb; c->w_part_gv = use_gv;
+  c->w_part_curve = cv;
   return BTF_OK;
 }
 }  // namespace
@@ -995,10 +1093,10 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
   if (!c->have_data || !c->have_V || !c->have_W) return fail(c, BTF_ESTATE, "set data, W and V first");
   HIPCHK(c, hipSetDevice(c->dev));
   const int K = c->K, KK = c->KK;
-  const bool wt = c->weighted;
+  const bool wt = lik_weighted(c), cv = c->weighted && !wt;
   const int want_mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_w && c->srcmap_w ? 2 : 1);
   int rc;
-  if (!(c->w_part_valid && c->w_part_mode == want_mode)) { if ((rc = w_accum_phase(c, compat))) return rc; }
+  if (!(c->w_part_valid && c->w_part_mode == want_mode && c->w_part_curve == cv)) { if ((rc = w_accum_phase(c, compat))) return rc; }
   const int nch = c->w_part_nch;
   const bool use_gv = c->w_part_gv;
   c->w_part_valid = false;                                 // consumed: W changes below
@@ -1027,6 +1125,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     a.W = c->W; a.row0 = c->row0; a.nl = c->nl;
     a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_w + 0x10000ULL;
     a.status = c->status;
+    if (cv) { a.cv = CurveLists{c->cv_rptr, c->cv_rcol, c->cv_rdef}; a.cv_blocks = c->gpart_v; }
     K_SWITCH(K, launch_wsolve<KT>(c, a));
     c->ngp_w = a.gout ? wblocks : 0;
     c->ngp_v = 0;   // V'V partials are consumed once; any other W/V change must recompute
@@ -1044,7 +1143,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
 static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t seed, int nch, bool use_gw, double eps0,
                              int attempts, double* out, bool prior_only) {
   const int K = c->K, KK = c->KK, T = c->T, n = T * K;
-  const bool wt = c->weighted;
+  const bool wt = lik_weighted(c), cv = c->weighted && !wt && !prior_only;
   const bool whole = c->nl == c->N && c->ml == c->M;
   int rc;
   const int bw = (c->TF + 1) * K, R1 = bw + 1, D1 = c->TF + 2;
@@ -1075,6 +1174,7 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
   a.V = c->V; a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_v + 0x10001ULL;
   a.eps0 = eps0; a.attempts = attempts; a.status = c->status; a.tries = c->tries; a.dbg = c->dbg;
   if (prior_only) { a.nch = 0; a.ngp = 0; a.s = 0.0; a.sR = 0.0; a.hyp_noise = 0; }
+  if (cv) { a.cv = CurveLists{c->cv_cptr, c->cv_crow, c->cv_cdef}; a.cv_W = c->W; }
   a.V = out;
   hipError_t e = hipSuccess;
   bool handled = false;
@@ -1118,7 +1218,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
   if (attempts < 0) attempts = 0;
   HIPCHK(c, hipSetDevice(c->dev));
   const int K = c->K, KK = c->KK, T = c->T, n = T * K;
-  const bool wt = c->weighted;
+  const bool wt = lik_weighted(c), cv = c->weighted && !wt;
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_v && c->srcmap_v ? 2 : 1);
   const int NV = wt ? K + KK : K;
   const int tiles = c->ldv / ACC_TILE;
@@ -1147,7 +1247,12 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       }
       side = EigSide{use_gw ? c->gpart_w : c->gpart, use_gw ? c->ngp_w : c->ngp_gram, K, c->eig};
     }
-    K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb, nch, side));
+    // curve columns: a few ride along as side tasks too; many would keep the stream waiting and are solved by
+    // their sampler workgroups instead
+    EigSideCols sidec{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr};
+    const bool cols_aside = choice == 3 && cv && c->cv_ndef <= 32;
+    if (cols_aside) sidec = EigSideCols{c->cv_dcols, c->cv_ndef, CurveLists{c->cv_cptr, c->cv_crow, c->cv_cdef}, c->W, 1.0 / c->R, c->eig_cols};
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb, nch, side, sidec));
     hipError_t e = hipSuccess;
     if (choice == 3) {
       // spectral sampler (complete data): K scalar banded systems per column in the eigen-basis of the Gram
@@ -1161,6 +1266,11 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       sa.V = c->V; sa.z = dz; sa.seed = seed; sa.stream = 2 * c->sweep_v + 0x10001ULL;
       sa.eps0 = eps0; sa.attempts = attempts; sa.status = c->status; sa.tries = c->tries;
       sa.hyp = c->dev_scalars ? c->hyp : nullptr; sa.Rrep = c->R; sa.hyp_noise = c->binomial ? 0 : 1; sa.dbg = c->dbg;
+      if (cv) {
+        sa.cv = CurveLists{c->cv_cptr, c->cv_crow, c->cv_cdef}; sa.cv_W = c->W;
+        sa.gpart = side.gpart; sa.ngp = side.ngp; sa.eig_cols = c->eig_cols;
+        sa.eig_cols_ready = cols_aside ? 1 : 0;
+      }
       const bool emit = whole && c->fuse_gram &&
                         (size_t)c->ml * KK + 16 * KK <= ws_gram_stage(K, false);
       if (emit) {
@@ -1857,12 +1967,15 @@ int btf_draw_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double 
       Prof p(c, BTF_K_SSE);
       const double* gp = c->w_part_gv ? c->gpart_v : c->gpart;
       const int ngp = c->w_part_gv ? c->ngp_v : c->ngp_gram;
-      if (c->weighted) {
+      const CurveLists cvl = c->w_part_curve ? CurveLists{c->cv_rptr, c->cv_rcol, c->cv_rdef} : CurveLists{nullptr, nullptr, nullptr};
+      if (c->w_part_mode != 0) {
         K_SWITCH(c->K, p.launch(sse_part_kernel<KT, true>, dim3(blocks), dim3(WS_ROWS * ws_split(KT)), 0, (const double*)c->part,
-                                c->w_part_nch, c->ldw, gp, ngp, (double)c->R, (const double*)c->W, c->row0, c->nl, c->bsum));
+                                c->w_part_nch, c->ldw, gp, ngp, (double)c->R, (const double*)c->W, c->row0, c->nl, c->bsum, cvl,
+                                (const double*)c->gpart_v));
       } else {
         K_SWITCH(c->K, p.launch(sse_part_kernel<KT, false>, dim3(blocks), dim3(WS_ROWS * ws_split(KT)), 0, (const double*)c->part,
-                                c->w_part_nch, c->ldw, gp, ngp, (double)c->R, (const double*)c->W, c->row0, c->nl, c->bsum));
+                                c->w_part_nch, c->ldw, gp, ngp, (double)c->R, (const double*)c->W, c->row0, c->nl, c->bsum, cvl,
+                                (const double*)c->gpart_v));
       }
       HIPCHK(c, hipGetLastError());
       nb = (size_t)blocks;
@@ -2060,6 +2173,44 @@ int btf_sym_eig(int device, int K, int nparts, const double* parts, double* out,
   return BTF_OK;
 }
 
+// Measurement aid (bench.py roofline.read_ceiling_GBs): the rate of a plain streaming read - one 16-byte load
+// per lane and trip, 512 workgroups of 1024 threads - over `bytes` of device memory, averaged over `reps` launches.
+namespace {
+__global__ __launch_bounds__(1024) void read_probe_kernel(const double2* __restrict__ x, size_t n2, double* __restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) s += x[i].x + x[i].y;
+  if (s == 1.2345e300) out[0] = s;       // never true (the buffer holds zeros): keeps the loads alive
+}
+}  // namespace
+int btf_read_probe(int device, size_t bytes, int reps, double* gb_per_s) {
+  if (bytes < 1024 || reps < 1 || !gb_per_s) return fail(nullptr, BTF_EINVAL, "bad read_probe arguments");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, BTF_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  double2* x = nullptr; double* out = nullptr;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  auto cleanup = [&]() { if (x) (void)hipFree(x); if (out) (void)hipFree(out); if (t0) (void)hipEventDestroy(t0); if (t1) (void)hipEventDestroy(t1); };
+#define RP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return fail(nullptr, BTF_EHIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+  const size_t n2 = bytes / sizeof(double2);
+  RP(hipMalloc((void**)&x, n2 * sizeof(double2)));
+  RP(hipMalloc((void**)&out, sizeof(double)));
+  RP(hipMemset(x, 0, n2 * sizeof(double2)));
+  RP(hipEventCreate(&t0));
+  RP(hipEventCreate(&t1));
+  hipLaunchKernelGGL(read_probe_kernel, dim3(512), dim3(1024), 0, 0, (const double2*)x, n2, out);      // warm-up
+  RP(hipDeviceSynchronize());
+  RP(hipEventRecord(t0, 0));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(read_probe_kernel, dim3(512), dim3(1024), 0, 0, (const double2*)x, n2, out);
+  RP(hipEventRecord(t1, 0));
+  RP(hipEventSynchronize(t1));
+  float ms = 0.f;
+  RP(hipEventElapsedTime(&ms, t0, t1));
+#undef RP
+  *gb_per_s = (double)n2 * sizeof(double2) * reps / (ms * 1e-3) / 1e9;
+  cleanup();
+  return BTF_OK;
+}
+
 int btf_sync(btf_ctx* c) {
   if (!c) return BTF_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
@@ -2184,9 +2335,21 @@ int btf_set_option(btf_ctx* c, int option, int value) {
       c->fuse_gram = value != 0;
       c->ngp_v = c->ngp_w = 0;
       return BTF_OK;
+    case BTF_OPT_CURVE_COUNTS:
+      c->curve_opt = value != 0;
+      c->ngp_v = c->ngp_w = 0;
+      c->w_part_valid = false;
+      return BTF_OK;
     default:
       return fail(c, BTF_EINVAL, "unknown option");
   }
+}
+
+int btf_get_likelihood_form(btf_ctx* c, int32_t* form) {
+  if (!c || !form) return BTF_EINVAL;
+  if (!c->have_data) return fail(c, BTF_ESTATE, "set data first");
+  *form = !c->weighted ? BTF_LIK_COMPLETE : (curve_on(c) ? BTF_LIK_CURVE_COUNTS : BTF_LIK_WEIGHTED);
+  return BTF_OK;
 }
 
 int btf_get_V_sampler(btf_ctx* c, int32_t* which) {

@@ -43,6 +43,33 @@ constexpr int ACC_RG = (ACC_THREADS / ACC_TILE) < 4 ? (ACC_THREADS / ACC_TILE) :
 
 __device__ inline void reduce_gram(const double* __restrict__ gpart, int ngp, int KK, double scale, double* scratch, double* G);
 
+// curve-structured replicate counts (see the section above colgram_kernel): CSR lists of deficient partners
+struct CurveLists {
+  const int* ptr;        // [n + 1]
+  const int* idx;        // partner index (column for a row list, row for a column list)
+  const double* def;     // R - c_ij > 0
+};
+// the per-column Gram of curve-structured counts: Ql (= sR W'W, LDS) -= s sum_{i in D(j)} (R - c_ij) w_i w_i'
+// (threads 0..KK-1; the caller's next barrier publishes it)
+__device__ __forceinline__ void curve_column_gram(const CurveLists& cv, const double* __restrict__ W, int jg, int K, int KK,
+                                                  double scale, double* Ql) {
+  if (!cv.ptr || (int)threadIdx.x >= KK) return;
+  const int q = threadIdx.x;
+  int p = 0;
+  while ((p + 1) * (p + 2) / 2 <= q) ++p;
+  const int pq = q - p * (p + 1) / 2;
+  double corr = 0.0;
+  for (int e = cv.ptr[jg]; e < cv.ptr[jg + 1]; ++e) {
+    const double* __restrict__ w = W + (size_t)cv.idx[e] * K;
+    corr = fma(cv.def[e] * w[p], w[pq], corr);
+  }
+  Ql[q] = fma(-scale, corr, Ql[q]);
+}
+
+// side tasks of the V accumulation launch (spectral sampler): workgroup 0 solves the eigen-problem of the shared
+// Gram W'W, workgroups 1..ncols those of the listed curve columns' own Grams (their eigen-systems in eig_cols)
+struct EigSideCols { const int* cols; int ncols; CurveLists cv; const double* W; double inv_R; double* eig_cols; };
+
 // MODE 0: X only (complete data)
 // MODE 1: X, C and the outer products UU
 // MODE 2: as 1, but the precision weight of output l is read from output srcmap[l] of the
@@ -63,7 +90,7 @@ template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double>
 __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     const double* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
-    int rows_per_block, EigSide side) {
+    int rows_per_block, EigSide side, EigSideCols sidec) {
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
@@ -78,18 +105,25 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
   if (side.out) {
     // side task (spectral V sampler): the first workgroup is dispatched first; one wave of it solves the K x K
     // eigenproblem of the Gram beside the stream, its other waves leave at once
-    if (b == 0) {
+    if (b <= sidec.ncols) {
 #ifndef BTF_EIG_NOP      // (timing aid: BTF_EIG_NOP builds skip the side task - results are wrong, only the clock is read)
       // the whole workgroup sums the Gram partials (one round of loads, whatever their number), wave 0 goes on
       double* sc = &red[0][0][0];
       double* gsum = sc + EIG_LDS_DOUBLES + ACC_WAVES * WAVE;
       static_assert(EIG_LDS_DOUBLES + ACC_WAVES * WAVE + tri(EIG_MAXK) <= ACC_WAVES * ACC_RG * ACC_TILE, "side task scratch");
       reduce_gram(side.gpart, side.ngp, tri(side.K), 1.0, sc + EIG_LDS_DOUBLES, gsum);
-      if (wave == 0) gram_eig_wave(gsum, 1, side.K, side.out, sc);
+      double* out = side.out;
+      if (b > 0) {      // a curve column: its own Gram, its own (warm-started) eigen-system
+        const int col = sidec.cols[b - 1];
+        curve_column_gram(sidec.cv, sidec.W, col, side.K, tri(side.K), sidec.inv_R, gsum);
+        __syncthreads();
+        out = sidec.eig_cols + (size_t)col * (side.K + side.K * side.K + 8);
+      }
+      if (wave == 0) gram_eig_wave(gsum, 1, side.K, out, sc);
 #endif
       return;
     }
-    --b;
+    b -= 1 + sidec.ncols;
   }
   const int ntiles = ld / ACC_TILE;
   const int chunk = b / ntiles, tile = b - chunk * ntiles;
@@ -313,6 +347,43 @@ __device__ inline void reduce_gram_finish(const double (&x)[8], int ngp, int KK,
 }
 
 // ============================================================================
+// Curve-structured replicate counts (Gaussian data whose counts c_ij do not vary along the depth axis: whole
+// curves held out or thinned, the pattern of the reference's examples - Y[:3, :3] = NaN in
+// examples/gaussian_tensor_filtering.py:16-18).  The weighted systems of factor.py:343-346 / :388-391 then are the
+// complete-data ones minus a few rank-one / per-column terms,
+//     row i:     sum_(j,t) c_ij v v' = R V'V - sum_{j in D(i)} (R - c_ij) V_j'V_j          (V_j'V_j: K x K per column)
+//     column j:  sum_i c_ij w w'     = R W'W - sum_{i in D(j)} (R - c_ij) w_i w_i'         (the same at every depth)
+// with D(.) the deficient partners (CSR lists, built once at upload): the streaming accumulation stays the
+// complete-data one (K values per cell, no counts read), and a column keeps the Kronecker structure the spectral
+// sampler needs - with its own Gram.
+// ============================================================================
+// per-column Gram of V: out[j][KK] = sum_t v_jt v_jt'   (one wave per column; the samplers emit the same blocks
+// for a column they have just drawn)
+template <int K>
+__global__ __launch_bounds__(WAVE) void colgram_kernel(const double* __restrict__ V, int T, int ncols, double* __restrict__ out) {
+  constexpr int KK = tri(K);
+  const int j = blockIdx.x, lane = threadIdx.x;
+  if (j >= ncols) return;
+  double acc[KK];
+#pragma unroll
+  for (int q = 0; q < KK; ++q) acc[q] = 0.0;
+  for (int t = lane; t < T; t += WAVE) {
+    double v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = V[((size_t)j * T + t) * K + k];
+#pragma unroll
+    for (int a = 0; a < K; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) acc[lidx(a, b)] = fma(v[a], v[b], acc[lidx(a, b)]);
+  }
+#pragma unroll
+  for (int q = 0; q < KK; ++q) {
+    const double t = wave_sum(acc[q]);
+    if (lane == 0) out[(size_t)j * KK + q] = t;
+  }
+}
+
+// ============================================================================
 // W half-sweep: batched K x K Cholesky draw, one lane per row  (BTF_K_W_SOLVE)
 //   factor.py:349-362:  Q = X'CX + I/sigma2 ; Lt = chol(Q)' ;
 //                       W[i,:d] = cho_solve(Lt, m) + Lt^-1 z
@@ -331,6 +402,8 @@ struct WSolveArgs {
   const double* hyp;   // device-resident scalars (HYP_*) or nullptr: when set they override s, sR, inv_sigma2
   double Rrep;         // nreps (sR = s * Rrep)
   int hyp_noise;       // 1: the noise scale s comes from hyp[HYP_NU2] (scalar-nu2 models only)
+  CurveLists cv;       // curve-structured counts: deficient columns of every row (global row index), or ptr == nullptr
+  const double* cv_blocks;   // [M][KK] per-column Grams V_j'V_j
 };
 
 // device-resident scalar hyper-parameters (rng="device": drawn by scalars_kernel / lam2_kernel,
@@ -474,6 +547,16 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
       Q[q] = G[q];
     }
   }
+  if constexpr (!WEIGHTED) {
+    if (a.cv.ptr && live) {          // curve-structured counts: take the missing replicates' share out again
+      for (int e = a.cv.ptr[i]; e < a.cv.ptr[i + 1]; ++e) {
+        const double* __restrict__ blk = a.cv_blocks + (size_t)a.cv.idx[e] * KK;
+        const double f = a.s * a.cv.def[e];
+#pragma unroll
+        for (int q = 0; q < KK; ++q) Q[q] = fma(-f, blk[q], Q[q]);
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < K; ++k) Q[lidx(k, k)] += a.inv_sigma2;
   // rows/cols >= d are frozen (W is lower triangular in its first K rows): identity there
@@ -599,6 +682,8 @@ struct VBandArgs {
   int panel4;          // 1: panelised MFMA factorisation where it applies (bw == 15)
   const int* fill;     // band assembly program of the twisted kernel: [nfill][4] = {dst, src, diag-src or -1, 0} (LDS word offsets)
   int nfill;           // multiple of the workgroup size (padded with writes to a dummy word)
+  CurveLists cv;       // curve-structured counts: deficient rows of every column (global column index), or ptr == nullptr
+  const double* cv_W;  // the factor W (rows of the rank-one terms)
 };
 __device__ __forceinline__ void vband_load_hyp(VBandArgs& a) {
   if (a.hyp) {
@@ -1940,7 +2025,8 @@ template <int K, bool WEIGHTED>
 __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void sse_part_kernel(const double* __restrict__ part, int nch, int ld,
                                                                         const double* __restrict__ gpart, int ngp, double Rrep,
                                                                         const double* __restrict__ W, int row0, int nl,
-                                                                        double* __restrict__ bsum) {
+                                                                        double* __restrict__ bsum, CurveLists cv,
+                                                                        const double* __restrict__ cv_blocks) {
   constexpr int KK = tri(K);
   constexpr int WS_SPLIT = ws_split(K);
   constexpr int NV = WEIGHTED ? K + KK : K;
@@ -1999,6 +2085,16 @@ __global__ __launch_bounds__(WS_ROWS * ws_split(K)) void sse_part_kernel(const d
         Q[q] = t;
       } else {
         Q[q] = G[q];
+      }
+    }
+    if constexpr (!WEIGHTED) {
+      if (cv.ptr) {
+        for (int e = cv.ptr[row0 + il]; e < cv.ptr[row0 + il + 1]; ++e) {
+          const double* __restrict__ blk = cv_blocks + (size_t)cv.idx[e] * KK;
+          const double f = cv.def[e];
+#pragma unroll
+          for (int q = 0; q < KK; ++q) Q[q] = fma(-f, blk[q], Q[q]);
+        }
       }
     }
     double lin = 0.0, quad = 0.0;

@@ -54,6 +54,10 @@ struct VSpecArgs {
   double* gout;                          // [ml][KK] V_j'V_j of the fresh column, or nullptr
   const double* hyp; double Rrep; int hyp_noise;
   long long* dbg;
+  // curve-structured replicate counts (btf_kernels.h, CurveLists): a column with deficient rows solves the eigen-problem
+  // of ITS Gram  W'W - sum_i (1 - c_ij / R) w_i w_i'  here (warm-started from its own previous solution in eig_cols)
+  CurveLists cv; const double* cv_W; const double* gpart; int ngp; double* eig_cols;
+  int eig_cols_ready;                    // 1: the accumulation launch's side tasks already solved the curve columns
 };
 
 // Elimination order inside one system (the order the build declares for this sampler; z[j][k*T + i]
@@ -75,7 +79,7 @@ __host__ __device__ inline int spectral_depth_of_pivot(int i, int T, int S) {
 }
 
 struct VsLayout {      // LDS offsets in doubles
-  int U, g, itau, P, Pm, mraw, mt, mtm, zz, rec, win, gs, flag, total;
+  int U, g, itau, P, Pm, mraw, mt, mtm, zz, rec, win, gs, flag, eG, eo, esc, total;
   int Tp, RS;
 };
 __host__ __device__ inline VsLayout vs_layout(int T, int K, int TF, int nD) {
@@ -98,6 +102,9 @@ __host__ __device__ inline VsLayout vs_layout(int T, int K, int TF, int nD) {
   L.win = o; o += 2 * K * (S * (S + 1) + S);   // the two chains' windows at the separator
   L.gs = o; o += VS_THREADS;       // Gram-share scratch: at most 16 groups of KK <= 256 doubles
   L.flag = o; o += 8;
+  L.eG = o; o += (tri(K) + 1) & ~1;              // a curve column's own Gram
+  L.eo = o; o += (K + K * K + 8 + 1) & ~1;       // ... its eigen-system (gram_eig_wave's output record)
+  L.esc = o; o += EIG_LDS_DOUBLES;               // ... the solver's scratch
   L.total = o;
   return L;
 }
@@ -233,9 +240,14 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
       scf[u] = c2.x; scf[u + 1] = c2.y;
     }
   }
-  for (int idx = tid; idx < K + K * K; idx += VS_THREADS) {
-    const double v = a.eig[idx];
-    if (idx < K) gsh[idx] = v; else Ush[idx - K] = v;
+  const bool curve_col = a.cv.ptr && a.cv.ptr[jg + 1] > a.cv.ptr[jg];      // (workgroup-uniform)
+  const bool own_eig = curve_col && !a.eig_cols_ready;
+  if (!own_eig) {
+    const double* __restrict__ es = curve_col ? a.eig_cols + (size_t)jg * (K + K * K + 8) : a.eig;
+    for (int idx = tid; idx < K + K * K; idx += VS_THREADS) {
+      const double v = es[idx];
+      if (idx < K) gsh[idx] = v; else Ush[idx - K] = v;
+    }
   }
   // 1 / (lam2 Tau2[j, r]) once per penalty row (the diagonal matrix of factor.py:404)
   for (int idx = tid; idx < a.nD; idx += VS_THREADS) itau[idx] = 1.0 / (a.lam2 * a.Tau2[(size_t)jg * a.nD + idx]);
@@ -264,6 +276,23 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
   }
   const int scnt = se1 - se0;
   for (int idx = tid; idx < (T + S + 1) * D1; idx += VS_THREADS) Pm[idx] = 0.0;
+  if (own_eig) {
+    double* Gl = lds + L.eG;
+    double* eo = lds + L.eo;
+    const int ne = K + K * K + 8;
+    double* ecol = a.eig_cols + (size_t)jg * ne;
+    for (int idx = tid; idx < ne; idx += VS_THREADS) eo[idx] = ecol[idx];       // the column's previous solution
+    reduce_gram(a.gpart, a.ngp, KK, 1.0, lds + L.gs, Gl);                       // W'W (ends with a barrier)
+    curve_column_gram(a.cv, a.cv_W, jg, K, KK, 1.0 / a.Rrep, Gl);
+    __syncthreads();
+    if (wave == 0) gram_eig_wave(Gl, 1, K, eo, lds + L.esc);
+    __syncthreads();
+    for (int idx = tid; idx < ne; idx += VS_THREADS) {
+      const double v = eo[idx];
+      ecol[idx] = v;
+      if (idx < K) gsh[idx] = v; else if (idx < K + K * K) Ush[idx - K] = v;
+    }
+  }
   __syncthreads();
   stamp[1] = __builtin_amdgcn_s_memtime();
   // ---- prior band P[t][d] = sum_r Delta[r,t] Delta[r,t+d] / (lam2 Tau2_r)  (rows ascending), its mirror image,

@@ -614,6 +614,16 @@ class BayesianTensorFiltering(_BayesianModel):
         self._ctx.call("btf_get_V_sampler", ctypes.byref(which))
         return {v: k for k, v in _native.SAMPLERS.items()}[which.value]
 
+    def likelihood_form(self):
+        """"complete", "weighted" or "curve_counts": which form of the likelihood part the half-sweeps run for the
+        bound data (include/btf.h, btf_get_likelihood_form).  "curve_counts": Gaussian data whose replicate counts
+        do not vary along the depth axis (whole curves held out, as in the reference's examples) - complete-data
+        kernels plus per-row / per-column corrections, the same conditionals as factor.py:343-346, :388-391."""
+        import ctypes
+        form = ctypes.c_int32()
+        self._ctx.call("btf_get_likelihood_form", ctypes.byref(form))
+        return ("complete", "weighted", "curve_counts")[form.value]
+
     def sync(self):
         """Wait for the GPU; raises NotPositiveDefiniteError if a factorisation failed."""
         self._ctx.call("btf_sync")

@@ -73,6 +73,10 @@ enum {
   BTF_OPT_NB_HISTOGRAMS = 1, /* 1 (default): Negative-Binomial rate update from per-row count
                                 histograms where they apply; 0: always the full-tensor kernel          */
   BTF_OPT_FUSE_GRAM = 2,     /* 1 (default): W'W / V'V partials come out of the preceding solve kernel */
+  BTF_OPT_CURVE_COUNTS = 4,  /* 1 (default): Gaussian data whose replicate counts do not vary along the depth axis
+                                (whole curves missing, as Y[:3,:3] = NaN in the reference's examples) run the
+                                complete-data kernels plus per-row / per-column corrections (same conditionals as the
+                                weighted form of factor.py:343-346, :388-391); 0: always the weighted form         */
   BTF_OPT_PG_EXACT = 3       /* Polya-Gamma sampler of btf_pg_draw.  0 (default): integer trial counts 1 and 2 by
                                 Devroye's exact alternating-series sampler, every other count by the sum-of-gammas
                                 series with a normal remainder (approximate; validated against the exact sampler).
@@ -243,6 +247,18 @@ int btf_get_V_order(btf_ctx* ctx, int32_t* order /* (K*T) */);
  * packed-lower K x K matrices parts[p][r(r+1)/2 + c], returns out[0..K-1] eigenvalues ascending,
  * out[K + r*K + c] component r of eigenvector c (largest-magnitude entry positive), out[K+K*K] sweeps. */
 int btf_sym_eig(int device, int nembeds, int nparts, const double* parts, double* out, const double* warm_from);
+
+/* Measurement aid: rate (GB/s) of a plain streaming read of `bytes` of device memory, averaged over `reps`
+ * launches - the practical read ceiling bench.py reports beside the spec peak (roofline.read_ceiling_GBs). */
+int btf_read_probe(int device, size_t bytes, int reps, double* gb_per_s);
+/* Which form of the likelihood part the half-sweeps of this context run (after btf_set_data_*):
+ *   BTF_LIK_COMPLETE      complete Gaussian data: K sums per cell, one shared Gram (factor.py:347-348, :392-393)
+ *   BTF_LIK_WEIGHTED      per-cell weights (missing replicates, Polya-Gamma omegas): K + K(K+1)/2 sums per cell
+ *   BTF_LIK_CURVE_COUNTS  replicate counts constant along the depth axis: the complete-data stream plus per-row /
+ *                         per-column corrections (BTF_OPT_CURVE_COUNTS) - the same conditionals as the weighted form */
+enum { BTF_LIK_COMPLETE = 0, BTF_LIK_WEIGHTED = 1, BTF_LIK_CURVE_COUNTS = 2 };
+int btf_get_likelihood_form(btf_ctx* ctx, int32_t* form);
+
 /* warm_from: NULL (cyclic Jacobi from the identity) or the `out` of a nearby matrix, refined by the
  * Ogita-Aishima iteration (the path the sampler takes from the second sweep on; out[K+K*K] = 0 then). */
 int btf_set_option(btf_ctx* ctx, int option, int value);

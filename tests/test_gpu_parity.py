@@ -630,7 +630,8 @@ def test_device_scalar_draws_have_the_right_conditionals(golden):
     from oracle import btf_oracle as orc
     from functionalmf_amd import _native
     g = golden("g1_c1_heldout.npz")
-    model, st = gaussian_model(g, "s0_", rng="device", device_seed=11)
+    # (sampler="banded": the host-scalar twin below uses it, and held-out curves now qualify for the spectral one)
+    model, st = gaussian_model(g, "s0_", rng="device", device_seed=11, sampler="banded")
     Y = g["Y"]
     sse, nobs = orc.sse_and_count(st, Y)
     wfree = model._pack_W(st["W"])
@@ -969,7 +970,7 @@ def _spectral_model(golden, tag, **kw):
     return model, Y, st, (N, M, T, R, K, tf), z, Vref
 
 
-@pytest.mark.parametrize("tag", ["g2", "k5", "tf0", "tf1", "tf3", "short"])
+@pytest.mark.parametrize("tag", ["g2", "k5", "tf0", "tf1", "tf3", "short", "held"])
 def test_spectral_v_step_vs_reference(golden, tag, monkeypatch):
     """The spectral kernel against the fixture the reference's own _resample_V produced under the declared
     spectral square root (tests/golden/make_golden_spectral.py), from the same state and normals."""
@@ -977,6 +978,8 @@ def test_spectral_v_step_vs_reference(golden, tag, monkeypatch):
     monkeypatch.setattr(model, "_v_normals", lambda: z)
     model._resample_V(Y)
     assert model.v_sampler() == "spectral"
+    # held: whole curves missing (the reference examples' pattern) - complete-data kernels plus corrections
+    assert model.likelihood_form() == ("curve_counts" if tag == "held" else "complete")
     assert relerr(model.V, Vref) < V_TOL
 
 
@@ -1214,3 +1217,122 @@ def test_nonconjugate_device_slices_sample_the_conditional(ess):
         # slice-sampler draws are autocorrelated: a generous effective sample size
         assert abs(draws[:, i].mean() - m) < 6 * sd / np.sqrt(len(draws) / 10), (i, draws[:, i].mean(), m)
         assert abs(draws[:, i].std() - sd) < 0.1 * sd, (i, draws[:, i].std(), sd)
+
+
+# ---- curve-structured replicate counts (whole curves missing / thinned): complete-data kernels + corrections ----
+def _curve_data(seed=3, dims=(14, 9, 13, 3, 3, 2)):
+    N, M, T, R, K, tf = dims
+    rs = np.random.RandomState(seed)
+    Wt = rs.normal(size=(N, K))
+    Wt[np.triu_indices(K, 1)] = 0
+    Vt = 0.3 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    Y = np.einsum("nk,mtk->nmt", Wt, Vt)[..., None] + rs.normal(0, 0.5, size=(N, M, T, R))
+    Y[:3, :3] = np.nan                      # held-out block, as examples/gaussian_tensor_filtering.py:16-18
+    Y[7, 5] = np.nan                        # one more whole curve
+    Y[4, 2, :, 1] = np.nan                  # thinned curves: one / two replicates gone at every depth
+    Y[9, 6, :, :2] = np.nan
+    Y[12, 0, :, 2] = np.nan
+    st = dict(W=Wt + 0.1 * rs.normal(size=Wt.shape), V=Vt + 0.1 * rs.normal(size=Vt.shape), lam2=0.2, sigma2=0.6, nu2=0.4)
+    st["W"][np.triu_indices(K, 1)] = 0
+    from oracle import btf_oracle as orc
+    st["Tau2"] = rs.gamma(2.0, 0.5, size=(M, orc.trend_penalty(T, tf).shape[0]))
+    return Y, st, dims
+
+
+def _curve_model(Y, st, dims, chain=False, **kw):
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    N, M, T, R, K, tf = dims
+    if not chain:
+        kw["Tau2_init"] = st["Tau2"]        # (whole sweeps draw Tau2: the model must build its own horseshoe+ chain, quirk Q6)
+    return GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                           nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], compat="exact", **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", ["spectral", "banded"])
+def test_curve_counts_half_sweeps_vs_oracle_and_weighted_form(sampler, monkeypatch):
+    """Counts constant along the depth axis: the W and V half-sweeps run the complete-data stream plus per-row /
+    per-column corrections.  They must equal (i) the oracle's weighted steps (factor.py:343-346, :388-391 restated)
+    and (ii) the same model with BTF_OPT_CURVE_COUNTS off, from the same state and normals; the residual sum of
+    squares taken from the W partials must equal the oracle's."""
+    from oracle import btf_oracle as orc
+    from functionalmf_amd import _native
+    Y, st, dims = _curve_data()
+    N, M, T, R, K, tf = dims
+    Delta = orc.trend_penalty(T, tf)
+    rs = np.random.RandomState(11)
+    zw = rs.normal(size=K * (K + 1) // 2 + (N - K) * K)
+    zv = rs.normal(size=(M, K * T))
+    out = {}
+    for curve in (1, 0):
+        model = _curve_model(Y, st, dims, sampler=sampler)
+        model.set_data(Y)
+        model._ctx.call("btf_set_option", _native.OPT_CURVE_COUNTS, curve)
+        assert model.likelihood_form() == ("curve_counts" if curve else "weighted")
+        assert model.v_sampler() == (sampler if curve else "banded")          # the weighted form has no spectral sampler
+        monkeypatch.setattr(model, "_w_normals", lambda: zw)
+        monkeypatch.setattr(model, "_v_normals", lambda: zv)
+        model._resample_W(Y)
+        Wd = model.W.copy()
+        model._resample_V(Y)
+        out[curve] = (Wd, model.V.copy(), model.v_order())
+    o = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    orc.w_step(o, Y, z=zw)
+    assert relerr(out[1][0], o["W"]) < 1e-10 and relerr(out[0][0], o["W"]) < 1e-10
+    perm = "spectral" if sampler == "spectral" else orc.perm_from_order(out[1][2], K, T)
+    orc.v_step(o, Y, Delta, perm=perm, z=zv, compat="exact")
+    assert relerr(out[1][1], o["V"]) < 1e-7
+    if sampler == "banded":
+        assert relerr(out[1][1], out[0][1]) < 1e-7
+
+
+@pytest.mark.gpu
+def test_curve_counts_device_chain_matches_weighted_form():
+    """rng="device", whole sweeps: with the banded sampler the curve-counts form and the weighted form consume the same
+    Philox streams, so the two chains must coincide (up to rounding) - scalars drawn from the partials' residual sum of
+    squares included."""
+    from functionalmf_amd import _native
+    Y, st, dims = _curve_data(seed=5, dims=(40, 12, 16, 3, 3, 2))
+    chains = []
+    for curve in (1, 0):
+        np.random.seed(7)
+        m = _curve_model(Y, st, dims, chain=True, sampler="banded", rng="device", device_seed=13)
+        m.set_data(Y)
+        m._ctx.call("btf_set_option", _native.OPT_CURVE_COUNTS, curve)
+        assert m.likelihood_form() == ("curve_counts" if curve else "weighted")
+        for _ in range(4):
+            m.resample(Y)
+        chains.append((m.W.copy(), m.V.copy(), float(m.nu2), float(m.sigma2), np.array(m.Tau2).copy()))
+    a, b = chains
+    assert abs(a[2] - b[2]) / b[2] < 1e-9 and abs(a[3] - b[3]) / b[3] < 1e-9
+    assert relerr(a[0], b[0]) < 1e-7 and relerr(a[1], b[1]) < 1e-5 and relerr(a[4], b[4]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_counts_varying_with_depth_keep_the_weighted_form():
+    Y, st, dims = _curve_data()
+    Y[5, 5, 3, 0] = np.nan                  # a single replicate at a single depth
+    model = _curve_model(Y, st, dims, sampler="spectral")
+    model.set_data(Y)
+    assert model.likelihood_form() == "weighted" and model.v_sampler() == "banded"
+
+
+@pytest.mark.gpu
+def test_curve_counts_spectral_chain_samples_the_same_posterior():
+    """The per-column eigen-systems are warm-started from sweep to sweep: a longer rng="device" chain with the spectral
+    sampler must agree with the banded-sampler chain in its posterior means (two square roots, one distribution)."""
+    Y, st, dims = _curve_data(seed=9, dims=(30, 10, 12, 3, 3, 2))
+    means = {}
+    for sampler in ("spectral", "banded"):
+        np.random.seed(3)
+        m = _curve_model(Y, st, dims, chain=True, sampler=sampler, rng="device", device_seed=21, lam2_true=0.2)
+        acc, n = 0.0, 0
+        for it in range(700):
+            m.resample(Y)
+            if it >= 100:
+                acc = acc + np.einsum("nk,mtk->nmt", m.W, m.V)
+                n += 1
+        assert m.likelihood_form() == "curve_counts" and m.v_sampler() == sampler
+        means[sampler] = acc / n
+    d = np.abs(means["spectral"] - means["banded"])
+    assert d.mean() < 0.05 and np.corrcoef(means["spectral"].ravel(), means["banded"].ravel())[0, 1] > 0.995

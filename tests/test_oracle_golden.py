@@ -246,7 +246,7 @@ def _spectral_case(golden, tag):
     return g8[tag + "_Y"], st, [int(x) for x in g8[tag + "_dims"]], g8[tag + "_z_V"], g8[tag + "_V_after_spectral"]
 
 
-@pytest.mark.parametrize("tag", ["g2", "k5", "tf0", "tf1", "tf3", "short"])
+@pytest.mark.parametrize("tag", ["g2", "k5", "tf0", "tf1", "tf3", "short", "held"])
 def test_v_step_spectral_square_root_vs_reference(golden, tag):
     """factor.py:364-409 + fast_mvn.py:35-47 run by the reference itself with the spectral shim: the
     oracle's restatement (faithful per-column assembly and the vectorised strong path) must reproduce it,
@@ -257,10 +257,11 @@ def test_v_step_spectral_square_root_vs_reference(golden, tag):
     tol = 1e-6 if tag == "g2" else 1e-9        # g2: lam2 on its floor after two sweeps, cond(Q) ~ 1e9 (cond * eps)
     orc.v_step(a, Y, Delta, perm="spectral", z=z)
     assert relerr(a["V"], Vref) < tol
-    b = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
-    Rr, ybar = orc.hoisted_stats(Y)
-    orc.v_step_strong(b, Rr, ybar, Delta, z=z, order="spectral")
-    assert relerr(b["V"], Vref) < tol
+    if tag != "held":           # (held: whole curves missing - every column its own K x K block; the strong path is complete-data only)
+        b = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+        Rr, ybar = orc.hoisted_stats(Y)
+        orc.v_step_strong(b, Rr, ybar, Delta, z=z, order="spectral")
+        assert relerr(b["V"], Vref) < tol
     c = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
     d = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
     orc.v_step(c, Y, Delta, perm="spectral", z=0 * z)
