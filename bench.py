@@ -74,8 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--strong", action="store_true", help="(default for N>1; kept for compatibility)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--rpb", type=int, nargs=2, default=[0, 0], help="rows per workgroup (W, V) tuning override")
-    ap.add_argument("--variant", default="complete", choices=["complete", "heldout", "missing5", "binomial", "negbinom"],
-                    help="complete: headline; heldout: Y[:3,:3]=NaN; missing5: 5%% curves + 5%% single replicates NaN; "
+    ap.add_argument("--variant", default="complete", choices=["complete", "heldout", "curves5", "missing5", "binomial", "negbinom"],
+                    help="complete: headline; heldout: Y[:3,:3]=NaN; curves5: 5%% of the (i,j) curves NaN; "
+                         "missing5: 5%% curves + 5%% single replicates NaN; "
                          "binomial: 4 trials per cell, device Polya-Gamma draw included in the step (config C4); "
                          "negbinom: NB(4, p) counts, step = 30 MH steps on the rate R + PG draw + W + V (SURVEY 8(f) rank 2)")
     ap.add_argument("--sampler", default="auto", help="V sampler: auto (spectral on complete data, banded otherwise), banded, spectral, chain")
@@ -165,6 +166,8 @@ def main():
         rs = np.random.RandomState(7)
         if args.variant == "heldout":
             Y[:3, :3] = np.nan
+        elif args.variant == "curves5":
+            Y[rs.rand(N, M) < 0.05] = np.nan
         elif args.variant == "missing5":
             Y[rs.rand(N, M) < 0.05] = np.nan
             Y[rs.rand(N, M, T, R) < 0.05] = np.nan
@@ -278,7 +281,7 @@ def main():
     cells_local = (N // world if world > 1 else N) * M * T
     cells_local_v = N * (M // world if world > 1 else M) * T
     form = model.likelihood_form()     # "curve_counts": held-out whole curves run the complete-data stream (no counts read)
-    bpc = 8.0 if form in ("complete", "curve_counts") else ({"heldout": 9.0, "missing5": 9.0}.get(args.variant, 16.0))
+    bpc = 8.0 if form in ("complete", "curve_counts") else ({"heldout": 9.0, "curves5": 9.0, "missing5": 9.0}.get(args.variant, 16.0))
     acc_ms = kt["w_accum"][0] + kt["v_accum"][0]
     acc_n = kt["w_accum"][1] + kt["v_accum"][1]
     acc_us = 1e3 * acc_ms / max(acc_n, 1)

@@ -184,10 +184,10 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     }
   } else if (g_early) {
     reduce_gram_finish(gx, a.ngp, KK, a.sR, lds + W.L.band, Ql);
-    curve_column_gram(a.cv, a.cv_W, jg, K, KK, a.s, Ql);      // (thread q wrote Ql[q] itself)
+    curve_column_gram(a.cv, a.cv_W, jg, K, KK, a.s, Ql, lds + W.L.band, VT_THREADS * 2);
   } else {
     reduce_gram(a.gpart, a.ngp, KK, a.sR, lds + W.L.band, Ql);
-    curve_column_gram(a.cv, a.cv_W, jg, K, KK, a.s, Ql);
+    curve_column_gram(a.cv, a.cv_W, jg, K, KK, a.s, Ql, lds + W.L.band, VT_THREADS * 2);
   }
   // (the static zero regions of the three views - pads, scratch rows, dummy words - are part of the one wide
   //  zero fill at the top of the assembly below: the views and the dummy block are contiguous in LDS)

@@ -49,21 +49,51 @@ struct CurveLists {
   const int* idx;        // partner index (column for a row list, row for a column list)
   const double* def;     // R - c_ij > 0
 };
-// the per-column Gram of curve-structured counts: Ql (= sR W'W, LDS) -= s sum_{i in D(j)} (R - c_ij) w_i w_i'
-// (threads 0..KK-1; the caller's next barrier publishes it)
+// the per-column Gram of curve-structured counts: Ql (= sR W'W, LDS) -= scale sum_{i in D(j)} (R - c_ij) w_i w_i'.
+// Workgroup-collective (barriers inside; every thread of the workgroup calls it, ptr == nullptr returns at once):
+// the listed rows of W are staged in LDS, blockDim/K of them per pass - two dependent global round trips per
+// pass instead of two per row - and threads 0..KK-1 add the rank-one terms in list order.  scratch: at least
+// (blockDim/K)(K+1) doubles, or fewer rows go into a pass.  The caller's next barrier publishes Ql.
 __device__ __forceinline__ void curve_column_gram(const CurveLists& cv, const double* __restrict__ W, int jg, int K, int KK,
-                                                  double scale, double* Ql) {
-  if (!cv.ptr || (int)threadIdx.x >= KK) return;
+                                         double scale, double* Ql, double* scratch, int scratch_doubles) {
+  if (!cv.ptr) return;
+  const int e0 = cv.ptr[jg], e1 = cv.ptr[jg + 1];
+  if (e0 == e1) return;                                  // (uniform: jg is the workgroup's column)
   const int q = threadIdx.x;
   int p = 0;
   while ((p + 1) * (p + 2) / 2 <= q) ++p;
   const int pq = q - p * (p + 1) / 2;
   double corr = 0.0;
-  for (int e = cv.ptr[jg]; e < cv.ptr[jg + 1]; ++e) {
-    const double* __restrict__ w = W + (size_t)cv.idx[e] * K;
-    corr = fma(cv.def[e] * w[p], w[pq], corr);
+  if (e1 - e0 <= 6) {                                    // a handful of rows: straight from memory, no barriers
+    if (q < KK) {
+      for (int e = e0; e < e1; ++e) {
+        const double* __restrict__ w = W + (size_t)cv.idx[e] * K;
+        corr = fma(cv.def[e] * w[p], w[pq], corr);
+      }
+      Ql[q] = fma(-scale, corr, Ql[q]);
+    }
+    return;
   }
-  Ql[q] = fma(-scale, corr, Ql[q]);
+  int per = (int)blockDim.x / K;
+  if (per * (K + 1) > scratch_doubles) per = scratch_doubles / (K + 1);
+  const int el = threadIdx.x / K, k = threadIdx.x - el * K;
+  double* rows = scratch;                                // [per][K]
+  double* defs = scratch + per * K;                      // [per]
+  for (int eb = e0; eb < e1; eb += per) {
+    const int e = eb + el;
+    if (el < per && e < e1) {
+      const int i = cv.idx[e];
+      rows[el * K + k] = W[(size_t)i * K + k];
+      if (k == 0) defs[el] = cv.def[e];
+    }
+    __syncthreads();
+    if (q < KK) {
+      const int cnt = min(per, e1 - eb);
+      for (int u = 0; u < cnt; ++u) corr = fma(defs[u] * rows[u * K + p], rows[u * K + pq], corr);
+    }
+    __syncthreads();
+  }
+  if (q < KK) Ql[q] = fma(-scale, corr, Ql[q]);
 }
 
 // side tasks of the V accumulation launch (spectral sampler): workgroup 0 solves the eigen-problem of the shared
@@ -115,7 +145,7 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
       double* out = side.out;
       if (b > 0) {      // a curve column: its own Gram, its own (warm-started) eigen-system
         const int col = sidec.cols[b - 1];
-        curve_column_gram(sidec.cv, sidec.W, col, side.K, tri(side.K), sidec.inv_R, gsum);
+        curve_column_gram(sidec.cv, sidec.W, col, side.K, tri(side.K), sidec.inv_R, gsum, sc + EIG_LDS_DOUBLES, ACC_WAVES * WAVE);
         __syncthreads();
         out = sidec.eig_cols + (size_t)col * (side.K + side.K * side.K + 8);
       }
@@ -441,7 +471,39 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
   __shared__ double G[KK];
   __shared__ double red[WS_SPLIT][K + KK][WS_ROWS];   // also the staging area of the Gram partials
   __shared__ double zsh[K][WS_ROWS];
+  __shared__ double cvq[WEIGHTED ? 1 : RW][WEIGHTED ? 1 : KK];   // curve counts: sum_{j in D(i)} (R - c_ij) V_j'V_j per row
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  if constexpr (!WEIGHTED) {
+    if (a.cv.ptr) {
+      // The rows of a workgroup are consecutive, so their lists are ONE range of the CSR arrays: thread (g, q) takes
+      // entries g, g + G, ... and parks def * block[q] in LDS (`red` is free until the chunk sums land there); thread
+      // (row, q) then adds its row's entries in list order.  Two dependent round trips per pass, whatever the lists.
+      constexpr int NT = WS_ROWS * WS_SPLIT, G = NT / KK, CAP = (WS_SPLIT * (K + KK) * WS_ROWS) / KK;
+      const int i0 = a.row0 + blockIdx.x * RW, i1 = min(i0 + RW, a.row0 + a.nl);
+      const int e0 = a.cv.ptr[i0], e1 = a.cv.ptr[i1];
+      double* stage = &red[0][0][0];
+      const int g = threadIdx.x / KK, q = threadIdx.x - g * KK;
+      if (g < G)
+        for (int r = g; r < RW; r += G) cvq[r][q] = 0.0;
+      for (int eb = e0; eb < e1; eb += CAP) {
+        const int ee = min(eb + CAP, e1);
+        if (g < G) {
+          for (int e = eb + g; e < ee; e += G)
+            stage[(size_t)(e - eb) * KK + q] = a.cv.def[e] * a.cv_blocks[(size_t)a.cv.idx[e] * KK + q];
+        }
+        __syncthreads();
+        if (g < G) {
+          for (int r = g; r < RW && i0 + r < i1; r += G) {          // thread (g, q) owns rows g, g + G, ... of entry q
+            double acc = cvq[r][q];
+            for (int e = max(a.cv.ptr[i0 + r], eb); e < min(a.cv.ptr[i0 + r + 1], ee); ++e) acc += stage[(size_t)(e - eb) * KK + q];
+            cvq[r][q] = acc;
+          }
+        }
+        __syncthreads();
+      }
+      // (published by the barrier that follows the chunk sums)
+    }
+  }
   if (a.hyp) {
     if (a.hyp_noise) { a.s = 1.0 / a.hyp[HYP_NU2]; a.sR = a.s * a.Rrep; }
     a.inv_sigma2 = 1.0 / a.hyp[HYP_SIGMA2];
@@ -549,12 +611,8 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
   }
   if constexpr (!WEIGHTED) {
     if (a.cv.ptr && live) {          // curve-structured counts: take the missing replicates' share out again
-      for (int e = a.cv.ptr[i]; e < a.cv.ptr[i + 1]; ++e) {
-        const double* __restrict__ blk = a.cv_blocks + (size_t)a.cv.idx[e] * KK;
-        const double f = a.s * a.cv.def[e];
 #pragma unroll
-        for (int q = 0; q < KK; ++q) Q[q] = fma(-f, blk[q], Q[q]);
-      }
+      for (int q = 0; q < KK; ++q) Q[q] = fma(-a.s, cvq[rr][q], Q[q]);
     }
   }
 #pragma unroll

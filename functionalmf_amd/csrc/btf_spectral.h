@@ -283,7 +283,7 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
     double* ecol = a.eig_cols + (size_t)jg * ne;
     for (int idx = tid; idx < ne; idx += VS_THREADS) eo[idx] = ecol[idx];       // the column's previous solution
     reduce_gram(a.gpart, a.ngp, KK, 1.0, lds + L.gs, Gl);                       // W'W (ends with a barrier)
-    curve_column_gram(a.cv, a.cv_W, jg, K, KK, 1.0 / a.Rrep, Gl);
+    curve_column_gram(a.cv, a.cv_W, jg, K, KK, 1.0 / a.Rrep, Gl, lds + L.esc, EIG_LDS_DOUBLES);
     __syncthreads();
     if (wave == 0) gram_eig_wave(Gl, 1, K, eo, lds + L.esc);
     __syncthreads();
