@@ -278,7 +278,7 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
                   const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr},
                   EigSideCols sidec = EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}) {
   Prof p(c, kid);
-  dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 + sidec.ncols : 0));   // (+ the side tasks' workgroups)
+  dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 + eig_side_groups(sidec.ncols, acc_waves(K, mode)) : 0));   // (+ the side tasks' workgroups)
   if (mode >= 1 && C8) {       // byte weights (Gaussian replicate counts)
     if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec);
     else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec);
@@ -1247,10 +1247,10 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       }
       side = EigSide{use_gw ? c->gpart_w : c->gpart, use_gw ? c->ngp_w : c->ngp_gram, K, c->eig};
     }
-    // curve columns: a few ride along as side tasks too; many would keep the stream waiting and are solved by
-    // their sampler workgroups instead
+    // curve columns ride along as side tasks too, a wave each (their sampler workgroups can solve them as well:
+    // eig_cols_ready = 0 - kept as the fallback path)
     EigSideCols sidec{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr};
-    const bool cols_aside = choice == 3 && cv && c->cv_ndef <= 32;
+    const bool cols_aside = choice == 3 && cv;
     if (cols_aside) sidec = EigSideCols{c->cv_dcols, c->cv_ndef, CurveLists{c->cv_cptr, c->cv_crow, c->cv_cdef}, c->W, 1.0 / c->R, c->eig_cols};
     K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb, nch, side, sidec));
     hipError_t e = hipSuccess;

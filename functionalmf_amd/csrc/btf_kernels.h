@@ -96,9 +96,40 @@ __device__ __forceinline__ void curve_column_gram(const CurveLists& cv, const do
   if (q < KK) Ql[q] = fma(-scale, corr, Ql[q]);
 }
 
+// one-wave form (side tasks: a wave per column): lane l takes entries e0 + l, + 64, ...;
+// out[q] = sum_{i in D(col)} (R - c_i,col) w_i[p] w_i[p'] (the caller scales and subtracts)
+template <int K>
+__device__ __forceinline__ void curve_column_sum_wave(const CurveLists& cv, const double* __restrict__ W, int col, double* out) {
+  constexpr int KK = tri(K);
+  const int lane = threadIdx.x & 63;
+  const int e0 = cv.ptr[col], e1 = cv.ptr[col + 1];
+  double acc[KK];
+#pragma unroll
+  for (int q = 0; q < KK; ++q) acc[q] = 0.0;
+  for (int e = e0 + lane; e < e1; e += WAVE) {
+    const double* __restrict__ w = W + (size_t)cv.idx[e] * K;
+    const double d = cv.def[e];
+    double wr[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) wr[k] = w[k];
+#pragma unroll
+    for (int a = 0; a < K; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) acc[lidx(a, b)] = fma(d * wr[a], wr[b], acc[lidx(a, b)]);
+  }
+#pragma unroll
+  for (int q = 0; q < KK; ++q) {
+    const double t = wave_sum(acc[q]);
+    if (lane == 0) out[q] = t;
+  }
+}
+
 // side tasks of the V accumulation launch (spectral sampler): workgroup 0 solves the eigen-problem of the shared
 // Gram W'W, workgroups 1..ncols those of the listed curve columns' own Grams (their eigen-systems in eig_cols)
+// (EIG_SIDE_TPW columns per workgroup, a wave each)
 struct EigSideCols { const int* cols; int ncols; CurveLists cv; const double* W; double inv_R; double* eig_cols; };
+__host__ __device__ constexpr int eig_side_tpw(int waves) { return waves >= 4 ? 4 : waves; }      // one per SIMD
+__host__ __device__ constexpr int eig_side_groups(int ncols, int waves) { return (ncols + eig_side_tpw(waves) - 1) / eig_side_tpw(waves); }
 
 // MODE 0: X only (complete data)
 // MODE 1: X, C and the outer products UU
@@ -135,25 +166,35 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
   if (side.out) {
     // side task (spectral V sampler): the first workgroup is dispatched first; one wave of it solves the K x K
     // eigenproblem of the Gram beside the stream, its other waves leave at once
-    if (b <= sidec.ncols) {
+    constexpr int TPW = eig_side_tpw(WAVES);
+    const int nside = 1 + eig_side_groups(sidec.ncols, WAVES);
+    if (b < nside) {
 #ifndef BTF_EIG_NOP      // (timing aid: BTF_EIG_NOP builds skip the side task - results are wrong, only the clock is read)
-      // the whole workgroup sums the Gram partials (one round of loads, whatever their number), wave 0 goes on
+      // the whole workgroup sums the Gram partials (one round of loads, whatever their number); then workgroup 0's
+      // first wave solves the shared Gram, and in the others wave w takes curve column (b-1) TPW + w: its own Gram,
+      // its own (warm-started) eigen-system
       double* sc = &red[0][0][0];
-      double* gsum = sc + EIG_LDS_DOUBLES + ACC_WAVES * WAVE;
-      static_assert(EIG_LDS_DOUBLES + ACC_WAVES * WAVE + tri(EIG_MAXK) <= ACC_WAVES * ACC_RG * ACC_TILE, "side task scratch");
-      reduce_gram(side.gpart, side.ngp, tri(side.K), 1.0, sc + EIG_LDS_DOUBLES, gsum);
-      double* out = side.out;
-      if (b > 0) {      // a curve column: its own Gram, its own (warm-started) eigen-system
-        const int col = sidec.cols[b - 1];
-        curve_column_gram(sidec.cv, sidec.W, col, side.K, tri(side.K), sidec.inv_R, gsum, sc + EIG_LDS_DOUBLES, ACC_WAVES * WAVE);
-        __syncthreads();
-        out = sidec.eig_cols + (size_t)col * (side.K + side.K * side.K + 8);
+      double* gsum = sc + TPW * EIG_LDS_DOUBLES;                 // [64]
+      double* gown = gsum + 64;                                  // [TPW][64]
+      double* rsc = gown + TPW * 64;                             // reduce_gram's scratch: <= blockDim doubles
+      static_assert(TPW * EIG_LDS_DOUBLES + 64 + TPW * 64 + ACC_WAVES * WAVE <= ACC_WAVES * ACC_RG * ACC_TILE, "side task scratch");
+      static_assert(tri(EIG_MAXK) <= 64, "side task Gram slots");
+      const int t = (b - 1) * TPW + wave;
+      const bool task = b > 0 && wave < TPW && t < sidec.ncols;
+      const int col = task ? sidec.cols[t] : 0;
+      if (task) curve_column_sum_wave<K>(sidec.cv, sidec.W, col, gown + wave * 64);    // (its loads fly with reduce_gram's)
+      reduce_gram(side.gpart, side.ngp, KK, 1.0, rsc, gsum);
+      if (b == 0) {
+        if (wave == 0) gram_eig_wave(gsum, 1, K, side.out, sc);
+      } else if (task) {
+        if (lane < KK) gown[wave * 64 + lane] = fma(-sidec.inv_R, gown[wave * 64 + lane], gsum[lane]);
+        wave_lds_sync();
+        gram_eig_wave(gown + wave * 64, 1, K, sidec.eig_cols + (size_t)col * (K + K * K + 8), sc + wave * EIG_LDS_DOUBLES);
       }
-      if (wave == 0) gram_eig_wave(gsum, 1, side.K, out, sc);
 #endif
       return;
     }
-    b -= 1 + sidec.ncols;
+    b -= nside;
   }
   const int ntiles = ld / ACC_TILE;
   const int chunk = b / ntiles, tile = b - chunk * ntiles;
