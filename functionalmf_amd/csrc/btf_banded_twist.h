@@ -178,9 +178,42 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     for (int idx = tid; idx < T * D1; idx += VT_THREADS) P[idx] = a.pband[(size_t)j * T * D1 + idx];
   }
   if (a.weighted) {
-    for (int idx = tid; idx < T * KK; idx += VT_THREADS) {
-      const int t = idx / KK, q = idx - t * KK;
-      Ql[idx] = chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t) * a.s;
+    // per-depth likelihood blocks: element e = q*T + t, so that consecutive lanes read consecutive depths of one
+    // Gram entry (coalesced 8-B words; the scatter to Ql[t*KK + q] is on the LDS side), four elements' chunks in
+    // flight per thread and trip (one or two global round trips for the 960 entries of C3 instead of four)
+    const int tot = T * KK;
+    const size_t st = (size_t)NV * a.ld;
+    for (int base = 0; base < tot; base += 4 * VT_THREADS) {
+      const double* pp[4];
+      int dst[4];
+      bool has[4];
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = base + u * VT_THREADS + tid;
+        has[u] = e < tot;
+        const int ec = has[u] ? e : 0;
+        const int q = ec / T, t = ec - q * T;
+        pp[u] = a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t;
+        dst[u] = t * KK + q;
+      }
+      int c = 0;
+      for (; c + 2 <= a.nch; c += 2) {                  // fixed order, c ascending
+        double x0[4], x1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { x0[u] = pp[u][(size_t)c * st]; x1[u] = pp[u][(size_t)(c + 1) * st]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc[u] += x0[u]; acc[u] += x1[u]; }
+      }
+      for (; c < a.nch; ++c) {
+        double x0[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x0[u] = pp[u][(size_t)c * st];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += x0[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (has[u]) Ql[dst[u]] = acc[u] * a.s;
     }
   } else if (g_early) {
     reduce_gram_finish(gx, a.ngp, KK, a.sR, lds + W.L.band, Ql);

@@ -1,5 +1,5 @@
 """Diagnostic: where does the fast banded kernel spend its cycles (phase stamps).
-BTF_SAMPLER=banded|spectral|chain, BTF_HELDOUT=1 (weighted data)."""
+BTF_SAMPLER=banded|spectral|chain, BTF_HELDOUT=1 (whole curves held out), BTF_MISSING5=1 (weighted data)."""
 import ctypes as C
 import sys, os
 import numpy as np
@@ -12,6 +12,10 @@ Vt = synth_V(1, M, T, K)
 Y, _ = synth_rows(1, range(N), M, T, R, K, Vt)
 if os.environ.get("BTF_HELDOUT"):
     Y[:3, :3] = np.nan
+if os.environ.get("BTF_MISSING5"):
+    rs = np.random.RandomState(7)
+    Y[rs.rand(N, M) < 0.05] = np.nan
+    Y[rs.rand(N, M, T, R) < 0.05] = np.nan
 np.random.seed(1)
 m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, nu2_init=1.0, rng="device")
 import os

@@ -9,7 +9,8 @@ out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 shutil.copy(os.path.join(root, "gpurun_out", "prof_%s" % name, "%s_kernel_stats.csv" % name),
             os.path.join(out, "%s_kernel_stats.csv" % name))
-log = open(os.path.join(root, "gpurun_out", "prof_%s.log" % name)).read().splitlines()
+clean = os.path.join(root, "gpurun_out", "bench_%s.log" % name)      # the un-profiled run of the same command, when the job made one
+log = open(clean if os.path.exists(clean) else os.path.join(root, "gpurun_out", "prof_%s.log" % name)).read().splitlines()
 line = [ln for ln in log if ln.startswith("{") and '"metric"' in ln]
 if line:
     open(os.path.join(out, "%s_bench.json" % name), "w").write(line[-1] + "\n")

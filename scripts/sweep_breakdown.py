@@ -25,3 +25,15 @@ t_all = time.perf_counter() - t_all
 print("full sweep %.1f us" % (1e6 * t_all / n))
 for k in acc:
     print("  %-7s %.1f us host time" % (k, 1e6 * acc[k] / n))
+# device-side view: per-kernel event times of the same full sweeps
+m._ctx.call("btf_set_profiling", 1)
+try:
+    kt0 = m._ctx.kernel_times()
+    for _ in range(100):
+        m.resample(Y)
+    m.sync()
+    kt = m._ctx.kernel_times()
+    print("per-kernel us per sweep (events):", {k: round(1e3 * (kt[k][0] - kt0[k][0]) / 100, 2) for k in kt if kt[k][1] > kt0[k][1]},
+          "launches per sweep:", {k: (kt[k][1] - kt0[k][1]) / 100 for k in kt if kt[k][1] > kt0[k][1]})
+except Exception as e:
+    print("kernel times unavailable:", e)
