@@ -96,6 +96,8 @@ SIGNATURES = {
     "btf_set_option": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "btf_sym_eig": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp]),
     "btf_read_probe": (C.c_int, [C.c_int, C.c_size_t, C.c_int, _c_dp]),
+    "btf_mvn_dense": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp, _c_dp, C.c_uint64, C.c_double, C.c_int,
+                                _c_dp, _c_ip]),
     "btf_get_likelihood_form": (C.c_int, [_ctx, _c_ip]),
     "btf_get_V_sampler": (C.c_int, [_ctx, _c_ip]),
 }

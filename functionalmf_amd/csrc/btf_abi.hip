@@ -2259,6 +2259,44 @@ int btf_mvn_banded(int device, int batch, int n, int bw, const double* band, con
   return BTF_OK;
 }
 
+int btf_mvn_dense(int device, int batch, int n, const double* A, int form, const double* mu, const double* mu_part,
+                  const double* z, uint64_t seed, double eps0, int attempts, double* x_out, int32_t* tries_out) {
+  if (batch < 1 || n < 1 || n > 1024 || !A || !x_out || (form & ~3) || (mu && mu_part))
+    return fail(nullptr, BTF_EINVAL, "bad dense mvn arguments (1 <= n <= 1024; mu and mu_part are mutually exclusive)");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, BTF_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  const size_t nm = (size_t)batch * n * n, nv = (size_t)batch * n;
+  double *dA = nullptr, *dmu = nullptr, *dmp = nullptr, *dz = nullptr, *dx = nullptr, *dwork = nullptr;
+  int *dtries = nullptr, *dstatus = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)dA, (void*)dmu, (void*)dmp, (void*)dz, (void*)dx, (void*)dwork, (void*)dtries, (void*)dstatus})
+      if (p) (void)hipFree(p);
+  };
+#define MD(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return fail(nullptr, BTF_EHIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+  MD(hipMalloc((void**)&dA, nm * sizeof(double)));
+  MD(hipMemcpy(dA, A, nm * sizeof(double), hipMemcpyHostToDevice));
+  if (mu) { MD(hipMalloc((void**)&dmu, nv * sizeof(double))); MD(hipMemcpy(dmu, mu, nv * sizeof(double), hipMemcpyHostToDevice)); }
+  if (mu_part) { MD(hipMalloc((void**)&dmp, nv * sizeof(double))); MD(hipMemcpy(dmp, mu_part, nv * sizeof(double), hipMemcpyHostToDevice)); }
+  if (z) { MD(hipMalloc((void**)&dz, nv * sizeof(double))); MD(hipMemcpy(dz, z, nv * sizeof(double), hipMemcpyHostToDevice)); }
+  MD(hipMalloc((void**)&dx, nv * sizeof(double)));
+  MD(hipMalloc((void**)&dwork, nm * sizeof(double)));
+  MD(hipMalloc((void**)&dtries, batch * sizeof(int)));
+  MD(hipMalloc((void**)&dstatus, 2 * sizeof(int)));
+  MD(hipMemset(dstatus, 0, 2 * sizeof(int)));
+  MvnDenseArgs a{dA, dmu, dmp, dz, dx, dwork, n, form, (unsigned long long)seed, eps0, attempts < 0 ? 0 : attempts, dtries, dstatus};
+  hipLaunchKernelGGL(mvn_dense_kernel, dim3(batch), dim3(MVD_THREADS), 2 * (size_t)n * sizeof(double), 0, a);
+  MD(hipGetLastError());
+  MD(hipDeviceSynchronize());
+  int st[2];
+  MD(hipMemcpy(st, dstatus, sizeof(st), hipMemcpyDeviceToHost));
+  MD(hipMemcpy(x_out, dx, nv * sizeof(double), hipMemcpyDeviceToHost));
+  if (tries_out) MD(hipMemcpy(tries_out, dtries, batch * sizeof(int), hipMemcpyDeviceToHost));
+  cleanup();
+#undef MD
+  if (st[0]) return fail(nullptr, BTF_ENOTPD, "matrix not positive definite in batch item " + std::to_string(st[1]));
+  return BTF_OK;
+}
+
 // ------------------------------------------------------------------ measurement
 int btf_set_profiling(btf_ctx* c, int on) {
   if (!c) return BTF_EINVAL;

@@ -1012,6 +1012,112 @@ __global__ __launch_bounds__(WAVE) void mvn_banded_kernel(MvnArgs a) {
 }
 
 // ============================================================================
+// Dense Gaussian sampler: the sparse=False branches of fast_mvn (sample_mvn_from_precision fast_mvn.py:49-60,
+// sample_mvn_from_covariance :126-142; dispatcher sample_mvn :145-179).  One workgroup per system, the n x n
+// matrix in an HBM work area (small n: it lives in L2), vectors in LDS.
+//   precision:  L L' = Q (or L given);  x = L^-T (z + L^-1 mu_part)  |  L^-T z + mu
+//   covariance: L L' = S (or L given);  x = L (z + L' mu_part)       |  L z + mu         (S mu_part = L L' mu_part)
+// Not positive definite: eps added to the diagonal cumulatively, x10 per retry (fast_mvn.py:62-68), at most
+// `attempts` times, then the failure is reported (np.linalg.cholesky raises LinAlgError there).
+// ============================================================================
+constexpr int MVD_THREADS = 256;
+enum { MVD_PRECISION = 1, MVD_FACTOR = 2 };
+struct MvnDenseArgs {
+  const double* A; const double* mu; const double* mu_part; const double* z; double* x; double* work;
+  int n; int form; unsigned long long seed; double eps0; int attempts; int* tries; int* status;
+};
+__global__ __launch_bounds__(MVD_THREADS) void mvn_dense_kernel(MvnDenseArgs a) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.x, tid = threadIdx.x, n = a.n;
+  const double* __restrict__ A = a.A + (size_t)b * n * n;
+  double* __restrict__ L = a.work + (size_t)b * n * n;
+  double* v = lds;              // [n] working vector
+  double* u = lds + n;          // [n] second vector
+  const bool prec = a.form & MVD_PRECISION, fact = a.form & MVD_FACTOR;
+  double shift = 0.0, eps = a.eps0;
+  int tried = 0;
+  bool ok = true;
+  while (true) {
+    for (int idx = tid; idx < n * n; idx += MVD_THREADS) {
+      const int r = idx / n, c = idx - r * n;
+      L[idx] = c <= r ? A[idx] + ((r == c && !fact) ? shift : 0.0) : 0.0;
+    }
+    ok = true;
+    if (!fact) {
+      for (int c = 0; c < n; ++c) {           // right-looking Cholesky, lower
+        __syncthreads();
+        const double d = L[(size_t)c * n + c];
+        if (!(d > 0.0)) { ok = false; break; }         // (uniform: everybody reads the same word after the barrier)
+        const double l = sqrt(d), inv = 1.0 / l;
+        __syncthreads();
+        if (tid == 0) L[(size_t)c * n + c] = l;
+        for (int r = c + 1 + tid; r < n; r += MVD_THREADS) L[(size_t)r * n + c] *= inv;
+        __syncthreads();
+        for (int r = c + 1 + (tid >> 5); r < n; r += MVD_THREADS / 32) {
+          const double lr = L[(size_t)r * n + c];
+          for (int q = c + 1 + (tid & 31); q <= r; q += 32) L[(size_t)r * n + q] = fma(-lr, L[(size_t)q * n + c], L[(size_t)r * n + q]);
+        }
+      }
+    }
+    __syncthreads();
+    if (ok || tried >= a.attempts) break;
+    shift += eps;
+    eps *= 10.0;
+    ++tried;
+  }
+  if (tid == 0 && a.tries) a.tries[b] = tried;
+  if (!ok) {
+    if (tid == 0 && atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = b;
+    return;
+  }
+  // v = z (given, or Philox keyed by (seed, system, coordinate)); u = mu_part
+  for (int i = tid; i < n; i += MVD_THREADS) {
+    v[i] = a.z ? a.z[(size_t)b * n + i] : philox_normal(a.seed, 0x4d564eULL, (unsigned long long)b * n + i);
+    u[i] = a.mu_part ? a.mu_part[(size_t)b * n + i] : 0.0;
+  }
+  __syncthreads();
+  if (prec) {
+    if (a.mu_part) {            // u <- L^-1 mu_part (forward substitution), v += u
+      for (int c = 0; c < n; ++c) {
+        const double yc = u[c] / L[(size_t)c * n + c];
+        __syncthreads();
+        if (tid == 0) u[c] = yc;
+        for (int r = c + 1 + tid; r < n; r += MVD_THREADS) u[r] = fma(-L[(size_t)r * n + c], yc, u[r]);
+        __syncthreads();
+      }
+      for (int i = tid; i < n; i += MVD_THREADS) v[i] += u[i];
+      __syncthreads();
+    }
+    for (int c = n - 1; c >= 0; --c) {       // v <- L^-T v (back substitution with the columns of L')
+      const double xc = v[c] / L[(size_t)c * n + c];
+      __syncthreads();
+      if (tid == 0) v[c] = xc;
+      for (int r = tid; r < c; r += MVD_THREADS) v[r] = fma(-L[(size_t)c * n + r], xc, v[r]);
+      __syncthreads();
+    }
+  } else {
+    if (a.mu_part) {            // v += L' mu_part
+      for (int i = tid; i < n; i += MVD_THREADS) {
+        double s = 0.0;
+        for (int r = i; r < n; ++r) s = fma(L[(size_t)r * n + i], u[r], s);
+        v[i] += s;
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += MVD_THREADS) {       // u <- L v
+      double s = 0.0;
+      for (int c = 0; c <= i; ++c) s = fma(L[(size_t)i * n + c], v[c], s);
+      u[i] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += MVD_THREADS) v[i] = u[i];
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += MVD_THREADS)
+    a.x[(size_t)b * n + i] = v[i] + ((a.mu && !a.mu_part) ? a.mu[(size_t)b * n + i] : 0.0);
+}
+
+// ============================================================================
 // one-time sufficient statistics  (BTF_K_STATS)
 //   replaces the per-half-sweep nanmean / count of factor.py:329-330, :374-375
 // ============================================================================

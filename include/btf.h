@@ -295,6 +295,21 @@ int btf_mvn_banded(int device, int batch, int n, int bw, const double* band,
                    const double* mu_part, const double* z, uint64_t seed,
                    double eps0, int attempts, double* x_out, int32_t* tries_out);
 
+/* Dense forms of fast_mvn (the sparse=False branches: sample_mvn_from_precision fast_mvn.py:49-60,
+ * sample_mvn_from_covariance fast_mvn.py:126-142, reached through the dispatcher sample_mvn :145-179).
+ * A: batch row-major n x n matrices (only the lower triangle is read), n <= 1024.
+ *   form & BTF_MVN_PRECISION: A is a precision Q:  x = Lt^-1 z + Q^-1 mu_part   (or + mu),  L L' = Q
+ *   otherwise A is a covariance S:                 x = L z + S mu_part          (or + mu),  L L' = S
+ *   form & BTF_MVN_FACTOR: A already IS the lower Cholesky factor L (chol_factor=True)
+ * mu / mu_part: [batch][n] or NULL (at most one).  z: [batch][n] standard normals (the reference draws
+ * np.random.normal(size=n) after the factorisation) or NULL: Philox(seed).  Not positive definite: eps0 is added to
+ * the diagonal cumulatively, x10 per retry, at most `attempts` times (fast_mvn.py:62-68, :133-139); then
+ * BTF_ENOTPD with the batch index in the message (the reference's dense branches raise LinAlgError / warn forever).
+ * tries_out: [batch] retries used, or NULL. */
+enum { BTF_MVN_PRECISION = 1, BTF_MVN_FACTOR = 2 };
+int btf_mvn_dense(int device, int batch, int n, const double* A, int form, const double* mu, const double* mu_part,
+                  const double* z, uint64_t seed, double eps0, int attempts, double* x_out, int32_t* tries_out);
+
 /* ---- elliptical slice sampling for non-conjugate likelihoods -----------------
  * Replaces NonconjugateBayesianTensorFiltering._resample_W / _resample_V (factor.py:567-590): a prior draw nu
  * (sample_mvn_from_precision on the packed prior precision of factor.py:155-195 - for V the banded sampler with

@@ -1336,3 +1336,82 @@ def test_curve_counts_spectral_chain_samples_the_same_posterior():
         means[sampler] = acc / n
     d = np.abs(means["spectral"] - means["banded"])
     assert d.mean() < 0.05 and np.corrcoef(means["spectral"].ravel(), means["banded"].ravel())[0, 1] > 0.995
+
+
+# ---- dense fast_mvn branches on the device (btf_mvn_dense; fast_mvn.py:49-60, :126-142, :145-179) ---------------
+@pytest.mark.gpu
+def test_dense_mvn_branches_vs_reference_fixture(golden):
+    """The ten argument combinations the reference's own sample_mvn produced (tests/golden/make_golden_ess.py (b)),
+    through the product's dispatcher and the dense kernel, from the same legacy-RNG normals."""
+    from functionalmf_amd.fast_mvn import sample_mvn
+    g = golden("g9_ess.npz")
+    S, mu = g["mvn_S"], g["mvn_mu"]
+    kws = (dict(precision=True), dict(precision=True, mu_part=mu), dict(precision=True, mu=mu), dict(precision=False),
+           dict(precision=False, mu=mu), dict(precision=False, mu_part=mu), dict(precision=False, chol_factor=True),
+           dict(precision=True, chol_factor=True, mu_part=mu))
+    for i, kw in enumerate(kws):
+        Q = np.linalg.cholesky(S) if kw.get("chol_factor") else S
+        np.random.seed(900 + i)
+        x = sample_mvn(Q, sparse=False, Q_shape=Q.shape if kw.get("chol_factor") else None, **kw)
+        assert relerr(x, g["mvn_out"][i]) < 1e-12, kw
+    np.random.seed(950)
+    assert relerr(sample_mvn(0.7, mu=mu, sparse=False), g["mvn_out"][8]) < 1e-12
+    np.random.seed(951)
+    assert relerr(sample_mvn(np.full(mu.size, 2.5), mu_part=mu, sparse=False, precision=True), g["mvn_out"][9]) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 33, 130, 300])
+def test_dense_mvn_batches_vs_oracle(n):
+    from oracle import btf_oracle as orc
+    from functionalmf_amd.fast_mvn import sample_dense_batch
+    rs = np.random.RandomState(n)
+    B = 5
+    A = rs.normal(size=(B, n, n))
+    S = A @ A.transpose(0, 2, 1) + n * np.eye(n)
+    m = rs.normal(size=(B, n))
+    z = rs.normal(size=(B, n))
+    for prec in (True, False):
+        for fac in (False, True):
+            Q = np.linalg.cholesky(S) if fac else S
+            for kw in (dict(), dict(mu=m), dict(mu_part=m)):
+                x, tries = sample_dense_batch(Q, precision=prec, chol_factor=fac, z=z, **kw)
+                ref = np.stack([orc.sample_mvn_dense(Q[b], precision=prec, chol_factor=fac, z=z[b],
+                                                     **{k: v[b] for k, v in kw.items()}) for b in range(B)])
+                assert relerr(x, ref) < 1e-9 and not tries.any(), (n, prec, fac, list(kw))
+
+
+@pytest.mark.gpu
+def test_dense_mvn_jitter_schedule_and_failure():
+    """fast_mvn.py:62-68 / :133-139: eps, then 10 eps more, ... added to the diagonal until the factorisation goes
+    through; without force_psd the failure is reported (np.linalg.cholesky raises LinAlgError there)."""
+    from oracle import btf_oracle as orc
+    from functionalmf_amd import _native
+    from functionalmf_amd.fast_mvn import sample_dense_batch
+    rs = np.random.RandomState(4)
+    n = 12
+    A = rs.normal(size=(n, 3))
+    S = A @ A.T                                        # rank 3: not positive definite
+    S[np.diag_indices(n)] -= 5e-6                      # needs 1e-6 + 1e-5 (two shifts)
+    z = rs.normal(size=(1, n))
+    with pytest.raises(_native.NotPositiveDefiniteError):
+        sample_dense_batch(S[None], precision=True, z=z)
+    x, tries = sample_dense_batch(S[None], precision=True, z=z, force_psd=True, force_psd_eps=1e-6, force_psd_attempts=4)
+    assert tries[0] == 2
+    ref = orc.sample_mvn_dense(S + 1.1e-5 * np.eye(n), precision=True, z=z[0])
+    assert relerr(x[0], ref) < 1e-6
+
+
+@pytest.mark.gpu
+def test_dense_mvn_device_rng_has_the_right_covariance():
+    from functionalmf_amd.fast_mvn import sample_dense_batch
+    rs = np.random.RandomState(8)
+    n, B = 6, 40000
+    A = rs.normal(size=(n, n))
+    S = A @ A.T + np.eye(n)
+    mu = rs.normal(size=n)
+    x, _ = sample_dense_batch(np.broadcast_to(S, (B, n, n)).copy(), precision=False, mu=np.broadcast_to(mu, (B, n)).copy(), seed=5)
+    assert np.abs(x.mean(0) - mu).max() < 5 * np.sqrt(np.diag(S).max() / B)
+    assert np.abs(np.cov(x.T) - S).max() < 0.06 * np.abs(S).max()
+    xp, _ = sample_dense_batch(np.broadcast_to(S, (B, n, n)).copy(), precision=True, seed=6)
+    assert np.abs(np.cov(xp.T) - np.linalg.inv(S)).max() < 0.06 * np.abs(np.linalg.inv(S)).max()
