@@ -96,6 +96,13 @@ SIGNATURES = {
     "btf_set_option": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "btf_sym_eig": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp]),
     "btf_read_probe": (C.c_int, [C.c_int, C.c_size_t, C.c_int, _c_dp]),
+    "btf_gass_set_constraints": (C.c_int, [_ctx, _c_dp, C.c_int, _c_dp, C.c_int]),
+    "btf_gass_begin": (C.c_int, [_ctx, C.c_int, C.c_int, _c_dp, _c_dp, C.c_uint64, C.c_double, C.c_int, C.c_int]),
+    "btf_gass_grid": (C.c_int, [_ctx, C.c_int, _c_ip, C.POINTER(C.c_uint8), _c_dp, _c_dp]),
+    "btf_gass_eval": (C.c_int, [_ctx, C.c_int, _c_dp, _c_ip, _c_dp]),
+    "btf_gass_commit": (C.c_int, [_ctx, C.c_int, _c_dp, _c_ip]),
+    "btf_gass_select": (C.c_int, [_ctx, C.c_int, C.c_uint64, _c_ip]),
+    "btf_gass_run": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int]),
     "btf_mvn_dense": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp, _c_dp, C.c_uint64, C.c_double, C.c_int,
                                 _c_dp, _c_ip]),
     "btf_get_likelihood_form": (C.c_int, [_ctx, _c_ip]),

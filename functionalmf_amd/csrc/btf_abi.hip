@@ -6,7 +6,7 @@
 #include "btf_banded_fast.h"
 #include "btf_banded_twist.h"
 #include "btf_spectral.h"
-#include "btf_ess.h"
+#include "btf_gass.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -63,6 +63,12 @@ struct btf_ctx {
   // elliptical slice sampling (btf_ess_*): current state, prior draw, per-chain {hh, lo, hi, theta, ll}, partial sums
   double* essX0 = nullptr; double* essNu = nullptr; double* ess_st = nullptr; double* ess_theta = nullptr; int* ess_done = nullptr;
   double* ess_part = nullptr; size_t ess_part_elems = 0; int ess_last_chains = 0;
+  // generalized analytic slice sampling (btf_gass_*): constraints, per-chain grids / candidates / likelihoods
+  double* gs_cons = nullptr; double* gs_cc = nullptr; double* gs_rc = nullptr; int gs_J = 0, gs_nrc = 0;
+  double* gs_av = nullptr; unsigned char* gs_mask = nullptr; int* gs_info = nullptr;
+  double* gs_thetas = nullptr; int* gs_ntheta = nullptr; double* gs_ll = nullptr; double* gs_hh = nullptr; double* gs_cur = nullptr;
+  int* gs_nacc = nullptr; double* gs_u = nullptr;
+  int gs_chains = 0, gs_what = -1, gs_link = 0;
   long long* dbg = nullptr;
   double* pband = nullptr;
   double* Ta = nullptr; double* Tb = nullptr; double* Tc = nullptr; double* lsum = nullptr;   // horseshoe+ chain (device mode)
@@ -695,7 +701,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
@@ -1467,6 +1473,208 @@ int btf_ess_run(btf_ctx* c, int what, int link, int mode, const double* z, uint6
   c->w_part_valid = false;
   c->nb_L_valid = false;
   return BTF_OK;
+}
+
+// ------------------------------------------------------------------ generalized analytic slice sampling
+namespace {
+int gass_alloc(btf_ctx* c) {
+  if (c->gs_mask) return BTF_OK;
+  const size_t nc = (size_t)std::max(c->N, c->M);
+  int rc;
+  if ((rc = dev_alloc(c, &c->gs_mask, nc * GASS_GRID))) return rc;
+  if ((rc = dev_alloc(c, &c->gs_info, nc * 2))) return rc;
+  if ((rc = dev_alloc(c, &c->gs_thetas, nc * GASS_MAXC))) return rc;
+  if ((rc = dev_alloc(c, &c->gs_ntheta, nc))) return rc;
+  if ((rc = dev_alloc(c, &c->gs_ll, nc * GASS_MAXC))) return rc;
+  if ((rc = dev_alloc(c, &c->gs_hh, nc))) return rc;
+  if ((rc = dev_alloc(c, &c->gs_cur, nc))) return rc;
+  if ((rc = dev_alloc(c, &c->gs_nacc, nc))) return rc;
+  if ((rc = dev_alloc(c, &c->gs_u, nc))) return rc;
+  return BTF_OK;
+}
+int gass_check(btf_ctx* c, int what, int link) {
+  int rc;
+  if ((rc = ess_check(c, what, link))) return rc;
+  if (!c->gs_cons) return fail(c, BTF_ESTATE, "btf_gass_set_constraints first");
+  return BTF_OK;
+}
+int gass_eval_launch(btf_ctx* c, int what, int link) {
+  GassEvalArgs a{};
+  a.X0 = c->essX0; a.Nu = c->essNu; a.N = c->N; a.M = c->M; a.T = c->T; a.K = c->K; a.Rc = (double)c->R;
+  a.thetas = c->gs_thetas; a.ntheta = c->gs_ntheta; a.ll = c->gs_ll;
+  Prof p(c, BTF_K_ESS);
+  if (what == 0) {
+    a.F = c->V; a.A = c->A_v; a.C8 = c->C8_v; a.Cd = c->C_v; a.ld = c->ldv;
+    if (link == ESS_LINK_LOG) p.launch(gass_eval_kernel<ESS_LINK_LOG, true>, dim3(c->N), dim3(GASS_THREADS), 0, a);
+    else p.launch(gass_eval_kernel<ESS_LINK_IDENTITY, true>, dim3(c->N), dim3(GASS_THREADS), 0, a);
+  } else {
+    a.F = c->W; a.A = c->A_wT; a.C8 = c->C8_wT; a.Cd = c->C_wT; a.ld = c->ldw;
+    if (link == ESS_LINK_LOG) p.launch(gass_eval_kernel<ESS_LINK_LOG, false>, dim3(c->M), dim3(GASS_THREADS), 0, a);
+    else p.launch(gass_eval_kernel<ESS_LINK_IDENTITY, false>, dim3(c->M), dim3(GASS_THREADS), 0, a);
+  }
+  HIPCHK(c, hipGetLastError());
+  return BTF_OK;
+}
+}  // namespace
+
+int btf_gass_set_constraints(btf_ctx* c, const double* cons, int J, const double* row_cons, int nrc) {
+  if (!c || !cons || J < 1 || nrc < 0 || (nrc > 0 && !row_cons)) return fail(c, BTF_EINVAL, "bad constraint arguments");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const int T = c->T, K = c->K;
+  std::vector<double> A((size_t)J * T), cc((size_t)J);
+  for (int q = 0; q < J; ++q) {
+    for (int t = 0; t < T; ++t) A[(size_t)q * T + t] = cons[(size_t)q * (T + 1) + t];
+    cc[q] = cons[(size_t)q * (T + 1) + T];
+  }
+  int rc;
+  if ((rc = dev_alloc(c, &c->gs_cons, A.size()))) return rc;
+  if ((rc = dev_alloc(c, &c->gs_cc, cc.size()))) return rc;
+  HIPCHK(c, hipMemcpy(c->gs_cons, A.data(), A.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->gs_cc, cc.data(), cc.size() * sizeof(double), hipMemcpyHostToDevice));
+  if ((rc = dev_alloc(c, &c->gs_av, (size_t)c->M * J * K))) return rc;
+  if (c->gs_rc) { (void)hipFree(c->gs_rc); c->gs_rc = nullptr; }
+  if (nrc > 0) {
+    if ((rc = dev_alloc(c, &c->gs_rc, (size_t)nrc * (K + 1)))) return rc;
+    HIPCHK(c, hipMemcpy(c->gs_rc, row_cons, (size_t)nrc * (K + 1) * sizeof(double), hipMemcpyHostToDevice));
+  }
+  c->gs_J = J; c->gs_nrc = nrc;
+  return BTF_OK;
+}
+
+int btf_gass_begin(btf_ctx* c, int what, int link, const double* z, const double* u, uint64_t seed, double eps0, int attempts,
+                   int pick_ngrid) {
+  if (!c) return BTF_EINVAL;
+  int rc;
+  if ((rc = gass_check(c, what, link))) return rc;
+  if (pick_ngrid < 0 || pick_ngrid > GASS_MAXC) return fail(c, BTF_EINVAL, "at most 128 candidates per chain");
+  HIPCHK(c, hipSetDevice(c->dev));
+  if ((rc = gass_alloc(c))) return rc;
+  if ((rc = ess_begin(c, what, z, seed, eps0, attempts < 0 ? 0 : attempts))) return rc;     // X0 <- state, Nu <- prior draw
+  const int nch = what == 0 ? c->N : c->M;
+  // slice heights from the likelihood of the current state, chain by chain
+  const EssDims d = ess_dims(c, what, 1);
+  if ((rc = ess_ensure_part(c, d))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->ess_done, 0, (size_t)d.nchains * sizeof(int), c->stream));
+  K_SWITCH(c->K, launch_ess_ll<KT>(c, what, 1, link, d.nbx));
+  const double* du = nullptr;
+  if (u) {
+    HIPCHK(c, hipMemcpyAsync(c->gs_u, u, (size_t)nch * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    du = c->gs_u;
+  }
+  const unsigned long long dseed = seed * 0x9E3779B97F4A7C15ULL + 0x6A09E667F3BCC909ULL;
+  {
+    Prof p(c, BTF_K_ESS);
+    p.launch(gass_slice_kernel, dim3((nch + 255) / 256), dim3(256), 0, (const double*)c->ess_part, d.nsum, nch, du, dseed, c->gs_hh, c->gs_cur);
+  }
+  GassArgs a{};
+  a.X0 = c->essX0; a.Nu = c->essNu; a.Cons = c->gs_cons; a.Cc = c->gs_cc; a.J = c->gs_J;
+  a.AV = c->gs_av; a.Rc = c->gs_rc; a.nrc = what == 0 ? c->gs_nrc : 0; a.W = c->W;
+  a.N = c->N; a.M = c->M; a.T = c->T; a.K = c->K;
+  a.vmask = c->gs_mask; a.info = c->gs_info; a.pick = pick_ngrid > 0 ? 1 : 0; a.ngrid = pick_ngrid;
+  a.thetas = c->gs_thetas; a.ntheta = c->gs_ntheta; a.seed = dseed;
+  {
+    Prof p(c, BTF_K_ESS);
+    if (what == 0) {
+      p.launch(gass_av_kernel, dim3(c->M), dim3(GASS_THREADS), 0, (const double*)c->V, (const double*)c->gs_cons, c->T, c->K, c->gs_J, c->gs_av);
+      p.launch(gass_analyse_rows_kernel, dim3(c->N), dim3(GASS_THREADS), 0, a);
+    } else {
+      const size_t dyn = ((size_t)2 * GASS_RT * c->T + (size_t)c->gs_J * c->T) * sizeof(double);
+      if (dyn + sizeof(GassScratch) > 158 * 1024) return fail(c, BTF_EINVAL, "constraint matrix too large for the column analysis");
+      static bool attr_set = false;
+      if (!attr_set) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)gass_analyse_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+        attr_set = true;
+      }
+      p.launch(gass_analyse_cols_kernel, dim3(c->M), dim3(GASS_THREADS), dyn, a);
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  c->gs_chains = nch; c->gs_what = what; c->gs_link = link;
+  return BTF_OK;
+}
+
+int btf_gass_grid(btf_ctx* c, int what, int32_t* info, uint8_t* mask, double* slice, double* cur_ll) {
+  if (!c || !info) return BTF_EINVAL;
+  if (c->gs_what != what || c->gs_chains < 1) return fail(c, BTF_ESTATE, "btf_gass_grid follows btf_gass_begin of the same factor");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const size_t nch = (size_t)c->gs_chains;
+  HIPCHK(c, hipMemcpyAsync(info, c->gs_info, nch * 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (mask) HIPCHK(c, hipMemcpyAsync(mask, c->gs_mask, nch * GASS_GRID, hipMemcpyDeviceToHost, c->stream));
+  if (slice) HIPCHK(c, hipMemcpyAsync(slice, c->gs_hh, nch * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (cur_ll) HIPCHK(c, hipMemcpyAsync(cur_ll, c->gs_cur, nch * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  return check_status(c);
+}
+
+int btf_gass_eval(btf_ctx* c, int what, const double* thetas, const int32_t* ntheta, double* ll_out) {
+  if (!c) return BTF_EINVAL;
+  if (c->gs_what != what || c->gs_chains < 1) return fail(c, BTF_ESTATE, "btf_gass_eval follows btf_gass_begin of the same factor");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const size_t nch = (size_t)c->gs_chains;
+  if (thetas) {
+    if (!ntheta) return fail(c, BTF_EINVAL, "candidate counts missing");
+    for (size_t q = 0; q < nch; ++q) if (ntheta[q] < 0 || ntheta[q] > GASS_MAXC) return fail(c, BTF_EINVAL, "at most 128 candidates per chain");
+    HIPCHK(c, hipMemcpyAsync(c->gs_thetas, thetas, nch * GASS_MAXC * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->gs_ntheta, ntheta, nch * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  int rc;
+  if ((rc = gass_eval_launch(c, what, c->gs_link))) return rc;
+  if (ll_out) {
+    HIPCHK(c, hipMemcpyAsync(ll_out, c->gs_ll, nch * GASS_MAXC * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return check_status(c);
+  }
+  return BTF_OK;
+}
+
+int btf_gass_commit(btf_ctx* c, int what, const double* theta, const int32_t* keep) {
+  if (!c || !theta || !keep) return BTF_EINVAL;
+  if (c->gs_what != what || c->gs_chains < 1) return fail(c, BTF_ESTATE, "btf_gass_commit follows btf_gass_begin of the same factor");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const size_t nch = (size_t)c->gs_chains;
+  HIPCHK(c, hipMemcpyAsync(c->ess_theta, theta, nch * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->ess_done, keep, nch * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int per = what == 0 ? c->K : c->T * c->K;
+  const long long n = (long long)nch * per;
+  {
+    Prof p(c, BTF_K_ESS);
+    p.launch(ess_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const double*)c->essX0, (const double*)c->essNu,
+             what == 0 ? c->W : c->V, n, per, (const double*)c->ess_theta, (const int*)c->ess_done, 0);
+  }
+  HIPCHK(c, hipGetLastError());
+  if (what == 0) c->ngp_w = 0; else c->ngp_v = 0;
+  c->w_part_valid = false; c->nb_L_valid = false;
+  return BTF_OK;
+}
+
+int btf_gass_select(btf_ctx* c, int what, uint64_t seed, int32_t* naccept_out) {
+  if (!c) return BTF_EINVAL;
+  if (c->gs_what != what || c->gs_chains < 1) return fail(c, BTF_ESTATE, "btf_gass_select follows btf_gass_begin of the same factor");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const int nch = c->gs_chains, per = what == 0 ? c->K : c->T * c->K;
+  {
+    Prof p(c, BTF_K_ESS);
+    p.launch(gass_select_kernel, dim3(nch), dim3(GASS_THREADS), 0, (const double*)c->gs_ll, (const int*)c->gs_ntheta, (const double*)c->gs_thetas,
+             (const double*)c->gs_hh, (const double*)c->essX0, (const double*)c->essNu, what == 0 ? c->W : c->V, per,
+             (unsigned long long)(seed * 0x9E3779B97F4A7C15ULL + 0xBB67AE8584CAA73BULL), c->gs_nacc, (double*)nullptr);
+  }
+  HIPCHK(c, hipGetLastError());
+  if (what == 0) c->ngp_w = 0; else c->ngp_v = 0;
+  c->w_part_valid = false; c->nb_L_valid = false;
+  if (naccept_out) {
+    HIPCHK(c, hipMemcpyAsync(naccept_out, c->gs_nacc, (size_t)nch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    return check_status(c);
+  }
+  return BTF_OK;
+}
+
+int btf_gass_run(btf_ctx* c, int what, int link, uint64_t seed, int ngrid, double eps0, int attempts) {
+  if (ngrid < 1) return fail(c, BTF_EINVAL, "ngrid must be positive");
+  int rc;
+  if ((rc = btf_gass_begin(c, what, link, nullptr, nullptr, seed, eps0, attempts, ngrid))) return rc;
+  if ((rc = btf_gass_eval(c, what, nullptr, nullptr, nullptr))) return rc;
+  return btf_gass_select(c, what, seed, nullptr);
 }
 
 int btf_ess_info(btf_ctx* c, int32_t* unfinished, double* ll_first) {

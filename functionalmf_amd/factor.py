@@ -1076,3 +1076,124 @@ class NonconjugateBayesianTensorFiltering(BayesianTensorFiltering):
         u = ctypes.c_int32()
         self._ctx.call("btf_ess_info", ctypes.byref(u), None)
         return u.value
+
+
+class ConstrainedNonconjugateBayesianTensorFiltering(NonconjugateBayesianTensorFiltering):
+    """Non-conjugate likelihood under linear constraints on every curve tau_ij = (w_i . v_jt)_t, by generalized analytic
+    slice sampling (factor.py:893-1010, worker functions :665-855, gass.py:13-130).  All rows of W (then all columns of
+    V) are updated together on the GPU (include/btf.h, btf_gass_*): the reference maps them over a worker pool with the
+    model in shared memory; `nthreads`, `multiprocessing`, `sharedprefix`, `worker_init` are accepted and ignored.
+
+    Constraints: (J, T+1) array, row q = (c_q, bound_q): c_q . tau_ij >= bound_q for every curve (e.g. positivity
+    `[I_T | 0]`, monotonicity rows `e_t - e_{t+1} >= -1e-2`, examples/poisson_tensor_filtering.py:42-48).
+    Row_constraints: optional (n, K+1) fixed constraints on every row of W.
+    loglikelihood: a device likelihood name as for NonconjugateBayesianTensorFiltering (the constrained Poisson model of
+    the examples is "poisson_identity").  ep_approx (the optional Gaussian centering of the proposals) is not supported.
+
+    rng="host": per row / column the slice height, the proposal normals, the grid subsample and the selection are drawn
+    from `chain_rngs(what)[c]` (default: RandomState objects seeded from the global legacy generator) in the reference's
+    order - with the same streams the update reproduces the reference's worker functions (tests/golden/g10_gass.npz).
+    rng="device": everything on the GPU (btf_gass_run), nothing read back."""
+
+    def __init__(self, nrows, ncols, ndepth, loglikelihood, Constraints, ep_approx=None, nthreads=3, gass_ngrid=100,
+                 Row_constraints=None, multiprocessing=True, sharedprefix=None, worker_init=None, **kwargs):
+        if ep_approx is not None:
+            raise NotImplementedError("ep_approx (EP-centred proposals, factor.py:677-688) is not supported")
+        kwargs.setdefault("ess", "joint")
+        super().__init__(nrows, ncols, ndepth, loglikelihood, **kwargs)
+        Constraints = _native.as_f64(np.atleast_2d(Constraints))
+        if Constraints.shape[1] != ndepth + 1:
+            raise ValueError("Constraints must be (J, ndepth + 1): the bound in the last column")
+        if not 1 <= int(gass_ngrid) <= 128:
+            raise ValueError("gass_ngrid must be in 1..128")
+        self.Constraints_A, self.Constraints_C = Constraints[:, :-1], Constraints[:, -1:]
+        self.nconstraints = Constraints.shape[0]
+        self.gass_ngrid = int(gass_ngrid)
+        self.Row_constraints = None if Row_constraints is None else _native.as_f64(np.atleast_2d(Row_constraints))
+        if self.Row_constraints is not None and self.Row_constraints.shape[1] != self.nembeds + 1:
+            raise ValueError("Row_constraints must be (n, nembeds + 1)")
+        self._cons = Constraints
+        self._cons_set = False
+        self.chain_rngs = None            # optional: callable what -> list of RandomState, one per row / column
+        self.gass_info = {}
+
+    def shutdown(self):
+        """(the reference releases its worker pool and shared arrays here)"""
+
+    GRID = 10000
+
+    def _gass_step(self, what, data):
+        import ctypes
+        self._bind_data(data)
+        self._push_state()
+        if not self._cons_set:
+            rc = self.Row_constraints
+            self._ctx.call("btf_gass_set_constraints", _native.dptr(self._cons), int(self._cons.shape[0]),
+                           _native.dptr(rc), 0 if rc is None else int(rc.shape[0]))
+            self._cons_set = True
+        o = self.linalg_opts
+        eps, att = float(o["force_psd_eps"]), int(o["force_psd_attempts"]) if o["force_psd"] else 0
+        if self.rng == "device":
+            self._ctx.call("btf_gass_run", what, self._link, self._next_seed(), self.gass_ngrid, eps, att)
+        else:
+            N, M, T, K = self.nrows, self.ncols, self.ndepth, self.nembeds
+            nch = N if what == 0 else M
+            rngs = self.chain_rngs(what) if self.chain_rngs is not None else \
+                [np.random.RandomState(np.random.randint(0, 2 ** 31 - 1)) for _ in range(nch)]
+            # gass.py:21-24 per chain: the slice uniform, then the proposal normals
+            u = np.empty(nch)
+            if what == 0:
+                z = np.zeros(K * (K + 1) // 2 + (N - K) * K if N >= K else N * (N + 1) // 2)
+                off = 0
+                for i in range(N):
+                    d = min(K, i + 1)
+                    u[i] = rngs[i].random_sample()
+                    z[off:off + d] = rngs[i].normal(size=d)
+                    off += d
+            else:
+                z = np.empty((M, K * T))
+                for j in range(M):
+                    u[j] = rngs[j].random_sample()
+                    z[j] = rngs[j].normal(size=K * T)
+            self._keep_z = (z, u)
+            self._ctx.call("btf_gass_begin", what, self._link, _native.dptr(z), _native.dptr(u), self._next_seed(), eps, att, 0)
+            info = np.zeros((nch, 2), dtype=np.int32)
+            mask = np.zeros((nch, self.GRID), dtype=np.uint8)
+            hh = np.empty(nch)
+            self._ctx.call("btf_gass_grid", what, info.ctypes.data_as(_native._c_ip), mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                           _native.dptr(hh), None)
+            full = np.linspace(-np.pi, np.pi, self.GRID)
+            thetas = np.zeros((nch, 128))
+            nth = np.zeros(nch, dtype=np.int32)
+            for c in range(nch):
+                grid = np.linspace(-np.pi, np.pi, self.gass_ngrid) if info[c, 1] else full[mask[c] != 0]
+                if len(grid) > self.gass_ngrid:
+                    grid = rngs[c].choice(grid, size=self.gass_ngrid, replace=False)      # gass.py:110-111
+                nth[c] = len(grid)
+                thetas[c, :len(grid)] = grid
+            ll = np.empty((nch, 128))
+            self._ctx.call("btf_gass_eval", what, _native.dptr(thetas), nth.ctypes.data_as(_native._c_ip), _native.dptr(ll))
+            theta = np.zeros(nch)
+            keep = np.ones(nch, dtype=np.int32)
+            acc = np.zeros(nch, dtype=np.int64)
+            for c in range(nch):
+                ok = np.nonzero(ll[c, :nth[c]] >= hh[c])[0]
+                acc[c] = len(ok)
+                if len(ok) > 0:
+                    theta[c] = thetas[c, ok[rngs[c].choice(len(ok))]]                      # gass.py:121-124
+                    keep[c] = 0
+            self._ctx.call("btf_gass_commit", what, _native.dptr(theta), keep.ctypes.data_as(_native._c_ip))
+            self.gass_info = {"valid": info[:, 0].copy(), "unrestricted": info[:, 1].copy(), "candidates": nth, "accepted": acc}
+        self._ess_ready = True
+        if what == 0:
+            self._W_dev_new = True
+        else:
+            self._V_dev_new = True
+            self._lsum_valid = False
+            self._lsum_on_device = False
+
+    def _resample_W(self, data):
+        self._gass_step(0, data)
+
+    def _resample_V(self, data):
+        self._gass_step(1, data)

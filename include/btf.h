@@ -338,6 +338,36 @@ int btf_ess_run(btf_ctx* ctx, int what, int link, int mode, const double* z, uin
                 double eps0, int attempts);
 int btf_ess_info(btf_ctx* ctx, int32_t* unfinished, double* ll_first);
 
+/* ---- generalized analytic slice sampling (gass.py:13-130) for the constrained non-conjugate model
+ * (ConstrainedNonconjugateBayesianTensorFiltering._resample_W / _resample_V, factor.py:665-855): every row of W (what = 0)
+ * or every column of V (what = 1) is one chain, all chains advance together.  Likelihood: the device Poisson likelihoods
+ * of btf_ess_* (link 0 = log, 1 = identity) on the statistics of btf_set_data_gaussian.  Unsharded contexts.
+ *
+ * btf_gass_set_constraints: cons [J][T+1], row q = (Cons_q, bound_q): every curve tau_ij = (w_i . v_jt)_t must satisfy
+ *   Cons_q . tau_ij >= bound_q (the reference's `Constraints`, factor.py:910); row_cons [nrc][K+1]: fixed constraints on
+ *   every row of W (`Row_constraints`), or NULL.
+ * btf_gass_begin: x0 <- current state, v <- prior draw (W: sigma z on the free entries; V: the banded sampler with the
+ *   likelihood off - z / seed as btf_ess_begin), slice heights ll(x0) + log u (u: [nchains] uniforms, or NULL: Philox),
+ *   and the constraint analysis: which of the 10000 grid angles of gass.py:68 are valid for every chain.
+ *   pick_ngrid > 0: the device also draws the candidate angles (<= 128): all valid ones, or pick_ngrid of them
+ *   without replacement; linspace(-pi, pi, pick_ngrid) when no constraint restricts the ellipse (gass.py:81-83).
+ * btf_gass_grid: info [nchains][2] = {valid angles, 1 if unrestricted}; mask [nchains][10000] bytes, slice [nchains],
+ *   cur_ll [nchains] (each optional).
+ * btf_gass_eval: log-likelihood of every candidate, ll_out [nchains][128] (-inf beyond a chain's count).  thetas
+ *   [nchains][128] + ntheta [nchains]: the caller's candidates (host-driven: the reference's np.random.choice), or NULL:
+ *   the device's own.
+ * btf_gass_commit: x = x0 cos(theta_c) + v sin(theta_c) for chains with keep[c] == 0 (host-driven selection).
+ * btf_gass_select: one candidate above the slice per chain, uniformly (Philox); none: the state stays (gass.py:121-128).
+ * btf_gass_run = begin(pick) + eval + select, nothing read back. */
+int btf_gass_set_constraints(btf_ctx* ctx, const double* cons, int J, const double* row_cons, int nrc);
+int btf_gass_begin(btf_ctx* ctx, int what, int link, const double* z, const double* u, uint64_t seed, double eps0, int attempts,
+                   int pick_ngrid);
+int btf_gass_grid(btf_ctx* ctx, int what, int32_t* info, uint8_t* mask, double* slice, double* cur_ll);
+int btf_gass_eval(btf_ctx* ctx, int what, const double* thetas, const int32_t* ntheta, double* ll_out);
+int btf_gass_commit(btf_ctx* ctx, int what, const double* theta, const int32_t* keep);
+int btf_gass_select(btf_ctx* ctx, int what, uint64_t seed, int32_t* naccept_out);
+int btf_gass_run(btf_ctx* ctx, int what, int link, uint64_t seed, int ngrid, double eps0, int attempts);
+
 /* ---- posterior summaries (stateless) --------------------------------
  * Mean and percentiles over the kept samples of f(w_s[i] . v_s[j,t]) for every cell: what the
  * reference's example scripts compute on the host as einsum('znk,zmtk->znmt', Ws, Vs).mean(0) /

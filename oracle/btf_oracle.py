@@ -856,47 +856,57 @@ def elliptical_slice(xx, prior, log_like_fn, cur_log_like=None, angle_range=0, l
 # generalized analytic slice sampling   (gass.py:13-130)
 # --------------------------------------------------------------------------
 
-def gass(x, v, loglikelihood, Constraints, cur_ll=None, mu=None, ll_args=None, ngrid=100, info=None):
+def gass_valid_grid(x0, v, A, c, ngrid=100):
+    """The candidate angles of one GASS update before any subsampling (gass.py:38-83): for every constraint row
+    a = A x0, b = A v the valid angles are an interval or the complement of one; the reference intersects them
+    numerically on linspace(-pi, pi, 10000).  Returns (grid, restricted); no constraint restricts the ellipse:
+    linspace(-pi, pi, ngrid)."""
+    a, b = A @ x0, A @ v
+    sqrt_term = a ** 2 + b ** 2 - c ** 2
+    eps = 1e-6
+    concerning = (sqrt_term >= 0) & (a != -c)
+    if not np.any(concerning):
+        return np.linspace(-np.pi, np.pi, ngrid), False
+    denom = a + c
+    rt = np.sqrt(sqrt_term[concerning])
+    theta1 = 2 * np.arctan((b[concerning] + rt) / denom[concerning])
+    theta2 = 2 * np.arctan((b[concerning] - rt) / denom[concerning])
+    comp = a[concerning] ** 2 < c[concerning] ** 2
+    grid = np.linspace(-np.pi, np.pi, 10000)
+    for t1, t2 in zip(theta1[comp], theta2[comp]):          # convex: outside [min, max]
+        grid = grid[(grid <= min(t1, t2)) | (grid >= max(t1, t2))]
+    if np.any(~comp):                                       # concave: inside every [min, max]
+        t1i, t2i = theta1[~comp], theta2[~comp]
+        lo = np.minimum(t1i, t2i).max() + eps
+        hi = np.maximum(t1i, t2i).min() - eps
+        grid = grid[(grid >= lo) & (grid <= hi)]
+    return grid, True
+
+
+def gass(x, v, loglikelihood, Constraints, cur_ll=None, mu=None, ll_args=None, ngrid=100, info=None, rng=None):
     """One GASS update of x under the linear constraints  Constraints[:, :-1] x >= Constraints[:, -1].
     v: the proposal the reference draws with sample_mvn (gass.py:24) - passed in, because which fast_mvn branch
     draws it is the caller's choice (sample_mvn_dense / mvn_from_precision above).  RNG order after v:
     rand (slice height, drawn BEFORE v in the reference: the caller draws v after calling np.random.random
-    once - see tests), [choice(grid, ngrid) if the valid grid is longer than ngrid], choice(#accepted)."""
+    once - see tests), [choice(grid, ngrid) if the valid grid is longer than ngrid], choice(#accepted).
+    rng: a RandomState to draw them from (default: the global legacy generator, as the reference)."""
+    rng = np.random if rng is None else rng
     x = np.asarray(x, float)
     if cur_ll is None:
         cur_ll = loglikelihood(x, ll_args)
-    ll = cur_ll + np.log(np.random.random())
+    ll = cur_ll + np.log(rng.random_sample())
     v = v() if callable(v) else np.asarray(v, float)
     mu = np.zeros_like(x) if mu is None else np.asarray(mu, float)
     A, cvec = Constraints[:, :-1], Constraints[:, -1]
     if not np.all(A @ x >= cvec):
         raise ValueError("invalid starting point")
     x0 = x - mu
-    a, b, c = A @ x0, A @ v, cvec - A @ mu
-    sqrt_term = a ** 2 + b ** 2 - c ** 2
-    eps = 1e-6
-    concerning = (sqrt_term >= 0) & (a != -c)
-    if np.any(concerning):
-        denom = a + c
-        rt = np.sqrt(sqrt_term[concerning])
-        theta1 = 2 * np.arctan((b[concerning] + rt) / denom[concerning])
-        theta2 = 2 * np.arctan((b[concerning] - rt) / denom[concerning])
-        comp = a[concerning] ** 2 < c[concerning] ** 2
-        grid = np.linspace(-np.pi, np.pi, 10000)
-        for t1, t2 in zip(theta1[comp], theta2[comp]):          # convex: outside [min, max]
-            grid = grid[(grid <= min(t1, t2)) | (grid >= max(t1, t2))]
-        if np.any(~comp):                                       # concave: inside every [min, max]
-            t1i, t2i = theta1[~comp], theta2[~comp]
-            lo = np.minimum(t1i, t2i).max() + eps
-            hi = np.maximum(t1i, t2i).min() - eps
-            grid = grid[(grid >= lo) & (grid <= hi)]
-    else:
-        grid = np.linspace(-np.pi, np.pi, ngrid)
+    grid, _ = gass_valid_grid(x0, v, A, cvec - A @ mu, ngrid)
     if len(grid) == 0:
         options, opt_ll = [], []
     else:
         if len(grid) > ngrid:
-            grid = np.random.choice(grid, size=ngrid, replace=False)
+            grid = rng.choice(grid, size=ngrid, replace=False)
         options = x0[None] * np.cos(grid[:, None]) + v[None] * np.sin(grid[:, None]) + mu[None]
         opt_ll = loglikelihood(options, ll_args)
         keep = opt_ll >= ll
@@ -904,10 +914,121 @@ def gass(x, v, loglikelihood, Constraints, cur_ll=None, mu=None, ll_args=None, n
     if info is not None:
         info["grid"] = len(grid)
         info["accepted"] = len(options)
+        info["slice"] = ll
     if len(options) > 0:
-        sel = np.random.choice(len(options))
+        sel = rng.choice(len(options))
         return options[sel], opt_ll[sel]
     return x, cur_ll
+
+
+# --------------------------------------------------------------------------
+# constrained non-conjugate model: GASS per row / per column   (factor.py:665-855)
+# --------------------------------------------------------------------------
+
+def constrained_w_constraints(V, Cons, ndims, Row_constraints=None):
+    """Constraint matrix of one row of W given V (factor.py:713-727): for every column j and constraint q the row
+    (Cons_q V_j)[:ndims] with bound Cons[q, -1] - ordered column-major over (j, q) - then the fixed row constraints."""
+    A, C = Cons[:, :-1], Cons[:, -1:]
+    M = V.shape[0]
+    AV = np.einsum("qt,jtk->jqk", A, V)[..., :ndims].reshape(-1, ndims)
+    out = np.concatenate([AV, np.tile(C, (M, 1))], axis=1)
+    if Row_constraints is not None:
+        out = np.concatenate([out, np.concatenate([Row_constraints[:, :ndims], Row_constraints[:, -1:]], axis=1)], axis=0)
+    return out
+
+
+def constrained_v_constraints(W, Cons, T):
+    """Constraint matrix of one column of V (k-major vector) given W (factor.py:848-855): rows (i, q) ->
+    coefficient W[i,k] Cons[q,t] at position k*T + t."""
+    A, C = Cons[:, :-1], Cons[:, -1:]
+    N, K = W.shape
+    J = A.shape[0]
+    Am = (A[None, :, None, :] * W[:, None, :, None]).reshape(N * J, K * T)
+    return np.concatenate([Am, np.tile(C, (N, 1))], axis=1)
+
+
+def poisson_curves_loglik(Y, tau, link):
+    """nansum of log Poisson(y | lambda(tau)) over a block of curves (the row / column likelihood of
+    examples/poisson_tensor_filtering.py:26-37); the y-only term -lgamma(y+1) is dropped (it cancels in every
+    comparison GASS makes).  tau: (..., T); Y: (..., T) or (..., T, R)."""
+    Y4 = Y[..., None] if Y.ndim == tau.ndim else Y
+    obs = ~np.isnan(Y4)
+    y = np.where(obs, Y4, 0.0)
+    t = tau[..., None]
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        if link == "log":
+            term = y * t - np.exp(t)
+        else:
+            term = np.where(t > 0, y * np.log(np.where(t > 0, t, 1.0)) - t, -np.inf)
+    return float(np.where(obs, term, 0.0).sum())
+
+
+def constrained_w_step(st, Y, Cons, link="identity", ngrid=100, z=None, rngs=None, Row_constraints=None, info=None):
+    """_resample_W_i for every row (factor.py:665-711, no EP approximation): prior precision I/sigma2 on the free
+    entries (z[i]: the normals of row i's proposal; sqrt(sigma2) z), constraints from the current V, Poisson row
+    likelihood.  All rows see the same V (the reference maps them over a worker pool).  rngs[i]: RandomState of row i
+    (slice height, subsample, selection)."""
+    W, V = st["W"], st["V"]
+    N, K = W.shape
+    out = W.copy()
+    for i in range(N):
+        d = min(K, i + 1)
+        Ci = constrained_w_constraints(V, Cons, d, Row_constraints)
+        Vi = V[:, :, :d]
+
+        def ll(w, _):
+            w = np.atleast_2d(w)
+            r = np.array([poisson_curves_loglik(Y[i], np.einsum("jtk,k->jt", Vi, wk), link) for wk in w])
+            return r if r.size > 1 else r[0]
+        rng = None if rngs is None else rngs[i]
+        if z is None:       # drawn AFTER the slice height, from the row's own stream (gass.py:21-24)
+            prop = lambda d=d, rng=rng: np.sqrt(st["sigma2"]) * (np.random if rng is None else rng).normal(size=d)
+        else:
+            prop = np.sqrt(st["sigma2"]) * np.asarray(z[i], float)[:d]
+        inf = {}
+        new, _ = gass(W[i, :d], prop, ll, Ci, ngrid=ngrid, info=inf, rng=rng)
+        out[i, :d] = new
+        if info is not None:
+            info.setdefault("grid", []).append(inf["grid"])
+            info.setdefault("accepted", []).append(inf["accepted"])
+    st["W"] = out
+    return out
+
+
+def constrained_v_step(st, Y, Delta, Cons, link="identity", ngrid=100, perm="depth", z=None, rngs=None, info=None):
+    """_resample_V_j for every column (factor.py:759-846, no EP approximation): prior precision
+    I_K (x) Delta' Lambda_j Delta (k-major), proposal drawn in the declared order `perm`, constraints from the
+    current W, Poisson column likelihood."""
+    W, V = st["W"], st["V"]
+    M, T, K = V.shape
+    n = K * T
+    if isinstance(perm, str):
+        p = twisted_perm(K, T, band_halfwidth(Delta.T @ Delta) - 1) if perm == "twist" else \
+            (depth_major_perm(K, T) if perm == "depth" else np.arange(n))
+    else:
+        p = np.asarray(perm)
+    Cv = constrained_v_constraints(W, Cons, T)
+    out = V.copy()
+    for j in range(M):
+        Q = np.kron(np.eye(K), prior_precision_1d(Delta, st["lam2"], st["Tau2"][j]))
+        rng = None if rngs is None else rngs[j]
+        if z is None:
+            v = lambda Q=Q, rng=rng: mvn_from_precision(Q, perm=p, z=(np.random if rng is None else rng).normal(size=n))
+        else:
+            v = mvn_from_precision(Q, perm=p, z=np.asarray(z[j], float))
+
+        def ll(vec, _):
+            vec = np.atleast_2d(vec)
+            r = np.array([poisson_curves_loglik(Y[:, j], np.einsum("nk,kt->nt", W, vk.reshape(K, T)), link) for vk in vec])
+            return r if r.size > 1 else r[0]
+        inf = {}
+        new, _ = gass(V[j].T.reshape(-1), v, ll, Cv, ngrid=ngrid, info=inf, rng=rng)
+        out[j] = new.reshape(K, T).T
+        if info is not None:
+            info.setdefault("grid", []).append(inf["grid"])
+            info.setdefault("accepted", []).append(inf["accepted"])
+    st["V"] = out
+    return out
 
 
 # --------------------------------------------------------------------------

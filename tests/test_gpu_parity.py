@@ -1415,3 +1415,129 @@ def test_dense_mvn_device_rng_has_the_right_covariance():
     assert np.abs(np.cov(x.T) - S).max() < 0.06 * np.abs(S).max()
     xp, _ = sample_dense_batch(np.broadcast_to(S, (B, n, n)).copy(), precision=True, seed=6)
     assert np.abs(np.cov(xp.T) - np.linalg.inv(S)).max() < 0.06 * np.abs(np.linalg.inv(S)).max()
+
+
+# ---- constrained non-conjugate model: GASS on the device (btf_gass_*; gass.py:13-130, factor.py:665-855) ---------
+def _gass_model(golden, **kw):
+    from functionalmf_amd.factor import ConstrainedNonconjugateBayesianTensorFiltering
+    from test_oracle_golden import _gass_case
+    g, st, (N, M, T, R, K, tf) = _gass_case(golden)
+    model = ConstrainedNonconjugateBayesianTensorFiltering(
+        N, M, T, "poisson_identity", g["Cons"], Row_constraints=g["Row_constraints"], gass_ngrid=int(g["ngrid"]),
+        nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], W_init=st["W"], V_init=st["V"],
+        Tau2_init=st["Tau2"], **kw)
+    return model, g, st, (N, M, T, R, K, tf)
+
+
+@pytest.mark.gpu
+def test_gass_row_and_column_updates_vs_reference_fixture(golden):
+    """The reference's own _resample_W_i / _resample_V_j (tests/golden/make_golden_gass.py) against the device path
+    driven with the same per-chain streams: constraint analysis, candidate likelihoods and the commit run on the GPU,
+    the reference's np.random.choice calls on the host."""
+    model, g, st, (N, M, T, R, K, tf) = _gass_model(golden, sampler="banded")
+    model.chain_rngs = lambda what: [np.random.RandomState((2000 if what == 0 else 3000) + c) for c in range(N if what == 0 else M)]
+    model._resample_W(g["Y"])
+    assert relerr(model.W, g["W_after"]) < 1e-10
+    assert model.gass_info["accepted"].max() > 0
+    model.W = st["W"]
+    model._resample_V(g["Y"])
+    assert relerr(model.V, g["V_after"]) < 1e-7
+
+
+@pytest.mark.gpu
+def test_gass_valid_grid_equals_the_oracles(golden):
+    """The validity of each of the 10000 grid angles (difference array + scan on the device) against the oracle's
+    sequential pruning (gass.py:66-80), for every row and every column, from random proposals."""
+    import ctypes
+    from oracle import btf_oracle as orc
+    from functionalmf_amd import _native
+    model, g, st, (N, M, T, R, K, tf) = _gass_model(golden, sampler="banded")
+    Y = g["Y"]
+    model._bind_data(Y)
+    model._push_state()
+    rc = model.Row_constraints
+    model._ctx.call("btf_gass_set_constraints", _native.dptr(model._cons), int(model._cons.shape[0]), _native.dptr(rc), int(rc.shape[0]))
+    rs = np.random.RandomState(5)
+    full = np.linspace(-np.pi, np.pi, 10000)
+    # rows
+    z = rs.normal(size=K * (K + 1) // 2 + (N - K) * K)
+    u = rs.rand(N)
+    model._ctx.call("btf_gass_begin", 0, 1, _native.dptr(z), _native.dptr(u), 1, 1e-6, 0, 0)
+    info = np.zeros((N, 2), dtype=np.int32)
+    mask = np.zeros((N, 10000), dtype=np.uint8)
+    hh, cur = np.empty(N), np.empty(N)
+    model._ctx.call("btf_gass_grid", 0, info.ctypes.data_as(_native._c_ip), mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                    _native.dptr(hh), _native.dptr(cur))
+    off = 0
+    for i in range(N):
+        d = min(K, i + 1)
+        v = np.sqrt(st["sigma2"]) * z[off:off + d]
+        off += d
+        Ci = orc.constrained_w_constraints(st["V"], g["Cons"], d, g["Row_constraints"])
+        grid, restricted = orc.gass_valid_grid(st["W"][i, :d], v, Ci[:, :-1], Ci[:, -1])
+        assert bool(info[i, 1]) == (not restricted)
+        if restricted:
+            assert np.array_equal(full[mask[i] != 0], grid), i
+        ll = orc.poisson_curves_loglik(Y[i], np.einsum("jtk,k->jt", st["V"][:, :, :d], st["W"][i, :d]), "identity")
+        assert abs(cur[i] - ll) < 1e-9 * max(1.0, abs(ll)) and abs(hh[i] - (ll + np.log(u[i]))) < 1e-9 * max(1.0, abs(ll))
+    # columns
+    Delta = orc.trend_penalty(T, tf)
+    p = orc.perm_from_order(model.v_order(), K, T)
+    zv = rs.normal(size=(M, K * T))
+    uv = rs.rand(M)
+    model._ctx.call("btf_gass_begin", 1, 1, _native.dptr(zv), _native.dptr(uv), 2, 1e-6, 0, 0)
+    info = np.zeros((M, 2), dtype=np.int32)
+    mask = np.zeros((M, 10000), dtype=np.uint8)
+    model._ctx.call("btf_gass_grid", 1, info.ctypes.data_as(_native._c_ip), mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), None, None)
+    Cv = orc.constrained_v_constraints(st["W"], g["Cons"], T)
+    for j in range(M):
+        Q = np.kron(np.eye(K), orc.prior_precision_1d(Delta, st["lam2"], st["Tau2"][j]))
+        v = orc.mvn_from_precision(Q, perm=p, z=zv[j])
+        grid, restricted = orc.gass_valid_grid(st["V"][j].T.reshape(-1), v, Cv[:, :-1], Cv[:, -1])
+        assert bool(info[j, 1]) == (not restricted)
+        if restricted:
+            dev = full[mask[j] != 0]
+            # (a proposal from an ill-conditioned prior: arc ends agree to ~1e-9, one boundary angle may differ)
+            assert abs(len(dev) - len(grid)) <= 2 and len(np.setxor1d(dev, grid)) <= 2, j
+
+
+@pytest.mark.gpu
+def test_gass_device_chain_stays_feasible_and_fits(golden):
+    """rng="device": whole sweeps on the GPU.  Every state satisfies every constraint (positivity and monotone curves),
+    and the chain moves to a good fit of the Poisson rates it was simulated from."""
+    from functionalmf_amd.factor import ConstrainedNonconjugateBayesianTensorFiltering
+    rs = np.random.RandomState(12)
+    N, M, T, R, K = 24, 10, 12, 3, 3
+    Wt = rs.gamma(2.0, 0.5, size=(N, K))
+    Wt[np.triu_indices(K, 1)] = 0
+    Vt = np.zeros((M, T, K))
+    for j in range(M):
+        Vt[j, -1] = rs.gamma(2.0, 0.5, size=K)
+        for t in range(T - 2, -1, -1):
+            Vt[j, t] = Vt[j, t + 1] + (rs.gamma(1.0, 0.6, size=K) if rs.rand() < 0.4 else 0.0)
+    rate = np.einsum("nk,mtk->nmt", Wt, Vt)
+    Y = rs.poisson(np.repeat(rate[..., None], R, axis=-1)).astype(float)
+    Y[:2, :2] = np.nan
+    Cons = np.concatenate([np.eye(T), np.zeros((T, 1))], axis=1)
+    mono = np.array([np.concatenate([np.zeros(t), [1, -1], np.zeros(T - t - 2), [-1e-2]]) for t in range(T - 1)])
+    Cons = np.concatenate([Cons, mono], axis=0)
+    np.random.seed(4)
+    W0 = np.abs(Wt + 0.3 * rs.normal(size=Wt.shape)) + 0.05
+    W0[np.triu_indices(K, 1)] = 0
+    V0 = np.maximum.accumulate((np.abs(Vt + 0.2 * rs.normal(size=Vt.shape)) + 0.05)[:, ::-1], axis=1)[:, ::-1]   # decreasing in t
+    model = ConstrainedNonconjugateBayesianTensorFiltering(N, M, T, "poisson_identity", Cons, gass_ngrid=64, nembeds=K, tf_order=0,
+                                                           sigma2_init=1.0, lam2_init=0.5, W_init=W0, V_init=V0, rng="device",
+                                                           device_seed=3)
+    ll0 = model.log_likelihood(Y)
+    acc, n = 0.0, 0
+    for it in range(300):
+        model.resample(Y)
+        if it % 25 == 24 or it >= 200:
+            tau = np.einsum("nk,mtk->nmt", model.W, model.V)
+            assert (np.einsum("qt,nmt->nmq", Cons[:, :-1], tau) >= Cons[:, -1] - 1e-9).all(), it
+        if it >= 150:
+            acc = acc + np.einsum("nk,mtk->nmt", model.W, model.V)
+            n += 1
+    assert model.log_likelihood(Y) > ll0
+    fit = acc / n
+    assert np.corrcoef(fit.ravel(), rate.ravel())[0, 1] > 0.9

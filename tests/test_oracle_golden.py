@@ -369,3 +369,45 @@ def test_nonconjugate_joint_slice_steps_vs_reference(golden, link):
     np.random.seed(1200)
     orc.nonconjugate_v_step(st, Y, Delta, link=link, perm="twist", info=info)
     assert relerr(st["V"], g[tag + "V_after"]) < 1e-9 and info["evaluations"] == int(g[tag + "V_nev"])
+
+
+# ---- constrained non-conjugate model: the reference's own worker functions (make_golden_gass.py) ----
+def _gass_case(golden):
+    g = golden("g10_gass.npz")
+    N, M, T, R, K, tf = [int(x) for x in g["dims"]]
+    st = {k: (float(g["s0_" + k]) if k in ("lam2", "sigma2") else g["s0_" + k].copy()) for k in ("W", "V", "Tau2", "lam2", "sigma2")}
+    return g, st, (N, M, T, R, K, tf)
+
+
+def test_constrained_row_and_column_updates_vs_reference(golden):
+    """_resample_W_i / _resample_V_j (factor.py:665-855) run by the reference itself, row by row and column by column,
+    each from its own seed: the oracle's restatement with the same per-chain streams must land on the same states."""
+    g, st, (N, M, T, R, K, tf) = _gass_case(golden)
+    ngrid = int(g["ngrid"])
+    a = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    info = {}
+    orc.constrained_w_step(a, g["Y"], g["Cons"], link="identity", ngrid=ngrid,
+                           rngs=[np.random.RandomState(2000 + i) for i in range(N)], Row_constraints=g["Row_constraints"], info=info)
+    assert relerr(a["W"], g["W_after"]) < 1e-12
+    assert min(info["grid"]) > 0 and max(info["accepted"]) > 0
+    b = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    orc.constrained_v_step(b, g["Y"], orc.trend_penalty(T, tf), g["Cons"], link="identity", ngrid=ngrid, perm="twist",
+                           rngs=[np.random.RandomState(3000 + j) for j in range(M)])
+    assert relerr(b["V"], g["V_after"]) < 1e-9
+
+
+def test_gass_valid_grid_is_the_intersection_of_the_constraint_arcs():
+    """Every returned grid angle satisfies all constraints on the ellipse, every dropped one violates one (up to the
+    eps margin of gass.py:47)."""
+    rs = np.random.RandomState(2)
+    D = 4
+    A = rs.normal(size=(30, D))
+    x0 = np.abs(rs.normal(size=D)) + 0.2
+    c = A @ x0 - np.abs(rs.normal(size=30)) * 0.5           # x0 strictly feasible
+    v = rs.normal(size=D)
+    grid, restricted = orc.gass_valid_grid(x0, v, A, c)
+    assert restricted and 0 < len(grid) < 10000
+    full = np.linspace(-np.pi, np.pi, 10000)
+    slack = (A @ (x0[None] * np.cos(full[:, None]) + v[None] * np.sin(full[:, None])).T - c[:, None]).min(axis=0)
+    assert np.all(slack[np.isin(full, grid)] >= -1e-9)
+    assert np.all(slack[~np.isin(full, grid)] < 1e-4)
