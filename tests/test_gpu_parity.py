@@ -1541,3 +1541,16 @@ def test_gass_device_chain_stays_feasible_and_fits(golden):
     assert model.log_likelihood(Y) > ll0
     fit = acc / n
     assert np.corrcoef(fit.ravel(), rate.ravel())[0, 1] > 0.9
+
+
+@pytest.mark.gpu
+def test_constrained_poisson_example_runs_end_to_end():
+    """examples/poisson_constrained_tensor_filtering.py: positivity + monotone curves, GASS on the device."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("poisson_constrained", os.path.join(ROOT, "examples", "poisson_constrained_tensor_filtering.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rel_in, rel_out, corr, feasible = mod.main(seed=1, nburn=400, nsamples=200)
+    assert feasible and corr > 0.8 and rel_in < 0.5
