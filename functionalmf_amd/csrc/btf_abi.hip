@@ -108,6 +108,8 @@ struct btf_ctx {
   double* eig_cols = nullptr;                                         // [M][K + K*K + 8] per-column eigen-systems
   int* cv_dcols = nullptr; int cv_ndef = 0;                           // the columns that have deficient rows
   bool w_part_curve = false;                                          // the W-step partials were made in curve mode
+  bool tau_pending = false; unsigned long long tau_seed = 0; double tau_stability = 1e-6;   // btf_queue_Tau2
+  bool lam_pending = false; unsigned long long lam_seed = 0; int lam_exact = 0;            // btf_queue_lam2
   unsigned long long sweep_w = 0, sweep_v = 0;
   bool profiling = false;
   std::vector<EvPair> ev_pool;
@@ -282,15 +284,18 @@ int build_stencil(btf_ctx* c) {
 template <int K>
 void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const unsigned char* C8, const double* U,
                   const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr},
-                  EigSideCols sidec = EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}) {
+                  EigSideCols sidec = EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
+                  TauSide tau = TauSide{}) {
   Prof p(c, kid);
-  dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 + eig_side_groups(sidec.ncols, acc_waves(K, mode)) : 0));   // (+ the side tasks' workgroups)
+  const int cpw = TAU_SIDE_CPW;
+  dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 + eig_side_groups(sidec.ncols, acc_waves(K, mode)) : 0) +
+            (tau.Tau2 ? (tau.M + cpw - 1) / cpw : 0));   // (+ the side tasks' workgroups)
   if (mode >= 1 && C8) {       // byte weights (Gaussian replicate counts)
-    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec);
-    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec);
-  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec);
-  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec);
-  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec);
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
+  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
+  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
+  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
 }
 // which Polya-Gamma passes a draw needs: exact mode - the exact sampler alone; otherwise the series for every cell
 // that is not an integer count of 1 or 2, and the exact sampler for those (each launch only if such cells exist)
@@ -993,17 +998,34 @@ int btf_get_tau(btf_ctx* c, double* Tau2, double* Ta, double* Tb, double* Tc) {
   return BTF_OK;
 }
 
+static TauSide tau_side_of(btf_ctx* c, uint64_t seed, double lam2, double stability) {
+  TauSide t{};
+  t.V = c->V; t.T = c->T; t.nD = c->nD; t.M = c->M;
+  t.dr_ptr = c->dr_ptr; t.dr_col = c->dr_col; t.dr_val = c->dr_val;
+  t.lam2 = lam2; t.lo = stability; t.hi = 1.0 / stability;
+  t.Tau2 = c->Tau2; t.Ta = c->Ta; t.Tb = c->Tb; t.Tc = c->Tc; t.lsum = c->lsum;
+  t.seed = (unsigned long long)seed; t.hyp = c->dev_scalars ? c->hyp : nullptr;
+  return t;
+}
+
+int btf_queue_Tau2(btf_ctx* c, uint64_t seed, double stability) {
+  if (!c || !(stability > 0.0)) return fail(c, BTF_EINVAL, "bad Tau2 update arguments");
+  if (!c->dev_scalars) return fail(c, BTF_ESTATE, "btf_queue_Tau2 needs device-resident scalars");
+  if (!c->have_V || !c->have_hyper || !c->have_chain) return fail(c, BTF_ESTATE, "set V, Tau2 and the horseshoe+ chain first");
+  c->tau_pending = true; c->tau_seed = seed; c->tau_stability = stability;
+  return BTF_OK;
+}
+
 int btf_resample_Tau2(btf_ctx* c, uint64_t seed, double lam2, double stability, double* lsum_out) {
   if (!c || !(stability > 0.0)) return fail(c, BTF_EINVAL, "bad Tau2 update arguments");
   if (c->dev_scalars) lam2 = 1.0;   // the kernel reads the device-resident value
   if (!(lam2 > 0.0)) return fail(c, BTF_EINVAL, "bad Tau2 update arguments");
   if (!c->have_V || !c->have_hyper || !c->have_chain) return fail(c, BTF_ESTATE, "set V, Tau2 and the horseshoe+ chain first");
   HIPCHK(c, hipSetDevice(c->dev));
+  c->tau_pending = false;
   {
     Prof p(c, BTF_K_HYPER);
-    p.launch(tau2_kernel, dim3(c->M), dim3(256), 0, (const double*)c->V, c->T, c->K, c->nD, (const int*)c->dr_ptr,
-             (const int*)c->dr_col, (const double*)c->dr_val, lam2, stability, 1.0 / stability, c->Tau2, c->Ta, c->Tb,
-             c->Tc, c->lsum, (unsigned long long)seed, (const double*)(c->dev_scalars ? c->hyp : nullptr));
+    p.launch(tau2_kernel, dim3(c->M), dim3(256), 0, tau_side_of(c, seed, lam2, stability), c->K);
   }
   HIPCHK(c, hipGetLastError());
   if (lsum_out) {   // through pinned memory: a pageable destination makes the small copy several times slower
@@ -1078,7 +1100,11 @@ int w_accum_phase(btf_ctx* c, int compat) {
   }
   if (c->nl > 0) {
     if (!wt && !use_gv) { K_SWITCH(K, launch_gram<KT>(c, c->V, MT)); }
-    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, rpb, nch));
+    TauSide tau{};
+    if (c->tau_pending && c->dev_scalars && c->have_chain) tau = tau_side_of(c, c->tau_seed, 1.0, c->tau_stability);
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, rpb, nch,
+                                 EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}, tau));
+    c->tau_pending = false;
   }
   HIPCHK(c, hipGetLastError());
   c->w_part_valid = true; c->w_part_mode = mode; c->w_part_nch = nch; c->w_part_rpb = rpb; c->w_part_gv = use_gv;
@@ -2195,12 +2221,22 @@ int btf_draw_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double 
   const int h = std::min(c->K, c->N);
   const double nfree = (double)c->N * c->K - (double)h * (h - 1) / 2.0 - (double)(c->K - h) * c->N;   // factor.py:155-174
   {
+    const bool with_lam = c->lam_pending && phase != 1 && c->lsum && c->have_chain;     // (not with the reduce-only half)
     Prof p(c, BTF_K_HYPER);
-    p.launch(scalars_kernel, dim3(1), dim3(256), 0, (const double*)c->bsum, (int)nb, ssw,
+    p.launch(scalars_kernel, dim3(with_lam ? 2 : 1), dim3(256), 0, (const double*)c->bsum, (int)nb, ssw,
              c->nobs_global >= 0.0 ? c->nobs_global : c->nobs, (const double*)c->W,
-             c->N, c->K, nfree, nu2_a, nu2_b, sigma2_a, sigma2_b, which & 3, (unsigned long long)seed, c->hyp, phase);
+             c->N, c->K, nfree, nu2_a, nu2_b, sigma2_a, sigma2_b, which & 3, (unsigned long long)seed, c->hyp, phase,
+             (const double*)c->lsum, c->M, (double)c->nD * c->M * c->K + 1.0, c->lam_exact, c->lam_seed);
+    if (with_lam) c->lam_pending = false;
   }
   HIPCHK(c, hipGetLastError());
+  return BTF_OK;
+}
+
+int btf_queue_lam2(btf_ctx* c, uint64_t seed, int compat) {
+  if (!c || !c->dev_scalars) return fail(c, BTF_ESTATE, "enable device-resident scalars first");
+  if (!c->have_chain) return fail(c, BTF_ESTATE, "set the horseshoe+ chain first");
+  c->lam_pending = true; c->lam_seed = seed; c->lam_exact = compat == BTF_COMPAT_EXACT ? 1 : 0;
   return BTF_OK;
 }
 
@@ -2209,6 +2245,7 @@ int btf_draw_lam2(btf_ctx* c, uint64_t seed, int compat) {
   if (!c->lsum || !c->have_chain) return fail(c, BTF_ESTATE, "btf_draw_lam2 follows btf_resample_Tau2");
   HIPCHK(c, hipSetDevice(c->dev));
   const double shape = (double)c->nD * c->M * c->K + 1.0;
+  c->lam_pending = false;
   {
     Prof p(c, BTF_K_HYPER);
     p.launch(lam2_kernel, dim3(1), dim3(256), 0, (const double*)c->lsum, c->M, shape, compat == BTF_COMPAT_EXACT ? 1 : 0,

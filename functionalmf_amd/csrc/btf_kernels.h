@@ -131,6 +131,21 @@ struct EigSideCols { const int* cols; int ncols; CurveLists cv; const double* W;
 __host__ __device__ constexpr int eig_side_tpw(int waves) { return waves >= 4 ? 4 : waves; }      // one per SIMD
 __host__ __device__ constexpr int eig_side_groups(int ncols, int waves) { return (ncols + eig_side_tpw(waves) - 1) / eig_side_tpw(waves); }
 
+// the horseshoe+ chain update (tau2_kernel below) as side workgroups of the W accumulation launch: it depends on V
+// only and is transcendental-bound, the stream is memory-bound and leaves half the CUs idle at C3 - every 256-thread
+// slice of a side workgroup takes one column
+struct TauSide {
+  const double* V; int T, nD, M;
+  const int* dr_ptr; const int* dr_col; const double* dr_val;
+  double lam2, lo, hi;
+  double* Tau2; double* Ta; double* Tb; double* Tc; double* lsum;
+  unsigned long long seed; const double* hyp;
+};
+__device__ void tau2_column(const TauSide& t, int K, int j, int tid256, double* red4);
+// two columns per side workgroup: its waves land one per SIMD per column, and the gamma draws are f64-issue-bound
+// (four columns: 14.4 us for the launch at C3, two: hidden under the 11 us stream); the other waves leave at once
+constexpr int TAU_SIDE_CPW = 2;
+
 // MODE 0: X only (complete data)
 // MODE 1: X, C and the outer products UU
 // MODE 2: as 1, but the precision weight of output l is read from output srcmap[l] of the
@@ -151,7 +166,7 @@ template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double>
 __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     const double* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
-    int rows_per_block, EigSide side, EigSideCols sidec) {
+    int rows_per_block, EigSide side, EigSideCols sidec, TauSide tau) {
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
@@ -195,6 +210,17 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
       return;
     }
     b -= nside;
+  }
+  if (tau.Tau2) {
+    constexpr int CPW = TAU_SIDE_CPW;                       // columns per side workgroup
+    const int ntw = (tau.M + CPW - 1) / CPW;
+    if (b < ntw) {
+      const int slot = threadIdx.x >> 8;
+      if (slot < CPW) tau2_column(tau, K, b * CPW + slot, threadIdx.x & 255, &red[0][0][0] + 4 * slot);
+      else __syncthreads();                                 // (12-wave workgroups have no such threads; kept for safety)
+      return;
+    }
+    b -= ntw;
   }
   const int ntiles = ld / ACC_TILE;
   const int chunk = b / ntiles, tile = b - chunk * ntiles;
@@ -1674,40 +1700,52 @@ __global__ void pg_batch_kernel(const double* b, const double* psi, double* out,
 //   plus the per-column sums  lsum[j] = sum_r dsq[j,r] / Tau2_new[j,r]  that the lam2 update needs
 //   (factor.py:148-150).  One workgroup per column; Philox keyed by (seed, j*nD + r).
 // ============================================================================
-__global__ __launch_bounds__(256) void tau2_kernel(const double* __restrict__ V, int T, int K, int nD,
-                                                   const int* __restrict__ dr_ptr, const int* __restrict__ dr_col,
-                                                   const double* __restrict__ dr_val, double lam2, double lo, double hi,
-                                                   double* __restrict__ Tau2, double* __restrict__ Ta,
-                                                   double* __restrict__ Tb, double* __restrict__ Tc,
-                                                   double* __restrict__ lsum, unsigned long long seed,
-                                                   const double* __restrict__ hyp) {
-  __shared__ double red[4];
-  const int j = blockIdx.x;
-  if (hyp) lam2 = hyp[HYP_LAM2];
-  const double* Vj = V + (size_t)j * T * K;
+// one column: 256 threads (tid256), red4: four doubles of LDS of this column's slot; every thread of the WORKGROUP
+// reaches the barrier inside (columns past the end do no work)
+__device__ void tau2_column(const TauSide& t, int K, int j, int tid256, double* red4) {
   double acc = 0.0;
-  for (int r = threadIdx.x; r < nD; r += blockDim.x) {
-    double dsq = 0.0;
-    for (int k = 0; k < K; ++k) {
-      double d = 0.0;
-      for (int e = dr_ptr[r]; e < dr_ptr[r + 1]; ++e) d = fma(dr_val[e], Vj[(size_t)dr_col[e] * K + k], d);
-      dsq = fma(d, d, dsq);
+  if (j < t.M) {
+    const double lam2 = t.hyp ? t.hyp[HYP_LAM2] : t.lam2;
+    const double lo = t.lo, hi = t.hi;
+    const int nD = t.nD;
+    const double* Vj = t.V + (size_t)j * t.T * K;
+    for (int r = tid256; r < nD; r += 256) {
+      const size_t o = (size_t)j * nD + r;
+      const double tc0 = t.Tc[o], tb0 = t.Tb[o], ta0 = t.Ta[o];          // (in flight with the stencil gathers)
+      // (Delta V_j)[r, :]: the stencil row once (<= tf+2 entries), then its rows of V_j - two dependent round trips,
+      // not two per embedding dimension
+      const int e0 = t.dr_ptr[r], e1 = t.dr_ptr[r + 1];
+      double dv[EIG_MAXK];
+#pragma unroll
+      for (int k = 0; k < EIG_MAXK; ++k) dv[k] = 0.0;
+      for (int e = e0; e < e1; ++e) {
+        const double cv = t.dr_val[e];
+        const double* __restrict__ vr = Vj + (size_t)t.dr_col[e] * K;
+#pragma unroll
+        for (int k = 0; k < EIG_MAXK; ++k) if (k < K) dv[k] = fma(cv, vr[k], dv[k]);
+      }
+      double dsq = 0.0;
+#pragma unroll
+      for (int k = 0; k < EIG_MAXK; ++k) dsq = fma(dv[k], dv[k], dsq);
+      CellRng g(t.seed, (unsigned long long)o);
+      auto clip = [&](double x) { return fmin(fmax(x, lo), hi); };
+      const double rate = dsq / (2.0 * lam2) + 1.0 / clip(tc0);
+      const double tau = clip(rate) / gamma_mt(0.5 * (K + 1), g);
+      const double c = clip(1.0 / tau + 1.0 / tb0) / g.expo();
+      const double b = clip(1.0 / c + 1.0 / ta0) / g.expo();
+      const double a = clip(1.0 / b + 1.0) / g.expo();
+      t.Tau2[o] = tau; t.Tc[o] = c; t.Tb[o] = b; t.Ta[o] = a;
+      acc += dsq / tau;
     }
-    const size_t o = (size_t)j * nD + r;
-    CellRng g(seed, (unsigned long long)o);
-    auto clip = [&](double x) { return fmin(fmax(x, lo), hi); };
-    const double rate = dsq / (2.0 * lam2) + 1.0 / clip(Tc[o]);
-    const double tau = clip(rate) / gamma_mt(0.5 * (K + 1), g);
-    const double c = clip(1.0 / tau + 1.0 / Tb[o]) / g.expo();
-    const double b = clip(1.0 / c + 1.0 / Ta[o]) / g.expo();
-    const double a = clip(1.0 / b + 1.0) / g.expo();
-    Tau2[o] = tau; Tc[o] = c; Tb[o] = b; Ta[o] = a;
-    acc += dsq / tau;
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  if ((tid256 & 63) == 0) red4[tid256 >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) lsum[j] = red[0] + red[1] + red[2] + red[3];
+  if (tid256 == 0 && j < t.M) t.lsum[j] = red4[0] + red4[1] + red4[2] + red4[3];
+}
+__global__ __launch_bounds__(256) void tau2_kernel(TauSide t, int K) {
+  __shared__ double red[4];
+  tau2_column(t, K, blockIdx.x, threadIdx.x, red);
 }
 
 // ============================================================================
@@ -1729,6 +1767,9 @@ __device__ inline double block_sum_fixed(double x, double* red) {   // all 256 t
   return s;
 }
 
+__device__ inline void lam2_draw(const double* __restrict__ lsum, int M, double shape, int exact,
+                                 unsigned long long seed, double* __restrict__ hyp, double* red);
+
 // which: bit 0 = nu2 (needs the SSE block partials), bit 1 = sigma2
 // phase 0: reduce and draw (one GPU).  Sharded runs split the nu2 part around an all-reduce of the rank-local sum:
 // phase 1 = reduce only, hyp[HYP_SSE] <- this rank's residual sum of squares; phase 2 = draw from hyp[HYP_SSE]
@@ -1736,9 +1777,15 @@ __device__ inline double block_sum_fixed(double x, double* red) {   // all 256 t
 __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__ bsum, int nb, double ssw, double nobs,
                                                       const double* __restrict__ W, int N, int K, double nfree,
                                                       double nu2_a, double nu2_b, double sig_a, double sig_b, int which,
-                                                      unsigned long long seed, double* __restrict__ hyp, int phase) {
+                                                      unsigned long long seed, double* __restrict__ hyp, int phase,
+                                                      const double* __restrict__ lsum, int M, double lam_shape, int lam_exact,
+                                                      unsigned long long lam_seed) {
   __shared__ double red[4];
   __shared__ double stat[2];
+  if (blockIdx.x == 1) {       // a queued lam2 | rest draw rides in this launch (btf_queue_lam2): lam2_kernel's body
+    lam2_draw(lsum, M, lam_shape, lam_exact, lam_seed, hyp, red);
+    return;
+  }
   // both reductions first (all threads), then the two draws side by side: thread 0 draws nu2 while thread 64
   // (another wave) draws sigma2 - a Gamma draw with shape ~1e7 is ~2 us of dependent f64 work on one lane
   if ((which & 1) && phase != 2) {
@@ -1774,9 +1821,8 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void lam2_kernel(const double* __restrict__ lsum, int M, double shape, int exact,
-                                                   unsigned long long seed, double* __restrict__ hyp) {
-  __shared__ double red[4];
+__device__ inline void lam2_draw(const double* __restrict__ lsum, int M, double shape, int exact,
+                                 unsigned long long seed, double* __restrict__ hyp, double* red) {
   double rate;
   if (exact) {
     double acc = 0.0;
@@ -1791,6 +1837,11 @@ __global__ __launch_bounds__(256) void lam2_kernel(const double* __restrict__ ls
     hyp[HYP_LAM2] = lam2;
     hyp[HYP_LAM2A] = (1.0 / lam2 + 1.0) / g.expo();
   }
+}
+__global__ __launch_bounds__(256) void lam2_kernel(const double* __restrict__ lsum, int M, double shape, int exact,
+                                                   unsigned long long seed, double* __restrict__ hyp) {
+  __shared__ double red[4];
+  lam2_draw(lsum, M, shape, exact, seed, hyp, red);
 }
 
 // ============================================================================

@@ -449,7 +449,7 @@ class BayesianTensorFiltering(_BayesianModel):
             self._dsq_key = key
         return self._dsq
 
-    def _resample_Tau2_device(self):
+    def _resample_Tau2_device(self, queue=False):
         """rng="device": all columns at once on the GPU (Philox gamma draws); also leaves the
         per-column terms of the lam2 rate in self._lsum."""
         self._push_state()
@@ -460,7 +460,10 @@ class BayesianTensorFiltering(_BayesianModel):
                            _native.dptr(self._Tau2_c))
             self._chain_dirty = False
         if self._dev_scalars:       # lam2 is read, and the lam2-rate terms are left, on the device
-            self._ctx.call("btf_resample_Tau2", self._next_seed(), 1.0, float(self.stability), None)
+            if queue:               # as side workgroups of the W accumulation launch that follows (btf_queue_Tau2)
+                self._ctx.call("btf_queue_Tau2", self._next_seed(), float(self.stability))
+            else:
+                self._ctx.call("btf_resample_Tau2", self._next_seed(), 1.0, float(self.stability), None)
             self._lsum_on_device, self._lsum_valid = True, False
         else:
             lsum = np.empty(self.ncols)
@@ -472,6 +475,9 @@ class BayesianTensorFiltering(_BayesianModel):
     def _resample_Tau2(self):
         """Horseshoe+ local scales, one column after the other so that the legacy RNG
         stream matches the reference (4 vector gamma draws per column, factor.py:134-141)."""
+        if getattr(self, "_tau2_drawn", False):            # rode along in this sweep's W accumulation launch
+            self._tau2_drawn = False
+            return
         if self.rng == "device" and hasattr(self, "_Tau2_a"):
             return self._resample_Tau2_device()
         lo, hi = self.stability, 1 / self.stability
@@ -491,10 +497,15 @@ class BayesianTensorFiltering(_BayesianModel):
     def _resample_lam2(self):
         """Global scale.  compat="reference": the rate keeps only the LAST column's term
         (quirk Q3, factor.py:147-150); "exact": 1/lam2_a plus the sum over columns."""
+        if getattr(self, "_lam2_drawn", False):            # rode along in this sweep's scalar-draw launch
+            self._lam2_drawn = False
+            return
         if self._dev_scalars and getattr(self, "_lsum_on_device", False):
             self._lsum_on_device = False
             self._push_scalars()
-            self._ctx.call("btf_draw_lam2", self._next_seed(), _native.COMPAT[self.compat])
+            seed = getattr(self, "_lam2_seed", None)
+            self._lam2_seed = None
+            self._ctx.call("btf_draw_lam2", self._next_seed() if seed is None else seed, _native.COMPAT[self.compat])
             self._sc_dev_new = True
             return
         if self.rng == "device" and getattr(self, "_lsum_valid", False):
@@ -638,6 +649,7 @@ class BayesianTensorFiltering(_BayesianModel):
 class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
     _queue_sse = True      # scalar-noise model: nu2 needs the residual sum of squares every sweep
     _scalar_noise = True   # nu2 is one number (device-resident in rng="device" mode)
+    fuse_tau2 = True       # rng="device" sweeps: the horseshoe+ chain rides in the W accumulation launch (A/B switch)
 
     nu2 = property(lambda self: self._sc_get("nu2"), lambda self, v: self._sc_set("nu2", v))
 
@@ -715,6 +727,20 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
                 # the W half-sweep's accumulation depends on the data and V only: queue it now and take the
                 # residual sum of squares from its partials (no pass of its own over the data); the W step
                 # later in this sweep goes straight to the solve
+                # ... and the horseshoe+ chain, which depends on V and lam2 only (not on nu2 / sigma2: the same
+                # conditionals in either order), rides in that launch as side workgroups
+                if self.sample_Tau2 and self.fuse_tau2 and hasattr(self, "_Tau2_a"):
+                    self._resample_Tau2_device(queue=True)
+                    self._tau2_drawn = True
+                    if self.sample_lam2:
+                        lam_seed = self._next_seed()       # (taken here whatever the sharding: one seed order for all)
+                        if self._exchange.active:          # the scalar draw is split around an all-reduce: lam2 keeps its own launch
+                            self._lam2_seed = lam_seed
+                        else:
+                            # lam2 | Tau2_new, ...: a second workgroup of the scalar-draw launch below
+                            self._push_scalars()
+                            self._ctx.call("btf_queue_lam2", lam_seed, _native.COMPAT[self.compat])
+                            self._lam2_drawn, self._lsum_on_device = True, False
                 self._ctx.call("btf_w_accum", _native.COMPAT[self.compat])
                 which |= 4
             seed = self._next_seed()

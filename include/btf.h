@@ -174,6 +174,13 @@ int btf_set_hyper(btf_ctx* ctx, const double* Tau2 /* (M,nD) */, double lam2, do
 int btf_set_tau_chain(btf_ctx* ctx, const double* Tau2_a, const double* Tau2_b, const double* Tau2_c);
 int btf_get_tau(btf_ctx* ctx, double* Tau2, double* Tau2_a, double* Tau2_b, double* Tau2_c); /* a,b,c may be NULL */
 int btf_resample_Tau2(btf_ctx* ctx, uint64_t seed, double lam2, double stability, double* lsum_out /* (M) or NULL */);
+/* Device-resident scalars only: the NEXT btf_w_accum launch also runs this horseshoe+ update, as side workgroups
+ * beside the stream (Tau2 | V, lam2 does not depend on nu2 / sigma2: the same conditionals as btf_resample_Tau2 after
+ * the scalar draws; same Philox streams).  The lam2-rate terms stay on the device for btf_draw_lam2. */
+int btf_queue_Tau2(btf_ctx* ctx, uint64_t seed, double stability);
+/* ... and the NEXT drawing btf_draw_scalars launch also draws lam2 | rest (a second workgroup of that launch; the
+ * lam2-rate terms must be on the device by then: a Tau2 update queued with btf_queue_Tau2, or btf_resample_Tau2). */
+int btf_queue_lam2(btf_ctx* ctx, uint64_t seed, int compat);
 int btf_set_nu2(btf_ctx* ctx, double nu2);               /* Gaussian scalar noise variance */
 /* Device-resident scalar hyper-parameters (rng="device" only, unsharded
  * contexts).  After btf_device_scalars(ctx,1) the half-sweep, prior-band and Tau2 kernels read
