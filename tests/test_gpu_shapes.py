@@ -14,7 +14,11 @@ def make_case(N, M, T, R, K, tf, missing, seed):
     Wt = rs.normal(size=(N, K))
     Vt = 0.3 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
     Y = np.einsum("nk,mtk->nmt", Wt, Vt)[..., None] + rs.normal(0, 0.7, size=(N, M, T, R))
-    if missing:
+    if missing == "curves":                 # counts constant along the depth axis: the curve-counts form
+        Y[rs.rand(N, M) < 0.15] = np.nan
+        Y[rs.rand(N, M) < 0.1, :, 0] = np.nan
+        Y[0, min(1, M - 1)] = np.nan
+    elif missing:
         Y[rs.rand(N, M, T, R) < 0.2] = np.nan
         Y[0, min(1, M - 1)] = np.nan
     if R == 1 and seed % 2:
@@ -51,6 +55,12 @@ CASES = [
     (7, 2, 4, 2, 5, 2, False),
     (9, 2, 8, 2, 3, 2, False),      # T = 2(tf+1)+2: smallest depth the twisted kernel takes
     (9, 2, 7, 2, 3, 2, False),      # one less: single chain
+    (600, 2, 6, 2, 3, 1, False),    # w_solve with 16 rows per workgroup
+    (1100, 2, 6, 1, 5, 2, True),    # ... 32, weighted
+    (2100, 3, 5, 2, 2, 1, False),   # ... 64
+    (40, 9, 12, 3, 5, 2, "curves"), # whole / thinned curves missing: complete-data kernels plus corrections
+    (600, 5, 8, 2, 3, 1, "curves"),
+    (23, 70, 9, 2, 8, 2, "curves"), # more deficient columns than one side workgroup takes; K = 8
 ]
 
 
@@ -76,7 +86,10 @@ def test_half_sweeps_match_oracle(N, M, T, R, K, tf, missing, variant):
     orc.w_step(ost, Y, z=zw)
     assert relerr(model.W, ost["W"]) < 1e-10
     spectral = model.v_sampler() == "spectral"
-    assert spectral == (variant == "spectral" and not missing)      # weighted data falls back to the banded sampler
+    # weighted data falls back to the banded sampler; curve counts keep the spectral one
+    assert spectral == (variant == "spectral" and missing in (False, "curves"))
+    if missing == "curves":
+        assert model.likelihood_form() == ("curve_counts" if variant in ("banded", "banded_nopanel", "spectral") else "weighted")
     orc.v_step(ost, Y, Delta, z=zv, perm="spectral" if spectral else orc.perm_from_order(model.v_order(), K, T))
     assert relerr(model.V, ost["V"]) < 1e-8
     # nu2 statistics on the new state
