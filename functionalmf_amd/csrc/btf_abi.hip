@@ -1211,7 +1211,12 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
   hipError_t e = hipSuccess;
   bool handled = false;
   const bool fast = choice >= 0;
-  if (fast) {
+  // the twisted kernel builds the prior band itself from the fixed-slot stencil (as the spectral one does)
+  const int tw_npl = std::max(1, ((bw - 1) * (bw - 2) / 2 + WAVE - 1) / WAVE);      // (dispatch_vbanded_twist's own test)
+  const bool tw_handles = bw <= 15 ? tw_npl <= 2 : (tw_npl >= 2 && tw_npl <= 8);
+  const bool own_prior = choice == 2 && tw_handles && c->st_dense_ok && c->st_drow && (c->TF + 2) * T >= c->nD;
+  if (own_prior) { a.st_drow = c->st_drow; a.st_dcoef = c->st_dcoef; a.pband = nullptr; }
+  if (fast && !own_prior) {
     const int TD1 = T * D1;
     if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; }
     {   // rebuilt on every call, as the reference rebuilds Q_prior per column (factor.py:404-405)

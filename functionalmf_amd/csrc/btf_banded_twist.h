@@ -25,7 +25,7 @@ constexpr int VT_THREADS = 256;
 
 struct TwLayout {
   VbLayout L, R, S;      // left chain, right chain, separator: views for the shared routines
-  int m0, zs, P, Ql, flag;
+  int m0, zs, P, Ql, flag, itau;
   int total;
   int ts, nl, nr, ns, nL, nR;
 };
@@ -70,6 +70,7 @@ __host__ __device__ inline TwLayout tw_layout(int T, int K, int TF, int weighted
   W.P = o; o += T * D1;
   W.Ql = o; o += weighted ? T * KK : KK;
   W.flag = o; o += 8;
+  W.itau = o; o += (TF + 2) * T;            // 1 / (lam2 Tau2_jr) per penalty row (at most (tf+2) T rows)
   W.total = o;
   return W;
 }
@@ -132,6 +133,28 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
       fdst[u] = f.x; fsrc[u] = f.y; fdia[u] = f.z;
     }
   }
+  // prior band built here (no prior_band_kernel launch): 1 / (lam2 Tau2) per penalty row into LDS, and the fixed-slot
+  // stencil of this thread's band entry (t, d) = tid into registers - all in the same round trip as the loads below
+  const bool fuse_prior = a.pband == nullptr;
+  double* itau = lds + W.itau;
+  int prow[PB_MAXE], pcnt = 0;
+  double pcf[PB_MAXE], pacc = 0.0;
+  if (fuse_prior) {
+    for (int r = tid; r < a.nD; r += VT_THREADS) itau[r] = 1.0 / (a.lam2 * a.Tau2[(size_t)jg * a.nD + r]);
+    if (tid < T * D1) {
+      pcnt = a.st_ptr[tid + 1] - a.st_ptr[tid];
+#pragma unroll
+      for (int u = 0; u < PB_MAXE; u += 4) {
+        const int4 r4 = *reinterpret_cast<const int4*>(a.st_drow + (size_t)tid * PB_MAXE + u);
+        prow[u] = r4.x; prow[u + 1] = r4.y; prow[u + 2] = r4.z; prow[u + 3] = r4.w;
+      }
+#pragma unroll
+      for (int u = 0; u < PB_MAXE; u += 2) {
+        const double2 c2 = *reinterpret_cast<const double2*>(a.st_dcoef + (size_t)tid * PB_MAXE + u);
+        pcf[u] = c2.x; pcf[u + 1] = c2.y;
+      }
+    }
+  }
   double gx[8];
   const bool g_early = !a.weighted && gram_early_ok(a.ngp, KK);     // Gram partials: fetched now, summed below
   if (g_early) reduce_gram_fetch(a.gpart, a.ngp, KK, gx);
@@ -148,10 +171,12 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     // (the prior band of this column rides in the same batch of loads: issued any earlier, the register-starved
     //  compiler sinks it below the Gram reduction and a second global round trip shows up)
     double pb_reg[4];
+    if (!fuse_prior) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + u * VT_THREADS;
-      pb_reg[u] = idx < T * D1 ? a.pband[(size_t)j * T * D1 + idx] : 0.0;
+      for (int u = 0; u < 4; ++u) {
+        const int idx = tid + u * VT_THREADS;
+        pb_reg[u] = idx < T * D1 ? a.pband[(size_t)j * T * D1 + idx] : 0.0;
+      }
     }
     double s0 = 0.0, s1 = 0.0;
     int c = 0;
@@ -164,18 +189,34 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     for (; c < a.nch; ++c) { s0 += p0[(size_t)c * st]; s1 += p1[(size_t)c * st]; }
     if (h0) m0[t0 * K + k0] = s0 * a.s;
     if (h1) m0[t1 * K + k1] = s1 * a.s;
+    if (!fuse_prior) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + u * VT_THREADS;
-      if (idx < T * D1) P[idx] = pb_reg[u];
+      for (int u = 0; u < 4; ++u) {
+        const int idx = tid + u * VT_THREADS;
+        if (idx < T * D1) P[idx] = pb_reg[u];
+      }
+      for (int idx = tid + 4 * VT_THREADS; idx < T * D1; idx += VT_THREADS) P[idx] = a.pband[(size_t)j * T * D1 + idx];
     }
-    for (int idx = tid + 4 * VT_THREADS; idx < T * D1; idx += VT_THREADS) P[idx] = a.pband[(size_t)j * T * D1 + idx];
   } else {
     for (int idx = tid; idx < n; idx += VT_THREADS) {
       const int t = idx / K, k = idx - t * K;
       m0[idx] = chunk_sum(a.part + (size_t)k * a.ld + (size_t)j * T + t) * a.s;
     }
-    for (int idx = tid; idx < T * D1; idx += VT_THREADS) P[idx] = a.pband[(size_t)j * T * D1 + idx];
+    if (!fuse_prior)
+      for (int idx = tid; idx < T * D1; idx += VT_THREADS) P[idx] = a.pband[(size_t)j * T * D1 + idx];
+  }
+  if (fuse_prior) {
+    // prior band P[t][d] = sum_r Delta[r,t] Delta[r,t+d] / (lam2 Tau2_jr), rows ascending (factor.py:404-405): the
+    // reciprocal once per penalty row, this thread's entry from its fixed-slot stencil (fetched above, with everything else)
+    __syncthreads();                                       // itau complete
+#pragma unroll
+    for (int u = 0; u < PB_MAXE; ++u) if (u < pcnt) pacc = fma(pcf[u], itau[prow[u]], pacc);
+    if (tid < T * D1) P[tid] = pacc;
+    for (int idx = tid + VT_THREADS; idx < T * D1; idx += VT_THREADS) {
+      double sacc = 0.0;
+      for (int e = a.st_ptr[idx]; e < a.st_ptr[idx + 1]; ++e) sacc = fma(a.st_coef[e], itau[a.st_row[e]], sacc);
+      P[idx] = sacc;
+    }
   }
   if (a.weighted) {
     // per-depth likelihood blocks: element e = q*T + t, so that consecutive lanes read consecutive depths of one

@@ -809,7 +809,10 @@ struct VBandArgs {
   int nfill;           // multiple of the workgroup size (padded with writes to a dummy word)
   CurveLists cv;       // curve-structured counts: deficient rows of every column (global column index), or ptr == nullptr
   const double* cv_W;  // the factor W (rows of the rank-one terms)
+  const int* st_drow; const double* st_dcoef;   // the stencil with VS_MAXE fixed slots per (t,d): the twisted kernel builds
+                                                // its prior band itself when pband == nullptr (no prior_band_kernel launch)
 };
+constexpr int PB_MAXE = 16;                     // (= VS_MAXE of btf_spectral.h)
 __device__ __forceinline__ void vband_load_hyp(VBandArgs& a) {
   if (a.hyp) {
     if (a.hyp_noise) { a.s = 1.0 / a.hyp[HYP_NU2]; a.sR = a.s * a.Rrep; }
