@@ -40,6 +40,9 @@ def test_w_step_vs_reference(golden, name, seed):
     np.random.seed(seed)                      # same legacy stream the reference consumed
     model._resample_W(g["Y"])
     assert relerr(model.W, g["W_after"]) < W_TOL
+    # G1: held-out whole curves -> complete-data kernels plus corrections; G2 complete; G3 (replicates missing at
+    # single depths) the per-cell weighted form
+    assert model.likelihood_form() == {"g1": "curve_counts", "g2": "complete", "g3": "weighted"}[name[:2]]
 
 
 @pytest.mark.parametrize("kernel", ["twist", "fast", "generic"])
@@ -55,6 +58,7 @@ def test_v_step_vs_reference(golden, name, seed, kernel):
     T, K = model.ndepth, model.nembeds
     from oracle import btf_oracle as orc
     if kernel == "twist":        # the declared elimination order of the default kernel
+        assert model.likelihood_form() == {"g1": "curve_counts", "g2": "complete", "g3": "weighted"}[name[:2]]
         assert np.array_equal(model.v_order(), orc.twisted_order(K, T, 2))
         assert relerr(model.V, g["V_after_twist"]) < V_TOL
     else:
