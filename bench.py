@@ -277,11 +277,15 @@ def main():
     value = sweeps_per_s * units
 
     # algorithmic bytes: the local slab of the linear statistic once per accumulation launch
-    # (8 B/cell complete data; + a byte of replicate count with missing data; + f64 weights for Binomial)
+    # (8 B/cell complete data; + a byte of replicate count with missing data; Binomial: f64 weights + the pseudo-data
+    #  as one byte when the counts are integers, else as f64) - asked of the context, which knows what it streams
     cells_local = (N // world if world > 1 else N) * M * T
     cells_local_v = N * (M // world if world > 1 else M) * T
     form = model.likelihood_form()     # "curve_counts": held-out whole curves run the complete-data stream (no counts read)
-    bpc = 8.0 if form in ("complete", "curve_counts") else ({"heldout": 9.0, "curves5": 9.0, "missing5": 9.0}.get(args.variant, 16.0))
+    import ctypes as _C
+    _b = _C.c_double()
+    model._ctx.call("btf_get_accum_bytes_per_cell", _C.byref(_b))
+    bpc = _b.value                     # 8: statistic alone; 9: + byte counts, or byte pseudo-data + f64 weights; 16: f64 + f64
     acc_ms = kt["w_accum"][0] + kt["v_accum"][0]
     acc_n = kt["w_accum"][1] + kt["v_accum"][1]
     acc_us = 1e3 * acc_ms / max(acc_n, 1)

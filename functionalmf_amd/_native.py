@@ -108,6 +108,7 @@ SIGNATURES = {
     "btf_mvn_dense": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp, _c_dp, C.c_uint64, C.c_double, C.c_int,
                                 _c_dp, _c_ip]),
     "btf_get_likelihood_form": (C.c_int, [_ctx, _c_ip]),
+    "btf_get_accum_bytes_per_cell": (C.c_int, [_ctx, _c_dp]),
     "btf_get_V_sampler": (C.c_int, [_ctx, _c_ip]),
 }
 

@@ -39,6 +39,7 @@ struct btf_ctx {
   double* A_wT = nullptr; double* C_wT = nullptr; double* A_v = nullptr; double* C_v = nullptr;
   double* B_wT = nullptr; double* B_v = nullptr;   // binomial: trials (0 where missing)
   unsigned char* C8_wT = nullptr; unsigned char* C8_v = nullptr;   // Gaussian data with missing replicates: counts as bytes (C_* freed)
+  signed char* A8_wT = nullptr; signed char* A8_v = nullptr;       // Binomial data with integer counts: 2 (Y - N/2) as bytes
   double* W = nullptr; double* V = nullptr;
   double* Tau2 = nullptr;
   double lam2 = 1.0, sigma2 = 1.0, nu2 = 1.0;
@@ -290,6 +291,12 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
   const int cpw = TAU_SIDE_CPW;
   dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 + eig_side_groups(sidec.ncols, acc_waves(K, mode)) : 0) +
             (tau.Tau2 ? (tau.M + cpw - 1) / cpw : 0));   // (+ the side tasks' workgroups)
+  const signed char* A8 = (mode >= 1 && !C8 && X == c->A_wT) ? c->A8_wT : ((mode >= 1 && !C8 && X == c->A_v) ? c->A8_v : nullptr);
+  if (A8) {                    // Binomial pseudo-data as bytes (f64 weights)
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), double, signed char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), double, signed char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
+    return;
+  }
   if (mode >= 1 && C8) {       // byte weights (Gaussian replicate counts)
     if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
     else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
@@ -706,7 +713,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->A8_wT, c->A8_v, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
@@ -800,6 +807,8 @@ static int finish_data(btf_ctx* c) {
   HIPCHK(c, hipMemcpy(&flag, c->status + 2, sizeof(int), hipMemcpyDeviceToHost));
   c->weighted = c->binomial || flag != 0;
   c->curve = false; c->cv_cij.clear();
+  if (c->A8_wT) { (void)hipFree(c->A8_wT); c->A8_wT = nullptr; }
+  if (c->A8_v) { (void)hipFree(c->A8_v); c->A8_v = nullptr; }
   if (c->C8_wT) { (void)hipFree(c->C8_wT); c->C8_wT = nullptr; }
   if (c->C8_v) { (void)hipFree(c->C8_v); c->C8_v = nullptr; }
   if (!c->weighted) {  // complete Gaussian data: counts are the constant R, drop them
@@ -881,7 +890,21 @@ int btf_set_data_binomial(btf_ctx* c, const double* succ_rows, const double* tri
   // until the first PG draw / set_omega the weights are zero
   HIPCHK(c, hipMemset(c->C_wT, 0, (size_t)MT * c->ldw * sizeof(double)));
   HIPCHK(c, hipMemset(c->C_v, 0, (size_t)c->N * c->ldv * sizeof(double)));
-  return finish_data(c);
+  if ((rc = finish_data(c))) return rc;
+  {   // integer counts: the pseudo-data kappa = Y - N/2 as one byte per cell for the accumulation launches
+    const size_t ew = (size_t)MT * c->ldw, ev = (size_t)c->N * c->ldv;
+    if ((rc = dev_alloc(c, &c->A8_wT, ew))) return rc;
+    if ((rc = dev_alloc(c, &c->A8_v, ev))) return rc;
+    HIPCHK(c, hipMemcpy(c->status + 3, &zero, sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kappa_to_i8_kernel, dim3((unsigned)std::min<size_t>(4096, (ew + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->A_wT, c->A8_wT, ew, c->status + 3);
+    hipLaunchKernelGGL(kappa_to_i8_kernel, dim3((unsigned)std::min<size_t>(4096, (ev + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->A_v, c->A8_v, ev, c->status + 3);
+    HIPCHK(c, hipGetLastError());
+    int bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad, c->status + 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bad) { (void)hipFree(c->A8_wT); (void)hipFree(c->A8_v); c->A8_wT = nullptr; c->A8_v = nullptr; }
+  }
+  return BTF_OK;
 }
 
 int btf_set_stale_sources(btf_ctx* c, const int32_t* src_row, const int32_t* src_col) {
@@ -2637,6 +2660,16 @@ int btf_get_likelihood_form(btf_ctx* c, int32_t* form) {
   if (!c || !form) return BTF_EINVAL;
   if (!c->have_data) return fail(c, BTF_ESTATE, "set data first");
   *form = !c->weighted ? BTF_LIK_COMPLETE : (curve_on(c) ? BTF_LIK_CURVE_COUNTS : BTF_LIK_WEIGHTED);
+  return BTF_OK;
+}
+
+int btf_get_accum_bytes_per_cell(btf_ctx* c, double* bytes) {
+  if (!c || !bytes) return BTF_EINVAL;
+  if (!c->have_data) return fail(c, BTF_ESTATE, "set data first");
+  if (!lik_weighted(c)) *bytes = 8.0;                                 // the linear statistic alone
+  else if (c->C8_wT) *bytes = 9.0;                                    // + replicate counts as bytes
+  else if (c->A8_wT) *bytes = 9.0;                                    // pseudo-data as bytes + f64 weights
+  else *bytes = 16.0;
   return BTF_OK;
 }
 

@@ -162,9 +162,11 @@ __host__ __device__ constexpr int acc_waves(int K, int MODE) { return MODE >= 1 
 
 // CT: storage type of the weights C: double (Binomial: the Polya-Gamma draws) or unsigned char (Gaussian data with
 // missing replicates: C is the replicate count 0..R, 1 byte instead of 8 per cell: 9 instead of 16 B/cell)
-template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double>
+// XT: storage type of the linear statistic X: double, or signed char for Binomial pseudo-data kappa = Y - N/2 with
+// integer counts (2 kappa in -127..127 stored, 1 byte instead of 8 per cell: 9 instead of 16 B/cell with f64 weights)
+template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double, typename XT = double>
 __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
-    const double* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
+    const XT* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
     int rows_per_block, EigSide side, EigSideCols sidec, TauSide tau) {
   constexpr int KK = tri(K);
@@ -251,7 +253,12 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
         for (int k = 0; k < K; ++k) R.uk[u][k] = up[k];
       }
       if (FULL || r < r1) {
-        R.x[u] = *reinterpret_cast<const double2*>(X + (size_t)r * ld + col);
+        if constexpr (sizeof(XT) == 1) {
+          const char2 xx = *reinterpret_cast<const char2*>(X + (size_t)r * ld + col);
+          R.x[u] = make_double2(0.5 * (double)xx.x, 0.5 * (double)xx.y);
+        } else {
+          R.x[u] = *reinterpret_cast<const double2*>(X + (size_t)r * ld + col);
+        }
         if constexpr (MODE >= 1) {
           if constexpr (sizeof(CT) == 1) {
             const uchar2 cc = *reinterpret_cast<const uchar2*>(Cx + (size_t)r * ld + col);
@@ -1237,6 +1244,18 @@ __global__ void relayout_kernel(const double* src, int rows, int cols, double* d
     if (zero_nan && !(v == v)) v = 0.0;
     dst[transposed ? col * ld + row : row * ld + col] = v;
   }
+}
+
+// Binomial pseudo-data kappa = Y - N/2 as bytes: dst = 2 kappa when every value is an integer in -127..127
+// (*bad is set otherwise and the f64 array stays in use)
+__global__ void kappa_to_i8_kernel(const double* __restrict__ src, signed char* __restrict__ dst, size_t n, int* __restrict__ bad) {
+  bool b = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double h = 2.0 * src[i];
+    b |= !(h == floor(h)) || h > 127.0 || h < -127.0;
+    dst[i] = (signed char)h;
+  }
+  if (b) *bad = 1;
 }
 
 __global__ void f64_to_u8_kernel(const double* __restrict__ src, unsigned char* __restrict__ dst, size_t n) {

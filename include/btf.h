@@ -265,6 +265,10 @@ int btf_read_probe(int device, size_t bytes, int reps, double* gb_per_s);
  *                         per-column corrections (BTF_OPT_CURVE_COUNTS) - the same conditionals as the weighted form */
 enum { BTF_LIK_COMPLETE = 0, BTF_LIK_WEIGHTED = 1, BTF_LIK_CURVE_COUNTS = 2 };
 int btf_get_likelihood_form(btf_ctx* ctx, int32_t* form);
+/* Algorithmic bytes per cell one accumulation launch streams for the bound data: 8 (linear statistic alone: complete data,
+ * curve counts), 9 (+ replicate counts as bytes; or Binomial pseudo-data kappa = Y - N/2 as bytes + f64 weights when
+ * the counts are integers up to 127), 16 (f64 statistic + f64 weights).  bench.py's roofline uses it. */
+int btf_get_accum_bytes_per_cell(btf_ctx* ctx, double* bytes);
 
 /* warm_from: NULL (cyclic Jacobi from the identity) or the `out` of a nearby matrix, refined by the
  * Ogita-Aishima iteration (the path the sampler takes from the second sweep on; out[K+K*K] = 0 then). */
