@@ -1543,6 +1543,40 @@ __device__ __forceinline__ double pg_draw_exact(double b, double psi, CellRng& g
   return sum;
 }
 
+// The candidate loop of the series sampler draws ~10 words per cell; Philox4x32-10 costs twenty 32 x 32 -> 64
+// multiplies (quarter rate) per four of them - two thirds of that loop.  xoshiro128++ (Blackman & Vigna), seeded
+// per cell from ONE Philox block of the same (seed, cell) key, gives a word in a dozen full-rate integer
+// instructions; the stream is still a function of (seed, global cell) alone, so layouts and shardings see the same draws.
+struct FastRng {
+  uint32_t s0, s1, s2, s3;
+  float sparef;
+  bool has_spare;
+  __device__ FastRng(uint64_t seed, uint64_t cell) : sparef(0.0f), has_spare(false) {
+    uint32_t r[4];
+    Philox::gen(seed, cell, 0x78736f7368ULL << 16, r);      // a counter no CellRng reaches
+    s0 = r[0]; s1 = r[1]; s2 = r[2]; s3 = r[3] | 1u;         // never the all-zero state
+  }
+  __device__ __forceinline__ uint32_t next() {
+    const uint32_t sum = s0 + s3;
+    const uint32_t result = ((sum << 7) | (sum >> 25)) + s0;
+    const uint32_t t = s1 << 9;
+    s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t;
+    s3 = (s3 << 11) | (s3 >> 21);
+    return result;
+  }
+  __device__ __forceinline__ float uniform32f() { return ((float)(next() >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+  __device__ __forceinline__ float normal32f() {            // f32 Box-Muller as CellRng::normal32f
+    if (has_spare) { has_spare = false; return sparef; }
+    const uint32_t lo = next(), hi = next();
+    const float u1 = ((float)(lo >> 1) + 0.5f) * (1.0f / 2147483648.0f);
+    const float u2 = (float)(hi >> 8) * (1.0f / 16777216.0f);
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    sparef = r * __builtin_amdgcn_sinf(u2);
+    has_spare = true;
+    return r * __builtin_amdgcn_cosf(u2);
+  }
+};
+
 __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& g) {
   // any other b: PG(b, psi) = 1/(2 pi^2) sum_k g_k / ((k-1/2)^2 + c2), g_k ~ Gamma(b, 1), c2 = psi^2/(4 pi^2).
   // The first NT terms are drawn; the remainder - a sum of many comparably small independent terms -
@@ -1553,6 +1587,7 @@ __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& 
   // the weights are flat up to k ~ sc: start the tail only where they decay (k^-2)
   const int NT = min(PG_SERIES_NT_MAX, (b >= 3.0 ? PG_SERIES_NT / 4 : PG_SERIES_NT) + (int)(2.0 * sc));
   double s = 0.0;
+  FastRng f(g.seed, g.cell);         // (the candidate loop and the remainder's normal)
   if (b < 1.0) {
     for (int k = 1; k <= NT; ++k) s += gamma_mt<true>(b, g) / ((k - 0.5) * (k - 0.5) + c2);
   } else {
@@ -1574,10 +1609,10 @@ __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& 
     int k = 1;
     float wk = weight(1);
     while (k <= NT) {
-      const float xf = g.normal32f();
+      const float xf = f.normal32f();
       const float v1 = fmaf(ccf, xf, 1.0f);
       const float vf = v1 * v1 * v1;
-      const float lnu = 0.69314718f * __builtin_amdgcn_logf(g.uniform32f());
+      const float lnu = 0.69314718f * __builtin_amdgcn_logf(f.uniform32f());
       const float rhs = 0.5f * xf * xf + df * (1.0f - vf + 0.69314718f * __builtin_amdgcn_logf(vf));
       if (v1 > 0.0f && lnu < rhs) {
         s += (double)(vf * wk);
@@ -1606,7 +1641,7 @@ __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& 
     tvar -= NTf / (6.0f * q2 * q2 * q2);
   }
   const float bf = (float)b;
-  const double x = s + (double)(bf * tmean + __builtin_amdgcn_sqrtf(bf * tvar) * g.normal32f());
+  const double x = s + (double)(bf * tmean + __builtin_amdgcn_sqrtf(bf * tvar) * f.normal32f());
   return fmax(x, 1e-300) / (2.0 * PG_PI * PG_PI);
 }
 
