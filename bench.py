@@ -267,8 +267,11 @@ def main():
         model.resample(data)
     fence()
     t0 = time.perf_counter()
-    for _ in range(nfull):
-        model.resample(data)
+    if hasattr(model, "resample_sweeps"):
+        model.resample_sweeps(data, nfull)      # one GPU, rng="device": the sweeps are queued by the C side (btf_gibbs_sweeps);
+    else:                                       # otherwise this is the same loop of resample() calls
+        for _ in range(nfull):
+            model.resample(data)
     fence()
     full_per_s = nfull / (time.perf_counter() - t0)
 

@@ -1731,6 +1731,30 @@ int btf_gass_run(btf_ctx* c, int what, int link, uint64_t seed, int ngrid, doubl
   return btf_gass_select(c, what, seed, nullptr);
 }
 
+// n whole Gibbs sweeps of the scalar-noise Gaussian model with every draw on the device, queued from here: the order and
+// the launches of GaussianBTF.resample under rng="device" (nu2, sigma2 | Tau2 chain in the W accumulation launch | lam2 |
+// W | V; factor.py:306-311, :112-128), the five seeds of sweep s being seed_base + draws0 + 5 s + 1..5 - the sequence
+// functionalmf_amd.factor draws them in, so a chain driven from here equals one driven sweep by sweep from Python.
+int btf_gibbs_sweeps(btf_ctx* c, int n, uint64_t seed_base, uint64_t draws0, int compat, double nu2_a, double nu2_b,
+                     double sigma2_a, double sigma2_b, double stability, double eps0, int attempts) {
+  if (!c || n < 0) return BTF_EINVAL;
+  if (!c->dev_scalars || c->binomial || c->counts) return fail(c, BTF_ESTATE, "btf_gibbs_sweeps: Gaussian data with device-resident scalars");
+  if (c->nl != c->N || c->ml != c->M) return fail(c, BTF_ESTATE, "btf_gibbs_sweeps: unsharded contexts (a sharded sweep has exchanges between its steps)");
+  if (!c->have_data || !c->have_W || !c->have_V || !c->have_hyper || !c->have_chain)
+    return fail(c, BTF_ESTATE, "set data, W, V, the hyper-parameters and the horseshoe+ chain first");
+  int rc;
+  for (int s = 0; s < n; ++s) {
+    const uint64_t d = seed_base + draws0 + 5ULL * (uint64_t)s;
+    if ((rc = btf_queue_Tau2(c, d + 1, stability))) return rc;
+    if ((rc = btf_queue_lam2(c, d + 2, compat))) return rc;
+    if ((rc = btf_w_accum(c, compat))) return rc;
+    if ((rc = btf_draw_scalars(c, d + 3, 7, nu2_a, nu2_b, sigma2_a, sigma2_b))) return rc;
+    if ((rc = btf_resample_W(c, nullptr, d + 4, compat))) return rc;
+    if ((rc = btf_resample_V(c, nullptr, d + 5, compat, eps0, attempts))) return rc;
+  }
+  return BTF_OK;
+}
+
 int btf_ess_info(btf_ctx* c, int32_t* unfinished, double* ll_first) {
   if (!c || !unfinished) return BTF_EINVAL;
   if (!c->essX0 || c->ess_last_chains < 1) return fail(c, BTF_ESTATE, "no elliptical-slice run yet");

@@ -545,14 +545,28 @@ class BayesianTensorFiltering(_BayesianModel):
                                      print_freq=print_freq, callback=callback, **kwargs)
         self._ctx.call("btf_collect_begin", int(nsamples))
         self._collected = 0
-        for step in range(nburn + nthin * nsamples):
-            if verbose and step % print_freq == 0:
-                print('\tStep {}'.format(step))
-            self.resample(data, **kwargs)
-            kept, rem = divmod(step - nburn, nthin)
-            if step >= nburn and rem == 0:
-                self._push_state()                     # (anything the caller touched between sweeps)
+        if self._sweeps_on_device():
+            # whole sweeps queued by the C side (btf_gibbs_sweeps): the same chain as the loop below, without a
+            # Python round trip per step
+            done = 0
+            for kept in range(nsamples):
+                target = nburn + kept * nthin + 1
+                while done < target:
+                    n = min(target - done, max(1, print_freq - done % print_freq)) if verbose else target - done
+                    if verbose and done % print_freq == 0:
+                        print('\tStep {}'.format(done))
+                    self.resample_sweeps(data, n)
+                    done += n
                 self._ctx.call("btf_collect", kept)
+        else:
+            for step in range(nburn + nthin * nsamples):
+                if verbose and step % print_freq == 0:
+                    print('\tStep {}'.format(step))
+                self.resample(data, **kwargs)
+                kept, rem = divmod(step - nburn, nthin)
+                if step >= nburn and rem == 0:
+                    self._push_state()                     # (anything the caller touched between sweeps)
+                    self._ctx.call("btf_collect", kept)
         N, M, T, K, nD = self.nrows, self.ncols, self.ndepth, self.nembeds, self.Delta.shape[0]
         out = {"W": np.zeros((nsamples, N, K)), "V": np.zeros((nsamples, M, T, K)), "Tau2": np.zeros((nsamples, M, nD))}
         sc = np.zeros((nsamples, 8))
@@ -561,6 +575,9 @@ class BayesianTensorFiltering(_BayesianModel):
         self._collected = nsamples
         out["nu2"], out["sigma2"], out["lam2"] = sc[:, 0:1].copy(), sc[:, 1:2].copy(), sc[:, 2:3].copy()
         return out
+
+    def _sweeps_on_device(self):
+        return False
 
     def posterior_summary(self, q=(5, 95), transform=None):
         """Mean and percentiles of f(W V') over the samples the last device-collecting run_gibbs kept,
@@ -689,6 +706,37 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
             super().resample(data)
         finally:
             self._in_sweep = False
+
+    def _sweeps_on_device(self):
+        """Can n whole sweeps be queued by one C call (btf_gibbs_sweeps)?  Every parameter sampled, all of them on the
+        device, one GPU."""
+        return bool(self._dev_scalars and self._scalar_noise and self.fuse_tau2 and not self._exchange.active
+                    and self._plan.world == 1 and hasattr(self, "_Tau2_a") and type(self).resample is GaussianBayesianTensorFiltering.resample
+                    and all((self.sample_nu2, self.sample_sigma2, self.sample_Tau2, self.sample_lam2, self.sample_W, self.sample_V)))
+
+    def resample_sweeps(self, data, n):
+        """n sweeps of resample(data); with rng="device" on one GPU they are queued by a single call into the C side
+        (the same launches and seeds as n calls of resample: the chains coincide)."""
+        if not self._sweeps_on_device():
+            for _ in range(int(n)):
+                self.resample(data)
+            return
+        self._bind_data(data)
+        self._push_state()
+        if getattr(self, "_chain_dirty", True):
+            for nm in ("_Tau2_a", "_Tau2_b", "_Tau2_c"):
+                setattr(self, nm, _native.as_f64(getattr(self, nm)))
+            self._ctx.call("btf_set_tau_chain", _native.dptr(self._Tau2_a), _native.dptr(self._Tau2_b), _native.dptr(self._Tau2_c))
+            self._chain_dirty = False
+        self._push_scalars()
+        o = self.linalg_opts
+        self._ctx.call("btf_gibbs_sweeps", int(n), (self._device_seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF, int(self._draws),
+                       _native.COMPAT[self.compat], float(self.nu2_a), float(self.nu2_b), float(self.sigma2_a), float(self.sigma2_b),
+                       float(self.stability), float(o["force_psd_eps"]), int(o["force_psd_attempts"]) if o["force_psd"] else 0)
+        self._draws += 5 * int(n)
+        self._W_dev_new = self._V_dev_new = self._sc_dev_new = True
+        self._tau_dev_new, self._tau_dirty = True, False
+        self._lsum_valid = self._lsum_on_device = False
 
     def _set_noise(self):
         if not self._dev_scalars:

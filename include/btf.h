@@ -181,6 +181,14 @@ int btf_queue_Tau2(btf_ctx* ctx, uint64_t seed, double stability);
 /* ... and the NEXT drawing btf_draw_scalars launch also draws lam2 | rest (a second workgroup of that launch; the
  * lam2-rate terms must be on the device by then: a Tau2 update queued with btf_queue_Tau2, or btf_resample_Tau2). */
 int btf_queue_lam2(btf_ctx* ctx, uint64_t seed, int compat);
+
+/* n whole Gibbs sweeps (nu2, sigma2, Tau2 chain, lam2, W, V: GaussianBTF.resample, factor.py:306-311 over :112-128)
+ * queued by one call: scalar-noise Gaussian data, device-resident scalars, unsharded.  Seeds: sweep s uses
+ * seed_base + draws0 + 5 s + k, k = 1..5 for (Tau2, lam2, nu2/sigma2, W, V) - the sequence the Python driver
+ * consumes (functionalmf_amd/factor.py:_next_seed), so both drivers walk the same chain.  Nothing is read back;
+ * errors of the factorisations surface at the next btf_sync. */
+int btf_gibbs_sweeps(btf_ctx* ctx, int nsweeps, uint64_t seed_base, uint64_t draws0, int compat, double nu2_a, double nu2_b,
+                     double sigma2_a, double sigma2_b, double stability, double eps0, int attempts);
 int btf_set_nu2(btf_ctx* ctx, double nu2);               /* Gaussian scalar noise variance */
 /* Device-resident scalar hyper-parameters (rng="device" only, unsharded
  * contexts).  After btf_device_scalars(ctx,1) the half-sweep, prior-band and Tau2 kernels read

@@ -15,8 +15,7 @@ for (N, M, T, R, K, tf, sweeps) in ((64, 32, 16, 2, 3, 2, 20000), (512, 256, 64,
     np.random.seed(1)
     m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=0.5, lam2_init=0.1, nu2_init=1.0, rng="device")
     t0 = time.time()
-    for s in range(sweeps):
-        m.resample(Y)
+    m.resample_sweeps(Y, sweeps)
     m.sync()
     dt = time.time() - t0
     ok = np.isfinite(m.W).all() and np.isfinite(m.V).all() and np.isfinite(m.Tau2).all()

@@ -1558,3 +1558,39 @@ def test_constrained_poisson_example_runs_end_to_end():
     spec.loader.exec_module(mod)
     rel_in, rel_out, corr, feasible = mod.main(seed=1, nburn=400, nsamples=200)
     assert feasible and corr > 0.8 and rel_in < 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["g2_c2_complete.npz", "g1_c1_heldout.npz", "g3_partial_reps.npz"])
+def test_c_driven_sweeps_walk_the_python_driven_chain(golden, name, monkeypatch):
+    """btf_gibbs_sweeps queues whole sweeps from the C side with the seed sequence the Python driver consumes: the two
+    chains - and two run_gibbs result dicts - must be bit-identical."""
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    g = golden(name)
+    N, M, T, R, K, tf = [int(x) for x in g["dims"]]
+    st = state_from(g, "s0_")
+
+    def make():
+        np.random.seed(11)
+        return GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                               nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], rng="device", device_seed=5)
+    a, b = make(), make()
+    assert b._sweeps_on_device()
+    for _ in range(7):
+        a.resample(g["Y"])
+    b.resample_sweeps(g["Y"], 3)
+    b.resample_sweeps(g["Y"], 4)
+    for x, y in ((a.W, b.W), (a.V, b.V), (a.Tau2, b.Tau2)):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert (a.nu2, a.sigma2, a.lam2) == (b.nu2, b.sigma2, b.lam2)
+    a.resample(g["Y"])
+    b.resample(g["Y"])                       # the drivers can be mixed
+    assert np.array_equal(a.V, b.V)
+    # run_gibbs: the C-driven loop against the step-by-step one
+    c, d = make(), make()
+    monkeypatch.setattr(d, "_sweeps_on_device", lambda: False)
+    rc = c.run_gibbs(g["Y"], nburn=3, nthin=2, nsamples=4, verbose=False)
+    rd = d.run_gibbs(g["Y"], nburn=3, nthin=2, nsamples=4, verbose=False)
+    assert set(rc) == set(rd)
+    for k in rc:
+        assert np.array_equal(rc[k], rd[k]), k
