@@ -1594,3 +1594,63 @@ def test_c_driven_sweeps_walk_the_python_driven_chain(golden, name, monkeypatch)
     assert set(rc) == set(rd)
     for k in rc:
         assert np.array_equal(rc[k], rd[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ntrials", [4, 150, 2.5])
+def test_binomial_pseudo_data_bytes_and_fallback(ntrials):
+    """Integer counts up to 127 stream the pseudo-data kappa = Y - N/2 as one byte per cell (9 B/cell); larger or
+    non-integer trial counts keep the f64 array (16 B/cell).  Either way the weighted half-sweeps given omega equal
+    the oracle's (factor.py:437-460 with :343-346 / :388-391)."""
+    import ctypes
+    from oracle import btf_oracle as orc
+    from functionalmf_amd.factor import BinomialBayesianTensorFiltering
+    rs = np.random.RandomState(17)
+    N, M, T, K, tf = 14, 6, 10, 3, 2
+    Wt = rs.normal(size=(N, K))
+    Vt = 0.3 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    p = 1 / (1 + np.exp(-np.einsum("nk,mtk->nmt", Wt, Vt)))
+    Ntr = np.full((N, M, T), float(ntrials))
+    Ys = rs.binomial(int(np.ceil(ntrials)), p).astype(float) * (ntrials / np.ceil(ntrials))
+    Ys[:2, :2] = np.nan
+    Ntr[:2, :2] = np.nan
+    st = dict(W=rs.normal(size=(N, K)), V=0.2 * rs.normal(size=(M, T, K)), Tau2=np.exp(rs.normal(size=(M, 3 * T - 1))), lam2=0.3,
+              sigma2=0.8)
+    st["W"][np.triu_indices(N, 1, K)] = 0
+    model = BinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                            W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], compat="exact")
+    data = (Ys, Ntr)
+    model._bind_data(data)
+    b = ctypes.c_double()
+    model._ctx.call("btf_get_accum_bytes_per_cell", ctypes.byref(b))
+    assert b.value == (9.0 if ntrials == 4 else 16.0)
+    omega = rs.gamma(2.0, 0.2, size=(N, M, T))
+    with np.errstate(divide="ignore"):
+        nu2 = np.where(np.isnan(Ys), np.inf, 1.0 / omega)
+    model.nu2 = nu2                                   # 1 / omega, as factor.py:459-460 leaves it
+    np.random.seed(9)
+    zw = np.random.normal(size=K * (K + 1) // 2 + (N - K) * K)
+    zv = np.random.normal(size=(M, K * T))
+    np.random.seed(9)
+    model._resample_W(data)
+    model._resample_V(data)
+    ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in dict(st, nu2=nu2).items()}
+    Yk = orc.binomial_kappa(Ys, Ntr, nu2)
+    # (compat="exact": every row / column with its own weights - the stale-weight quirks have their own fixtures)
+    W = ost["W"].copy()
+    Vf = ost["V"].reshape(-1, K)
+    zpos = 0
+    for i in range(N):
+        d = min(i + 1, K)
+        obs = ~np.isnan(Yk[i].reshape(-1))
+        c = np.where(obs, 1.0 / nu2[i].reshape(-1), 0.0)
+        y = np.where(obs, Yk[i].reshape(-1), 0.0)
+        Q = (Vf[:, :d] * c[:, None]).T @ Vf[:, :d] + np.eye(d) / ost["sigma2"]
+        m = (Vf[:, :d] * c[:, None]).T @ y
+        L = np.linalg.cholesky(Q)
+        W[i, :d] = np.linalg.solve(Q, m) + np.linalg.solve(L.T, zw[zpos:zpos + d])
+        zpos += d
+    assert relerr(model.W, W) < 1e-10
+    ost["W"] = W
+    orc.v_step(ost, Yk, orc.trend_penalty(T, tf), z=zv, compat="exact", perm=orc.perm_from_order(model.v_order(), K, T))
+    assert relerr(model.V, ost["V"]) < 1e-8

@@ -61,6 +61,7 @@ CASES = [
     (40, 9, 12, 3, 5, 2, "curves"), # whole / thinned curves missing: complete-data kernels plus corrections
     (600, 5, 8, 2, 3, 1, "curves"),
     (23, 70, 9, 2, 8, 2, "curves"), # more deficient columns than one side workgroup takes; K = 8
+    (31, 6, 9, 1, 4, 2, "curves"),  # 3-D input: counts 0 / 1
 ]
 
 
