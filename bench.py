@@ -67,7 +67,7 @@ def synth_V(seed, M, T, K):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 2000 for the C2 / C3-sized workloads - 90 ms of GPU time -, 200 for C5)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: c3 at --gpus 1, c5 beyond")
     ap.add_argument("--weak", action="store_true", help="N>1: weak scaling over rows (one C3-sized slab per rank) instead of the fixed C5 tensor")
@@ -116,6 +116,8 @@ def main():
     dry = os.environ.get("BTF_BENCH_DRY", "0") == "1"       # CPU rehearsal of the launch / timing / reporting plumbing
     if args.config is None:
         args.config = "c3" if (world == 1 or args.weak) else "c5"
+    if args.steps is None:
+        args.steps = 200 if args.config == "c5" else (500 if args.variant in ("binomial", "negbinom") else 2000)
 
     import torch
     import torch.distributed as dist
