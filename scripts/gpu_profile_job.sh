@@ -14,6 +14,9 @@ timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc
 echo "fetch pass done"
 timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write_$NAME -o $NAME --output-format csv -- python3 $R/bench.py $ARGS --steps 20 --warmup 2 --burn 2 > $R/gpurun_out/pmc_write_$NAME.log 2>&1 || exit 1
 echo "write pass done"
+# occupancy / stall counters of the same command (their own pass)
+timeout -k 10 900 rocprofv3 --pmc SQ_WAVES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --kernel-trace -d $R/gpurun_out/pmc_sq_$NAME -o $NAME --output-format csv -- python3 $R/bench.py $ARGS --steps 20 --warmup 2 --burn 2 > $R/gpurun_out/pmc_sq_$NAME.log 2>&1 || echo "sq pass failed (counters unavailable?)"
+echo "sq pass done"
 # the bench line kept beside the profile comes from a clean run of the same command: under rocprofv3 the HIP-event
 # timings of bench.py carry the tool's per-dispatch overhead (its own AverageNs column does not)
 cd $R && timeout -k 10 900 python3 $R/bench.py $ARGS --steps $STEPS --warmup 10 > $R/gpurun_out/bench_$NAME.log 2>/dev/null || exit 1
