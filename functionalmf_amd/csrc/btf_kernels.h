@@ -521,8 +521,10 @@ constexpr int WS_ROWS = 64;   // rows per workgroup (one per lane)
 __host__ __device__ constexpr int ws_split(int K) { return K <= 6 ? 8 : (K <= 8 ? 4 : 2); }
 // (complete data, 16 waves so that the 64 chunks of a C3 row come in with one batch of loads per wave: measured
 //  10.2 us against 8.2 us for 8 waves - the 1024-thread workgroup costs more than the second batch)
+// (with 8 rows per workgroup - 8 chunk subgroups per wave - four waves cover the 32 chunks of a C3 row with one chunk per
+//  (wave, subgroup) pair: 6.1 us against 6.35 us for eight waves; sixteen do not fit LDS)
 #ifndef BTF_WS_SPLIT_U
-#define BTF_WS_SPLIT_U 8
+#define BTF_WS_SPLIT_U 4
 #endif
 __host__ __device__ constexpr int ws_split_of(int K, bool weighted) { return weighted ? ws_split(K) : (K <= 6 ? BTF_WS_SPLIT_U : ws_split(K)); }
 // bound on the doubles of fused Gram partials a V half-sweep hands to w_solve (historically its LDS staging area)
