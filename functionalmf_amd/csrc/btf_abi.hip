@@ -286,23 +286,23 @@ template <int K>
 void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const unsigned char* C8, const double* U,
                   const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr},
                   EigSideCols sidec = EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
-                  TauSide tau = TauSide{}) {
+                  TauSide tau = TauSide{}, GramSide gram = GramSide{nullptr, 0, nullptr, 0}) {
   Prof p(c, kid);
   const int cpw = TAU_SIDE_CPW;
   dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 + eig_side_groups(sidec.ncols, acc_waves(K, mode)) : 0) +
-            (tau.Tau2 ? (tau.M + cpw - 1) / cpw : 0));   // (+ the side tasks' workgroups)
+            (tau.Tau2 ? (tau.M + cpw - 1) / cpw : 0) + (gram.gpart ? gram.nblocks : 0));   // (+ the side tasks' workgroups)
   const signed char* A8 = (mode >= 1 && !C8 && X == c->A_wT) ? c->A8_wT : ((mode >= 1 && !C8 && X == c->A_v) ? c->A8_v : nullptr);
   if (A8) {                    // Binomial pseudo-data as bytes (f64 weights)
-    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), double, signed char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
-    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), double, signed char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), double, signed char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), double, signed char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
     return;
   }
   if (mode >= 1 && C8) {       // byte weights (Gaussian replicate counts)
-    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
-    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
-  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
-  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
-  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau);
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
+  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
+  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
+  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
 }
 // which Polya-Gamma passes a draw needs: exact mode - the exact sampler alone; otherwise the series for every cell
 // that is not an integer count of 1 or 2, and the exact sampler for those (each launch only if such cells exist)
@@ -1122,11 +1122,17 @@ int w_accum_phase(btf_ctx* c, int compat) {
     use_gv = true;
   }
   if (c->nl > 0) {
-    if (!wt && !use_gv) { K_SWITCH(K, launch_gram<KT>(c, c->V, MT)); }
+    // V'V when no sampler left its per-column blocks (sharded runs, long V): partial Grams by side workgroups of the
+    // accumulation launch itself - the solve that consumes them is the next kernel (no gram_kernel launch)
+    GramSide gram{nullptr, 0, nullptr, 0};
+    if (!wt && !use_gv) {
+      c->ngp_gram = std::min(gram_blocks(MT), 32);
+      gram = GramSide{c->V, MT, c->gpart, c->ngp_gram};
+    }
     TauSide tau{};
     if (c->tau_pending && c->dev_scalars && c->have_chain) tau = tau_side_of(c, c->tau_seed, 1.0, c->tau_stability);
     K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, rpb, nch,
-                                 EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}, tau));
+                                 EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}, tau, gram));
     c->tau_pending = false;
   }
   HIPCHK(c, hipGetLastError());

@@ -146,6 +146,10 @@ __device__ void tau2_column(const TauSide& t, int K, int j, int tid256, double* 
 // (four columns: 14.4 us for the launch at C3, two: hidden under the 11 us stream); the other waves leave at once
 constexpr int TAU_SIDE_CPW = 2;
 
+// the Gram of the fixed factor (what gram_kernel computes) as side workgroups of the accumulation launch that the
+// solve kernel FOLLOWS: nblocks partial Grams of U's rows, one per side workgroup, consumed across the kernel boundary
+struct GramSide { const double* U; int Rdim; double* gpart; int nblocks; };
+
 // MODE 0: X only (complete data)
 // MODE 1: X, C and the outer products UU
 // MODE 2: as 1, but the precision weight of output l is read from output srcmap[l] of the
@@ -168,7 +172,7 @@ template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double,
 __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     const XT* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
-    int rows_per_block, EigSide side, EigSideCols sidec, TauSide tau) {
+    int rows_per_block, EigSide side, EigSideCols sidec, TauSide tau, GramSide gram) {
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
@@ -223,6 +227,37 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
       return;
     }
     b -= ntw;
+  }
+  if (gram.gpart) {
+    if (b < gram.nblocks) {
+      // rows b, b + nblocks*threads, ... (strided like gram_kernel), K(K+1)/2 sums per thread, fixed-order reduction
+      double* scr = &red[0][0][0];                              // [ACC_WAVES][KK]
+      double gacc[KK];
+#pragma unroll
+      for (int q = 0; q < KK; ++q) gacc[q] = 0.0;
+      for (int r = b * (WAVES * WAVE) + (int)threadIdx.x; r < gram.Rdim; r += gram.nblocks * (WAVES * WAVE)) {
+        double u[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) u[k] = gram.U[(size_t)r * K + k];
+#pragma unroll
+        for (int p = 0; p < K; ++p)
+#pragma unroll
+          for (int q = 0; q <= p; ++q) gacc[lidx(p, q)] = fma(u[p], u[q], gacc[lidx(p, q)]);
+      }
+#pragma unroll
+      for (int q = 0; q < KK; ++q) {
+        const double t = wave_sum(gacc[q]);
+        if (lane == 0) scr[wave * KK + q] = t;
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < KK) {
+        double t = 0.0;
+        for (int w = 0; w < ACC_WAVES; ++w) t += scr[w * KK + threadIdx.x];
+        gram.gpart[(size_t)b * KK + threadIdx.x] = t;
+      }
+      return;
+    }
+    b -= gram.nblocks;
   }
   const int ntiles = ld / ACC_TILE;
   const int chunk = b / ntiles, tile = b - chunk * ntiles;
