@@ -1302,8 +1302,11 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
   if (c->ml > 0) {
     const bool whole = c->nl == c->N && c->ml == c->M;
     const bool use_gw = !wt && whole && c->fuse_gram && c->ngp_w > 0;
-    if (!wt && !use_gw) { K_SWITCH(K, launch_gram<KT>(c, c->W, c->N)); }
     const int choice = banded_choice(c);
+    // W'W: partials of w_solve, or gram_kernel - except for the spectral sampler without partials (sharded runs), whose only
+    // consumer of the Gram is the eigen side task of the accumulation launch: that workgroup then forms it from W itself
+    const bool gram_aside = !wt && !use_gw && choice == 3 && c->N <= 16384;
+    if (!wt && !use_gw && !gram_aside) { K_SWITCH(K, launch_gram<KT>(c, c->W, c->N)); }
     EigSide side{nullptr, 0, 0, nullptr};
     if (choice == 3) {
       // spectral sampler: the eigen-system of the Gram W'W rides along in the accumulation launch (btf_eig.h)
@@ -1311,7 +1314,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
         if ((rc = dev_alloc(c, &c->eig, (size_t)K + K * K + 8))) return rc;
         HIPCHK(c, hipMemsetAsync(c->eig, 0, ((size_t)K + K * K + 8) * sizeof(double), c->stream));   // no previous solution
       }
-      side = EigSide{use_gw ? c->gpart_w : c->gpart, use_gw ? c->ngp_w : c->ngp_gram, K, c->eig};
+      side = EigSide{use_gw ? c->gpart_w : c->gpart, use_gw ? c->ngp_w : c->ngp_gram, K, c->eig, gram_aside ? c->W : nullptr, c->N};
     }
     // curve columns ride along as side tasks too, a wave each (their sampler workgroups can solve them as well:
     // eig_cols_ready = 0 - kept as the fallback path)

@@ -254,7 +254,8 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
 }
 
 // side task of a streaming launch (accum_kernel): out == nullptr: none
-struct EigSide { const double* gpart; int ngp; int K; double* out; };
+// (Usrc != nullptr: no partials exist - the side workgroup forms the Gram of Usrc's nrows rows itself)
+struct EigSide { const double* gpart; int ngp; int K; double* out; const double* Usrc; int nrows; };
 
 __global__ __launch_bounds__(WAVE) void gram_eig_kernel(const double* __restrict__ gpart, int ngp, int K,
                                                         double* __restrict__ out, int warm) {

@@ -204,7 +204,34 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
       const bool task = b > 0 && wave < TPW && t < sidec.ncols;
       const int col = task ? sidec.cols[t] : 0;
       if (task) curve_column_sum_wave<K>(sidec.cv, sidec.W, col, gown + wave * 64);    // (its loads fly with reduce_gram's)
-      reduce_gram(side.gpart, side.ngp, KK, 1.0, rsc, gsum);
+      if (side.Usrc) {         // (sharded runs: W has just been all-gathered, nobody summed its Gram)
+        double gacc[KK];
+#pragma unroll
+        for (int q = 0; q < KK; ++q) gacc[q] = 0.0;
+        for (int r = threadIdx.x; r < side.nrows; r += WAVES * WAVE) {
+          double u[K];
+#pragma unroll
+          for (int k = 0; k < K; ++k) u[k] = side.Usrc[(size_t)r * K + k];
+#pragma unroll
+          for (int p = 0; p < K; ++p)
+#pragma unroll
+            for (int q = 0; q <= p; ++q) gacc[lidx(p, q)] = fma(u[p], u[q], gacc[lidx(p, q)]);
+        }
+#pragma unroll
+        for (int q = 0; q < KK; ++q) {
+          const double t2 = wave_sum(gacc[q]);
+          if (lane == 0) rsc[wave * KK + q] = t2;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < KK) {
+          double t2 = 0.0;
+          for (int w = 0; w < ACC_WAVES; ++w) t2 += rsc[w * KK + threadIdx.x];
+          gsum[threadIdx.x] = t2;
+        }
+        __syncthreads();
+      } else {
+        reduce_gram(side.gpart, side.ngp, KK, 1.0, rsc, gsum);
+      }
       if (b == 0) {
         if (wave == 0) gram_eig_wave(gsum, 1, K, side.out, sc);
       } else if (task) {
