@@ -233,3 +233,66 @@ def test_c5_rank_slab_half_sweeps(rank, sampler):
 
 def orc_w_offset(i, K_):
     return i * (i + 1) // 2 if i < K_ else K_ * (K_ + 1) // 2 + (i - K_) * K_
+
+
+@pytest.mark.parametrize("sampler", ["spectral", "banded"])
+def test_full_size_held_out_curves_vs_weighted_conditionals(sampler):
+    """(512,256,64,4) K=5 with the reference examples' held-out block and 3 % more whole curves missing: the
+    curve-counts form (complete-data kernels + per-row / per-column corrections) against the weighted conditionals of
+    factor.py:343-346 / :388-391 - every row of W, a spread of columns of V (deficient and complete ones), and the
+    residual sum of squares, from identical state and normals."""
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    from oracle import btf_oracle as orc
+    rs = np.random.RandomState(4)
+    Wt = rs.normal(size=(N, K))
+    Wt[np.triu_indices(K, 1)] = 0
+    Vt = 0.1 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    Y = np.einsum("nk,mtk->nmt", Wt, Vt)[..., None] + rs.normal(0, 0.5, size=(N, M, T, R))
+    Y[:3, :3] = np.nan
+    Y[rs.rand(N, M) < 0.03] = np.nan
+    Y[rs.rand(N, M) < 0.02, :, 1] = np.nan            # thinned curves: one replicate gone at every depth
+    st = dict(W=Wt + 0.1 * rs.normal(size=Wt.shape), V=Vt + 0.05 * rs.normal(size=Vt.shape), Tau2=rs.gamma(2.0, 0.5, size=(M, 3 * T - 1)),
+              lam2=0.2, sigma2=0.6, nu2=0.3)
+    st["W"][np.triu_indices(K, 1)] = 0
+    model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                            nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"],
+                                            compat="exact", sampler=sampler)
+    np.random.seed(3)
+    zw = np.random.normal(size=K * (K + 1) // 2 + (N - K) * K)
+    zv = np.random.normal(size=(M, K * T))
+    np.random.seed(3)
+    model._resample_W(Y)
+    assert model.likelihood_form() == "curve_counts" and model.v_sampler() == sampler
+    # W: vectorised weighted conditional, row by row from the per-cell counts
+    cnt = np.sum(~np.isnan(Y), axis=3).astype(float)                 # (N,M,T)
+    S1 = np.nansum(Y, axis=3)
+    Vf = st["V"].reshape(-1, K)
+    c = cnt.reshape(N, -1) / st["nu2"]
+    m = (S1.reshape(N, -1) / st["nu2"]) @ Vf                          # (N,K)
+    W = st["W"].copy()
+    zpos = 0
+    for i in range(N):
+        d = min(i + 1, K)
+        Q = (Vf[:, :d] * c[i][:, None]).T @ Vf[:, :d] + np.eye(d) / st["sigma2"]
+        L = np.linalg.cholesky(Q)
+        W[i, :d] = np.linalg.solve(Q, m[i, :d]) + np.linalg.solve(L.T, zw[zpos:zpos + d])
+        zpos += d
+    assert relerr(model.W, W) < 1e-10
+    # SSE identity with the corrected Grams (the nu2 draw of a device sweep uses it): through the public statistic
+    np.random.seed(8)
+    model._resample_nu2(Y)
+    ost = dict(st, W=W)
+    sse, n = orc.sse_and_count(ost, Y)
+    np.random.seed(8)
+    ref = 1.0 / np.random.gamma(0.1 + n / 2.0, 1.0 / (0.1 + sse / 2.0))
+    assert abs(model.nu2 - ref) / ref < 1e-9
+    model.nu2 = st["nu2"]
+    # V: a spread of columns
+    np.random.seed(5)
+    model._v_normals = lambda: zv
+    model._resample_V(Y)
+    cols = [0, 1, 2, 3, 17, 100, 255]
+    ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in dict(st, W=W).items()}
+    perm = "spectral" if sampler == "spectral" else orc.perm_from_order(model.v_order(), K, T)
+    orc.v_step(ost, Y, orc.trend_penalty(T, 2), perm=perm, z=zv, compat="exact", cols=cols)
+    assert relerr(model.V[cols], ost["V"][cols]) < 1e-6
