@@ -341,6 +341,12 @@ def main():
     if world > 1 or exercise:
         out["config"].update({"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
                               "collective_us": coll})
+    if world > 1:
+        # the one-GPU figure of THIS workload (a `--gpus 1` run reports the headline C3 instead): strong scaling - the
+        # whole fixed tensor on one GPU; weak - one rank's slab.  From the committed profile of that run, with its file.
+        ref = same_config_one_gpu("c5" if not weak else "c3", "complete")
+        if ref is not None:
+            out["config"]["one_gpu_same_workload"] = ref
     if world == 1 and not args.no_cpu and args.variant not in ("binomial", "negbinom"):
         out["cpu_baseline"] = cpu_baseline(Y, model, cfg)
 
@@ -418,6 +424,21 @@ def copy_ceiling(torch):
         ms = e0.elapsed_time(e1) / 10
         del a, b
         return round(2 * n * 8 / (ms * 1e-3) / 1e9, 1)
+    except Exception:
+        return None
+
+
+def same_config_one_gpu(config, variant):
+    """sweeps/s of `python bench.py --gpus 1 --config <config>` as committed under profiles/ (the bench line kept beside
+    the rocprofv3 run of that workload), for the denominator of a scaling figure; None if no such file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_%s_bench.json" % (config, variant))))
+    if not files:
+        return None
+    try:
+        d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "n_gpus": d["n_gpus"],
+                "source": os.path.relpath(files[-1], ROOT)}
     except Exception:
         return None
 
