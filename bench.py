@@ -344,7 +344,7 @@ def main():
     if world > 1:
         # the one-GPU figure of THIS workload (a `--gpus 1` run reports the headline C3 instead): strong scaling - the
         # whole fixed tensor on one GPU; weak - one rank's slab.  From the committed profile of that run, with its file.
-        ref = same_config_one_gpu("c5" if not weak else "c3", "complete")
+        ref = same_config_one_gpu(args.config, "complete")      # (weak: args.config names one rank's slab)
         if ref is not None:
             out["config"]["one_gpu_same_workload"] = ref
     if world == 1 and not args.no_cpu and args.variant not in ("binomial", "negbinom"):
