@@ -168,7 +168,9 @@ __host__ __device__ constexpr int acc_waves(int K, int MODE) { return MODE >= 1 
 // missing replicates: C is the replicate count 0..R, 1 byte instead of 8 per cell: 9 instead of 16 B/cell)
 // XT: storage type of the linear statistic X: double, or signed char for Binomial pseudo-data kappa = Y - N/2 with
 // integer counts (2 kappa in -127..127 stored, 1 byte instead of 8 per cell: 9 instead of 16 B/cell with f64 weights)
-template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double, typename XT = double>
+// UNRV: rows in flight per wave; 0 = the build's default (2).  Long row ranges per workgroup (C5-sized slabs) stream
+// 1-2 % faster with 3 (359 / 346 us against 361 / 353 us per launch at C5), short ones (C3: 32 rows per wave) slower.
+template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double, typename XT = double, int UNRV = 0>
 __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     const XT* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
-  constexpr int ACC_UNR = MODE >= 1 ? BTF_ACC_UNR_WT : BTF_ACC_UNR;
+  constexpr int ACC_UNR = UNRV > 0 ? UNRV : (MODE >= 1 ? BTF_ACC_UNR_WT : BTF_ACC_UNR);
   constexpr int ACC_RG = (WAVES * WAVE / ACC_TILE) < 4 ? (WAVES * WAVE / ACC_TILE) : 4;
   __shared__ double red[ACC_WAVES][ACC_RG][ACC_TILE];
 

@@ -212,3 +212,27 @@ def test_long_depth_axis_band_in_hbm_scratch(weighted):
     ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
     orc.v_step(ost, Y, orc.trend_penalty(T, tf), z=zv, perm=orc.perm_from_order(model.v_order(), K, T))
     assert relerr(model.V, ost["V"]) < 1e-8
+
+
+@pytest.mark.parametrize("N,M,T,R,K,tf", [(2100, 3, 5, 2, 2, 1), (9, 40, 64, 1, 3, 2), (2300, 36, 64, 1, 8, 2)])
+def test_long_row_ranges_per_workgroup(N, M, T, R, K, tf):
+    """Row ranges of >= 2048 rows per workgroup take the three-rows-in-flight build of the complete-data accumulation
+    (what C5-sized slabs run): forced here through btf_set_tuning on shapes the oracle handles."""
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    from oracle import btf_oracle as orc
+    Y, st = make_case(N, M, T, R, K, tf, False, seed=N + M)
+    model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                            nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], sampler="spectral")
+    model._ctx.call("btf_set_tuning", 2048, 2048)
+    np.random.seed(5)
+    zw = np.random.normal(size=sum(min(i + 1, K) for i in range(N)))
+    zv = np.random.normal(size=(M, K * T))
+    np.random.seed(5)
+    model._resample_W(Y)
+    model._resample_V(Y)
+    ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    Rr, ybar = orc.hoisted_stats(Y if Y.ndim == 4 else Y[..., None])
+    orc.w_step_strong(ost, Rr, ybar, z=zw)
+    assert relerr(model.W, ost["W"]) < 1e-10
+    orc.v_step_strong(ost, Rr, ybar, orc.trend_penalty(T, tf), z=zv, order="spectral")
+    assert relerr(model.V, ost["V"]) < 1e-7
