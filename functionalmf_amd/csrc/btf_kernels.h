@@ -1395,6 +1395,7 @@ constexpr int PG_NORMAL_B = 200;
 constexpr int PG_DEVROYE_MAX = 2;   // integer b up to here: exact alternating-series draws, one per unit of b
 constexpr int PG_SERIES_NT = 16;     // terms of the sum-of-gammas series drawn for every other b (4 for b >= 3: the remainder then holds 3e-4 of the variance and 3e-6 of the third cumulant), + 2|psi|/(2 pi)
 constexpr int PG_SERIES_NT_MAX = 96;
+constexpr int PG_PRODUCT_B = 8;      // integer shapes up to here draw their Gamma(b) terms as -ln(U_1...U_b) in the series sampler
 
 struct CellRng {
   uint64_t seed, cell, ctr;
@@ -1669,13 +1670,35 @@ __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& 
     const float df = (float)d, ccf = __builtin_amdgcn_rsqf(9.0f * df);
     // weights 1/((k-1/2)^2 + c2) in single precision too (one v_rcp_f32 + a Newton step: ~1e-7, as the variates)
     const float c2f = (float)c2;
-    auto weight = [&](int kk) -> float {
+    auto weight1 = [&](int kk) -> float {
       const float q = fmaf((float)kk - 0.5f, (float)kk - 0.5f, c2f);
       const float r = __builtin_amdgcn_rcpf(q);
-      return df * r * fmaf(-q, r, 2.0f);                    // (d folded in: the term is d v^3 w_k)
+      return r * fmaf(-q, r, 2.0f);
     };
-    int k = 1;
-    float wk = weight(1);
+    // Integer shapes up to PG_PRODUCT_B (the Binomial case: b = number of trials): Gamma(b) = -ln(U_1 ... U_b), no
+    // rejection, so every lane finishes a term per trip - b uniforms and one hardware log per four of them instead
+    // of ~1.6 Marsaglia-Tsang trips of a normal, a uniform and two logs (and no trips spent waiting for the
+    // unluckiest lane).  24-bit uniforms: a product of four stays a normal f32 (>= 2^-100).
+    const bool prod = b <= (double)PG_PRODUCT_B && b == floor(b);
+    if (prod) {
+      const int bi = (int)b;
+      for (int kk = 1; kk <= NT; ++kk) {
+        // four uniforms per log, branch-free: the ones past b are replaced by 1 (their words are still consumed)
+        auto group = [&](int i0) -> float {
+          const float u0 = f.uniform32f(), u1 = f.uniform32f(), u2 = f.uniform32f(), u3 = f.uniform32f();
+          float p = u0;
+          p *= i0 + 1 < bi ? u1 : 1.0f;
+          p *= i0 + 2 < bi ? u2 : 1.0f;
+          p *= i0 + 3 < bi ? u3 : 1.0f;
+          return __builtin_amdgcn_logf(p);
+        };
+        float l2 = group(0);
+        if (bi > 4) l2 += group(4);
+        s += (double)(-0.69314718f * l2 * weight1(kk));
+      }
+    }
+    int k = prod ? NT + 1 : 1;
+    float wk = df * weight1(1);                             // (d folded in: the term is d v^3 w_k)
     while (k <= NT) {
       const float xf = f.normal32f();
       const float v1 = fmaf(ccf, xf, 1.0f);
@@ -1685,7 +1708,7 @@ __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& 
       if (v1 > 0.0f && lnu < rhs) {
         s += (double)(vf * wk);
         ++k;
-        wk = weight(k);
+        wk = df * weight1(k);
       }
     }
   }
