@@ -127,14 +127,39 @@ class NotPositiveDefiniteError(BTFError, np.linalg.LinAlgError):
     where it would loop forever after the jitter retries (fast_mvn.py:69-72)."""
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    deps = SOURCES + HEADERS
+INST_SOURCE = os.path.join(CSRC, "btf_instances.hip")
+INST_PARTS = 8                      # = BTF_INST_PARTS of csrc/btf_instances.h
+OBJ_DIR = os.path.join(CSRC, "_obj")
+
+
+def build(force=False, verbose=False, jobs=None):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU): the C-ABI unit and the
+    parts of btf_instances.hip (the large kernel families, one compilation each) in parallel, then one link."""
+    deps = SOURCES + [INST_SOURCE] + HEADERS
     if not force and os.path.exists(LIB_PATH) and \
             os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in deps):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH] + SOURCES
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    tag = os.path.splitext(os.path.basename(LIB_PATH))[0]
+    base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function",
+            "-I", os.path.join(ROOT, "include")]
+    units = [(SOURCES[0], os.path.join(OBJ_DIR, tag + "_abi.o"), [])]
+    units += [(INST_SOURCE, os.path.join(OBJ_DIR, "%s_inst%d.o" % (tag, p)), ["-DBTF_INST_PART=%d" % p])
+              for p in range(INST_PARTS)]
+
+    def compile_unit(u):
+        src, obj, defs = u
+        cmd = base + defs + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        return obj
+
+    jobs = jobs or max(1, min(len(units), os.cpu_count() or 1))
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(compile_unit, units))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)

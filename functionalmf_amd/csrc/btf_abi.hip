@@ -7,6 +7,7 @@
 #include "btf_banded_twist.h"
 #include "btf_spectral.h"
 #include "btf_gass.h"
+#include "btf_instances.h"      // the large kernel families: extern templates, compiled in btf_instances.hip
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -1644,10 +1645,12 @@ int btf_gass_begin(btf_ctx* c, int what, int link, const double* z, const double
       p.launch(gass_analyse_rows_kernel, dim3(c->N), dim3(GASS_THREADS), 0, a);
     } else {
       const size_t dyn = ((size_t)2 * GASS_RT * c->T + (size_t)c->gs_J * c->T) * sizeof(double);
-      if (dyn + sizeof(GassScratch) > 158 * 1024) return fail(c, BTF_EINVAL, "constraint matrix too large for the column analysis");
+      constexpr size_t GASS_DYN_MAX = 112 * 1024;      // (the kernel's static scratch takes the rest of the 160 KB)
+      if (dyn > GASS_DYN_MAX || dyn + sizeof(GassScratch) > 158 * 1024)
+        return fail(c, BTF_EINVAL, "constraint matrix too large for the column analysis");
       static bool attr_set = false;
       if (!attr_set) {
-        HIPCHK(c, hipFuncSetAttribute((const void*)gass_analyse_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+        HIPCHK(c, hipFuncSetAttribute((const void*)gass_analyse_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GASS_DYN_MAX));
         attr_set = true;
       }
       p.launch(gass_analyse_cols_kernel, dim3(c->M), dim3(GASS_THREADS), dyn, a);

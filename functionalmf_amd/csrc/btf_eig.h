@@ -257,7 +257,7 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
 // (Usrc != nullptr: no partials exist - the side workgroup forms the Gram of Usrc's nrows rows itself)
 struct EigSide { const double* gpart; int ngp; int K; double* out; const double* Usrc; int nrows; };
 
-__global__ __launch_bounds__(WAVE) void gram_eig_kernel(const double* __restrict__ gpart, int ngp, int K,
+static __global__ __launch_bounds__(WAVE) void gram_eig_kernel(const double* __restrict__ gpart, int ngp, int K,
                                                         double* __restrict__ out, int warm) {
   __shared__ __attribute__((aligned(16))) double scratch[EIG_LDS_DOUBLES];
   gram_eig_wave(gpart, ngp, K, out, scratch, warm != 0);

@@ -27,7 +27,7 @@ constexpr int ESS_THREADS = 256;
 
 // prior draw of W: N(0, sigma2) on the free entries (lower triangle of the leading K rows, everything below),
 // z indexed as factor.py:155-174 packs them (= the W half-sweep's normal stream)
-__global__ void ess_w_prior_kernel(double* __restrict__ nu, int N, int K, double sigma2, const double* __restrict__ hyp,
+static __global__ void ess_w_prior_kernel(double* __restrict__ nu, int N, int K, double sigma2, const double* __restrict__ hyp,
                                    const double* __restrict__ z, unsigned long long seed, unsigned long long stream) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N * K) return;
@@ -44,7 +44,7 @@ __global__ void ess_w_prior_kernel(double* __restrict__ nu, int N, int K, double
 
 // x = x0 cos(theta_c) + nu sin(theta_c) for the chain c of element e (elements per chain: `per`; joint: one chain).
 // restore != 0: chains that never finished fall back to x0 (the current state is always on the slice).
-__global__ void ess_combine_kernel(const double* __restrict__ x0, const double* __restrict__ nu, double* __restrict__ x,
+static __global__ void ess_combine_kernel(const double* __restrict__ x0, const double* __restrict__ nu, double* __restrict__ x,
                                    long long n, int per, const double* __restrict__ theta, const int* __restrict__ done,
                                    int restore) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(ESS_THREADS) void poisson_ll_cols_kernel(
 //   round < 0: part holds ll(current state): hh = ll + log u, theta ~ U(0, 2 pi), bracket (theta - 2 pi, theta)
 //   round >= 0: part holds ll(proposal): on the slice -> done; else shrink the bracket to theta and redraw.
 // nsum: partials per chain (joint chains: all of them).  Uniforms: Philox (seed, chain), two per round.
-__global__ __launch_bounds__(ESS_THREADS) void ess_decide_kernel(const double* __restrict__ part, int nsum, int nchains,
+static __global__ __launch_bounds__(ESS_THREADS) void ess_decide_kernel(const double* __restrict__ part, int nsum, int nchains,
                                                                  double* __restrict__ st, double* __restrict__ theta,
                                                                  int* __restrict__ done, int round,
                                                                  unsigned long long seed) {

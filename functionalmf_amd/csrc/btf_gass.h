@@ -160,7 +160,7 @@ __device__ inline void gass_pick(int total, int unrestricted, int ngrid, int* li
 }
 
 // AV[j][c][k] = sum_t Cons[c][t] V[j][t][k]   (factor.py:719): one workgroup per column
-__global__ __launch_bounds__(GASS_THREADS) void gass_av_kernel(const double* __restrict__ V, const double* __restrict__ Cons,
+static __global__ __launch_bounds__(GASS_THREADS) void gass_av_kernel(const double* __restrict__ V, const double* __restrict__ Cons,
                                                                int T, int K, int J, double* __restrict__ AV) {
   const int j = blockIdx.x;
   for (int e = threadIdx.x; e < J * K; e += GASS_THREADS) {
@@ -183,7 +183,7 @@ struct GassArgs {
 };
 
 // rows: chain i, x = W[i, :], constraints (AV[j,c,:] . x >= Cc[c]) for all (j, c), then the fixed row constraints
-__global__ __launch_bounds__(GASS_THREADS) void gass_analyse_rows_kernel(GassArgs a) {
+static __global__ __launch_bounds__(GASS_THREADS) void gass_analyse_rows_kernel(GassArgs a) {
   __shared__ GassScratch S;
   const int i = blockIdx.x, tid = threadIdx.x, K = a.K;
   for (int g = tid; g < GASS_GRID + 8; g += GASS_THREADS) S.diff[g] = 0;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(GASS_THREADS) void gass_analyse_rows_kernel(GassArg
 
 // columns: chain j, x = V[j] (T x K), constraints  sum_t Cons[c,t] (w_i . x_t) >= Cc[c]  for all (i, c)  (factor.py:848-855)
 constexpr int GASS_RT = 32;      // rows of W per tile
-__global__ __launch_bounds__(GASS_THREADS) void gass_analyse_cols_kernel(GassArgs a) {
+static __global__ __launch_bounds__(GASS_THREADS) void gass_analyse_cols_kernel(GassArgs a) {
   __shared__ GassScratch S;
   extern __shared__ double dyn[];                   // E0[RT][T], E1[RT][T], Cons[J][T]
   const int j = blockIdx.x, tid = threadIdx.x, K = a.K, T = a.T, J = a.J;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(GASS_THREADS) void gass_eval_kernel(GassEvalArgs a)
 }
 
 // slice height of every chain: hh = ll(current) + log u   (u given, or Philox(seed, chain))
-__global__ void gass_slice_kernel(const double* __restrict__ part, int nsum, int nchains, const double* __restrict__ u,
+static __global__ void gass_slice_kernel(const double* __restrict__ part, int nsum, int nchains, const double* __restrict__ u,
                                   unsigned long long seed, double* __restrict__ hh, double* __restrict__ cur) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nchains) return;
@@ -334,7 +334,7 @@ __global__ void gass_slice_kernel(const double* __restrict__ part, int nsum, int
 }
 
 // one of the candidates above the slice, uniformly (gass.py:121-126); none: the state stays.  x = x0 cos + v sin.
-__global__ __launch_bounds__(GASS_THREADS) void gass_select_kernel(const double* __restrict__ ll, const int* __restrict__ ntheta,
+static __global__ __launch_bounds__(GASS_THREADS) void gass_select_kernel(const double* __restrict__ ll, const int* __restrict__ ntheta,
                                                                    const double* __restrict__ thetas, const double* __restrict__ hh,
                                                                    const double* __restrict__ X0, const double* __restrict__ Nu,
                                                                    double* __restrict__ X, int per, unsigned long long seed,

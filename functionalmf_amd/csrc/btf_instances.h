@@ -1,0 +1,96 @@
+// The kernel families that make up most of the code object (accumulation, W solve, Polya-Gamma, Negative-Binomial
+// log-likelihood, twisted banded sampler: 80 % of it) are instantiated in translation units of their own
+// (btf_instances.hip, compiled once per BTF_INST_PART, in parallel) and only declared here - `extern template` for
+// the C-ABI unit (btf_abi.hip), which launches them through their host stubs.  One list, two expansions.
+//
+//   BTF_INST_PART undefined : every family as `extern template` (include after the kernel headers)
+//   BTF_INST_PART = n       : explicit instantiation definitions of part n
+#pragma once
+#include "btf_kernels.h"
+#include "btf_banded_twist.h"
+
+namespace btf {
+
+#define BTF_ACC_ARGS(XT, CT) \
+  (const XT*, const CT*, const double*, const int*, double*, int, int, int, EigSide, EigSideCols, TauSide, GramSide)
+#define BTF_ACCUM_SET(P, K)                                                                              \
+  P void accum_kernel<K, 0> BTF_ACC_ARGS(double, double);                                                \
+  P void accum_kernel<K, 0, acc_waves(K, 0), double, double, 3> BTF_ACC_ARGS(double, double);            \
+  P void accum_kernel<K, 1> BTF_ACC_ARGS(double, double);                                                \
+  P void accum_kernel<K, 2> BTF_ACC_ARGS(double, double);                                                \
+  P void accum_kernel<K, 1, acc_waves(K, 1), unsigned char> BTF_ACC_ARGS(double, unsigned char);         \
+  P void accum_kernel<K, 2, acc_waves(K, 2), unsigned char> BTF_ACC_ARGS(double, unsigned char);         \
+  P void accum_kernel<K, 1, acc_waves(K, 1), double, signed char> BTF_ACC_ARGS(signed char, double);     \
+  P void accum_kernel<K, 2, acc_waves(K, 2), double, signed char> BTF_ACC_ARGS(signed char, double);
+
+#define BTF_WSOLVE_SET(P, K)                                                                             \
+  P void w_solve_kernel<K, false, 8>(WSolveArgs);  P void w_solve_kernel<K, true, 8>(WSolveArgs);        \
+  P void w_solve_kernel<K, false, 16>(WSolveArgs); P void w_solve_kernel<K, true, 16>(WSolveArgs);       \
+  P void w_solve_kernel<K, false, 32>(WSolveArgs); P void w_solve_kernel<K, true, 32>(WSolveArgs);       \
+  P void w_solve_kernel<K, false, 64>(WSolveArgs); P void w_solve_kernel<K, true, 64>(WSolveArgs);
+
+#define BTF_PG_ARGS                                                                                      \
+  (const double*, double*, const double*, const double*, int, int, int, int, unsigned long long, unsigned long long, \
+   unsigned long long, unsigned long long, int, int)
+#define BTF_PGT_ARGS \
+  (const double*, double*, double*, const double*, const double*, int, int, int, int, unsigned long long, int, int)
+#define BTF_PG_SET(P, K)                                                                                 \
+  P void pg_kernel<K, PG_PATH_SERIES> BTF_PG_ARGS;       P void pg_kernel<K, PG_PATH_EXACT> BTF_PG_ARGS;  \
+  P void pg_tile_kernel<K, PG_PATH_SERIES> BTF_PGT_ARGS; P void pg_tile_kernel<K, PG_PATH_EXACT> BTF_PGT_ARGS;
+
+#define BTF_NB_ARGS \
+  (const double*, int, const double*, const double*, int, int, const double*, const double*, long long, long long, long long, int, double*)
+#define BTF_NB_SET(P, K)                                                                                 \
+  P void nb_loglik_kernel<K, 0> BTF_NB_ARGS; P void nb_loglik_kernel<K, 1> BTF_NB_ARGS;                  \
+  P void nb_loglik_kernel<K, 2> BTF_NB_ARGS; P void nb_loglik_kernel<K, 3> BTF_NB_ARGS;                  \
+  P void nb_loglik_kernel<K, 4> BTF_NB_ARGS;
+
+#define BTF_TWIST_SET(P)                                                                                 \
+  P void v_banded_twist_kernel<1, true>(VBandArgs, int);  P void v_banded_twist_kernel<2, true>(VBandArgs, int);  \
+  P void v_banded_twist_kernel<2, false>(VBandArgs, int); P void v_banded_twist_kernel<3, false>(VBandArgs, int); \
+  P void v_banded_twist_kernel<4, false>(VBandArgs, int); P void v_banded_twist_kernel<5, false>(VBandArgs, int); \
+  P void v_banded_twist_kernel<6, false>(VBandArgs, int); P void v_banded_twist_kernel<7, false>(VBandArgs, int); \
+  P void v_banded_twist_kernel<8, false>(VBandArgs, int);
+
+#define BTF_FOR_K(SET, P) \
+  SET(P, 1) SET(P, 2) SET(P, 3) SET(P, 4) SET(P, 5) SET(P, 6) SET(P, 7) SET(P, 8) SET(P, 9) SET(P, 10)
+
+// The parts (balanced by code size: the accumulation kernels grow with K + K(K+1)/2):
+//   0: accumulation K = 10, 4      1: accumulation K = 9, 5      2: accumulation K = 8, 6
+//   3: accumulation K = 7, 3, 2, 1 4: W solve                    5: Polya-Gamma
+//   6: Negative-Binomial log-likelihood                         7: twisted banded sampler
+constexpr int BTF_INST_PARTS = 8;
+
+#ifndef BTF_INST_PART
+#define BTF_X extern template __global__
+BTF_FOR_K(BTF_ACCUM_SET, BTF_X)
+BTF_FOR_K(BTF_WSOLVE_SET, BTF_X)
+BTF_FOR_K(BTF_PG_SET, BTF_X)
+BTF_FOR_K(BTF_NB_SET, BTF_X)
+BTF_TWIST_SET(BTF_X)
+#undef BTF_X
+#else
+#define BTF_D template __global__
+#if BTF_INST_PART == 0
+BTF_ACCUM_SET(BTF_D, 10) BTF_ACCUM_SET(BTF_D, 4)
+#elif BTF_INST_PART == 1
+BTF_ACCUM_SET(BTF_D, 9) BTF_ACCUM_SET(BTF_D, 5)
+#elif BTF_INST_PART == 2
+BTF_ACCUM_SET(BTF_D, 8) BTF_ACCUM_SET(BTF_D, 6)
+#elif BTF_INST_PART == 3
+BTF_ACCUM_SET(BTF_D, 7) BTF_ACCUM_SET(BTF_D, 3) BTF_ACCUM_SET(BTF_D, 2) BTF_ACCUM_SET(BTF_D, 1)
+#elif BTF_INST_PART == 4
+BTF_FOR_K(BTF_WSOLVE_SET, BTF_D)
+#elif BTF_INST_PART == 5
+BTF_FOR_K(BTF_PG_SET, BTF_D)
+#elif BTF_INST_PART == 6
+BTF_FOR_K(BTF_NB_SET, BTF_D)
+#elif BTF_INST_PART == 7
+BTF_TWIST_SET(BTF_D)
+#else
+#error "BTF_INST_PART out of range"
+#endif
+#undef BTF_D
+#endif
+
+}  // namespace btf

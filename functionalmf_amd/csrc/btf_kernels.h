@@ -900,7 +900,7 @@ __device__ __forceinline__ void vband_load_hyp(VBandArgs& a) {
 // Prior band of every local column at once (depends on the hyper-parameters only, so it is
 // recomputed when they change, not per half-sweep): one thread per (column, t, d), Delta
 // rows ascending as in the sparse product of factor.py:404-405.
-__global__ void prior_band_kernel(const double* __restrict__ Tau2, double lam2, int nD,
+static __global__ void prior_band_kernel(const double* __restrict__ Tau2, double lam2, int nD,
                                   const int* __restrict__ st_ptr, const int* __restrict__ st_row,
                                   const double* __restrict__ st_coef, int TD1, int col0, int ml,
                                   double* __restrict__ pband, const double* __restrict__ hyp) {
@@ -1079,7 +1079,7 @@ struct MvnArgs {
   int n, bw; unsigned long long seed; double eps0; int attempts; int* tries; int* status;
 };
 
-__global__ __launch_bounds__(WAVE) void mvn_banded_kernel(MvnArgs a) {
+static __global__ __launch_bounds__(WAVE) void mvn_banded_kernel(MvnArgs a) {
   extern __shared__ double lds[];
   unsigned short* ptab = reinterpret_cast<unsigned short*>(lds);
   const int lane = threadIdx.x, b = blockIdx.x;
@@ -1132,7 +1132,7 @@ struct MvnDenseArgs {
   const double* A; const double* mu; const double* mu_part; const double* z; double* x; double* work;
   int n; int form; unsigned long long seed; double eps0; int attempts; int* tries; int* status;
 };
-__global__ __launch_bounds__(MVD_THREADS) void mvn_dense_kernel(MvnDenseArgs a) {
+static __global__ __launch_bounds__(MVD_THREADS) void mvn_dense_kernel(MvnDenseArgs a) {
   extern __shared__ double lds[];
   const int b = blockIdx.x, tid = threadIdx.x, n = a.n;
   const double* __restrict__ A = a.A + (size_t)b * n * n;
@@ -1240,7 +1240,7 @@ struct StatsArgs {
   int* incomplete;                    // set to 1 if any cell has cnt != R (Gaussian) / is missing (binomial)
 };
 
-__global__ __launch_bounds__(256) void stats_kernel(StatsArgs a) {
+static __global__ __launch_bounds__(256) void stats_kernel(StatsArgs a) {
   __shared__ double red[4][3];
   const size_t cells = (size_t)a.rows * a.cols;
   double ssw = 0.0, nobs = 0.0, sa2 = 0.0;
@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(256) void stats_kernel(StatsArgs a) {
 }
 
 // plain / transposing copy of a host-layout slab [rows][cols] into a padded device layout
-__global__ void relayout_kernel(const double* src, int rows, int cols, double* dst, int ld, int transposed, int zero_nan) {
+static __global__ void relayout_kernel(const double* src, int rows, int cols, double* dst, int ld, int transposed, int zero_nan) {
   const size_t cells = (size_t)rows * cols;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < cells; idx += (size_t)gridDim.x * blockDim.x) {
     size_t row, col;
@@ -1318,7 +1318,7 @@ __global__ void relayout_kernel(const double* src, int rows, int cols, double* d
 
 // Binomial pseudo-data kappa = Y - N/2 as bytes: dst = 2 kappa when every value is an integer in -127..127
 // (*bad is set otherwise and the f64 array stays in use)
-__global__ void kappa_to_i8_kernel(const double* __restrict__ src, signed char* __restrict__ dst, size_t n, int* __restrict__ bad) {
+static __global__ void kappa_to_i8_kernel(const double* __restrict__ src, signed char* __restrict__ dst, size_t n, int* __restrict__ bad) {
   bool b = false;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const double h = 2.0 * src[i];
@@ -1328,12 +1328,12 @@ __global__ void kappa_to_i8_kernel(const double* __restrict__ src, signed char* 
   if (b) *bad = 1;
 }
 
-__global__ void f64_to_u8_kernel(const double* __restrict__ src, unsigned char* __restrict__ dst, size_t n) {
+static __global__ void f64_to_u8_kernel(const double* __restrict__ src, unsigned char* __restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     dst[i] = (unsigned char)src[i];
 }
 
-__global__ void mask_kernel(double* C, const double* B, size_t n) {
+static __global__ void mask_kernel(double* C, const double* B, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     if (!(B[i] > 0.0)) C[i] = 0.0;
 }
@@ -1836,7 +1836,7 @@ __global__ __launch_bounds__(256, 2) void pg_tile_kernel(const double* __restric
 }
 
 // stand-alone batch of PG draws (validation entry point)
-__global__ void pg_batch_kernel(const double* b, const double* psi, double* out, long long n, unsigned long long seed,
+static __global__ void pg_batch_kernel(const double* b, const double* psi, double* out, long long n, unsigned long long seed,
                                 int exact_mode) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1895,7 +1895,7 @@ __device__ void tau2_column(const TauSide& t, int K, int j, int tid256, double* 
   __syncthreads();
   if (tid256 == 0 && j < t.M) t.lsum[j] = red4[0] + red4[1] + red4[2] + red4[3];
 }
-__global__ __launch_bounds__(256) void tau2_kernel(TauSide t, int K) {
+static __global__ __launch_bounds__(256) void tau2_kernel(TauSide t, int K) {
   __shared__ double red[4];
   tau2_column(t, K, blockIdx.x, threadIdx.x, red);
 }
@@ -1926,7 +1926,7 @@ __device__ inline void lam2_draw(const double* __restrict__ lsum, int M, double 
 // phase 0: reduce and draw (one GPU).  Sharded runs split the nu2 part around an all-reduce of the rank-local sum:
 // phase 1 = reduce only, hyp[HYP_SSE] <- this rank's residual sum of squares; phase 2 = draw from hyp[HYP_SSE]
 // as it stands (the collective has summed it over the ranks in between; every rank then draws the same value).
-__global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__ bsum, int nb, double ssw, double nobs,
+static __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__ bsum, int nb, double ssw, double nobs,
                                                       const double* __restrict__ W, int N, int K, double nfree,
                                                       double nu2_a, double nu2_b, double sig_a, double sig_b, int which,
                                                       unsigned long long seed, double* __restrict__ hyp, int phase,
@@ -1990,7 +1990,7 @@ __device__ inline void lam2_draw(const double* __restrict__ lsum, int M, double 
     hyp[HYP_LAM2A] = (1.0 / lam2 + 1.0) / g.expo();
   }
 }
-__global__ __launch_bounds__(256) void lam2_kernel(const double* __restrict__ lsum, int M, double shape, int exact,
+static __global__ __launch_bounds__(256) void lam2_kernel(const double* __restrict__ lsum, int M, double shape, int exact,
                                                    unsigned long long seed, double* __restrict__ hyp) {
   __shared__ double red[4];
   lam2_draw(lsum, M, shape, exact, seed, hyp, red);
@@ -2130,7 +2130,7 @@ __global__ __launch_bounds__(256) void nb_loglik_kernel(const double* __restrict
 }
 
 // out[o] = sum over the shared dims of src[(a0,a1,a2)], src C-contiguous (d0,d1,d2); sh* flag the shared dims
-__global__ __launch_bounds__(256) void nb_reduce_kernel(const double* __restrict__ src, int d0, int d1, int d2, int sh0,
+static __global__ __launch_bounds__(256) void nb_reduce_kernel(const double* __restrict__ src, int d0, int d1, int d2, int sh0,
                                                        int sh1, int sh2, double* __restrict__ out) {
   __shared__ double red[4];
   const int u0 = sh0 ? 1 : d0, u1 = sh1 ? 1 : d1, u2 = sh2 ? 1 : d2;   // unshared extents
@@ -2156,7 +2156,7 @@ __global__ __launch_bounds__(256) void nb_reduce_kernel(const double* __restrict
 }
 
 // S[cell] = sum of observed counts, cnt[cell] = number of observed replicates
-__global__ void nb_stats_kernel(const double* __restrict__ data, int Rr, size_t cells, double* __restrict__ S,
+static __global__ void nb_stats_kernel(const double* __restrict__ data, int Rr, size_t cells, double* __restrict__ S,
                                 double* __restrict__ cnt) {
   for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
     double s = 0.0, n = 0.0;
@@ -2169,7 +2169,7 @@ __global__ void nb_stats_kernel(const double* __restrict__ data, int Rr, size_t 
 }
 
 // 64 x 64 tiles of the (N, MT) cell grid: V layout written directly, W layout through an LDS transpose
-__global__ __launch_bounds__(256) void nb_trials_kernel(const double* __restrict__ S, const double* __restrict__ cnt,
+static __global__ __launch_bounds__(256) void nb_trials_kernel(const double* __restrict__ S, const double* __restrict__ cnt,
                                                        const double* __restrict__ Rv, long long sr0, long long sr1,
                                                        long long sr2, int N, int MT, int T, int ldv, int ldw,
                                                        double* __restrict__ Av, double* __restrict__ Bv,
@@ -2214,7 +2214,7 @@ __global__ __launch_bounds__(256) void nb_trials_kernel(const double* __restrict
 // H via integer atomics (exact, order-free).  Observed values that are not integers in [0, NB_TAB)
 // ("outliers": large counts, fractional pseudo-counts) are counted per row, then compacted IN DATA
 // ORDER into per-row lists (nb_outlier_fill_kernel) and summed term by term in that fixed order.
-__global__ __launch_bounds__(256) void nb_hist_kernel(const double* __restrict__ data, int Rr, int MT,
+static __global__ __launch_bounds__(256) void nb_hist_kernel(const double* __restrict__ data, int Rr, int MT,
                                                      unsigned int* __restrict__ H, int* __restrict__ nout) {
   __shared__ unsigned int h[NB_TAB];
   const int i = blockIdx.y;
@@ -2237,7 +2237,7 @@ __global__ __launch_bounds__(256) void nb_hist_kernel(const double* __restrict__
 }
 
 // in-order compaction of row i's outliers into val[ptr[i] ..): one block per row, chunks of 256 in order
-__global__ __launch_bounds__(256) void nb_outlier_fill_kernel(const double* __restrict__ data, int Rr, int MT,
+static __global__ __launch_bounds__(256) void nb_outlier_fill_kernel(const double* __restrict__ data, int Rr, int MT,
                                                              const int* __restrict__ ptr, double* __restrict__ val) {
   __shared__ int wcnt[4];
   __shared__ int base_s;
@@ -2262,7 +2262,7 @@ __global__ __launch_bounds__(256) void nb_outlier_fill_kernel(const double* __re
   }
 }
 
-__global__ void u32_to_f64_kernel(const unsigned int* __restrict__ src, double* __restrict__ dst, size_t n) {
+static __global__ void u32_to_f64_kernel(const unsigned int* __restrict__ src, double* __restrict__ dst, size_t n) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) dst[e] = (double)src[e];
 }
@@ -2291,7 +2291,7 @@ __global__ __launch_bounds__(256) void nb_l1p_kernel(const double* __restrict__ 
 
 // one block per row; rate_stride = 1: R per row, 0: one R for all rows (the caller then sums ll over rows):
 //   ll[i] = sum_y H[i][y] tab_y(R, c) + (c - R) L[i] + sum over row i's outliers
-__global__ __launch_bounds__(256) void nb_hist_loglik_kernel(const double* __restrict__ Hd, const double* __restrict__ L,
+static __global__ __launch_bounds__(256) void nb_hist_loglik_kernel(const double* __restrict__ Hd, const double* __restrict__ L,
                                                             const double* __restrict__ Rv, const double* __restrict__ Cv,
                                                             const int* __restrict__ optr, const double* __restrict__ oval,
                                                             int rate_stride, double* __restrict__ ll) {
@@ -2323,7 +2323,7 @@ __global__ __launch_bounds__(256) void nb_hist_loglik_kernel(const double* __res
 // llrow: per-row log-likelihood ratios; scalar != 0: one rate, ll = fixed-order sum of the nrow entries.
 // step < 0: propose only (start of the loop).  Philox streams keyed (seed, element), counters advance
 // with the step so that every step sees fresh numbers.  One block; elements strided over its threads.
-__global__ __launch_bounds__(256) void nb_mh_step_kernel(const double* __restrict__ llrow, int nrow, int nelem,
+static __global__ __launch_bounds__(256) void nb_mh_step_kernel(const double* __restrict__ llrow, int nrow, int nelem,
                                                         int scalar, double* __restrict__ Rv, double* __restrict__ Cv,
                                                         double rpropstdev, double rstdev, int step,
                                                         unsigned long long seed) {
