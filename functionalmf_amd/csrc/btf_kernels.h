@@ -1644,6 +1644,13 @@ struct FastRng {
     has_spare = true;
     return r * __builtin_amdgcn_cosf(u2);
   }
+  __device__ __forceinline__ float normal32f_single() {     // one variate, nothing kept (the last draw of a cell)
+    if (has_spare) { has_spare = false; return sparef; }
+    const uint32_t lo = next(), hi = next();
+    const float u1 = ((float)(lo >> 1) + 0.5f) * (1.0f / 2147483648.0f);
+    const float u2 = (float)(hi >> 8) * (1.0f / 16777216.0f);
+    return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+  }
 };
 
 __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& g) {
@@ -1668,12 +1675,11 @@ __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& 
     // for the f64 sum.
     const double d = b - 1.0 / 3.0;
     const float df = (float)d, ccf = __builtin_amdgcn_rsqf(9.0f * df);
-    // weights 1/((k-1/2)^2 + c2) in single precision too (one v_rcp_f32 + a Newton step: ~1e-7, as the variates)
+    // weights 1/((k-1/2)^2 + c2) in single precision too
     const float c2f = (float)c2;
     auto weight1 = [&](int kk) -> float {
       const float q = fmaf((float)kk - 0.5f, (float)kk - 0.5f, c2f);
-      const float r = __builtin_amdgcn_rcpf(q);
-      return r * fmaf(-q, r, 2.0f);
+      return __builtin_amdgcn_rcpf(q);                      // (v_rcp_f32: 1 ulp, as good as the variates)
     };
     // Integer shapes up to PG_PRODUCT_B (the Binomial case: b = number of trials): Gamma(b) = -ln(U_1 ... U_b), no
     // rejection, so every lane finishes a term per trip - b uniforms and one hardware log per four of them instead
@@ -1682,10 +1688,16 @@ __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& 
     const bool prod = b <= (double)PG_PRODUCT_B && b == floor(b);
     if (prod) {
       const int bi = (int)b;
+      float sf = 0.0f;                                      // (<= 96 positive f32 terms: ~1e-7 relative, as each term)
       for (int kk = 1; kk <= NT; ++kk) {
         // four uniforms per log, branch-free: the ones past b are replaced by 1 (their words are still consumed)
         auto group = [&](int i0) -> float {
-          const float u0 = f.uniform32f(), u1 = f.uniform32f(), u2 = f.uniform32f(), u3 = f.uniform32f();
+          // (four 24-bit uniforms from three words: the fourth takes the low bytes the other three leave unused)
+          const uint32_t w0 = f.next(), w1 = f.next(), w2 = f.next();
+          const uint32_t w3 = ((w0 & 0xffu) << 16) | ((w1 & 0xffu) << 8) | (w2 & 0xffu);
+          constexpr float S24 = 1.0f / 16777216.0f;
+          const float u0 = ((float)(w0 >> 8) + 0.5f) * S24, u1 = ((float)(w1 >> 8) + 0.5f) * S24;
+          const float u2 = ((float)(w2 >> 8) + 0.5f) * S24, u3 = ((float)w3 + 0.5f) * S24;
           float p = u0;
           p *= i0 + 1 < bi ? u1 : 1.0f;
           p *= i0 + 2 < bi ? u2 : 1.0f;
@@ -1694,8 +1706,9 @@ __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& 
         };
         float l2 = group(0);
         if (bi > 4) l2 += group(4);
-        s += (double)(-0.69314718f * l2 * weight1(kk));
+        sf = fmaf(-0.69314718f * l2, weight1(kk), sf);
       }
+      s = (double)sf;
     }
     int k = prod ? NT + 1 : 1;
     float wk = df * weight1(1);                             // (d folded in: the term is d v^3 w_k)
@@ -1732,7 +1745,7 @@ __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& 
     tvar -= NTf / (6.0f * q2 * q2 * q2);
   }
   const float bf = (float)b;
-  const double x = s + (double)(bf * tmean + __builtin_amdgcn_sqrtf(bf * tvar) * f.normal32f());
+  const double x = s + (double)(bf * tmean + __builtin_amdgcn_sqrtf(bf * tvar) * f.normal32f_single());
   return fmax(x, 1e-300) / (2.0 * PG_PI * PG_PI);
 }
 
