@@ -1393,7 +1393,7 @@ constexpr double PG_T = 0.64;
 constexpr double PG_PI = 3.141592653589793238462643383279502884;
 constexpr int PG_NORMAL_B = 200;
 constexpr int PG_DEVROYE_MAX = 2;   // integer b up to here: exact alternating-series draws, one per unit of b
-constexpr int PG_SERIES_NT = 16;     // terms of the sum-of-gammas series drawn for every other b (4 for b >= 3: the remainder then holds 3e-4 of the variance and 3e-6 of the third cumulant), + 2|psi|/(2 pi)
+constexpr int PG_SERIES_NT = 16;     // terms of the sum-of-gammas series drawn for b < 3, + 2|psi|/(2 pi); the rest enters through a normal
 constexpr int PG_SERIES_NT_BIG = 2;  // ... for b >= 3 (+ 2|psi|/(2 pi)): the rest enters through a moment-matched gamma (pg_draw_series)
 constexpr int PG_SERIES_NT_MAX = 96;
 constexpr int PG_PRODUCT_B = 8;      // integer shapes up to here draw their Gamma(b) terms as -ln(U_1...U_b) in the series sampler

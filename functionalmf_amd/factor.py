@@ -830,7 +830,7 @@ class BinomialBayesianTensorFiltering(GaussianBayesianTensorFiltering):
     def __init__(self, nrows, ncols, ndepth, pg_seed=42, pg_exact=False, **kwargs):
         """pg_exact: draw every omega ~ PG(N, psi) with Devroye's exact sampler summed N times (what pypolyagamma
         does for integer N, factor.py:459); default False: exact for N in {1, 2}, the validated sum-of-gammas
-        series with a normal remainder for larger N (include/btf.h, BTF_OPT_PG_EXACT)."""
+        series with a moment-matched remainder for larger N (include/btf.h, BTF_OPT_PG_EXACT)."""
         super().__init__(nrows, ncols, ndepth, **kwargs)
         self.pg_seed = pg_seed
         self.pg_exact = bool(pg_exact)

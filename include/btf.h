@@ -79,7 +79,7 @@ enum {
                                 weighted form of factor.py:343-346, :388-391); 0: always the weighted form         */
   BTF_OPT_PG_EXACT = 3       /* Polya-Gamma sampler of btf_pg_draw.  0 (default): integer trial counts 1 and 2 by
                                 Devroye's exact alternating-series sampler, every other count by the sum-of-gammas
-                                series with a normal remainder (approximate; validated against the exact sampler).
+                                series with a moment-matched remainder (approximate; validated against the exact sampler).
                                 1: the exact sampler for every count below 200 - floor(b) Devroye draws, as
                                 pypolyagamma does for integer b (factor.py:459) - plus a 128-term series for a
                                 fractional part.  Counts >= 200: moment-matched normal in both modes.           */

@@ -274,15 +274,16 @@ def _cumulants3(x):
     return m, (d * d).mean(), (d * d * d).mean()
 
 
-@pytest.mark.parametrize("b", [3, 4, 8, 4.3])
-@pytest.mark.parametrize("c", [0.0, 1.0, 5.0, 20.0])
+@pytest.mark.parametrize("b,c", [(b, c) for b in [3, 4, 8, 4.3] for c in [0.0, 1.0, 5.0, 20.0]] +
+                         [(4, 3.0), (4, 3.3), (4, 8.0), (3, 6.4), (13, 0.5)])
 def test_pg_series_sampler_against_exact_sampler(b, c):
-    """A/B of the two device samplers (BTF_OPT_PG_EXACT): the default sum-of-gammas series (4 drawn Gamma(b)
-    terms + 2|psi|/2pi, f32-transcendental variates, normal remainder) against Devroye's exact sampler summed
+    """A/B of the two device samplers (BTF_OPT_PG_EXACT): the default sum-of-gammas series (2 drawn Gamma(b)
+    terms + 2|psi|/2pi - the extra pairs straddle the |psi| = pi, 2 pi steps of that count -, f32-transcendental
+    variates, the rest through a moment-matched Wilson-Hilferty gamma) against Devroye's exact sampler summed
     floor(b) times (+ a 128-term f64 series for a fractional part) - the algorithm pypolyagamma runs for
     integer b (factor.py:459).  b = 4 is config C4's trial count.  2e6 draws each: two-sample KS and
     Anderson-Darling (tail-weighted), and the first three cumulants - the exact sampler's against the closed
-    forms, the series sampler's against the exact sampler's within Monte-Carlo error."""
+    forms, the series sampler's (and its fourth) against the exact sampler's within Monte-Carlo error."""
     from scipy.stats import ks_2samp, anderson_ksamp
     from oracle import btf_oracle as orc
     n = 2000000 if b == int(b) else 400000
@@ -302,6 +303,10 @@ def test_pg_series_sampler_against_exact_sampler(b, c):
     assert abs(vy - v) < 6 * sev and abs(vx - v) < 6 * sev + 2e-3 * v, (vx, vy, v)
     se3 = np.sqrt(((y - my) ** 6).mean() / n) * 1.5
     assert abs(tx - ty) < 6 * se3 + 0.02 * abs(ty), (tx, ty)
+    # fourth cumulant (the tails the moment-matched remainder could lose)
+    k4x, k4y = ((x - mx) ** 4).mean() - 3 * vx * vx, k4 - 3 * vy * vy
+    se4 = np.sqrt(((y - my) ** 8).mean() / n) * 1.5
+    assert abs(k4x - k4y) < 6 * se4 + 0.03 * abs(k4y), (k4x, k4y)
 
 
 @pytest.mark.parametrize("b,c", [(1, 0.0), (2, 3.0), (4, 1.0), (7, 0.5), (2.5, 2.0), (0.4, 1.0)])
@@ -339,8 +344,8 @@ def test_pg_distribution_ks(b, c):
 
 @pytest.mark.parametrize("b,c", [(3, 0.0), (4, 1.0), (1.2, 0.0), (8, 0.3), (27.3, 4.0), (60, 12.0)])
 def test_pg_series_sampler_ks_large_sample(b, c):
-    """The sum-of-gammas path (every b but the integers 1, 2): 8-16 Gamma(b) terms from f32-transcendental
-    variates + a normal remainder.  200 k draws against the oracle's 256-term f64 series sampler:
+    """The sum-of-gammas path (every b but the integers 1, 2): 2-16 Gamma(b) terms from f32-transcendental
+    variates + a moment-matched remainder.  200 k draws against the oracle's 256-term f64 series sampler:
     a two-sample KS at this size sees CDF differences of ~0.4 %."""
     from scipy.stats import ks_2samp
     from oracle import btf_oracle as orc
