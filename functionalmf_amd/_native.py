@@ -129,7 +129,7 @@ class NotPositiveDefiniteError(BTFError, np.linalg.LinAlgError):
 
 INST_SOURCE = os.path.join(CSRC, "btf_instances.hip")
 INST_PARTS = 8                      # = BTF_INST_PARTS of csrc/btf_instances.h
-OBJ_DIR = os.path.join(CSRC, "_obj")
+OBJ_DIR = os.path.join(ROOT, "build", "obj")          # git- and gpurun-ignored
 
 
 def build(force=False, verbose=False, jobs=None):
