@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -89,6 +90,7 @@ struct btf_ctx {
   double* nb_L = nullptr;            // [N + 1]: per-row sum cnt*log(1-p), then the total
   int* fill_tab = nullptr; int fill_n = 0; int fill_key = -1;   // band assembly program of the twisted kernel
   int* nb_optr = nullptr; double* nb_oval = nullptr; int nb_nout = 0;   // per-row outlier lists (CSR)
+  int nb_ymax = 0;                   // largest tabulated count present (histogram bins above it are empty)
   bool nb_tabulable = false;        // every observed count is an integer in [0, NB_TAB)
   bool nb_L_valid = false;          // nb_L matches the current W, V
   bool nb_hist = true;              // BTF_OPT_NB_HISTOGRAMS
@@ -1950,6 +1952,13 @@ int btf_set_data_counts(btf_ctx* c, const double* counts, int nreps) {
     }
     c->nb_tabulable = !bad;
     c->nb_L_valid = false;
+    {
+      std::vector<double> hs((size_t)NB_TAB, 0.0);
+      HIPCHK(c, hipMemcpyAsync(hs.data(), c->nb_Hs, (size_t)NB_TAB * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      c->nb_ymax = 0;
+      for (int y = 0; y < NB_TAB; ++y) if (hs[y] != 0.0) c->nb_ymax = y;
+    }
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->weighted = true;
@@ -2078,9 +2087,19 @@ int btf_nb_mh(btf_ctx* c, uint64_t seed, int nsteps, double rpropstdev, double r
   if ((size_t)c->N > c->nb_out_elems) { if ((rc = dev_alloc(c, &c->nb_out, (size_t)c->N))) return rc; c->nb_out_elems = (size_t)c->N; }
   const int scalar = shared[0] ? 1 : 0;
   const int* optr = c->nb_nout > 0 ? c->nb_optr : nullptr;
+  // one rate for everything (the reference's default rdims): the whole loop is one launch of one workgroup.
+  // BTF_NB_MH_STEPWISE=1 (test hook) keeps the two-launches-per-step form, which every other sharing pattern uses.
+  const char* stepwise_env = getenv("BTF_NB_MH_STEPWISE");
+  // (the one workgroup takes the outlier terms too: beyond one per thread the per-step launches spread them better)
+  const bool fused = scalar && nR == 1 && c->nb_nout <= 256 && !(stepwise_env && stepwise_env[0] == '1');
+  if (fused) {
+    Prof p(c, BTF_K_NB);
+    p.launch(nb_mh_scalar_kernel, dim3(1), dim3(256), 0, (const double*)c->nb_Hs, c->nb_ymax, (const double*)c->nb_L, c->N, optr,
+             (const double*)c->nb_oval, c->nb_R, c->nb_C, rpropstdev, rstdev, nsteps, (unsigned long long)seed);
+  } else
   hipLaunchKernelGGL(nb_mh_step_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_out, c->N, (int)nR, scalar, c->nb_R,
                      c->nb_C, rpropstdev, rstdev, -1, (unsigned long long)seed);
-  for (int sidx = 0; sidx < nsteps; ++sidx) {
+  for (int sidx = 0; !fused && sidx < nsteps; ++sidx) {
     {
       Prof p(c, BTF_K_NB);
       p.launch(nb_hist_loglik_kernel, dim3(c->N), dim3(256), 0, (const double*)c->nb_Hd, (const double*)c->nb_L,

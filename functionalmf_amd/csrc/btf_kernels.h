@@ -2088,12 +2088,13 @@ __device__ inline double nb_count_part(double y, double r, double c, double& bas
 }
 
 // table of sum_{k<y} log((c+k)/(r+k)), y = 0..NB_TAB-1, by all 256 threads of a block (4 entries each)
-__device__ inline void nb_build_table(double r, double c, double* tab, double* wsum) {
+// (ymax: entries above ymax + 1 are not needed by the caller - their logarithms are skipped)
+__device__ inline void nb_build_table(double r, double c, double* tab, double* wsum, int ymax = NB_TAB) {
   static_assert(NB_TAB == 1024, "4 table entries per thread of a 256-thread block");
   const int k0 = 4 * threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double l[4], run = 0.0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { run += log((c + (k0 + q)) / (r + (k0 + q))); l[q] = run; }
+  for (int q = 0; q < 4; ++q) { if (k0 + q < ymax) run += log((c + (k0 + q)) / (r + (k0 + q))); l[q] = run; }
   double incl = run;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -2392,6 +2393,64 @@ static __global__ __launch_bounds__(256) void nb_mh_step_kernel(const double* __
     }
     Cv[e] = exp(log(r) + rpropstdev * g.normal());
   }
+}
+
+// The whole random-walk MH loop for ONE rate shared by every cell (rdims = (0,1,2), the reference's default), in one
+// launch by one workgroup: with a single rate the likelihood ratio needs only the histogram of all counts (Hs = sum of
+// the per-row histograms, counts <= ymax), the sum of the rows' L and the outlier list - per step one table of
+// ymax + 1 prefix sums, a dot product and the accept / propose arithmetic of nb_mh_step_kernel (same Philox stream:
+// element 0, two blocks per step), instead of two launches per step with every row rebuilding the same table.
+static __global__ __launch_bounds__(256) void nb_mh_scalar_kernel(const double* __restrict__ Hs, int ymax,
+                                                          const double* __restrict__ L, int nrow, const int* __restrict__ optr,
+                                                          const double* __restrict__ oval, double* __restrict__ Rv,
+                                                          double* __restrict__ Cv, double rpropstdev, double rstdev,
+                                                          int nsteps, unsigned long long seed) {
+  __shared__ double tab[NB_TAB];
+  __shared__ double wsum[4];
+  __shared__ double red[4];
+  __shared__ double rc[2];
+  const int tid = threadIdx.x;
+  double acc = 0.0;
+  for (int i = tid; i < nrow; i += 256) acc += L[i];
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  if (tid == 0) {                                            // the step "-1" of nb_mh_step_kernel: propose only
+    CellRng g(seed, 0ull);
+    g.ctr = 0ull;
+    const double r = Rv[0];
+    rc[0] = r;
+    rc[1] = exp(log(r) + rpropstdev * g.normal());
+  }
+  __syncthreads();
+  const double Ltot = red[0] + red[1] + red[2] + red[3];
+  const int e0 = optr ? optr[0] : 0, e1 = optr ? optr[nrow] : 0;
+  for (int step = 0; step < nsteps; ++step) {
+    const double r = rc[0], c = rc[1];
+    nb_build_table(r, c, tab, wsum, ymax);                   // (barriers inside: red / rc of the last step are consumed)
+    acc = 0.0;
+    for (int y = tid; y <= ymax; y += 256) acc = fma(Hs[y], tab[y], acc);
+    if (e1 > e0) {
+      const double base = lgamma_diff(r, c);
+      for (int e = e0 + tid; e < e1; e += 256) acc += lgamma_diff(oval[e] + c, oval[e] + r) + base;
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      const double ll = red[0] + red[1] + red[2] + red[3] + (c - r) * Ltot;
+      CellRng g(seed, 0ull);
+      g.ctr = 2ull * (unsigned long long)(step + 1);
+      const double lr = log(r), lc = log(c);
+      const double prior = (lr * lr - lc * lc) / (2.0 * rstdev * rstdev);
+      const double prob = exp(fmin(fmax(prior + ll, -10.0), 1.0));
+      double rn = r;
+      if (g.uniform() <= prob && c > 1.0) rn = c;
+      rc[0] = rn;
+      rc[1] = exp(log(rn) + rpropstdev * g.normal());
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { Rv[0] = rc[0]; Cv[0] = rc[1]; }
 }
 
 // ============================================================================

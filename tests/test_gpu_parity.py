@@ -867,6 +867,37 @@ def test_negbinom_device_mh_loop_samples_the_same_posterior(rdims):
     assert np.all(np.abs(sh - sd) < 0.35 * np.maximum(sh, sd) + 0.01), (sh, sd)
 
 
+def test_negbinom_single_rate_mh_loop_in_one_launch_equals_the_stepwise_loop(monkeypatch):
+    """rdims = (0,1,2) (one rate, the reference's default): btf_nb_mh runs its whole loop in one launch from the
+    histogram of all counts; BTF_NB_MH_STEPWISE=1 keeps the per-step launches every other sharing pattern uses.
+    Same Philox streams -> the same chain of rates (the sums are formed in a different order: rounding only)."""
+    from functionalmf_amd.factor import NegativeBinomialBayesianTensorFiltering
+    rs = np.random.RandomState(33)
+    N, M, T, Rr, K = 9, 7, 11, 3, 2
+    Wt = 0.7 * rs.normal(size=(N, K))
+    Vt = 0.3 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    P = 1 / (1 + np.exp(-np.einsum("nk,mtk->nmt", Wt, Vt)))
+    data = rs.negative_binomial(4.0, 1 - P[..., None].repeat(Rr, -1)).astype(float)
+    data[1, 2, 3, 0] = 2000.0               # an outlier beyond the count table
+    data[0, :2] = np.nan
+    chains = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BTF_NB_MH_STEPWISE", mode)
+        np.random.seed(4)
+        model = NegativeBinomialBayesianTensorFiltering(N, M, T, nembeds=K, W_true=Wt, V_true=Vt, sigma2_true=1.0,
+                                                        lam2_true=0.1, Tau2_true=np.ones((M, 3 * T - 1)),
+                                                        rdims=(0, 1, 2), nmetropolis=7, rng="device", device_seed=11)
+        model._bind_data(data)
+        out = []
+        for _ in range(25):
+            model._resample_R(data)
+            out.append(float(np.asarray(model.R).reshape(-1)[0]))
+        assert getattr(model, "_mh_on_device", True)
+        chains[mode] = np.array(out)
+    assert len(set(np.round(chains["0"], 9))) > 5          # the chain moves
+    np.testing.assert_allclose(chains["0"], chains["1"], rtol=1e-9)
+
+
 def test_run_gibbs_device_collection_equals_per_sample_copies():
     """rng='device': run_gibbs collects the kept states on the GPU (btf_collect*).  Same seeds -> the same
     Philox streams, so the result dict must equal, bit for bit, what per-sample host copies
