@@ -91,6 +91,7 @@ struct btf_ctx {
   int* fill_tab = nullptr; int fill_n = 0; int fill_key = -1;   // band assembly program of the twisted kernel
   int* nb_optr = nullptr; double* nb_oval = nullptr; int nb_nout = 0;   // per-row outlier lists (CSR)
   int nb_ymax = 0;                   // largest tabulated count present (histogram bins above it are empty)
+  double* nb_G = nullptr;            // suffix sums of the histogram of all counts: nb_G[k] = #{observations > k}, k < NB_TAB
   bool nb_tabulable = false;        // every observed count is an integer in [0, NB_TAB)
   bool nb_L_valid = false;          // nb_L matches the current W, V
   bool nb_hist = true;              // BTF_OPT_NB_HISTOGRAMS
@@ -722,7 +723,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
   if (c->pin_hyp) (void)hipHostFree(c->pin_hyp);
-  for (void* p : {(void*)c->nb_data, (void*)c->nb_S, (void*)c->nb_cnt, (void*)c->nb_R, (void*)c->nb_C, (void*)c->nb_tmp, (void*)c->nb_out, (void*)c->nb_H, (void*)c->nb_Hd, (void*)c->nb_Hs, (void*)c->nb_L, (void*)c->nb_optr, (void*)c->nb_oval, (void*)c->fill_tab, (void*)c->C8_wT, (void*)c->C8_v, (void*)c->smp_W, (void*)c->smp_V, (void*)c->smp_T, (void*)c->smp_s})
+  for (void* p : {(void*)c->nb_data, (void*)c->nb_S, (void*)c->nb_cnt, (void*)c->nb_R, (void*)c->nb_C, (void*)c->nb_tmp, (void*)c->nb_out, (void*)c->nb_H, (void*)c->nb_Hd, (void*)c->nb_Hs, (void*)c->nb_G, (void*)c->nb_L, (void*)c->nb_optr, (void*)c->nb_oval, (void*)c->fill_tab, (void*)c->C8_wT, (void*)c->C8_v, (void*)c->smp_W, (void*)c->smp_V, (void*)c->smp_T, (void*)c->smp_s})
     if (p) (void)hipFree(p);
   if (c->hyp) (void)hipFree(c->hyp);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1958,6 +1959,11 @@ int btf_set_data_counts(btf_ctx* c, const double* counts, int nreps) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
       c->nb_ymax = 0;
       for (int y = 0; y < NB_TAB; ++y) if (hs[y] != 0.0) c->nb_ymax = y;
+      std::vector<double> gs((size_t)NB_TAB, 0.0);
+      double run = 0.0;
+      for (int k = NB_TAB - 2; k >= 0; --k) { run += hs[k + 1]; gs[k] = run; }      // exact: integer counts < 2^53
+      if ((rc = dev_alloc(c, &c->nb_G, (size_t)NB_TAB))) return rc;
+      HIPCHK(c, hipMemcpy(c->nb_G, gs.data(), (size_t)NB_TAB * sizeof(double), hipMemcpyHostToDevice));
     }
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2081,25 +2087,44 @@ int btf_nb_mh(btf_ctx* c, uint64_t seed, int nsteps, double rpropstdev, double r
     K_SWITCH(c->K, p.launch(nb_l1p_kernel<KT>, dim3(lbx, c->N), dim3(256), 0, (const double*)c->nb_cnt, (const double*)c->W,
                             (const double*)c->V, MT, c->nb_tmp));
     hipLaunchKernelGGL(nb_reduce_kernel, dim3(c->N), dim3(256), 0, c->stream, (const double*)c->nb_tmp, c->N, lbx, 1, 0, 1, 1, c->nb_L);
+    hipLaunchKernelGGL(nb_reduce_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_L, c->N, 1, 1, 1, 1, 1, c->nb_L + c->N);
     HIPCHK(c, hipGetLastError());
     c->nb_L_valid = true;
   }
-  if ((size_t)c->N > c->nb_out_elems) { if ((rc = dev_alloc(c, &c->nb_out, (size_t)c->N))) return rc; c->nb_out_elems = (size_t)c->N; }
+  const size_t need_out = std::max((size_t)c->N, (size_t)1024);    // per-row values, or up to 1024 partial sums of a single rate
+  if (need_out > c->nb_out_elems) { if ((rc = dev_alloc(c, &c->nb_out, need_out))) return rc; c->nb_out_elems = need_out; }
   const int scalar = shared[0] ? 1 : 0;
   const int* optr = c->nb_nout > 0 ? c->nb_optr : nullptr;
   // one rate for everything (the reference's default rdims): the whole loop is one launch of one workgroup.
   // BTF_NB_MH_STEPWISE=1 (test hook) keeps the two-launches-per-step form, which every other sharing pattern uses.
   const char* stepwise_env = getenv("BTF_NB_MH_STEPWISE");
+  const bool single = scalar && nR == 1 && !(stepwise_env && stepwise_env[0] == '1');
   // (the one workgroup takes the outlier terms too: beyond one per thread the per-step launches spread them better)
-  const bool fused = scalar && nR == 1 && c->nb_nout <= 256 && !(stepwise_env && stepwise_env[0] == '1');
+  const bool fused = single && c->nb_nout <= 256;
   if (fused) {
     Prof p(c, BTF_K_NB);
-    p.launch(nb_mh_scalar_kernel, dim3(1), dim3(256), 0, (const double*)c->nb_Hs, c->nb_ymax, (const double*)c->nb_L, c->N, optr,
+    p.launch(nb_mh_scalar_kernel, dim3(1), dim3(256), 0, (const double*)c->nb_G, c->nb_ymax, (const double*)c->nb_L, c->N, optr,
              (const double*)c->nb_oval, c->nb_R, c->nb_C, rpropstdev, rstdev, nsteps, (unsigned long long)seed);
+  } else if (single) {
+    // ... with many outliers: per step one launch of a few workgroups over the suffix-sum form and the outlier list
+    // (instead of one workgroup per row, each rebuilding the same table), then the decision kernel
+    const int gparts = std::max((c->nb_ymax + 255) / 256, std::min(1024, (c->nb_nout + 255) / 256));      // ~ one outlier per thread
+    const int gp = std::max(1, gparts);
+    hipLaunchKernelGGL(nb_mh_step_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_out, gp, 1, 1, c->nb_R,
+                       c->nb_C, rpropstdev, rstdev, -1, (unsigned long long)seed);
+    for (int sidx = 0; sidx < nsteps; ++sidx) {
+      {
+        Prof p(c, BTF_K_NB);
+        p.launch(nb_scalar_part_kernel, dim3(gp), dim3(256), 0, (const double*)c->nb_G, c->nb_ymax, (const double*)(c->nb_L + c->N),
+                 (const double*)c->nb_oval, c->nb_nout, (const double*)c->nb_R, (const double*)c->nb_C, c->nb_out);
+      }
+      hipLaunchKernelGGL(nb_mh_step_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_out, gp, 1, 1, c->nb_R,
+                         c->nb_C, rpropstdev, rstdev, sidx, (unsigned long long)seed);
+    }
   } else
   hipLaunchKernelGGL(nb_mh_step_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_out, c->N, (int)nR, scalar, c->nb_R,
                      c->nb_C, rpropstdev, rstdev, -1, (unsigned long long)seed);
-  for (int sidx = 0; !fused && sidx < nsteps; ++sidx) {
+  for (int sidx = 0; !single && sidx < nsteps; ++sidx) {
     {
       Prof p(c, BTF_K_NB);
       p.launch(nb_hist_loglik_kernel, dim3(c->N), dim3(256), 0, (const double*)c->nb_Hd, (const double*)c->nb_L,

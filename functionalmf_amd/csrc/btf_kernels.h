@@ -2395,18 +2395,42 @@ static __global__ __launch_bounds__(256) void nb_mh_step_kernel(const double* __
   }
 }
 
+// Single shared rate, more outliers than one workgroup should take: the per-step likelihood ratio as gridDim.x
+// partial sums (workgroup g: logarithm k = 256 g + tid of the suffix-sum form, and its chunk of the outlier list;
+// workgroup 0 adds (c - r) * sum L) - nb_mh_step_kernel then sums them as it sums per-row values.
+static __global__ __launch_bounds__(256) void nb_scalar_part_kernel(const double* __restrict__ Gs, int ymax,
+                                                            const double* __restrict__ Ltot, const double* __restrict__ oval,
+                                                            int nout, const double* __restrict__ Rv,
+                                                            const double* __restrict__ Cv, double* __restrict__ part) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x, g = blockIdx.x;
+  const double r = Rv[0], c = Cv[0];
+  double acc = 0.0;
+  const int k = g * 256 + tid;
+  if (k < ymax) acc = Gs[k] * log((c + k) / (r + k));
+  const int chunk = (nout + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int e0 = g * chunk, e1 = min(e0 + chunk, nout);
+  if (e1 > e0) {
+    const double base = lgamma_diff(r, c);
+    for (int e = e0 + tid; e < e1; e += 256) acc += lgamma_diff(oval[e] + c, oval[e] + r) + base;
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) part[g] = red[0] + red[1] + red[2] + red[3] + (g == 0 ? (c - r) * Ltot[0] : 0.0);
+}
+
 // The whole random-walk MH loop for ONE rate shared by every cell (rdims = (0,1,2), the reference's default), in one
-// launch by one workgroup: with a single rate the likelihood ratio needs only the histogram of all counts (Hs = sum of
-// the per-row histograms, counts <= ymax), the sum of the rows' L and the outlier list - per step one table of
-// ymax + 1 prefix sums, a dot product and the accept / propose arithmetic of nb_mh_step_kernel (same Philox stream:
-// element 0, two blocks per step), instead of two launches per step with every row rebuilding the same table.
-static __global__ __launch_bounds__(256) void nb_mh_scalar_kernel(const double* __restrict__ Hs, int ymax,
+// launch by one workgroup: with a single rate the likelihood ratio needs only the histogram of all counts, as its
+// suffix sums Gs[k] = #{observations > k}, k < ymax:  sum_y H[y] sum_{k<y} log((c+k)/(r+k)) = sum_k Gs[k] log((c+k)/(r+k))
+// - ymax logarithms per step, no table, no scan -, the sum of the rows' L and the outlier list; then the accept /
+// propose arithmetic of nb_mh_step_kernel (same Philox stream: element 0, two blocks per step), instead of two
+// launches per step with every row rebuilding the same table.
+static __global__ __launch_bounds__(256) void nb_mh_scalar_kernel(const double* __restrict__ Gs, int ymax,
                                                           const double* __restrict__ L, int nrow, const int* __restrict__ optr,
                                                           const double* __restrict__ oval, double* __restrict__ Rv,
                                                           double* __restrict__ Cv, double rpropstdev, double rstdev,
                                                           int nsteps, unsigned long long seed) {
-  __shared__ double tab[NB_TAB];
-  __shared__ double wsum[4];
   __shared__ double red[4];
   __shared__ double rc[2];
   const int tid = threadIdx.x;
@@ -2426,9 +2450,8 @@ static __global__ __launch_bounds__(256) void nb_mh_scalar_kernel(const double* 
   const int e0 = optr ? optr[0] : 0, e1 = optr ? optr[nrow] : 0;
   for (int step = 0; step < nsteps; ++step) {
     const double r = rc[0], c = rc[1];
-    nb_build_table(r, c, tab, wsum, ymax);                   // (barriers inside: red / rc of the last step are consumed)
     acc = 0.0;
-    for (int y = tid; y <= ymax; y += 256) acc = fma(Hs[y], tab[y], acc);
+    for (int k = tid; k < ymax; k += 256) acc = fma(Gs[k], log((c + k) / (r + k)), acc);
     if (e1 > e0) {
       const double base = lgamma_diff(r, c);
       for (int e = e0 + tid; e < e1; e += 256) acc += lgamma_diff(oval[e] + c, oval[e] + r) + base;

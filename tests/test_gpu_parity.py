@@ -867,18 +867,22 @@ def test_negbinom_device_mh_loop_samples_the_same_posterior(rdims):
     assert np.all(np.abs(sh - sd) < 0.35 * np.maximum(sh, sd) + 0.01), (sh, sd)
 
 
-def test_negbinom_single_rate_mh_loop_in_one_launch_equals_the_stepwise_loop(monkeypatch):
+@pytest.mark.parametrize("noutliers", [1, 300])
+def test_negbinom_single_rate_mh_loop_in_one_launch_equals_the_stepwise_loop(monkeypatch, noutliers):
     """rdims = (0,1,2) (one rate, the reference's default): btf_nb_mh runs its whole loop in one launch from the
-    histogram of all counts; BTF_NB_MH_STEPWISE=1 keeps the per-step launches every other sharing pattern uses.
+    histogram of all counts (or, with many counts beyond the table, one partial-sum launch per step);
+    BTF_NB_MH_STEPWISE=1 keeps the per-row launches every other sharing pattern uses.
     Same Philox streams -> the same chain of rates (the sums are formed in a different order: rounding only)."""
     from functionalmf_amd.factor import NegativeBinomialBayesianTensorFiltering
     rs = np.random.RandomState(33)
-    N, M, T, Rr, K = 9, 7, 11, 3, 2
+    N, M, T, Rr, K = 12, 10, 12, 3, 2
     Wt = 0.7 * rs.normal(size=(N, K))
     Vt = 0.3 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
     P = 1 / (1 + np.exp(-np.einsum("nk,mtk->nmt", Wt, Vt)))
     data = rs.negative_binomial(4.0, 1 - P[..., None].repeat(Rr, -1)).astype(float)
-    data[1, 2, 3, 0] = 2000.0               # an outlier beyond the count table
+    # counts beyond the 1024-entry table: one -> the one-launch loop; 300 (> 256) -> one partial-sum launch per step
+    flat = data.reshape(-1)
+    flat[rs.choice(flat.size, noutliers, replace=False)] += 1500.0 + rs.randint(0, 700, size=noutliers)
     data[0, :2] = np.nan
     chains = {}
     for mode in ("0", "1"):
