@@ -137,10 +137,15 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   // stencil of this thread's band entry (t, d) = tid into registers - all in the same round trip as the loads below
   const bool fuse_prior = a.pband == nullptr;
   double* itau = lds + W.itau;
+  const bool tau_one = fuse_prior && a.nD <= VT_THREADS;
+  double tau_reg = 1.0;
   int prow[PB_MAXE], pcnt = 0;
   double pcf[PB_MAXE], pacc = 0.0;
   if (fuse_prior) {
-    for (int r = tid; r < a.nD; r += VT_THREADS) itau[r] = 1.0 / (a.lam2 * a.Tau2[(size_t)jg * a.nD + r]);
+    // (one penalty row per thread: only the load is issued here - dividing and storing now would put a whole global
+    //  round trip in front of the loads below; the reciprocal is formed after them)
+    if (tau_one) { if (tid < a.nD) tau_reg = a.Tau2[(size_t)jg * a.nD + tid]; }
+    else for (int r = tid; r < a.nD; r += VT_THREADS) itau[r] = 1.0 / (a.lam2 * a.Tau2[(size_t)jg * a.nD + r]);
     if (tid < T * D1) {
       pcnt = a.st_ptr[tid + 1] - a.st_ptr[tid];
 #pragma unroll
@@ -158,6 +163,23 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   double gx[8];
   const bool g_early = !a.weighted && gram_early_ok(a.ngp, KK);     // Gram partials: fetched now, summed below
   if (g_early) reduce_gram_fetch(a.gpart, a.ngp, KK, gx);
+  // per-depth likelihood blocks of weighted data, element e = q*T + t (see the general loop below)
+  const bool ql_now = a.weighted && n <= 2 * VT_THREADS && T * KK <= 4 * VT_THREADS;
+  const double* qp[4];
+  int qdst[4];
+  bool qhas[4];
+  double qacc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (ql_now) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = u * VT_THREADS + tid;
+      qhas[u] = e < T * KK;
+      const int ec = qhas[u] ? e : 0;
+      const int q = ec / T, t = ec - q * T;
+      qp[u] = a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t;
+      qdst[u] = t * KK + q;
+    }
+  }
   if (n <= 2 * VT_THREADS) {   // both elements of a thread at once: one round of global-load latency, not two
     // element e = k*T + t: consecutive lanes read consecutive depths t of one factor row k (coalesced 8-B
     // words of the partials; the depth-major scatter m0[t*K + k] happens on the LDS side)
@@ -180,6 +202,29 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     }
     double s0 = 0.0, s1 = 0.0;
     int c = 0;
+    if (ql_now) {
+      // weighted data whose per-depth blocks fit one pass (T*KK <= 4 per thread): their chunks ride in the same batches
+      // of loads as the mean part's (one global round trip less; same sums, c ascending)
+      for (; c + 2 <= a.nch; c += 2) {
+        const double x0 = p0[(size_t)c * st], x1 = p0[(size_t)(c + 1) * st];
+        const double y0 = p1[(size_t)c * st], y1 = p1[(size_t)(c + 1) * st];
+        double q0[4], q1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { q0[u] = qp[u][(size_t)c * st]; q1[u] = qp[u][(size_t)(c + 1) * st]; }
+        s0 += x0; s0 += x1;
+        s1 += y0; s1 += y1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { qacc[u] += q0[u]; qacc[u] += q1[u]; }
+      }
+      for (; c < a.nch; ++c) {
+        double q0[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q0[u] = qp[u][(size_t)c * st];
+        s0 += p0[(size_t)c * st]; s1 += p1[(size_t)c * st];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) qacc[u] += q0[u];
+      }
+    }
     for (; c + 4 <= a.nch; c += 4) {                     // fixed order c ascending, as chunk_sum
       const double x0 = p0[(size_t)c * st], x1 = p0[(size_t)(c + 1) * st], x2 = p0[(size_t)(c + 2) * st], x3 = p0[(size_t)(c + 3) * st];
       const double y0 = p1[(size_t)c * st], y1 = p1[(size_t)(c + 1) * st], y2 = p1[(size_t)(c + 2) * st], y3 = p1[(size_t)(c + 3) * st];
@@ -208,6 +253,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   if (fuse_prior) {
     // prior band P[t][d] = sum_r Delta[r,t] Delta[r,t+d] / (lam2 Tau2_jr), rows ascending (factor.py:404-405): the
     // reciprocal once per penalty row, this thread's entry from its fixed-slot stencil (fetched above, with everything else)
+    if (tau_one && tid < a.nD) itau[tid] = 1.0 / (a.lam2 * tau_reg);
     __syncthreads();                                       // itau complete
 #pragma unroll
     for (int u = 0; u < PB_MAXE; ++u) if (u < pcnt) pacc = fma(pcf[u], itau[prow[u]], pacc);
@@ -218,7 +264,10 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
       P[idx] = sacc;
     }
   }
-  if (a.weighted) {
+  if (ql_now) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (qhas[u]) Ql[qdst[u]] = qacc[u] * a.s;
+  } else if (a.weighted) {
     // per-depth likelihood blocks: element e = q*T + t, so that consecutive lanes read consecutive depths of one
     // Gram entry (coalesced 8-B words; the scatter to Ql[t*KK + q] is on the LDS side), four elements' chunks in
     // flight per thread and trip (one or two global round trips for the 960 entries of C3 instead of four)
