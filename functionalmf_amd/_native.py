@@ -110,6 +110,8 @@ SIGNATURES = {
     "btf_mvn_dense": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp, _c_dp, C.c_uint64, C.c_double, C.c_int,
                                 _c_dp, _c_ip]),
     "btf_get_likelihood_form": (C.c_int, [_ctx, _c_ip]),
+    "btf_get_draw_counters": (C.c_int, [_ctx, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "btf_set_draw_counters": (C.c_int, [_ctx, C.c_uint64, C.c_uint64]),
     "btf_get_accum_bytes_per_cell": (C.c_int, [_ctx, _c_dp]),
     "btf_get_V_sampler": (C.c_int, [_ctx, _c_ip]),
 }

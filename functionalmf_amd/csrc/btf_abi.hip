@@ -2744,6 +2744,18 @@ int btf_get_likelihood_form(btf_ctx* c, int32_t* form) {
   return BTF_OK;
 }
 
+int btf_get_draw_counters(btf_ctx* c, uint64_t* w, uint64_t* v) {
+  if (!c || !w || !v) return BTF_EINVAL;
+  *w = c->sweep_w; *v = c->sweep_v;
+  return BTF_OK;
+}
+
+int btf_set_draw_counters(btf_ctx* c, uint64_t w, uint64_t v) {
+  if (!c) return BTF_EINVAL;
+  c->sweep_w = w; c->sweep_v = v;
+  return BTF_OK;
+}
+
 int btf_get_accum_bytes_per_cell(btf_ctx* c, double* bytes) {
   if (!c || !bytes) return BTF_EINVAL;
   if (!c->have_data) return fail(c, BTF_ESTATE, "set data first");

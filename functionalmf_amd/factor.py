@@ -33,6 +33,8 @@ Extra keywords (all optional):
                      "banded" for data with missing cells / Binomial weights;
           "auto"     (default) as described above.
 """
+import ctypes
+
 import numpy as np
 
 from . import _native
@@ -656,6 +658,56 @@ class BayesianTensorFiltering(_BayesianModel):
         """Wait for the GPU; raises NotPositiveDefiniteError if a factorisation failed."""
         self._ctx.call("btf_sync")
 
+    # ---- checkpoint / resume (the reference keeps nothing between runs: genlasso.py:57-66 returns the samples and the
+    # applications np.save them, doseresponse/fit.py:428-439; SURVEY section 5) -----------------------------------
+    _CHAIN_ARRAYS = ("W", "V", "Tau2", "Tau2_a", "Tau2_b", "Tau2_c")
+    _CHAIN_SCALARS = ("sigma2", "lam2", "lam2_a")
+
+    def checkpoint(self):
+        """The chain's state between two sweeps as a dict of numpy arrays and numbers (np.savez-able): factors,
+        horseshoe+ levels, scalars, the device draw counter (rng="device": every Philox stream is keyed by
+        device_seed and that counter) and the legacy numpy generator's state (rng="host").  A model built with the
+        same arguments, `restore`d from it and given the same data continues the chain bit for bit."""
+        self.sync()
+        st = {"draws": int(self._draws), "device_seed": int(self._device_seed), "rng": self.rng}
+        cw, cv = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._ctx.call("btf_get_draw_counters", ctypes.byref(cw), ctypes.byref(cv))
+        st["half_sweeps_w"], st["half_sweeps_v"] = int(cw.value), int(cv.value)
+        for k in self._CHAIN_ARRAYS:
+            v = getattr(self, k, None)
+            if v is not None:
+                st[k] = np.array(v, dtype=float)
+        for k in self._CHAIN_SCALARS:
+            v = getattr(self, k, None)
+            if v is not None:
+                st[k] = float(v)
+        kind, keys, pos, has_gauss, cached = np.random.get_state()
+        st.update(np_kind=kind, np_keys=np.array(keys), np_pos=int(pos), np_has_gauss=int(has_gauss), np_cached=float(cached))
+        st.update(self._extra_state())
+        return st
+
+    def restore(self, st):
+        """Continue from `checkpoint()`'s dict (or an np.load of it)."""
+        if int(st["device_seed"]) != int(self._device_seed) or str(st["rng"]) != self.rng:
+            raise ValueError("checkpoint was taken with device_seed=%s rng=%s" % (st["device_seed"], st["rng"]))
+        for k in self._CHAIN_ARRAYS:
+            if k in st:
+                setattr(self, k, np.array(st[k], dtype=float))
+        for k in self._CHAIN_SCALARS:
+            if k in st:
+                setattr(self, k, float(st[k]))
+        self._draws = int(st["draws"])
+        self._ctx.call("btf_set_draw_counters", int(st["half_sweeps_w"]), int(st["half_sweeps_v"]))
+        np.random.set_state((str(st["np_kind"]), np.asarray(st["np_keys"], dtype=np.uint32), int(st["np_pos"]),
+                             int(st["np_has_gauss"]), float(st["np_cached"])))
+        self._set_extra_state(st)
+
+    def _extra_state(self):
+        return {}
+
+    def _set_extra_state(self, st):
+        pass
+
     def _resample_W(self, data):
         raise NotImplementedError
 
@@ -669,6 +721,17 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
     fuse_tau2 = True       # rng="device" sweeps: the horseshoe+ chain rides in the W accumulation launch (A/B switch)
 
     nu2 = property(lambda self: self._sc_get("nu2"), lambda self, v: self._sc_set("nu2", v))
+
+    def _extra_state(self):
+        st = super()._extra_state()
+        if self._scalar_noise:
+            st["nu2"] = float(self.nu2)
+        return st
+
+    def _set_extra_state(self, st):
+        super()._set_extra_state(st)
+        if self._scalar_noise:
+            self.nu2 = float(st["nu2"])
 
     def __init__(self, nrows, ncols, ndepth,
                  nu2_init=None, nu2_true=None,
@@ -826,6 +889,15 @@ class BinomialBayesianTensorFiltering(GaussianBayesianTensorFiltering):
 
     _queue_sse = False     # nu2 here is the tensor 1/omega (PG draw), not a variance to update from residuals
     _scalar_noise = False
+
+    def _extra_state(self):           # (omega itself is redrawn from W, V at the start of every sweep)
+        st = super()._extra_state()
+        st["pg_calls"] = int(self._pg_calls)
+        return st
+
+    def _set_extra_state(self, st):
+        super()._set_extra_state(st)
+        self._pg_calls = int(st["pg_calls"])
 
     def __init__(self, nrows, ncols, ndepth, pg_seed=42, pg_exact=False, **kwargs):
         """pg_exact: draw every omega ~ PG(N, psi) with Devroye's exact sampler summed N times (what pypolyagamma
@@ -1032,6 +1104,16 @@ class NegativeBinomialBayesianTensorFiltering(BinomialBayesianTensorFiltering):
     def _inferred_variables(self, var_map):
         super()._inferred_variables(var_map)
         var_map['R'] = np.copy(self.R)
+
+    def _extra_state(self):
+        st = super()._extra_state()
+        st["R"] = np.array(self.R, dtype=float)
+        return st
+
+    def _set_extra_state(self, st):
+        super()._set_extra_state(st)
+        self.R = np.array(st["R"], dtype=float)           # (uploaded with the data: _bind_data -> _push_rate)
+        self._rate_key = None
 
 
 class NonconjugateBayesianTensorFiltering(BayesianTensorFiltering):

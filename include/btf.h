@@ -273,6 +273,11 @@ int btf_read_probe(int device, size_t bytes, int reps, double* gb_per_s);
  *                         per-column corrections (BTF_OPT_CURVE_COUNTS) - the same conditionals as the weighted form */
 enum { BTF_LIK_COMPLETE = 0, BTF_LIK_WEIGHTED = 1, BTF_LIK_CURVE_COUNTS = 2 };
 int btf_get_likelihood_form(btf_ctx* ctx, int32_t* form);
+/* Checkpoint / resume (the reference keeps no state between runs - genlasso.py:57-66 returns the samples; SURVEY
+ * section 5): besides the caller's seeds, the rng="device" draws of W and V are keyed by how many W / V half-sweeps
+ * this context has run.  A chain continued in another context gets the same draws after handing these two over. */
+int btf_get_draw_counters(btf_ctx* ctx, uint64_t* w_half_sweeps, uint64_t* v_half_sweeps);
+int btf_set_draw_counters(btf_ctx* ctx, uint64_t w_half_sweeps, uint64_t v_half_sweeps);
 /* Algorithmic bytes per cell one accumulation launch streams for the bound data: 8 (linear statistic alone: complete data,
  * curve counts), 9 (+ replicate counts as bytes; or Binomial pseudo-data kappa = Y - N/2 as bytes + f64 weights when
  * the counts are integers up to 127), 16 (f64 statistic + f64 weights).  bench.py's roofline uses it. */
