@@ -57,11 +57,41 @@ static __global__ void ess_combine_kernel(const double* __restrict__ x0, const d
   x[e] = fma(x0[e], cs, nu[e] * sn);
 }
 
+// log(x) for the identity-link likelihood, evaluated once per (cell, proposal): libm's log is ~90 f64 instructions;
+// here x = 2^e m, m in [1,2) is divided by the left edge c_i = 1 + i/128 of its mantissa interval through a
+// 128-entry table (1/c_i rounded, and minus the log of exactly that number), leaving log1p(r) with 0 <= r < 2^-7 for a
+// degree-8 polynomial (truncation r^8/9 < 2e-18 relative): ~20 instructions, absolute error of the order of one
+// ulp of max(|e| ln 2, 1) - what libm gives away from x = 1.  The table is built per workgroup in LDS (one libm log
+// per thread): log_table_build, then a barrier.
+constexpr int LOGTAB_N = 128;
+__device__ __forceinline__ void log_table_build(double2* tab) {
+  for (int i = threadIdx.x; i < LOGTAB_N; i += blockDim.x) {
+    const double inv = 1.0 / (1.0 + (double)i * (1.0 / LOGTAB_N));
+    tab[i] = make_double2(inv, -log(inv));
+  }
+}
+__device__ __forceinline__ double log_tab(double x, const double2* __restrict__ tab) {
+  if (!(x >= 2.2250738585072014e-308 && x < INFINITY)) return log(x);        // subnormal / inf / nan: rare, exact path
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  const int e = (int)(b >> 52) - 1023;
+  const double m = __longlong_as_double((long long)((b & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL));
+  const double2 t = tab[(int)((b >> 45) & 127ULL)];
+  const double r = fma(m, t.x, -1.0);
+  double p = fma(r, -1.0 / 8.0, 1.0 / 7.0);
+  p = fma(r, p, -1.0 / 6.0);
+  p = fma(r, p, 1.0 / 5.0);
+  p = fma(r, p, -1.0 / 4.0);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -1.0 / 2.0);
+  p = fma(r * r, p, r);                                   // log1p(r) = r - r^2/2 + ... - r^8/8
+  return fma((double)e, 0.6931471805599453094, t.y + p);
+}
+
 template <int LINK>
-__device__ __forceinline__ double poisson_term(double s1, double cnt, double eta) {
+__device__ __forceinline__ double poisson_term(double s1, double cnt, double eta, const double2* __restrict__ ltab) {
   if (!(cnt > 0.0)) return 0.0;
   if constexpr (LINK == ESS_LINK_LOG) return fma(s1, eta, -cnt * exp(eta));
-  else return eta > 0.0 ? fma(s1, log(eta), -cnt * eta) : -INFINITY;
+  else return eta > 0.0 ? fma(s1, log_tab(eta, ltab), -cnt * eta) : -INFINITY;
 }
 
 // Poisson log-likelihood of the local rows, lanes along (j,t) (V layout): part[i][bx] = sum over the block's cells of
@@ -72,9 +102,11 @@ __global__ __launch_bounds__(ESS_THREADS) void poisson_ll_rows_kernel(
     const double* __restrict__ V, int row0, int ncols, int ld, size_t col0, const int* __restrict__ done, int per_row,
     double* __restrict__ part) {
   __shared__ double red[ESS_THREADS / WAVE];
+  __shared__ double2 ltab[LOGTAB_N];
   const int i = blockIdx.y;
   if (per_row && done[i]) return;
   if (!per_row && done[0]) return;
+  if constexpr (LINK != ESS_LINK_LOG) { log_table_build(ltab); __syncthreads(); }
   double w[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) w[k] = W[(size_t)(row0 + i) * K + k];
@@ -86,7 +118,7 @@ __global__ __launch_bounds__(ESS_THREADS) void poisson_ll_rows_kernel(
     for (int k = 0; k < K; ++k) eta = fma(w[k], v[k], eta);
     const double s1 = A[(size_t)i * ld + l];
     const double cnt = Cx ? (double)Cx[(size_t)i * ld + l] : Rc;
-    s += poisson_term<LINK>(s1, cnt, eta);
+    s += poisson_term<LINK>(s1, cnt, eta, ltab);
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -106,8 +138,10 @@ __global__ __launch_bounds__(ESS_THREADS) void poisson_ll_cols_kernel(
     const double* __restrict__ V, int row0, int nl, int ld, int col0, int T, const int* __restrict__ done,
     double* __restrict__ part) {
   __shared__ double red[ESS_THREADS / WAVE];
+  __shared__ double2 ltab[LOGTAB_N];
   const int j = blockIdx.y;
   if (done[j]) return;
+  if constexpr (LINK != ESS_LINK_LOG) { log_table_build(ltab); __syncthreads(); }
   double s = 0.0;
   for (int i = blockIdx.x * ESS_THREADS + threadIdx.x; i < nl; i += gridDim.x * ESS_THREADS) {
     double w[K];
@@ -120,7 +154,7 @@ __global__ __launch_bounds__(ESS_THREADS) void poisson_ll_cols_kernel(
       for (int k = 0; k < K; ++k) eta = fma(w[k], v[k], eta);
       const size_t o = ((size_t)j * T + t) * ld + i;
       const double cnt = Cx ? (double)Cx[o] : Rc;
-      s += poisson_term<LINK>(A[o], cnt, eta);
+      s += poisson_term<LINK>(A[o], cnt, eta, ltab);
     }
   }
   s = wave_sum(s);

@@ -1488,6 +1488,40 @@ def test_gass_row_and_column_updates_vs_reference_fixture(golden):
     assert relerr(model.V, g["V_after"]) < 1e-7
 
 
+def test_identity_link_logarithm_is_accurate_to_double_precision():
+    """The identity-link Poisson term takes its log from a 128-entry table + a degree-8 log1p (csrc/btf_ess.h: log_tab)
+    instead of libm.  Rates that depend on the row alone make a row's log-likelihood M T (y log w_i - w_i) with the
+    logarithm of ONE number in it: the per-row values the GASS set-up reports (btf_gass_grid: cur_ll) against numpy, for
+    rates across 30 binary orders of magnitude, next to 1 and at interval edges of the table."""
+    import ctypes
+    from functionalmf_amd.factor import ConstrainedNonconjugateBayesianTensorFiltering
+    from functionalmf_amd import _native
+    N, M, T, K, y = 96, 3, 8, 2, 3.0
+    rs = np.random.RandomState(8)
+    w = np.concatenate([2.0 ** rs.uniform(-15, 15, size=N - 24), 1 + rs.uniform(-1e-3, 1e-3, size=8),
+                        1 + np.arange(8) / 128.0, (1 + np.arange(8) / 128.0) * (1 - 2.0 ** -52)])
+    W = np.zeros((N, K)); W[:, 0] = w
+    V = np.zeros((M, T, K)); V[..., 0] = 1.0; V[..., 1] = 0.5
+    Cons = np.concatenate([np.eye(T), np.zeros((T, 1))], axis=1)
+    model = ConstrainedNonconjugateBayesianTensorFiltering(N, M, T, "poisson_identity", Cons, gass_ngrid=16, nembeds=K, tf_order=0,
+                                                           sigma2_init=1.0, lam2_init=0.1, W_init=W, V_init=V,
+                                                           Tau2_init=np.ones((M, T)), sampler="banded")
+    Y = np.full((N, M, T, 1), y)
+    model._bind_data(Y)
+    model._push_state()
+    model._ctx.call("btf_gass_set_constraints", _native.dptr(model._cons), int(model._cons.shape[0]), None, 0)
+    z = rs.normal(size=K * (K + 1) // 2 + (N - K) * K)
+    u = rs.rand(N)
+    model._ctx.call("btf_gass_begin", 0, 1, _native.dptr(z), _native.dptr(u), 1, 1e-6, 0, 0)
+    info = np.zeros((N, 2), dtype=np.int32)
+    cur = np.empty(N)
+    model._ctx.call("btf_gass_grid", 0, info.ctypes.data_as(_native._c_ip), None, None, _native.dptr(cur))
+    ref = M * T * (y * np.log(w) - w)
+    # error budget: the logarithm's (a few 1e-16 of max(|log w|, 1)) times y M T, plus the summation's
+    tol = 4e-16 * M * T * (y * np.maximum(np.abs(np.log(w)), 1.0) + w) + 1e-15 * np.abs(ref)
+    assert np.all(np.abs(cur - ref) <= tol), (np.abs(cur - ref) / tol).max()
+
+
 @pytest.mark.gpu
 def test_gass_valid_grid_equals_the_oracles(golden):
     """The validity of each of the 10000 grid angles (difference array + scan on the device) against the oracle's
