@@ -69,7 +69,7 @@ struct btf_ctx {
   // generalized analytic slice sampling (btf_gass_*): constraints, per-chain grids / candidates / likelihoods
   double* gs_cons = nullptr; double* gs_cc = nullptr; double* gs_rc = nullptr; int gs_J = 0, gs_nrc = 0;
   double* gs_av = nullptr; unsigned char* gs_mask = nullptr; int* gs_info = nullptr;
-  double* gs_thetas = nullptr; int* gs_ntheta = nullptr; double* gs_ll = nullptr; double* gs_hh = nullptr; double* gs_cur = nullptr;
+  double* gs_thetas = nullptr; int* gs_ntheta = nullptr; double* gs_ll = nullptr; double* gs_llp = nullptr; size_t gs_llp_elems = 0; double* gs_hh = nullptr; double* gs_cur = nullptr;
   int* gs_nacc = nullptr; double* gs_u = nullptr;
   int gs_chains = 0, gs_what = -1, gs_link = 0;
   long long* dbg = nullptr;
@@ -718,7 +718,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->A8_wT, c->A8_v, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->A8_wT, c->A8_v, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_llp, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
@@ -1569,17 +1569,32 @@ int gass_check(btf_ctx* c, int what, int link) {
 int gass_eval_launch(btf_ctx* c, int what, int link) {
   GassEvalArgs a{};
   a.X0 = c->essX0; a.Nu = c->essNu; a.N = c->N; a.M = c->M; a.T = c->T; a.K = c->K; a.Rc = (double)c->R;
-  a.thetas = c->gs_thetas; a.ntheta = c->gs_ntheta; a.ll = c->gs_ll;
+  a.thetas = c->gs_thetas; a.ntheta = c->gs_ntheta;
+  // few chains: a chain's cell tiles are dealt to several workgroups (>= ~1024 in all: four waves per SIMD hide the LDS
+  // and dependency stalls one 4-wave workgroup per CU leaves open), their partial sums added in order afterwards
+  const int nch = what == 0 ? c->N : c->M;
+  const int ntiles = ((what == 0 ? c->M : c->N) * c->T + GASS_CT - 1) / GASS_CT;
+  const int nsplit = std::max(1, std::min(std::min(8, ntiles), (1024 + nch - 1) / nch));
+  if (nsplit > 1) {
+    const size_t need = (size_t)nch * nsplit * GASS_MAXC;
+    if (need > c->gs_llp_elems) { int rc; if ((rc = dev_alloc(c, &c->gs_llp, need))) return rc; c->gs_llp_elems = need; }
+  }
+  a.ll = nsplit > 1 ? c->gs_llp : c->gs_ll;
+  a.nsplit = nsplit;
   Prof p(c, BTF_K_ESS);
+  const dim3 grid(nch, nsplit);
   if (what == 0) {
     a.F = c->V; a.A = c->A_v; a.C8 = c->C8_v; a.Cd = c->C_v; a.ld = c->ldv;
-    if (link == ESS_LINK_LOG) p.launch(gass_eval_kernel<ESS_LINK_LOG, true>, dim3(c->N), dim3(GASS_THREADS), 0, a);
-    else p.launch(gass_eval_kernel<ESS_LINK_IDENTITY, true>, dim3(c->N), dim3(GASS_THREADS), 0, a);
+    if (link == ESS_LINK_LOG) p.launch(gass_eval_kernel<ESS_LINK_LOG, true>, grid, dim3(GASS_THREADS), 0, a);
+    else p.launch(gass_eval_kernel<ESS_LINK_IDENTITY, true>, grid, dim3(GASS_THREADS), 0, a);
   } else {
     a.F = c->W; a.A = c->A_wT; a.C8 = c->C8_wT; a.Cd = c->C_wT; a.ld = c->ldw;
-    if (link == ESS_LINK_LOG) p.launch(gass_eval_kernel<ESS_LINK_LOG, false>, dim3(c->M), dim3(GASS_THREADS), 0, a);
-    else p.launch(gass_eval_kernel<ESS_LINK_IDENTITY, false>, dim3(c->M), dim3(GASS_THREADS), 0, a);
+    if (link == ESS_LINK_LOG) p.launch(gass_eval_kernel<ESS_LINK_LOG, false>, grid, dim3(GASS_THREADS), 0, a);
+    else p.launch(gass_eval_kernel<ESS_LINK_IDENTITY, false>, grid, dim3(GASS_THREADS), 0, a);
   }
+  if (nsplit > 1)
+    hipLaunchKernelGGL(gass_ll_sum_kernel, dim3((nch * GASS_MAXC + 255) / 256), dim3(256), 0, c->stream, (const double*)c->gs_llp, nsplit,
+                       (const int*)c->gs_ntheta, nch, c->gs_ll);
   HIPCHK(c, hipGetLastError());
   return BTF_OK;
 }

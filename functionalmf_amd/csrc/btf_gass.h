@@ -258,7 +258,8 @@ struct GassEvalArgs {
   const double* X0; const double* Nu; const double* F;   // chains' state / proposal, the fixed factor (V for rows, W for cols)
   const double* A; const unsigned char* C8; const double* Cd; double Rc;    // statistics of the chains' cells, counts (bytes / f64 / constant)
   int N, M, T, K, ld;
-  const double* thetas; const int* ntheta; double* ll;   // [nchains][GASS_MAXC]
+  const double* thetas; const int* ntheta; double* ll;   // [nchains][GASS_MAXC] (nsplit == 1) or partial sums [nchains][nsplit][GASS_MAXC]
+  int nsplit;                                           // workgroups per chain (blockIdx.y): tiles dealt round-robin
 };
 
 template <int LINK, bool ROWS>
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(GASS_THREADS) void gass_eval_kernel(GassEvalArgs a)
   sincos(th1, &s1, &c1);
   double acc0 = 0.0, acc1 = 0.0;
   const int ncell = ROWS ? a.M * T : a.N * T;
-  for (int base = 0; base < ncell; base += GASS_CT) {
+  for (int base = (int)blockIdx.y * GASS_CT; base < ncell; base += GASS_CT * a.nsplit) {
     __syncthreads();
     for (int e = tid; e < GASS_CT; e += GASS_THREADS) {
       const int cell = base + e;
@@ -317,8 +318,20 @@ __global__ __launch_bounds__(GASS_THREADS) void gass_eval_kernel(GassEvalArgs a)
   if (tid < GASS_MAXC) {
     double s = 0.0;
     for (int w = 0; w < GASS_THREADS / WAVE; ++w) s += red[w][tid];
-    a.ll[(size_t)ch * GASS_MAXC + tid] = tid < nth ? s : -INFINITY;
+    if (a.nsplit == 1) a.ll[(size_t)ch * GASS_MAXC + tid] = tid < nth ? s : -INFINITY;
+    else a.ll[((size_t)ch * a.nsplit + blockIdx.y) * GASS_MAXC + tid] = s;
   }
+}
+
+// ll[ch][q] = sum of the nsplit partial sums of gass_eval_kernel, in order; -inf beyond the chain's candidates
+static __global__ void gass_ll_sum_kernel(const double* __restrict__ part, int nsplit, const int* __restrict__ ntheta, int nchains,
+                                   double* __restrict__ ll) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nchains * GASS_MAXC) return;
+  const int ch = idx / GASS_MAXC, q = idx - ch * GASS_MAXC;
+  double s = 0.0;
+  for (int u = 0; u < nsplit; ++u) s += part[((size_t)ch * nsplit + u) * GASS_MAXC + q];
+  ll[idx] = q < ntheta[ch] ? s : -INFINITY;
 }
 
 // slice height of every chain: hh = ll(current) + log u   (u given, or Philox(seed, chain))
