@@ -667,7 +667,9 @@ class BayesianTensorFiltering(_BayesianModel):
         """The chain's state between two sweeps as a dict of numpy arrays and numbers (np.savez-able): factors,
         horseshoe+ levels, scalars, the device draw counter (rng="device": every Philox stream is keyed by
         device_seed and that counter) and the legacy numpy generator's state (rng="host").  A model built with the
-        same arguments, `restore`d from it and given the same data continues the chain bit for bit."""
+        same arguments, `restore`d from it and given the same data continues the chain bit for bit.  (Conjugate
+        models: Gaussian, Binomial, Negative-Binomial.  The slice-sampling models keep further generator state in
+        `chain_rngs` / the context's round counters, which a checkpoint does not carry.)"""
         self.sync()
         st = {"draws": int(self._draws), "device_seed": int(self._device_seed), "rng": self.rng}
         cw, cv = ctypes.c_uint64(0), ctypes.c_uint64(0)
