@@ -87,10 +87,32 @@ __device__ __forceinline__ double log_tab(double x, const double2* __restrict__ 
   return fma((double)e, 0.6931471805599453094, t.y + p);
 }
 
+// exp(x) for the log link, the same way: x = (128 k + j) ln2/128 + r, |r| <= ln2/256, so exp(x) = 2^k 2^(j/128) e^r
+// with 2^(j/128) from the table (second use of its 128 slots: .x of the exp table) and a degree-5 polynomial for e^r
+// (truncation r^6/720 < 6e-19); the reduction subtracts n ln2/128 in two pieces (hi with 11 trailing zero bits: exact
+// product for |n| < 2^11 * 128).  ~20 instructions instead of libm's ~55; |x| > 700 (overflow range) goes to libm.
+__device__ __forceinline__ void exp_table_build(double2* tab) {
+  for (int i = threadIdx.x; i < LOGTAB_N; i += blockDim.x) tab[i] = make_double2(exp2((double)i * (1.0 / LOGTAB_N)), 0.0);
+}
+__device__ __forceinline__ double exp_tab(double x, const double2* __restrict__ tab) {
+  if (!(fabs(x) < 700.0)) return exp(x);
+  const double n = rint(x * (LOGTAB_N * 1.4426950408889634074));            // x * 128 / ln 2
+  const double hi = 0x1.62e42fefa3800p-8, lo = 0x1.ef35793c76730p-52;       // ln2/128 = hi + lo, hi: 42 significant bits
+  const double r = fma(-n, lo, fma(-n, hi, x));
+  const int ni = (int)n;
+  const int j = ni & (LOGTAB_N - 1), k = (ni - j) / LOGTAB_N;               // ni = 128 k + j, 0 <= j < 128
+  double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = fma(r, p, 1.0 / 6.0);
+  p = fma(r, p, 0.5);
+  p = fma(r * r, p, r);                                                      // e^r - 1
+  const double t = tab[j].x;
+  return ldexp(fma(t, p, t), k);
+}
+
 template <int LINK>
 __device__ __forceinline__ double poisson_term(double s1, double cnt, double eta, const double2* __restrict__ ltab) {
   if (!(cnt > 0.0)) return 0.0;
-  if constexpr (LINK == ESS_LINK_LOG) return fma(s1, eta, -cnt * exp(eta));
+  if constexpr (LINK == ESS_LINK_LOG) return fma(s1, eta, -cnt * exp_tab(eta, ltab));
   else return eta > 0.0 ? fma(s1, log_tab(eta, ltab), -cnt * eta) : -INFINITY;
 }
 
@@ -106,7 +128,8 @@ __global__ __launch_bounds__(ESS_THREADS) void poisson_ll_rows_kernel(
   const int i = blockIdx.y;
   if (per_row && done[i]) return;
   if (!per_row && done[0]) return;
-  if constexpr (LINK != ESS_LINK_LOG) { log_table_build(ltab); __syncthreads(); }
+  if constexpr (LINK != ESS_LINK_LOG) log_table_build(ltab); else exp_table_build(ltab);
+  __syncthreads();
   double w[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) w[k] = W[(size_t)(row0 + i) * K + k];
@@ -141,7 +164,8 @@ __global__ __launch_bounds__(ESS_THREADS) void poisson_ll_cols_kernel(
   __shared__ double2 ltab[LOGTAB_N];
   const int j = blockIdx.y;
   if (done[j]) return;
-  if constexpr (LINK != ESS_LINK_LOG) { log_table_build(ltab); __syncthreads(); }
+  if constexpr (LINK != ESS_LINK_LOG) log_table_build(ltab); else exp_table_build(ltab);
+  __syncthreads();
   double s = 0.0;
   for (int i = blockIdx.x * ESS_THREADS + threadIdx.x; i < nl; i += gridDim.x * ESS_THREADS) {
     double w[K];

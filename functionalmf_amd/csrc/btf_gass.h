@@ -267,7 +267,7 @@ __global__ __launch_bounds__(GASS_THREADS) void gass_eval_kernel(GassEvalArgs a)
   __shared__ double e0s[GASS_CT], e1s[GASS_CT], s1s[GASS_CT], cns[GASS_CT];
   __shared__ double red[GASS_THREADS / WAVE][GASS_MAXC];
   __shared__ double2 ltab[LOGTAB_N];
-  if constexpr (LINK != ESS_LINK_LOG) log_table_build(ltab);        // (the tile loop's first barrier publishes it)
+  if constexpr (LINK != ESS_LINK_LOG) log_table_build(ltab); else exp_table_build(ltab);      // (the tile loop's first barrier publishes it)
   const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, K = a.K, T = a.T;
   const int nth = a.ntheta[ch];
   const double th0 = lane < nth ? a.thetas[(size_t)ch * GASS_MAXC + lane] : 0.0;

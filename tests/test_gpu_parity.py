@@ -1776,3 +1776,34 @@ def test_checkpoint_restore_continues_the_chain_bit_for_bit(tmp_path, family, rn
     assert float(b.sigma2) == ref["sigma2"] and float(b.lam2) == ref["lam2"]
     if family == "negbinom":
         assert np.array_equal(np.asarray(a.R), np.asarray(b.R))
+
+
+
+def test_log_link_exponential_is_accurate_to_double_precision():
+    """The log link's exp comes from a 128-entry table + a degree-5 polynomial (csrc/btf_ess.h: exp_tab).  With linear
+    predictors that depend on the row alone, a row's log-likelihood is M T (y eta_i - exp(eta_i)): one exponential
+    per row (btf_gass_begin with the log link, btf_gass_grid: cur_ll), against numpy."""
+    from functionalmf_amd.factor import ConstrainedNonconjugateBayesianTensorFiltering
+    from functionalmf_amd import _native
+    N, M, T, K, y = 96, 3, 8, 2, 2.0
+    rs = np.random.RandomState(9)
+    eta = np.concatenate([rs.uniform(-30, 30, size=N - 16), rs.uniform(-1e-3, 1e-3, size=8), np.log(2) / 128 * (np.arange(8) + 0.5)])
+    W = np.zeros((N, K)); W[:, 0] = eta
+    V = np.zeros((M, T, K)); V[..., 0] = 1.0; V[..., 1] = 0.5
+    Cons = np.concatenate([np.eye(T), np.full((T, 1), -1e6)], axis=1)
+    model = ConstrainedNonconjugateBayesianTensorFiltering(N, M, T, "poisson_identity", Cons, gass_ngrid=16, nembeds=K, tf_order=0,
+                                                           sigma2_init=1.0, lam2_init=0.1, W_init=W, V_init=V,
+                                                           Tau2_init=np.ones((M, T)), sampler="banded")
+    Y = np.full((N, M, T, 1), y)
+    model._bind_data(Y)
+    model._push_state()
+    model._ctx.call("btf_gass_set_constraints", _native.dptr(model._cons), int(model._cons.shape[0]), None, 0)
+    z = rs.normal(size=K * (K + 1) // 2 + (N - K) * K)
+    u = rs.rand(N)
+    model._ctx.call("btf_gass_begin", 0, 0, _native.dptr(z), _native.dptr(u), 1, 1e-6, 0, 0)        # link 0: log
+    info = np.zeros((N, 2), dtype=np.int32)
+    cur = np.empty(N)
+    model._ctx.call("btf_gass_grid", 0, info.ctypes.data_as(_native._c_ip), None, None, _native.dptr(cur))
+    ref = M * T * (y * eta - np.exp(eta))
+    tol = 4e-16 * M * T * (np.exp(eta) + np.abs(y * eta)) + 1e-15 * np.abs(ref)
+    assert np.all(np.abs(cur - ref) <= tol), (np.abs(cur - ref) / tol).max()
