@@ -311,7 +311,15 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
 }
 // which Polya-Gamma passes a draw needs: exact mode - the exact sampler alone; otherwise the series for every cell
 // that is not an integer count of 1 or 2, and the exact sampler for those (each launch only if such cells exist)
-void pg_passes(const btf_ctx* c, bool* series, bool* exact) {
+// Count data (Negative-Binomial): the pseudo-trial counts move with the rate and are integers only by accident - the
+// series takes every cell in one launch (smode = PG_MODE_SERIES_ALL) unless the exact mode is on.
+void pg_passes(const btf_ctx* c, bool* series, bool* exact, int* smode = nullptr) {
+  if (smode) *smode = PG_MODE_DEFAULT;
+  if (c->counts && !c->pg_exact) {
+    *series = true; *exact = false;
+    if (smode) *smode = PG_MODE_SERIES_ALL;
+    return;
+  }
   *exact = c->pg_exact || c->pg_has_small;
   *series = !c->pg_exact && (c->pg_has_big || !c->pg_has_small);
 }
@@ -323,10 +331,11 @@ void launch_pg(btf_ctx* c, const double* B, double* out, const double* Lf, const
   const int rpb = (Rdim + nrb - 1) / nrb;
   nrb = (Rdim + rpb - 1) / rpb;
   bool series, exact;
-  pg_passes(c, &series, &exact);
+  int smode;
+  pg_passes(c, &series, &exact, &smode);
   if (series) {
     Prof p(c, BTF_K_PG);
-    p.launch(pg_kernel<K, PG_PATH_SERIES>, dim3(gx, nrb), dim3(PG_THREADS), 0, B, out, Lf, Uf, nl, ld, Rdim, rpb, base, stride_r, stride_l, seed, 0, 1);
+    p.launch(pg_kernel<K, PG_PATH_SERIES>, dim3(gx, nrb), dim3(PG_THREADS), 0, B, out, Lf, Uf, nl, ld, Rdim, rpb, base, stride_r, stride_l, seed, smode, 1);
   }
   if (exact) {
     Prof p(c, BTF_K_PG);
@@ -2412,12 +2421,13 @@ int btf_pg_draw(btf_ctx* c, uint64_t seed) {
   if (c->nl == c->N && c->ml == c->M) {   // unsharded: every cell once, both layouts (LDS tile transpose)
     dim3 grid((unsigned)((MT + 63) / 64), (unsigned)((c->N + 63) / 64));
     bool series, exact;
-    pg_passes(c, &series, &exact);
+    int smode;
+    pg_passes(c, &series, &exact, &smode);
     if (series) {
       Prof p(c, BTF_K_PG);
       K_SWITCH(c->K, p.launch(pg_tile_kernel<KT, PG_PATH_SERIES>, grid, dim3(256), 0, (const double*)c->B_v, c->C_v, c->C_wT,
                               (const double*)c->W, (const double*)c->V, c->N, (int)MT, c->ldv, c->ldw,
-                              (unsigned long long)seed, 0, 1));
+                              (unsigned long long)seed, smode, 1));
     }
     if (exact) {
       Prof p(c, BTF_K_PG);

@@ -1780,12 +1780,16 @@ __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& 
 // which sampler a cell goes through.  exact_mode: every b below the normal range; otherwise the exact sampler
 // keeps the integer counts 1 and 2 (Bernoulli / two-trial data stay exact at one or two Devroye draws per cell)
 // and everything else takes the series.
-__device__ __forceinline__ int pg_path_of(double b, bool exact_mode) {
-  return (exact_mode || (b <= (double)PG_DEVROYE_MAX && b == floor(b))) ? PG_PATH_EXACT : PG_PATH_SERIES;
+// mode 2 (PG_MODE_SERIES_ALL): the series takes every cell - Negative-Binomial pseudo-trial counts sum(y) + n r are
+// integers only by accident, and a second launch that finds (next to) no cell of its own costs a pass over the tensor.
+enum { PG_MODE_DEFAULT = 0, PG_MODE_EXACT_ALL = 1, PG_MODE_SERIES_ALL = 2 };
+__device__ __forceinline__ int pg_path_of(double b, int mode) {
+  if (mode == PG_MODE_SERIES_ALL) return PG_PATH_SERIES;
+  return (mode == PG_MODE_EXACT_ALL || (b <= (double)PG_DEVROYE_MAX && b == floor(b))) ? PG_PATH_EXACT : PG_PATH_SERIES;
 }
 
 // one-call form (validation entry point, small problems): per-lane choice of the path
-__device__ __forceinline__ double pg_draw(double b, double psi, CellRng& g, bool exact_mode = false) {
+__device__ __forceinline__ double pg_draw(double b, double psi, CellRng& g, int exact_mode = 0) {
   if (!(b > 0.0)) return 0.0;
   if (b >= PG_NORMAL_B) return pg_draw_normal(b, psi, g);
   return pg_path_of(b, exact_mode) == PG_PATH_EXACT ? pg_draw_exact(b, psi, g) : pg_draw_series(b, psi, g);
@@ -1799,7 +1803,7 @@ constexpr int PG_THREADS = 256;
 // skips a launch no cell needs): each kernel carries one sampler's registers, not both.  `fill`: this launch also
 // writes the zeros of the cells without an observation and the normal-range draws (b >= PG_NORMAL_B).
 template <int PATH>
-__device__ __forceinline__ bool pg_cell(double b, double psi, bool exact_mode, bool fill, CellRng& g, double& om) {
+__device__ __forceinline__ bool pg_cell(double b, double psi, int exact_mode, bool fill, CellRng& g, double& om) {
   if (!(b > 0.0)) { om = 0.0; return fill; }
   if (b >= PG_NORMAL_B) { if (fill) om = pg_draw_normal(b, psi, g); return fill; }
   if (pg_path_of(b, exact_mode) != PATH) return false;
@@ -1828,7 +1832,7 @@ __global__ __launch_bounds__(PG_THREADS, 2) void pg_kernel(const double* __restr
     const double b = B[(size_t)r * ld + l];
     CellRng g(seed, base + (unsigned long long)r * stride_r + (unsigned long long)l * stride_l);
     double om;
-    if (pg_cell<PATH>(b, psi, exact_mode != 0, fill != 0, g, om)) out[(size_t)r * ld + l] = om;
+    if (pg_cell<PATH>(b, psi, exact_mode, fill != 0, g, om)) out[(size_t)r * ld + l] = om;
   }
 }
 
@@ -1860,7 +1864,7 @@ __global__ __launch_bounds__(256, 2) void pg_tile_kernel(const double* __restric
       const double b = Bv[(size_t)i * ldv + jt];
       CellRng g(seed, (unsigned long long)i * MT + jt);
       double x;
-      if (pg_cell<PATH>(b, psi, exact_mode != 0, fill != 0, g, x)) {
+      if (pg_cell<PATH>(b, psi, exact_mode, fill != 0, g, x)) {
         om = x;
         Cv[(size_t)i * ldv + jt] = om;
       }
@@ -1882,7 +1886,7 @@ static __global__ void pg_batch_kernel(const double* b, const double* psi, doubl
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   CellRng g(seed, (unsigned long long)i);
-  out[i] = pg_draw(b[i], psi[i], g, exact_mode != 0);
+  out[i] = pg_draw(b[i], psi[i], g, exact_mode != 0 ? PG_MODE_EXACT_ALL : PG_MODE_DEFAULT);
 }
 
 // ============================================================================
