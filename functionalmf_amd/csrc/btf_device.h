@@ -81,4 +81,57 @@ __host__ __device__ inline long long w_z_offset(int i, int K) {
   return i < K ? (long long)i * (i + 1) / 2 : (long long)K * (K + 1) / 2 + (long long)(i - K) * K;
 }
 
+// log(x) for the identity-link likelihood, evaluated once per (cell, proposal): libm's log is ~90 f64 instructions;
+// here x = 2^e m, m in [1,2) is divided by the left edge c_i = 1 + i/128 of its mantissa interval through a
+// 128-entry table (1/c_i rounded, and minus the log of exactly that number), leaving log1p(r) with 0 <= r < 2^-7 for a
+// degree-8 polynomial (truncation r^8/9 < 2e-18 relative): ~20 instructions, absolute error of the order of one
+// ulp of max(|e| ln 2, 1) - what libm gives away from x = 1.  The table is built per workgroup in LDS (one libm log
+// per thread): log_table_build, then a barrier.
+constexpr int LOGTAB_N = 128;
+__device__ __forceinline__ void log_table_build(double2* tab) {
+  for (int i = threadIdx.x; i < LOGTAB_N; i += blockDim.x) {
+    const double inv = 1.0 / (1.0 + (double)i * (1.0 / LOGTAB_N));
+    tab[i] = make_double2(inv, -log(inv));
+  }
+}
+__device__ __forceinline__ double log_tab(double x, const double2* __restrict__ tab) {
+  if (!(x >= 2.2250738585072014e-308 && x < INFINITY)) return log(x);        // subnormal / inf / nan: rare, exact path
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  const int e = (int)(b >> 52) - 1023;
+  const double m = __longlong_as_double((long long)((b & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL));
+  const double2 t = tab[(int)((b >> 45) & 127ULL)];
+  const double r = fma(m, t.x, -1.0);
+  double p = fma(r, -1.0 / 8.0, 1.0 / 7.0);
+  p = fma(r, p, -1.0 / 6.0);
+  p = fma(r, p, 1.0 / 5.0);
+  p = fma(r, p, -1.0 / 4.0);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -1.0 / 2.0);
+  p = fma(r * r, p, r);                                   // log1p(r) = r - r^2/2 + ... - r^8/8
+  return fma((double)e, 0.6931471805599453094, t.y + p);
+}
+
+// exp(x) for the log link, the same way: x = (128 k + j) ln2/128 + r, |r| <= ln2/256, so exp(x) = 2^k 2^(j/128) e^r
+// with 2^(j/128) from the table (second use of its 128 slots: .x of the exp table) and a degree-5 polynomial for e^r
+// (truncation r^6/720 < 6e-19); the reduction subtracts n ln2/128 in two pieces (hi with 11 trailing zero bits: exact
+// product for |n| < 2^11 * 128).  ~20 instructions instead of libm's ~55; |x| > 700 (overflow range) goes to libm.
+__device__ __forceinline__ void exp_table_build(double2* tab) {
+  for (int i = threadIdx.x; i < LOGTAB_N; i += blockDim.x) tab[i] = make_double2(exp2((double)i * (1.0 / LOGTAB_N)), 0.0);
+}
+__device__ __forceinline__ double exp_tab(double x, const double2* __restrict__ tab) {
+  if (!(fabs(x) < 700.0)) return exp(x);
+  const double n = rint(x * (LOGTAB_N * 1.4426950408889634074));            // x * 128 / ln 2
+  const double hi = 0x1.62e42fefa3800p-8, lo = 0x1.ef35793c76730p-52;       // ln2/128 = hi + lo, hi: 42 significant bits
+  const double r = fma(-n, lo, fma(-n, hi, x));
+  const int ni = (int)n;
+  const int j = ni & (LOGTAB_N - 1), k = (ni - j) / LOGTAB_N;               // ni = 128 k + j, 0 <= j < 128
+  double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = fma(r, p, 1.0 / 6.0);
+  p = fma(r, p, 0.5);
+  p = fma(r * r, p, r);                                                      // e^r - 1
+  const double t = tab[j].x;
+  return ldexp(fma(t, p, t), k);
+}
+
+
 }  // namespace btf

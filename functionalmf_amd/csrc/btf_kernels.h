@@ -2318,6 +2318,10 @@ template <int K>
 __global__ __launch_bounds__(256) void nb_l1p_kernel(const double* __restrict__ cnt, const double* __restrict__ W,
                                                     const double* __restrict__ V, int MT, double* __restrict__ part) {
   __shared__ double red[4];
+  __shared__ double2 ltab[LOGTAB_N], etab[LOGTAB_N];
+  log_table_build(ltab);
+  exp_table_build(etab);
+  __syncthreads();
   const int i = blockIdx.y;
   const double* __restrict__ w = W + (size_t)i * K;
   double acc = 0.0;
@@ -2327,7 +2331,8 @@ __global__ __launch_bounds__(256) void nb_l1p_kernel(const double* __restrict__ 
 #pragma unroll
     for (int k = 0; k < K; ++k) psi = fma(w[k], V[(size_t)jt * K + k], psi);
     psi = fmin(fmax(psi, -10.0), 10.0);
-    if (n > 0.0) acc = fma(n, -log1p(exp(psi)), acc);
+    // log(1 + e^psi) = max(psi, 0) + log(1 + e^-|psi|): table exp and log (btf_device.h), 1 + e in (1, 2]
+    if (n > 0.0) acc = fma(n, -(fmax(psi, 0.0) + log_tab(1.0 + exp_tab(-fabs(psi), etab), ltab)), acc);
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
