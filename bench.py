@@ -264,6 +264,9 @@ def main():
             step()
         fence()
         blocks.append(model._ctx.kernel_times())
+    if os.environ.get("BTF_BENCH_DEBUG") == "1" and rank == 0:
+        for k in ("w_accum", "w_solve", "v_accum", "v_banded"):
+            print("blocks %s: %s" % (k, ["%.2f" % (1e3 * blk[k][0] / max(blk[k][1], 1)) for blk in blocks]), file=sys.stderr)
     kt = {}
     for k in blocks[0]:
         avgs = sorted(blk[k][0] / blk[k][1] for blk in blocks if blk[k][1] > 0)
