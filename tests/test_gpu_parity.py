@@ -1807,3 +1807,34 @@ def test_log_link_exponential_is_accurate_to_double_precision():
     ref = M * T * (y * eta - np.exp(eta))
     tol = 4e-16 * M * T * (np.exp(eta) + np.abs(y * eta)) + 1e-15 * np.abs(ref)
     assert np.all(np.abs(cur - ref) <= tol), (np.abs(cur - ref) / tol).max()
+
+
+def test_negbinom_single_rate_partial_sum_launch_with_wide_count_range(monkeypatch):
+    """The per-step partial-sum launch of the single-rate MH loop with counts across the whole 1024-entry table (several
+    workgroups take the suffix-sum form) and a few thousand counts beyond it (their chunks spread over the workgroups):
+    the chain of rates equals the per-row loop's."""
+    from functionalmf_amd.factor import NegativeBinomialBayesianTensorFiltering
+    rs = np.random.RandomState(41)
+    N, M, T, Rr, K = 64, 24, 16, 2, 3
+    Wt = 0.9 * rs.normal(size=(N, K))
+    Vt = 0.5 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    eta = np.clip(np.einsum("nk,mtk->nmt", Wt, Vt), -6, 6.5)
+    P = 1 / (1 + np.exp(-eta))
+    data = rs.negative_binomial(3.0, 1 - P[..., None].repeat(Rr, -1)).astype(float)
+    nout = int((data >= 1024).sum())
+    assert 256 < nout < data.size // 8 and data[data < 1024].max() > 768, (nout, data[data < 1024].max())
+    chains = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BTF_NB_MH_STEPWISE", mode)
+        np.random.seed(4)
+        model = NegativeBinomialBayesianTensorFiltering(N, M, T, nembeds=K, W_true=Wt, V_true=Vt, sigma2_true=1.0,
+                                                        lam2_true=0.1, Tau2_true=np.ones((M, 3 * T - 1)),
+                                                        rdims=(0, 1, 2), nmetropolis=6, rng="device", device_seed=12)
+        model._bind_data(data)
+        out = []
+        for _ in range(20):
+            model._resample_R(data)
+            out.append(float(np.asarray(model.R).reshape(-1)[0]))
+        chains[mode] = np.array(out)
+    assert len(set(np.round(chains["0"], 9))) > 3
+    np.testing.assert_allclose(chains["0"], chains["1"], rtol=1e-9)
