@@ -80,7 +80,9 @@ def parse_args(argv=None):
                          "binomial: 4 trials per cell, device Polya-Gamma draw included in the step (config C4); "
                          "negbinom: NB(4, p) counts, step = 30 MH steps on the rate R + PG draw + W + V (SURVEY 8(f) rank 2)")
     ap.add_argument("--sampler", default="auto", help="V sampler: auto (spectral on complete data, banded otherwise), banded, spectral, chain")
-    ap.add_argument("--pg-exact", action="store_true", help="binomial / negbinom: Devroye's exact Polya-Gamma sampler for every count")
+    ap.add_argument("--pg-exact", action="store_true", help="binomial / negbinom: Devroye's exact Polya-Gamma sampler for every count "
+                    "(the default already draws integer counts up to 32 exactly)")
+    ap.add_argument("--pg-series", action="store_true", help="binomial / negbinom: the approximate sum-of-gammas series for every count")
     ap.add_argument("--burn", type=int, default=10, help="full Gibbs sweeps before timing (leave the initial state)")
     ap.add_argument("--master-port", type=int, default=29533)
     return ap.parse_args(argv)
@@ -187,9 +189,9 @@ def main():
                   compat="reference" if world == 1 else "exact", device=local_rank, stream=stream,
                   shard=(rank, world) if world > 1 else None, device_seed=1, sampler=args.sampler)
     if args.variant == "binomial":
-        model = BinomialBayesianTensorFiltering(N, M, T, pg_exact=args.pg_exact, **common)
+        model = BinomialBayesianTensorFiltering(N, M, T, pg_exact=(True if args.pg_exact else False if args.pg_series else None), **common)
     elif args.variant == "negbinom":
-        model = NegativeBinomialBayesianTensorFiltering(N, M, T, pg_exact=args.pg_exact, **common)
+        model = NegativeBinomialBayesianTensorFiltering(N, M, T, pg_exact=(True if args.pg_exact else False if args.pg_series else None), **common)
     else:
         model = GaussianBayesianTensorFiltering(N, M, T, nu2_init=1.0, **common)
     if args.rpb != [0, 0]:

@@ -95,8 +95,9 @@ struct btf_ctx {
   bool nb_tabulable = false;        // every observed count is an integer in [0, NB_TAB)
   bool nb_L_valid = false;          // nb_L matches the current W, V
   bool nb_hist = true;              // BTF_OPT_NB_HISTOGRAMS
-  bool pg_exact = false;            // BTF_OPT_PG_EXACT
-  bool pg_has_small = true, pg_has_big = true;   // trial counts: any integer 1..PG_DEVROYE_MAX / anything else below the normal range
+  int pg_mode = PG_MODE_DEFAULT;    // BTF_OPT_PG_EXACT: PG_MODE_DEFAULT / PG_MODE_EXACT_ALL / PG_MODE_SERIES_ALL
+  // trial counts below the normal range: any integer up to PG_AUTO_EXACT_MAX / any larger integer / any non-integer
+  bool pg_has_small = true, pg_has_big = true, pg_has_frac = true;
   // on-device sample collection (run_gibbs, rng="device"): [nsamp] slots of W, V, Tau2 and the scalars
   double* smp_W = nullptr; double* smp_V = nullptr; double* smp_T = nullptr; double* smp_s = nullptr; int smp_n = 0;
   double* hyp = nullptr;        // device-resident scalars [HYP_COUNT] (nu2, sigma2, lam2, lam2_a, ...)
@@ -309,19 +310,20 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
   else if (rpb >= 2048) p.launch(accum_kernel<K, 0, acc_waves(K, 0), double, double, 3>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
   else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
 }
-// which Polya-Gamma passes a draw needs: exact mode - the exact sampler alone; otherwise the series for every cell
-// that is not an integer count of 1 or 2, and the exact sampler for those (each launch only if such cells exist)
-// Count data (Negative-Binomial): the pseudo-trial counts move with the rate and are integers only by accident - the
-// series takes every cell in one launch (smode = PG_MODE_SERIES_ALL) unless the exact mode is on.
-void pg_passes(const btf_ctx* c, bool* series, bool* exact, int* smode = nullptr) {
-  if (smode) *smode = PG_MODE_DEFAULT;
-  if (c->counts && !c->pg_exact) {
-    *series = true; *exact = false;
-    if (smode) *smode = PG_MODE_SERIES_ALL;
-    return;
-  }
-  *exact = c->pg_exact || c->pg_has_small;
-  *series = !c->pg_exact && (c->pg_has_big || !c->pg_has_small);
+// Which Polya-Gamma launches a draw needs (pg_class_of): the flat exact kernel for the integer counts it takes
+// under the mode, the series kernel and / or the f64 Devroye kernel with a fractional part for the rest - each only
+// if the trial counts hold such a cell; the first launch also writes the zeros of the unobserved cells and the
+// normal-range draws.  Count data (Negative-Binomial): the pseudo-trial counts move with the rate and are integers
+// only by accident - the series takes every cell in one launch unless another mode was asked for.
+struct PgPasses { bool flat, series, frac; int mode; };
+PgPasses pg_passes(const btf_ctx* c) {
+  PgPasses p{false, false, false, c->pg_mode};
+  if (c->counts && p.mode == PG_MODE_DEFAULT) p.mode = PG_MODE_SERIES_ALL;
+  if (p.mode == PG_MODE_SERIES_ALL) { p.series = true; return p; }
+  if (p.mode == PG_MODE_EXACT_ALL) { p.flat = c->pg_has_small || c->pg_has_big; p.frac = c->pg_has_frac; }
+  else { p.flat = c->pg_has_small; p.series = c->pg_has_big || c->pg_has_frac; }
+  if (!p.flat && !p.series && !p.frac) p.series = true;      // nothing to draw: one launch for the zeros
+  return p;
 }
 template <int K>
 void launch_pg(btf_ctx* c, const double* B, double* out, const double* Lf, const double* Uf, int nl, int ld, int Rdim,
@@ -330,17 +332,23 @@ void launch_pg(btf_ctx* c, const double* B, double* out, const double* Lf, const
   int nrb = std::max(1, std::min(Rdim, 4096 / std::max(1, gx)));
   const int rpb = (Rdim + nrb - 1) / nrb;
   nrb = (Rdim + rpb - 1) / rpb;
-  bool series, exact;
-  int smode;
-  pg_passes(c, &series, &exact, &smode);
-  if (series) {
+  const PgPasses ps = pg_passes(c);
+  int fill = 1;
+  if (ps.flat) {
     Prof p(c, BTF_K_PG);
-    p.launch(pg_kernel<K, PG_PATH_SERIES>, dim3(gx, nrb), dim3(PG_THREADS), 0, B, out, Lf, Uf, nl, ld, Rdim, rpb, base, stride_r, stride_l, seed, smode, 1);
+    const int rpx = round_up(rpb, PGX_CPL);                   // whole lists
+    p.launch(pgx_kernel<K, PGX_CPL>, dim3(gx, (Rdim + rpx - 1) / rpx), dim3(256), pgx_rows_lds(PGX_CPL), B, out, Lf, Uf, nl, ld, Rdim,
+             rpx, base, stride_r, stride_l, seed, ps.mode, fill);
+    fill = 0;
   }
-  if (exact) {
+  if (ps.series) {
     Prof p(c, BTF_K_PG);
-    p.launch(pg_kernel<K, PG_PATH_EXACT>, dim3(gx, nrb), dim3(PG_THREADS), 0, B, out, Lf, Uf, nl, ld, Rdim, rpb, base, stride_r, stride_l, seed,
-             c->pg_exact ? 1 : 0, series ? 0 : 1);
+    p.launch(pg_kernel<K, PG_PATH_SERIES>, dim3(gx, nrb), dim3(PG_THREADS), 0, B, out, Lf, Uf, nl, ld, Rdim, rpb, base, stride_r, stride_l, seed, ps.mode, fill);
+    fill = 0;
+  }
+  if (ps.frac) {
+    Prof p(c, BTF_K_PG);
+    p.launch(pg_kernel<K, PG_PATH_EXACT>, dim3(gx, nrb), dim3(PG_THREADS), 0, B, out, Lf, Uf, nl, ld, Rdim, rpb, base, stride_r, stride_l, seed, ps.mode, fill);
   }
 }
 template <int K>
@@ -889,17 +897,19 @@ int btf_set_data_binomial(btf_ctx* c, const double* succ_rows, const double* tri
     return rc;
   }
   {   // which samplers the trial counts need (see pg_passes); both slabs hold every class a rank can meet
-    bool small = false, big = false;
+    bool small = false, big = false, frac = false;
     auto scan = [&](const double* t, size_t n) {
-      for (size_t i = 0; i < n && !(small && big); ++i) {
+      for (size_t i = 0; i < n && !(small && big && frac); ++i) {
         const double b = t[i];
         if (!(b > 0.0) || b >= (double)PG_NORMAL_B) continue;
-        if (b <= (double)PG_DEVROYE_MAX && b == std::floor(b)) small = true; else big = true;
+        if (b != std::floor(b)) frac = true;
+        else if (b <= (double)PG_AUTO_EXACT_MAX) small = true;
+        else big = true;
       }
     };
     scan(trials_cols, (size_t)c->N * c->ml * c->T);
     scan(trials_rows, (size_t)c->nl * MT);
-    c->pg_has_small = small; c->pg_has_big = big;
+    c->pg_has_small = small; c->pg_has_big = big; c->pg_has_frac = frac;
   }
   // until the first PG draw / set_omega the weights are zero
   HIPCHK(c, hipMemset(c->C_wT, 0, (size_t)MT * c->ldw * sizeof(double)));
@@ -1918,7 +1928,7 @@ int btf_set_data_counts(btf_ctx* c, const double* counts, int nreps) {
   const int MT = c->M * c->T;
   const size_t cells = (size_t)c->N * MT;
   c->R = 1; c->binomial = true; c->counts = true; c->nb_Rr = nreps;
-  c->pg_has_small = c->pg_has_big = true;      // pseudo-trial counts change with the rate: both passes
+  c->pg_has_small = c->pg_has_big = c->pg_has_frac = true;      // pseudo-trial counts change with the rate: every pass
   if (c->C8_wT) { (void)hipFree(c->C8_wT); c->C8_wT = nullptr; }
   if (c->C8_v) { (void)hipFree(c->C8_v); c->C8_v = nullptr; }
   c->ldw = round_up(c->N, ACC_TILE);
@@ -2420,20 +2430,29 @@ int btf_pg_draw(btf_ctx* c, uint64_t seed) {
   const unsigned long long MT = (unsigned long long)c->M * c->T;
   if (c->nl == c->N && c->ml == c->M) {   // unsharded: every cell once, both layouts (LDS tile transpose)
     dim3 grid((unsigned)((MT + 63) / 64), (unsigned)((c->N + 63) / 64));
-    bool series, exact;
-    int smode;
-    pg_passes(c, &series, &exact, &smode);
-    if (series) {
+    const PgPasses ps = pg_passes(c);
+    int fill = 1;
+    if (ps.flat) {
+      Prof p(c, BTF_K_PG);
+      constexpr int TI = PGX_NW * PGX_CPL;
+      dim3 gridx((unsigned)((MT + 63) / 64), (unsigned)((c->N + TI - 1) / TI));
+      K_SWITCH(c->K, p.launch(pgx_tile_kernel<KT, PGX_NW, PGX_CPL>, gridx, dim3(PGX_NW * 64), pgx_tile_lds(PGX_NW, PGX_CPL),
+                              (const double*)c->B_v, c->C_v, c->C_wT, (const double*)c->W, (const double*)c->V, c->N, (int)MT,
+                              c->ldv, c->ldw, (unsigned long long)seed, ps.mode, fill));
+      fill = 0;
+    }
+    if (ps.series) {
       Prof p(c, BTF_K_PG);
       K_SWITCH(c->K, p.launch(pg_tile_kernel<KT, PG_PATH_SERIES>, grid, dim3(256), 0, (const double*)c->B_v, c->C_v, c->C_wT,
                               (const double*)c->W, (const double*)c->V, c->N, (int)MT, c->ldv, c->ldw,
-                              (unsigned long long)seed, smode, 1));
+                              (unsigned long long)seed, ps.mode, fill));
+      fill = 0;
     }
-    if (exact) {
+    if (ps.frac) {
       Prof p(c, BTF_K_PG);
       K_SWITCH(c->K, p.launch(pg_tile_kernel<KT, PG_PATH_EXACT>, grid, dim3(256), 0, (const double*)c->B_v, c->C_v, c->C_wT,
                               (const double*)c->W, (const double*)c->V, c->N, (int)MT, c->ldv, c->ldw,
-                              (unsigned long long)seed, c->pg_exact ? 1 : 0, series ? 0 : 1));
+                              (unsigned long long)seed, ps.mode, fill));
     }
     HIPCHK(c, hipGetLastError());
     return BTF_OK;
@@ -2504,8 +2523,8 @@ int btf_pg_batch(int device, int64_t n, const double* b, const double* psi, uint
   return btf_pg_batch_mode(device, n, b, psi, seed, 0, out);
 }
 
-int btf_pg_batch_mode(int device, int64_t n, const double* b, const double* psi, uint64_t seed, int exact, double* out) {
-  if (n < 1 || !b || !psi || !out) return fail(nullptr, BTF_EINVAL, "bad pg_batch arguments");
+int btf_pg_batch_mode(int device, int64_t n, const double* b, const double* psi, uint64_t seed, int mode, double* out) {
+  if (n < 1 || !b || !psi || !out || mode < 0 || mode > PG_MODE_REF_F64 + 1) return fail(nullptr, BTF_EINVAL, "bad pg_batch arguments");
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return fail(nullptr, BTF_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
   double *db = nullptr, *dp = nullptr, *dout = nullptr;
@@ -2516,7 +2535,17 @@ int btf_pg_batch_mode(int device, int64_t n, const double* b, const double* psi,
   PB(hipMalloc((void**)&dout, n * sizeof(double)));
   PB(hipMemcpy(db, b, n * sizeof(double), hipMemcpyHostToDevice));
   PB(hipMemcpy(dp, psi, n * sizeof(double), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(pg_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, db, dp, dout, (long long)n, seed, exact);
+  const bool allf64 = mode == PG_MODE_REF_F64 + 1;      // 4: PG_MODE_EXACT_ALL with every trip of the flat sampler repeated in f64
+  if (allf64) mode = PG_MODE_EXACT_ALL;
+  const bool flat = mode == PG_MODE_DEFAULT || mode == PG_MODE_EXACT_ALL;
+  if (flat) {      // the integer counts the mode gives to the flat exact sampler
+    constexpr int CPL = 4;
+    const dim3 grid((unsigned)((n + 256 * CPL - 1) / (256 * CPL)));
+    if (allf64) hipLaunchKernelGGL((pgx_batch_kernel<CPL, true>), grid, dim3(256), pgx_rows_lds(CPL), 0, db, dp, dout, (long long)n, (unsigned long long)seed, mode);
+    else hipLaunchKernelGGL((pgx_batch_kernel<CPL, false>), grid, dim3(256), pgx_rows_lds(CPL), 0, db, dp, dout, (long long)n, (unsigned long long)seed, mode);
+    PB(hipGetLastError());
+  }
+  hipLaunchKernelGGL(pg_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, db, dp, dout, (long long)n, seed, mode, flat ? 1 : 0);
   PB(hipGetLastError());
   PB(hipDeviceSynchronize());
   PB(hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -2746,7 +2775,8 @@ int btf_set_option(btf_ctx* c, int option, int value) {
       c->nb_hist = value != 0;
       return BTF_OK;
     case BTF_OPT_PG_EXACT:
-      c->pg_exact = value != 0;
+      if (value < PG_MODE_DEFAULT || value > PG_MODE_SERIES_ALL) return fail(c, BTF_EINVAL, "unknown Polya-Gamma mode");
+      c->pg_mode = value;
       return BTF_OK;
     case BTF_OPT_FUSE_GRAM:
       c->fuse_gram = value != 0;

@@ -36,7 +36,8 @@ namespace btf {
   (const double*, double*, double*, const double*, const double*, int, int, int, int, unsigned long long, int, int)
 #define BTF_PG_SET(P, K)                                                                                 \
   P void pg_kernel<K, PG_PATH_SERIES> BTF_PG_ARGS;       P void pg_kernel<K, PG_PATH_EXACT> BTF_PG_ARGS;  \
-  P void pg_tile_kernel<K, PG_PATH_SERIES> BTF_PGT_ARGS; P void pg_tile_kernel<K, PG_PATH_EXACT> BTF_PGT_ARGS;
+  P void pg_tile_kernel<K, PG_PATH_SERIES> BTF_PGT_ARGS; P void pg_tile_kernel<K, PG_PATH_EXACT> BTF_PGT_ARGS; \
+  P void pgx_kernel<K, PGX_CPL> BTF_PG_ARGS;             P void pgx_tile_kernel<K, PGX_NW, PGX_CPL> BTF_PGT_ARGS;
 
 #define BTF_NB_ARGS \
   (const double*, int, const double*, const double*, int, int, const double*, const double*, long long, long long, long long, int, double*)

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include "btf_device.h"
 #include "btf_eig.h"
+#include "btf_pg_exact.h"
 
 namespace btf {
 
@@ -1386,13 +1387,10 @@ __global__ __launch_bounds__(SSE_THREADS) void sse_kernel(const double* __restri
 //   PG(1,psi) draws by Devroye's alternating-series method (Polson, Scott &
 //   Windle 2013, sec. 4); fractional remainder by the truncated sum-of-gammas
 //   representation; b >= PG_NORMAL_B by moment-matched normal.
+//   (integer b: the flat exact kernels of btf_pg_exact.h, the default for Binomial trial counts)
 //   RNG: Philox keyed by (seed, global cell index) - the draw of a cell does not
 //   depend on layout, launch geometry or sharding.
 // ============================================================================
-constexpr double PG_T = 0.64;
-constexpr double PG_PI = 3.141592653589793238462643383279502884;
-constexpr int PG_NORMAL_B = 200;
-constexpr int PG_DEVROYE_MAX = 2;   // integer b up to here: exact alternating-series draws, one per unit of b
 constexpr int PG_SERIES_NT = 16;     // terms of the sum-of-gammas series drawn for b < 3, + 2|psi|/(2 pi); the rest enters through a normal
 constexpr int PG_SERIES_NT_BIG = 2;  // ... for b >= 3 (+ 2|psi|/(2 pi)): the rest enters through a moment-matched gamma (pg_draw_series)
 constexpr int PG_SERIES_NT_MAX = 96;
@@ -1477,30 +1475,6 @@ struct CellRng {
     return r * cs;
   }
 };
-
-__device__ inline double log_ncdf(double x) {
-  if (x > -10.0) return log(0.5 * erfc(-x * 0.70710678118654752440));
-  const double x2 = x * x;  // Mills-ratio asymptotics for the far lower tail
-  return -0.5 * x2 - log(-x) - 0.91893853320467274178 + log1p(-1.0 / x2 + 3.0 / (x2 * x2));
-}
-
-__device__ inline double pg_a(int n, double x) {
-  const double Kc = (n + 0.5) * PG_PI;
-  if (x > PG_T) return Kc * exp(-0.5 * Kc * Kc * x);
-  const double r = 2.0 / (PG_PI * x);                       // (2/(pi x))^(3/2) without logarithms
-  return Kc * r * sqrt(r) * exp(-2.0 * (n + 0.5) * (n + 0.5) / x);
-}
-
-// probability of the exponential (right) piece of the proposal
-__device__ inline double pg_mass_texpon(double z) {
-  const double fz = 0.125 * PG_PI * PG_PI + 0.5 * z * z;
-  const double rt = 1.0 / sqrt(PG_T);
-  const double b = rt * (PG_T * z - 1.0), a = -rt * (PG_T * z + 1.0);
-  const double x0 = log(fz) + fz * PG_T;
-  const double xb = x0 - z + log_ncdf(b), xa = x0 + z + log_ncdf(a);
-  const double qdivp = 4.0 / PG_PI * (exp(xb) + exp(xa));
-  return 1.0 / (1.0 + qdivp);
-}
 
 // inverse-Gaussian(1/z, 1) truncated to (0, PG_T)
 __device__ __forceinline__ double pg_rtigauss(double z, CellRng& g) {
@@ -1777,22 +1751,25 @@ __device__ __forceinline__ double pg_draw_series(double b, double psi, CellRng& 
   return fmax(x, 1e-300) * (1.0 / (2.0 * PG_PI * PG_PI));      // (a multiplication: the IEEE f64 division is a dozen instructions)
 }
 
-// which sampler a cell goes through.  exact_mode: every b below the normal range; otherwise the exact sampler
-// keeps the integer counts 1 and 2 (Bernoulli / two-trial data stay exact at one or two Devroye draws per cell)
-// and everything else takes the series.
-// mode 2 (PG_MODE_SERIES_ALL): the series takes every cell - Negative-Binomial pseudo-trial counts sum(y) + n r are
-// integers only by accident, and a second launch that finds (next to) no cell of its own costs a pass over the tensor.
-enum { PG_MODE_DEFAULT = 0, PG_MODE_EXACT_ALL = 1, PG_MODE_SERIES_ALL = 2 };
-__device__ __forceinline__ int pg_path_of(double b, int mode) {
-  if (mode == PG_MODE_SERIES_ALL) return PG_PATH_SERIES;
-  return (mode == PG_MODE_EXACT_ALL || (b <= (double)PG_DEVROYE_MAX && b == floor(b))) ? PG_PATH_EXACT : PG_PATH_SERIES;
+// Which sampler a cell goes through: pg_class_of (btf_pg_exact.h).  Integer counts go to the flat exact kernels
+// (pgx_*; every integer count up to PG_AUTO_EXACT_MAX by default, every integer count in the exact mode); the kernels
+// below take the rest: PG_PATH_SERIES the sum-of-gammas series (non-integer counts - Negative-Binomial pseudo-trial
+// counts sum(y) + n r - and, by default, integer counts above PG_AUTO_EXACT_MAX; every cell in PG_MODE_SERIES_ALL),
+// PG_PATH_EXACT the f64 Devroye sampler with a series for the fractional part (non-integer counts of the exact mode).
+__device__ __forceinline__ int pg_path_of_class(int cls) {
+  return cls == PG_CLASS_SERIES ? PG_PATH_SERIES : cls == PG_CLASS_FRAC ? PG_PATH_EXACT : -1;
 }
 
-// one-call form (validation entry point, small problems): per-lane choice of the path
-__device__ __forceinline__ double pg_draw(double b, double psi, CellRng& g, int exact_mode = 0) {
+// one-call form (validation entry point, small problems): per-lane choice of the path.
+// mode: PG_MODE_* ; PG_MODE_REF_F64 (3): the f64 Devroye sampler for everything below the normal range (the
+// round-2 exact kernel, kept as the reference the flat f32-squeeze sampler is tested against).
+constexpr int PG_MODE_REF_F64 = 3;
+__device__ __forceinline__ double pg_draw(double b, double psi, CellRng& g, int mode = 0) {
   if (!(b > 0.0)) return 0.0;
   if (b >= PG_NORMAL_B) return pg_draw_normal(b, psi, g);
-  return pg_path_of(b, exact_mode) == PG_PATH_EXACT ? pg_draw_exact(b, psi, g) : pg_draw_series(b, psi, g);
+  if (mode == PG_MODE_REF_F64) return pg_draw_exact(b, psi, g);
+  const int cls = pg_class_of(b, mode);
+  return cls == PG_CLASS_SERIES ? pg_draw_series(b, psi, g) : pg_draw_exact(b, psi, g);
 }
 
 
@@ -1806,7 +1783,7 @@ template <int PATH>
 __device__ __forceinline__ bool pg_cell(double b, double psi, int exact_mode, bool fill, CellRng& g, double& om) {
   if (!(b > 0.0)) { om = 0.0; return fill; }
   if (b >= PG_NORMAL_B) { if (fill) om = pg_draw_normal(b, psi, g); return fill; }
-  if (pg_path_of(b, exact_mode) != PATH) return false;
+  if (pg_path_of_class(pg_class_of(b, exact_mode)) != PATH) return false;
   om = PATH == PG_PATH_EXACT ? pg_draw_exact(b, psi, g) : pg_draw_series(b, psi, g);
   return true;
 }
@@ -1881,12 +1858,14 @@ __global__ __launch_bounds__(256, 2) void pg_tile_kernel(const double* __restric
 }
 
 // stand-alone batch of PG draws (validation entry point)
+// (skip_flat: the elements of PG_CLASS_FLAT are left to pgx_batch_kernel)
 static __global__ void pg_batch_kernel(const double* b, const double* psi, double* out, long long n, unsigned long long seed,
-                                int exact_mode) {
+                                int mode, int skip_flat) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (skip_flat && pg_class_of(b[i], mode) == PG_CLASS_FLAT) return;
   CellRng g(seed, (unsigned long long)i);
-  out[i] = pg_draw(b[i], psi[i], g, exact_mode != 0 ? PG_MODE_EXACT_ALL : PG_MODE_DEFAULT);
+  out[i] = pg_draw(b[i], psi[i], g, mode);
 }
 
 // ============================================================================

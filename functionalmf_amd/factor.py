@@ -901,15 +901,22 @@ class BinomialBayesianTensorFiltering(GaussianBayesianTensorFiltering):
         super()._set_extra_state(st)
         self._pg_calls = int(st["pg_calls"])
 
-    def __init__(self, nrows, ncols, ndepth, pg_seed=42, pg_exact=False, **kwargs):
-        """pg_exact: draw every omega ~ PG(N, psi) with Devroye's exact sampler summed N times (what pypolyagamma
-        does for integer N, factor.py:459); default False: exact for N in {1, 2}, the validated sum-of-gammas
-        series with a moment-matched remainder for larger N (include/btf.h, BTF_OPT_PG_EXACT)."""
+    PG_MODES = {None: 0, "auto": 0, True: 1, "exact": 1, False: 2, "series": 2}
+
+    def __init__(self, nrows, ncols, ndepth, pg_seed=42, pg_exact=None, **kwargs):
+        """pg_exact (include/btf.h, BTF_OPT_PG_EXACT).  None / "auto" (default): every integer count up to 32 is drawn
+        as the sum of N exact Devroye draws - what pypolyagamma's pgdrawv does at factor.py:459 - and larger or
+        non-integer counts by the validated sum-of-gammas series with a moment-matched remainder; count data
+        (Negative-Binomial pseudo-trial counts, integers only by accident) take the series throughout.
+        True / "exact": the exact sampler for every count below 200.  False / "series": the series for every count
+        (faster, approximate: the round-2 default)."""
         super().__init__(nrows, ncols, ndepth, **kwargs)
         self.pg_seed = pg_seed
-        self.pg_exact = bool(pg_exact)
-        self.pg_sampler = "devroye-exact" if pg_exact else "devroye(N<=2)+gamma-series"
-        self._ctx.call("btf_set_option", _native.OPT_PG_EXACT, 1 if pg_exact else 0)
+        if pg_exact not in self.PG_MODES:
+            raise ValueError("pg_exact must be None / 'auto', True / 'exact' or False / 'series'")
+        self.pg_exact = pg_exact
+        self.pg_sampler = ("devroye-exact(N<=32)+gamma-series", "devroye-exact", "gamma-series")[self.PG_MODES[pg_exact]]
+        self._ctx.call("btf_set_option", _native.OPT_PG_EXACT, self.PG_MODES[pg_exact])
         self._pg_calls = 0
         self._nu2 = np.zeros((nrows, ncols, ndepth))
         self._omega_dev_new = False

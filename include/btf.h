@@ -77,12 +77,17 @@ enum {
                                 (whole curves missing, as Y[:3,:3] = NaN in the reference's examples) run the
                                 complete-data kernels plus per-row / per-column corrections (same conditionals as the
                                 weighted form of factor.py:343-346, :388-391); 0: always the weighted form         */
-  BTF_OPT_PG_EXACT = 3       /* Polya-Gamma sampler of btf_pg_draw.  0 (default): integer trial counts 1 and 2 by
-                                Devroye's exact alternating-series sampler, every other count by the sum-of-gammas
-                                series with a moment-matched remainder (approximate; validated against the exact sampler).
-                                1: the exact sampler for every count below 200 - floor(b) Devroye draws, as
-                                pypolyagamma does for integer b (factor.py:459) - plus a 128-term series for a
-                                fractional part.  Counts >= 200: moment-matched normal in both modes.           */
+  BTF_OPT_PG_EXACT = 3       /* Polya-Gamma sampler of btf_pg_draw (what pypolyagamma's pgdrawv does at factor.py:459).
+                                0 (default): every integer trial count up to 32 by Devroye's exact alternating-series
+                                sampler, summed b times, as pypolyagamma does (flat per-lane work-queue kernels: f32
+                                squeeze, f64 decisions inside the guard bands); larger and non-integer counts by the
+                                sum-of-gammas series with a moment-matched remainder (approximate; validated against the
+                                exact sampler).  Count data (btf_set_data_counts: pseudo-trial counts sum(y) + n r, integers
+                                only by accident): the series for every cell.
+                                1: exact for every count below 200 - floor(b) Devroye draws plus a 128-term series for a
+                                fractional part.
+                                2: the series for every count (opt-in; the round-2 default for counts >= 3).
+                                Counts >= 200: moment-matched normal in every mode.                             */
 };
 enum {
   BTF_SAMPLER_BANDED = 0,   /* block-banded LDL' in the declared elimination order (btf_get_V_order):
@@ -304,8 +309,10 @@ int btf_pg_draw(btf_ctx* ctx, uint64_t seed);
 /* Stand-alone batch of PG(b_i, psi_i) draws from the same device sampler (used to
  * validate its distribution; element i uses the Philox stream (seed, i)).      */
 int btf_pg_batch(int device, int64_t n, const double* b, const double* psi, uint64_t seed, double* out);
-/* the same with the sampler of BTF_OPT_PG_EXACT chosen by `exact` (0 / 1) */
-int btf_pg_batch_mode(int device, int64_t n, const double* b, const double* psi, uint64_t seed, int exact, double* out);
+/* the same with the sampler chosen by `mode`: 0 / 1 / 2 as BTF_OPT_PG_EXACT; 3: the f64 Devroye sampler for every
+ * count below 200 (the round-2 exact kernel: the reference the flat sampler is tested against); 4: as 1 with every
+ * trip of the flat sampler repeated in f64 (validation of its fallback: same decisions, same draws up to f32 rounding) */
+int btf_pg_batch_mode(int device, int64_t n, const double* b, const double* psi, uint64_t seed, int mode, double* out);
 
 int btf_sync(btf_ctx* ctx); /* waits; returns BTF_ENOTPD if a step failed since the last sync */
 

@@ -120,9 +120,10 @@ def c4():
     return Ys, Nt
 
 
-@pytest.mark.parametrize("compat,pg_exact", [("reference", False), ("exact", False), ("exact", True)])
+@pytest.mark.parametrize("compat,pg_exact", [("reference", None), ("exact", None), ("exact", "series")])
 def test_c4_binomial_full_size_pg_draw_and_weighted_half_sweeps(c4, compat, pg_exact):
-    """factor.py:437-460 at BASELINE config 4.  The device Polya-Gamma draw is checked against the closed-form
+    """factor.py:437-460 at BASELINE config 4, with the default Polya-Gamma sampler (four exact Devroye draws per cell,
+    as pypolyagamma) and with the opt-in series.  The device Polya-Gamma draw is checked against the closed-form
     moments over all 8.4 M cells, then - GIVEN that omega (btf_get_omega) - the weighted W and V half-sweeps
     against the oracle from identical state and normals (compat="reference": rows >= K reuse row K-1's weights
     and every column reuses column 0's, quirks Q1/Q2; the oracle's W step always carries Q1)."""

@@ -256,14 +256,20 @@ def test_binomial_exact_mode_differs_from_reference_quirk(golden):
     assert relerr(model.W, g["W_after"]) > 1e-3
 
 
-def pg_batch(b, psi, seed, exact=False):
+PG_BATCH_MODES = {"auto": 0, "exact": 1, "series": 2, "ref64": 3, "exact_allf64": 4}
+
+
+def pg_batch(b, psi, seed, exact=False, mode=None):
+    """mode (include/btf.h, btf_pg_batch_mode): "auto" (default) / "exact" / "series" / "ref64" (the f64 Devroye
+    kernel of round 2) / "exact_allf64" (the flat exact sampler with every trip repeated in f64)."""
     import ctypes as C
     from functionalmf_amd import _native
     lib = _native.load()
     b = _native.as_f64(b)
     psi = _native.as_f64(psi)
     out = np.empty_like(b)
-    rc = lib.btf_pg_batch_mode(0, b.size, _native.dptr(b), _native.dptr(psi), C.c_uint64(seed), 1 if exact else 0, _native.dptr(out))
+    m = PG_BATCH_MODES[mode] if mode is not None else (1 if exact else 0)
+    rc = lib.btf_pg_batch_mode(0, b.size, _native.dptr(b), _native.dptr(psi), C.c_uint64(seed), m, _native.dptr(out))
     assert rc == 0, lib.btf_last_error(None)
     return out
 
@@ -277,7 +283,7 @@ def _cumulants3(x):
 @pytest.mark.parametrize("b,c", [(b, c) for b in [3, 4, 8, 4.3] for c in [0.0, 1.0, 5.0, 20.0]] +
                          [(4, 3.0), (4, 3.3), (4, 8.0), (3, 6.4), (13, 0.5)])
 def test_pg_series_sampler_against_exact_sampler(b, c):
-    """A/B of the two device samplers (BTF_OPT_PG_EXACT): the default sum-of-gammas series (2 drawn Gamma(b)
+    """A/B of the two device samplers (BTF_OPT_PG_EXACT): the opt-in sum-of-gammas series (2 drawn Gamma(b)
     terms + 2|psi|/2pi - the extra pairs straddle the |psi| = pi, 2 pi steps of that count -, f32-transcendental
     variates, the rest through a moment-matched Wilson-Hilferty gamma) against Devroye's exact sampler summed
     floor(b) times (+ a 128-term f64 series for a fractional part) - the algorithm pypolyagamma runs for
@@ -287,7 +293,7 @@ def test_pg_series_sampler_against_exact_sampler(b, c):
     from scipy.stats import ks_2samp, anderson_ksamp
     from oracle import btf_oracle as orc
     n = 2000000 if b == int(b) else 400000
-    x = pg_batch(np.full(n, float(b)), np.full(n, c), seed=9000 + int(10 * b) + int(c))
+    x = pg_batch(np.full(n, float(b)), np.full(n, c), seed=9000 + int(10 * b) + int(c), mode="series")
     y = pg_batch(np.full(n, float(b)), np.full(n, c), seed=19000 + int(10 * b) + int(c), exact=True)
     assert np.all(x > 0) and np.all(y > 0)
     assert ks_2samp(x, y).pvalue > 1e-3
@@ -307,6 +313,85 @@ def test_pg_series_sampler_against_exact_sampler(b, c):
     k4x, k4y = ((x - mx) ** 4).mean() - 3 * vx * vx, k4 - 3 * vy * vy
     se4 = np.sqrt(((y - my) ** 8).mean() / n) * 1.5
     assert abs(k4x - k4y) < 6 * se4 + 0.03 * abs(k4y), (k4x, k4y)
+
+
+@pytest.mark.parametrize("b,c", [(1, 0.0), (1, 2.0), (2, 3.0), (4, 0.0), (4, 1.0), (4, 3.0), (4, 3.125), (4, 3.3), (4, 8.0),
+                                 (4, 40.0), (8, 0.5), (31, 1.5), (1, 120.0)])
+def test_pg_flat_exact_sampler_against_f64_devroye(b, c):
+    """The default sampler of integer counts - the flat per-lane work-queue kernel (csrc/btf_pg_exact.h: f32 squeeze,
+    f64 decisions inside the guard bands) - against the f64 Devroye kernel it replaces (mode "ref64": libm
+    throughout; the algorithm of pypolyagamma, factor.py:459).  Same distribution: 2e6 draws each (own seeds),
+    two-sample KS and Anderson-Darling, first four cumulants against the closed forms / each other.  |psi| = 3.125
+    sits on the switch between the two truncated inverse-Gaussian samplers (z = 1/t), 3.3 and up take
+    Michael-Schucany-Haas, 40 and 120 have a vanishing exponential piece."""
+    from scipy.stats import ks_2samp, anderson_ksamp
+    from oracle import btf_oracle as orc
+    n = 2000000
+    x = pg_batch(np.full(n, float(b)), np.full(n, c), seed=700 + int(10 * b) + int(c), mode="exact")
+    y = pg_batch(np.full(n, float(b)), np.full(n, c), seed=1700 + int(10 * b) + int(c), mode="ref64")
+    assert np.all(x > 0) and np.all(np.isfinite(x))
+    assert ks_2samp(x, y).pvalue > 1e-3
+    ad = anderson_ksamp([x[:400000], y[:400000]])
+    assert ad.statistic < ad.critical_values[-1], (ad.statistic, ad.critical_values)
+    m, v = float(orc.pg_mean(b, c)), float(orc.pg_var(b, c))
+    mx, vx, tx = _cumulants3(x)
+    my, vy, ty = _cumulants3(y)
+    assert abs(mx - m) < 5 * np.sqrt(v / n), (mx, m)
+    k4 = ((y - my) ** 4).mean()
+    assert abs(vx - v) < 6 * np.sqrt((k4 - v * v) / n), (vx, v)
+    se3 = np.sqrt(((y - my) ** 6).mean() / n) * 1.5
+    assert abs(tx - ty) < 6 * se3, (tx, ty)
+    k4x, k4y = ((x - mx) ** 4).mean() - 3 * vx * vx, k4 - 3 * vy * vy
+    assert abs(k4x - k4y) < 6 * np.sqrt(((y - my) ** 8).mean() / n) * 1.5, (k4x, k4y)
+
+
+def test_pg_flat_exact_sampler_f64_fallback_makes_the_same_decisions():
+    """Every trip of the flat sampler evaluated twice: squeezed (f32, f64 only inside the guard bands) and wholly in
+    f64 from the same words (mode "exact_allf64").  The accept / reject decisions must agree trip by trip - a single
+    different decision changes a draw by O(1) - so the two runs return the same omega for every element up to the
+    f32 rounding of the accepted variates.  Mixed counts and |psi| from 0 to 60 in one batch (lists of four cells per
+    lane with different counts; both inverse-Gaussian samplers; empty cells)."""
+    rs = np.random.RandomState(5)
+    n = 1 << 20
+    b = rs.randint(0, 9, size=n).astype(float)
+    b[rs.rand(n) < 0.02] = 31.0
+    psi = rs.normal(size=n) * rs.choice([0.3, 1.5, 3.2, 8.0, 30.0], size=n)
+    psi[:1000] = 0.0
+    psi[1000:2000] = 3.125                      # z = 1/t exactly
+    x = pg_batch(b, psi, seed=99, mode="exact")
+    y = pg_batch(b, psi, seed=99, mode="exact_allf64")
+    assert np.all(x[b == 0] == 0) and np.all(y[b == 0] == 0)
+    pos = b > 0
+    assert np.all(x[pos] > 0)
+    rel = np.abs(x[pos] - y[pos]) / y[pos]
+    # (f32 rounding of the variates: ~1e-7 each; rare draws of the z > 1/t branch lose up to ~1e-4 to v_cos_f32)
+    assert rel.max() < 1e-3 and (rel > 2e-5).mean() < 1e-5, (rel.max(), int((rel > 2e-5).sum()))
+    # ... and the f64 trips sample PG: z-scores of this batch against the closed-form moments
+    from oracle import btf_oracle as orc
+    zs = (y[pos] - orc.pg_mean(b[pos], psi[pos])) / np.sqrt(orc.pg_var(b[pos], psi[pos]))
+    assert abs(zs.mean()) < 5 / np.sqrt(pos.sum()) and abs(zs.var() - 1) < 0.01, (zs.mean(), zs.var())
+
+
+def test_pg_batch_classes_and_layout_independence():
+    """Which sampler an element goes through (pg_class_of): in the default mode integer counts up to 32 are the flat
+    exact sampler's - bit-identical to the exact mode's draws, whatever else is in the batch and wherever the element
+    sits in its lane's list - larger and non-integer counts the series', counts >= 200 the normal's; no observation: 0."""
+    rs = np.random.RandomState(8)
+    n = 50000
+    b = rs.choice([0.0, 1.0, 2.0, 4.0, 7.0, 32.0, 33.0, 4.5, 150.0, 250.0], size=n)
+    psi = rs.normal(size=n) * 2
+    a = pg_batch(b, psi, seed=3)
+    e = pg_batch(b, psi, seed=3, mode="exact")
+    s = pg_batch(b, psi, seed=3, mode="series")
+    small = (b >= 1) & (b <= 32) & (b == np.floor(b))
+    assert np.array_equal(a[small], e[small])
+    rest = (b > 32) | (b != np.floor(b))
+    assert np.array_equal(a[rest & (b < 200)], s[rest & (b < 200)])
+    assert np.array_equal(a[b >= 200], e[b >= 200])
+    assert np.all(a[b == 0] == 0) and np.all(a[b > 0] > 0)
+    # the stream of an element is keyed by (seed, index) alone: a shorter batch gives the same leading draws
+    assert np.array_equal(pg_batch(b[:1234], psi[:1234], seed=3), a[:1234])
+    assert not np.array_equal(pg_batch(b, psi, seed=4)[small], a[small])
 
 
 @pytest.mark.parametrize("b,c", [(1, 0.0), (2, 3.0), (4, 1.0), (7, 0.5), (2.5, 2.0), (0.4, 1.0)])
@@ -350,7 +435,7 @@ def test_pg_series_sampler_ks_large_sample(b, c):
     from scipy.stats import ks_2samp
     from oracle import btf_oracle as orc
     n = 200000
-    x = pg_batch(np.full(n, float(b)), np.full(n, c), seed=4242 + int(7 * b))
+    x = pg_batch(np.full(n, float(b)), np.full(n, c), seed=4242 + int(7 * b), mode="series")
     y = orc.pg_draw_series(b, c, n, np.random.default_rng(11))
     assert ks_2samp(x, y).pvalue > 1e-3
     # third central moment (the skewness the normal remainder could lose): within 5 % + noise
