@@ -11,6 +11,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -152,6 +153,10 @@ int dev_alloc(btf_ctx* c, T** p, size_t n) {
 }
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// "this function's attribute was set on device d": hipFuncSetAttribute is per device, and `device=` is a public
+// constructor keyword - a process-wide flag would skip the call for a second context on another GPU
+inline bool dev_flag_is_set(const std::atomic<unsigned long long>& f, int dev) { return dev >= 0 && dev < 64 && ((f.load() >> dev) & 1ULL); }
+inline void dev_flag_set(std::atomic<unsigned long long>& f, int dev) { if (dev >= 0 && dev < 64) f.fetch_or(1ULL << dev); }
 
 // One kernel launch, counted per BTF_K_* id.  With profiling on the launch goes through
 // hipExtLaunchKernelGGL so that the two events bracket exactly this dispatch (its start
@@ -370,11 +375,11 @@ void launch_wsolve(btf_ctx* c, const WSolveArgs& a) {
 }
 template <int K>
 hipError_t launch_vbanded(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};      // one bit per device: the attribute is per device
+  if (!dev_flag_is_set(attr_set, c->dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)v_banded_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    dev_flag_set(attr_set, c->dev);
   }
   Prof p(c, BTF_K_V_BANDED);
   p.launch(v_banded_kernel<K>, dim3(a.ml), dim3(WAVE), lds_bytes, a);
@@ -382,12 +387,12 @@ hipError_t launch_vbanded(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
 }
 template <int NPL, bool ROW16>
 hipError_t launch_vbanded_fast(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};      // one bit per device: the attribute is per device
+  if (!dev_flag_is_set(attr_set, c->dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)v_banded_fast_kernel<NPL, ROW16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    dev_flag_set(attr_set, c->dev);
   }
   Prof p(c, BTF_K_V_BANDED);
   p.launch(v_banded_fast_kernel<NPL, ROW16>, dim3(a.ml), dim3(VB_THREADS), lds_bytes, a, c->K);
@@ -417,12 +422,12 @@ hipError_t dispatch_vbanded_fast(btf_ctx* c, const VBandArgs& a, int bw, size_t 
 }
 template <int NPL, bool ROW16>
 hipError_t launch_vbanded_twist(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};      // one bit per device: the attribute is per device
+  if (!dev_flag_is_set(attr_set, c->dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)v_banded_twist_kernel<NPL, ROW16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    dev_flag_set(attr_set, c->dev);
   }
   Prof p(c, BTF_K_V_BANDED);
   p.launch(v_banded_twist_kernel<NPL, ROW16>, dim3(a.ml), dim3(VT_THREADS), lds_bytes, a, c->K);
@@ -507,11 +512,11 @@ bool lik_weighted(const btf_ctx* c) { return c->weighted && !curve_on(c); }
 int banded_choice(const btf_ctx* c, bool allow_spectral = true) { return banded_choice_for(c, lik_weighted(c), allow_spectral); }
 template <int S>
 hipError_t launch_vspectral(btf_ctx* c, const VSpecArgs& a, size_t lds_bytes) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};      // one bit per device: the attribute is per device
+  if (!dev_flag_is_set(attr_set, c->dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)v_spectral_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    dev_flag_set(attr_set, c->dev);
   }
   Prof p(c, BTF_K_V_BANDED);
   p.launch(v_spectral_kernel<S>, dim3(a.ml), dim3(VS_THREADS), lds_bytes, a);
@@ -1158,6 +1163,12 @@ int w_accum_phase(btf_ctx* c, int compat) {
     K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, rpb, nch,
                                  EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}, tau, gram));
     c->tau_pending = false;
+  } else if (c->tau_pending && c->dev_scalars && c->have_chain) {
+    // a rank without rows (ceil chunks: N = 10 over 8 ranks leaves ranks 5-7 empty) has no accumulation launch to
+    // carry the queued Tau2 chain: draw it on its own, so that this rank's Tau2 / lsum match the other ranks'
+    Prof p(c, BTF_K_HYPER);
+    p.launch(tau2_kernel, dim3(c->M), dim3(256), 0, tau_side_of(c, c->tau_seed, 1.0, c->tau_stability), c->K);
+    c->tau_pending = false;
   }
   HIPCHK(c, hipGetLastError());
   c->w_part_valid = true; c->w_part_mode = mode; c->w_part_nch = nch; c->w_part_rpb = rpb; c->w_part_gv = use_gv;
@@ -1685,10 +1696,10 @@ int btf_gass_begin(btf_ctx* c, int what, int link, const double* z, const double
       constexpr size_t GASS_DYN_MAX = 112 * 1024;      // (the kernel's static scratch takes the rest of the 160 KB)
       if (dyn > GASS_DYN_MAX || dyn + sizeof(GassScratch) > 158 * 1024)
         return fail(c, BTF_EINVAL, "constraint matrix too large for the column analysis");
-      static bool attr_set = false;
-      if (!attr_set) {
+      static std::atomic<unsigned long long> attr_set{0};
+      if (!dev_flag_is_set(attr_set, c->dev)) {
         HIPCHK(c, hipFuncSetAttribute((const void*)gass_analyse_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GASS_DYN_MAX));
-        attr_set = true;
+        dev_flag_set(attr_set, c->dev);
       }
       p.launch(gass_analyse_cols_kernel, dim3(c->M), dim3(GASS_THREADS), dyn, a);
     }
@@ -2808,6 +2819,13 @@ int btf_get_draw_counters(btf_ctx* c, uint64_t* w, uint64_t* v) {
 int btf_set_draw_counters(btf_ctx* c, uint64_t w, uint64_t v) {
   if (!c) return BTF_EINVAL;
   c->sweep_w = w; c->sweep_v = v;
+  // The spectral sampler refines the previous sweep's eigenvectors; a chain continued from a checkpoint has none.
+  // Forget them here, so that the chain that goes on (checkpoint() calls this too) and the restored one both start
+  // from a cold eigen-solve: the same basis bit for bit, also inside a cluster of near-equal eigenvalues.
+  HIPCHK(c, hipSetDevice(c->dev));
+  const size_t rec = (size_t)c->K + (size_t)c->K * c->K + 8;
+  if (c->eig) HIPCHK(c, hipMemsetAsync(c->eig, 0, rec * sizeof(double), c->stream));
+  if (c->eig_cols) HIPCHK(c, hipMemsetAsync(c->eig_cols, 0, (size_t)c->M * rec * sizeof(double), c->stream));
   return BTF_OK;
 }
 

@@ -97,32 +97,58 @@ __device__ __forceinline__ void curve_column_gram(const CurveLists& cv, const do
   if (q < KK) Ql[q] = fma(-scale, corr, Ql[q]);
 }
 
+// Packed lower-triangular Gram accumulators of a side task live in registers next to the streaming kernel's budget
+// (128 VGPRs under a 1024-thread launch bound): K(K+1)/2 doubles fit for K <= 9; K = 10 (55 entries, 110 VGPRs) is
+// summed in two passes over the rows of the packed triangle - the factor rows are read twice (they are tiny).
+template <int K>
+struct GramPasses {
+  static constexpr int NP = tri(K) > 45 ? 2 : 1;
+  static constexpr int SPLIT = NP == 2 ? (K * 7 + 9) / 10 : K;          // rows [0, SPLIT) then [SPLIT, K): 28 + 27 entries at K = 10
+  __host__ __device__ static constexpr int p0(int pass) { return pass == 0 ? 0 : SPLIT; }
+  __host__ __device__ static constexpr int p1(int pass) { return NP == 1 || pass == 1 ? K : SPLIT; }
+};
+// acc[lidx(p,q) - lidx(P0,0)] += d * u[p] * u[q] for P0 <= p < P1
+template <int K, int P0, int P1>
+__device__ __forceinline__ void gram_rank1(const double (&u)[K], double d, double (&acc)[tri(P1) - tri(P0)]) {
+#pragma unroll
+  for (int p = P0; p < P1; ++p)
+#pragma unroll
+    for (int q = 0; q <= p; ++q) acc[lidx(p, q) - tri(P0)] = fma(d * u[p], u[q], acc[lidx(p, q) - tri(P0)]);
+}
+// rows r = rbeg, rbeg + rstep, ... < rend of U (K doubles each): this wave's sums of u u' (times dfn(r) if given) to
+// out[q], q = 0..KK-1 (lane 0 writes)
+template <int K, int PASS, class RowFn>
+__device__ __forceinline__ void gram_pass_wave(RowFn row_of, int ebeg, int eend, int estep, double* out) {
+  constexpr int P0 = GramPasses<K>::p0(PASS), P1 = GramPasses<K>::p1(PASS), NQ = tri(P1) - tri(P0);
+  const int lane = threadIdx.x & 63;
+  double acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+  for (int e = ebeg; e < eend; e += estep) {
+    double u[K], d;
+    row_of(e, u, d);
+    gram_rank1<K, P0, P1>(u, d, acc);
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double t = wave_sum(acc[q]);
+    if (lane == 0) out[tri(P0) + q] = t;
+  }
+  if constexpr (PASS + 1 < GramPasses<K>::NP) gram_pass_wave<K, PASS + 1>(row_of, ebeg, eend, estep, out);
+}
+
 // one-wave form (side tasks: a wave per column): lane l takes entries e0 + l, + 64, ...;
 // out[q] = sum_{i in D(col)} (R - c_i,col) w_i[p] w_i[p'] (the caller scales and subtracts)
 template <int K>
 __device__ __forceinline__ void curve_column_sum_wave(const CurveLists& cv, const double* __restrict__ W, int col, double* out) {
-  constexpr int KK = tri(K);
   const int lane = threadIdx.x & 63;
   const int e0 = cv.ptr[col], e1 = cv.ptr[col + 1];
-  double acc[KK];
-#pragma unroll
-  for (int q = 0; q < KK; ++q) acc[q] = 0.0;
-  for (int e = e0 + lane; e < e1; e += WAVE) {
+  gram_pass_wave<K, 0>([&](int e, double (&wr)[K], double& d) {
     const double* __restrict__ w = W + (size_t)cv.idx[e] * K;
-    const double d = cv.def[e];
-    double wr[K];
+    d = cv.def[e];
 #pragma unroll
     for (int k = 0; k < K; ++k) wr[k] = w[k];
-#pragma unroll
-    for (int a = 0; a < K; ++a)
-#pragma unroll
-      for (int b = 0; b <= a; ++b) acc[lidx(a, b)] = fma(d * wr[a], wr[b], acc[lidx(a, b)]);
-  }
-#pragma unroll
-  for (int q = 0; q < KK; ++q) {
-    const double t = wave_sum(acc[q]);
-    if (lane == 0) out[q] = t;
-  }
+  }, e0 + lane, e1, WAVE, out);
 }
 
 // side tasks of the V accumulation launch (spectral sampler): workgroup 0 solves the eigen-problem of the shared
@@ -164,6 +190,10 @@ struct GramSide { const double* U; int Rdim; double* gpart; int nblocks; };
 // gathers) at 28-35 us.  A software-pipelined loop (BTF_ACC_PF_WT=1), 12 or 8 waves per workgroup for a larger
 // register budget: all equal or slower.
 __host__ __device__ constexpr int acc_waves(int K, int MODE) { return MODE >= 1 ? (K >= 6 ? 8 : BTF_ACC_WAVES_WT) : ACC_WAVES; }
+// outputs per lane: two adjacent ones (one 16-byte load per row and lane) wherever the K + K(K+1)/2 accumulator pairs
+// fit the register file; the weighted modes of K >= 9 (54 / 65 values: 216 / 260 VGPRs for the pairs alone) keep ONE
+// output per lane - the waves of a workgroup pair up over the two halves of the 128-column tile - and do not spill
+__host__ __device__ constexpr int acc_opl(int K, int MODE) { return MODE >= 1 && K >= 9 ? 1 : 2; }
 
 // CT: storage type of the weights C: double (Binomial: the Polya-Gamma draws) or unsigned char (Gaussian data with
 // missing replicates: C is the replicate count 0..R, 1 byte instead of 8 per cell: 9 instead of 16 B/cell)
@@ -171,7 +201,8 @@ __host__ __device__ constexpr int acc_waves(int K, int MODE) { return MODE >= 1 
 // integer counts (2 kappa in -127..127 stored, 1 byte instead of 8 per cell: 9 instead of 16 B/cell with f64 weights)
 // UNRV: rows in flight per wave; 0 = the build's default (2).  Long row ranges per workgroup (C5-sized slabs) stream
 // 1-2 % faster with 3 (359 / 346 us against 361 / 353 us per launch at C5), short ones (C3: 32 rows per wave) slower.
-template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double, typename XT = double, int UNRV = 0>
+template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double, typename XT = double, int UNRV = 0,
+          int OPL = acc_opl(K, MODE)>
 __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     const XT* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
@@ -208,23 +239,11 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
       const int col = task ? sidec.cols[t] : 0;
       if (task) curve_column_sum_wave<K>(sidec.cv, sidec.W, col, gown + wave * 64);    // (its loads fly with reduce_gram's)
       if (side.Usrc) {         // (sharded runs: W has just been all-gathered, nobody summed its Gram)
-        double gacc[KK];
-#pragma unroll
-        for (int q = 0; q < KK; ++q) gacc[q] = 0.0;
-        for (int r = threadIdx.x; r < side.nrows; r += WAVES * WAVE) {
-          double u[K];
+        gram_pass_wave<K, 0>([&](int r, double (&u)[K], double& d) {
+          d = 1.0;
 #pragma unroll
           for (int k = 0; k < K; ++k) u[k] = side.Usrc[(size_t)r * K + k];
-#pragma unroll
-          for (int p = 0; p < K; ++p)
-#pragma unroll
-            for (int q = 0; q <= p; ++q) gacc[lidx(p, q)] = fma(u[p], u[q], gacc[lidx(p, q)]);
-        }
-#pragma unroll
-        for (int q = 0; q < KK; ++q) {
-          const double t2 = wave_sum(gacc[q]);
-          if (lane == 0) rsc[wave * KK + q] = t2;
-        }
+        }, (int)threadIdx.x, side.nrows, WAVES * WAVE, rsc + wave * KK);
         __syncthreads();
         if ((int)threadIdx.x < KK) {
           double t2 = 0.0;
@@ -262,23 +281,11 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     if (b < gram.nblocks) {
       // rows b, b + nblocks*threads, ... (strided like gram_kernel), K(K+1)/2 sums per thread, fixed-order reduction
       double* scr = &red[0][0][0];                              // [ACC_WAVES][KK]
-      double gacc[KK];
-#pragma unroll
-      for (int q = 0; q < KK; ++q) gacc[q] = 0.0;
-      for (int r = b * (WAVES * WAVE) + (int)threadIdx.x; r < gram.Rdim; r += gram.nblocks * (WAVES * WAVE)) {
-        double u[K];
+      gram_pass_wave<K, 0>([&](int r, double (&u)[K], double& d) {
+        d = 1.0;
 #pragma unroll
         for (int k = 0; k < K; ++k) u[k] = gram.U[(size_t)r * K + k];
-#pragma unroll
-        for (int p = 0; p < K; ++p)
-#pragma unroll
-          for (int q = 0; q <= p; ++q) gacc[lidx(p, q)] = fma(u[p], u[q], gacc[lidx(p, q)]);
-      }
-#pragma unroll
-      for (int q = 0; q < KK; ++q) {
-        const double t = wave_sum(gacc[q]);
-        if (lane == 0) scr[wave * KK + q] = t;
-      }
+      }, b * (WAVES * WAVE) + (int)threadIdx.x, gram.Rdim, gram.nblocks * (WAVES * WAVE), scr + wave * KK);
       __syncthreads();
       if ((int)threadIdx.x < KK) {
         double t = 0.0;
@@ -291,48 +298,64 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
   }
   const int ntiles = ld / ACC_TILE;
   const int chunk = b / ntiles, tile = b - chunk * ntiles;
-  const size_t col = (size_t)tile * ACC_TILE + 2 * lane;
+  // OPL == 2: every wave covers the tile's 128 columns (two per lane) and takes every WAVES-th row.
+  // OPL == 1: wave w covers the half (w & 1) of the tile, one column per lane, and takes every (WAVES/2)-th row.
+  static_assert(OPL == 2 || (OPL == 1 && WAVES % 2 == 0), "outputs per lane");
+  constexpr int NWR = OPL == 2 ? WAVES : WAVES / 2;             // waves along the rows
+  const int half = OPL == 2 ? 0 : (wave & 1);
+  const int wv = OPL == 2 ? wave : (wave >> 1);
+  const size_t col = (size_t)tile * ACC_TILE + (OPL == 2 ? 2 * lane : 64 * half + lane);
   const int r0 = chunk * rows_per_block;
   const int r1 = min(r0 + rows_per_block, Rdim);
 
-  double acc[NV][2];
+  double acc[NV][OPL];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) acc[v][0] = acc[v][1] = 0.0;
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int o = 0; o < OPL; ++o) acc[v][o] = 0.0;
   int s0 = 0, s1 = 0;
   if constexpr (MODE == 2) {
     s0 = srcmap[col];
-    s1 = srcmap[col + 1];
+    if constexpr (OPL == 2) s1 = srcmap[col + 1];
   }
 
   // (uk: the wave-uniform factor row - scalar loads issued WITH the vector loads, one wait for all of them)
   // FULL: every row of the group exists - no guards, one basic block (the guarded form is the tail's)
+  // (OPL == 1: only the .x halves of the pairs are used)
   struct Rows { double2 x[ACC_UNR]; double2 c[MODE >= 1 ? ACC_UNR : 1]; double2 cs[MODE == 2 ? ACC_UNR : 1]; double uk[ACC_UNR][K]; };
   auto load_rows = [&](int rb, Rows& R, auto full) {
     constexpr bool FULL = decltype(full)::value;
 #pragma unroll
     for (int u = 0; u < ACC_UNR; ++u) {
-      const int r = rb + u * ACC_WAVES;  // wave-uniform
+      const int r = rb + u * NWR;  // wave-uniform
       {
         const double* __restrict__ up = U + (size_t)(FULL ? r : min(r, r1 - 1)) * K;      // clamp: x/c are zero beyond r1
 #pragma unroll
         for (int k = 0; k < K; ++k) R.uk[u][k] = up[k];
       }
       if (FULL || r < r1) {
-        if constexpr (sizeof(XT) == 1) {
-          const char2 xx = *reinterpret_cast<const char2*>(X + (size_t)r * ld + col);
-          R.x[u] = make_double2(0.5 * (double)xx.x, 0.5 * (double)xx.y);
+        if constexpr (OPL == 1) {
+          if constexpr (sizeof(XT) == 1) R.x[u] = make_double2(0.5 * (double)X[(size_t)r * ld + col], 0.0);
+          else R.x[u] = make_double2((double)X[(size_t)r * ld + col], 0.0);
+          if constexpr (MODE >= 1) R.c[u] = make_double2((double)Cx[(size_t)r * ld + col], 0.0);
+          if constexpr (MODE == 2) R.cs[u] = make_double2((double)Cx[(size_t)r * ld + s0], 0.0);
         } else {
-          R.x[u] = *reinterpret_cast<const double2*>(X + (size_t)r * ld + col);
-        }
-        if constexpr (MODE >= 1) {
-          if constexpr (sizeof(CT) == 1) {
-            const uchar2 cc = *reinterpret_cast<const uchar2*>(Cx + (size_t)r * ld + col);
-            R.c[u] = make_double2((double)cc.x, (double)cc.y);
+          if constexpr (sizeof(XT) == 1) {
+            const char2 xx = *reinterpret_cast<const char2*>(X + (size_t)r * ld + col);
+            R.x[u] = make_double2(0.5 * (double)xx.x, 0.5 * (double)xx.y);
           } else {
-            R.c[u] = *reinterpret_cast<const double2*>(Cx + (size_t)r * ld + col);
+            R.x[u] = *reinterpret_cast<const double2*>(X + (size_t)r * ld + col);
           }
+          if constexpr (MODE >= 1) {
+            if constexpr (sizeof(CT) == 1) {
+              const uchar2 cc = *reinterpret_cast<const uchar2*>(Cx + (size_t)r * ld + col);
+              R.c[u] = make_double2((double)cc.x, (double)cc.y);
+            } else {
+              R.c[u] = *reinterpret_cast<const double2*>(Cx + (size_t)r * ld + col);
+            }
+          }
+          if constexpr (MODE == 2) R.cs[u] = make_double2((double)Cx[(size_t)r * ld + s0], (double)Cx[(size_t)r * ld + s1]);
         }
-        if constexpr (MODE == 2) R.cs[u] = make_double2((double)Cx[(size_t)r * ld + s0], (double)Cx[(size_t)r * ld + s1]);
       } else {
         R.x[u] = make_double2(0.0, 0.0);
         if constexpr (MODE >= 1) R.c[u] = make_double2(0.0, 0.0);
@@ -347,7 +370,9 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
         // (reciprocal by v_rcp_f64 + two Newton steps: 0.5 ulp, a fifth of the instructions of an IEEE division)
         auto rcp2 = [](double d) { double r = __builtin_amdgcn_rcp(d); r = fma(fma(-d, r, 1.0), r, r); return fma(fma(-d, r, 1.0), r, r); };
         if (s0 != (int)col) R.x[u].x = R.c[u].x != 0.0 ? R.x[u].x * R.cs[u].x * rcp2(R.c[u].x) : 0.0;
-        if (s1 != (int)col + 1) R.x[u].y = R.c[u].y != 0.0 ? R.x[u].y * R.cs[u].y * rcp2(R.c[u].y) : 0.0;
+        if constexpr (OPL == 2) {
+          if (s1 != (int)col + 1) R.x[u].y = R.c[u].y != 0.0 ? R.x[u].y * R.cs[u].y * rcp2(R.c[u].y) : 0.0;
+        }
         R.c[u] = R.cs[u];
       }
       const double* up = R.uk[u];
@@ -355,7 +380,7 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
       for (int k = 0; k < K; ++k) {
         const double uk = up[k];
         acc[k][0] = fma(R.x[u].x, uk, acc[k][0]);
-        acc[k][1] = fma(R.x[u].y, uk, acc[k][1]);
+        if constexpr (OPL == 2) acc[k][1] = fma(R.x[u].y, uk, acc[k][1]);
       }
       if constexpr (MODE >= 1) {
         // outer products on the fly: (c u_p) u_q, K more multiplies per output instead of KK more scalar operands
@@ -363,20 +388,20 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
         // the rows in flight) were issued just in time and stalled every wave four times per row
 #pragma unroll
         for (int p = 0; p < K; ++p) {
-          const double cx = R.c[u].x * up[p], cy = R.c[u].y * up[p];
+          const double cx = R.c[u].x * up[p], cy = OPL == 2 ? R.c[u].y * up[p] : 0.0;
 #pragma unroll
           for (int q = 0; q <= p; ++q) {
             acc[K + lidx(p, q)][0] = fma(cx, up[q], acc[K + lidx(p, q)][0]);
-            acc[K + lidx(p, q)][1] = fma(cy, up[q], acc[K + lidx(p, q)][1]);
+            if constexpr (OPL == 2) acc[K + lidx(p, q)][1] = fma(cy, up[q], acc[K + lidx(p, q)][1]);
           }
         }
       }
     }
   };
-  constexpr int STEP = ACC_WAVES * ACC_UNR;
+  constexpr int STEP = NWR * ACC_UNR;
   constexpr bool PIPELINED = MODE >= 1 && BTF_ACC_PF_WT;      // (complete data: 5 FMAs per load, nothing to hide)
-  const int full_end = r1 - (ACC_UNR - 1) * ACC_WAVES;        // groups starting below it have all their rows
-  int rb = r0 + wave;
+  const int full_end = r1 - (ACC_UNR - 1) * NWR;              // groups starting below it have all their rows
+  int rb = r0 + wv;
   if constexpr (PIPELINED) {
     Rows A, B;
     bool more = rb < full_end;
@@ -412,14 +437,16 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
   for (int g = 0; g < NV; g += ACC_RG) {
 #pragma unroll
     for (int v = 0; v < ACC_RG; ++v) {
-      if (g + v < NV)
-        *reinterpret_cast<double2*>(&red[wave][v][2 * lane]) = make_double2(acc[g + v][0], acc[g + v][1]);
+      if (g + v < NV) {
+        if constexpr (OPL == 2) *reinterpret_cast<double2*>(&red[wave][v][2 * lane]) = make_double2(acc[g + v][0], acc[g + v][1]);
+        else red[wv][v][64 * half + lane] = acc[g + v][0];
+      }
     }
     __syncthreads();
     if (tv < ACC_RG && g + tv < NV) {
       double s = 0.0;
 #pragma unroll
-      for (int w = 0; w < ACC_WAVES; ++w) s += red[w][tv][tc];
+      for (int w = 0; w < NWR; ++w) s += red[w][tv][tc];
       part[((size_t)chunk * NV + (g + tv)) * ld + (size_t)tile * ACC_TILE + tc] = s;
     }
     __syncthreads();
@@ -610,7 +637,9 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
   constexpr int WS_SPLIT = ws_split_of(K, WEIGHTED);
   constexpr int NVMAX = WEIGHTED ? K + KK : K;
   constexpr int NV = NVMAX;
-  constexpr int UNR = WEIGHTED ? 2 : 4;                  // chunks whose loads are in flight together
+  // chunks whose loads are in flight together (weighted rows of K >= 6 carry 27+ values per chunk: two chunks' worth of
+  // them beside the running sums did not fit the 256 VGPRs of the 8-wave workgroup - 156 spilled at K = 6)
+  constexpr int UNR = WEIGHTED ? (K + KK > 24 ? 1 : 2) : 4;
   __shared__ double G[KK];
   __shared__ double red[WS_SPLIT][K + KK][WS_ROWS];   // also the staging area of the Gram partials
   __shared__ double zsh[K][WS_ROWS];

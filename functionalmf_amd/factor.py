@@ -675,6 +675,8 @@ class BayesianTensorFiltering(_BayesianModel):
         cw, cv = ctypes.c_uint64(0), ctypes.c_uint64(0)
         self._ctx.call("btf_get_draw_counters", ctypes.byref(cw), ctypes.byref(cv))
         st["half_sweeps_w"], st["half_sweeps_v"] = int(cw.value), int(cv.value)
+        # (also drops the spectral sampler's eigen warm start, as restore() does: both continuations start it cold)
+        self._ctx.call("btf_set_draw_counters", int(cw.value), int(cv.value))
         for k in self._CHAIN_ARRAYS:
             v = getattr(self, k, None)
             if v is not None:

@@ -280,7 +280,10 @@ enum { BTF_LIK_COMPLETE = 0, BTF_LIK_WEIGHTED = 1, BTF_LIK_CURVE_COUNTS = 2 };
 int btf_get_likelihood_form(btf_ctx* ctx, int32_t* form);
 /* Checkpoint / resume (the reference keeps no state between runs - genlasso.py:57-66 returns the samples; SURVEY
  * section 5): besides the caller's seeds, the rng="device" draws of W and V are keyed by how many W / V half-sweeps
- * this context has run.  A chain continued in another context gets the same draws after handing these two over. */
+ * this context has run.  A chain continued in another context gets the same draws after handing these two over.
+ * btf_set_draw_counters also forgets the spectral sampler's eigen warm start (the next V half-sweep solves the K x K
+ * eigenproblem from scratch), so a chain that calls it with its own counters and one restored elsewhere continue
+ * identically. */
 int btf_get_draw_counters(btf_ctx* ctx, uint64_t* w_half_sweeps, uint64_t* v_half_sweeps);
 int btf_set_draw_counters(btf_ctx* ctx, uint64_t w_half_sweeps, uint64_t v_half_sweeps);
 /* Algorithmic bytes per cell one accumulation launch streams for the bound data: 8 (linear statistic alone: complete data,

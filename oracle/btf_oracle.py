@@ -767,6 +767,33 @@ def v_step_strong(st, R, ybar, Delta, z=None, order=None):
     return V
 
 
+def v_column_system_strong(st, R, ybar, Delta, j):
+    """Dense depth-major precision Q_j and mean part of column j for complete data (the system v_step_strong
+    factorises: factor.py:377-408 with the hoisted statistics): for conditioning bounds and whitening checks."""
+    W = st["W"]
+    T = ybar.shape[2]
+    K = W.shape[1]
+    s = R / st["nu2"]
+    G = s * (W.T @ W)
+    lam = 1.0 / (st["lam2"] * st["Tau2"][j])
+    Pm = np.asarray((Delta.T @ np.diag(lam) @ Delta) if not hasattr(Delta, "toarray") else (Delta.T.toarray() * lam) @ Delta.toarray())
+    Q = np.kron(Pm, np.eye(K)) + np.kron(np.eye(T), G)            # depth-major: index t*K + k
+    mu = s * np.einsum("nk,nt->tk", W, ybar[:, j, :]).reshape(-1)
+    return Q, mu
+
+
+def v_column_conds(st, R, ybar, Delta, cols=None):
+    """2-norm condition numbers of the column systems (what bounds the agreement of two correct fp64 solves)."""
+    M = st["V"].shape[0]
+    cols = range(M) if cols is None else cols
+    out = []
+    for j in cols:
+        Q, _ = v_column_system_strong(st, R, ybar, Delta, j)
+        ev = np.linalg.eigvalsh(Q)
+        out.append(ev[-1] / ev[0])
+    return np.array(out)
+
+
 # --------------------------------------------------------------------------
 # fast_mvn: the dense branches and the dispatcher   (fast_mvn.py:49-60, :77-179)
 # --------------------------------------------------------------------------

@@ -1,7 +1,11 @@
 """Worker of test_two_ranks_share_one_gpu: two processes (gloo control plane, exchange staged
 through the host because RCCL refuses two ranks on one device) run the SHARDED kernels - row
 and column offsets, local slabs, per-rank partial SSE - on cuda:0 and must reproduce the
-unsharded oracle."""
+unsharded oracle.
+Also the worker of test_rccl_exchange_with_one_rank_reproduces_the_plain_chain (BTF_DIST_BACKEND=nccl,
+BTF_EXERCISE_EXCHANGE=1, one rank): the same checks with the DEVICE collectives - all_gather_into_tensor on the
+context's W / V buffers and the 8-byte all-reduce of the residual sum of squares, issued under the context's own
+stream - in the call sequence of an N-rank RCCL run."""
 import os
 import sys
 
@@ -17,7 +21,14 @@ from functionalmf_amd.factor import GaussianBayesianTensorFiltering  # noqa: E40
 
 
 def main():
-    dist.init_process_group("gloo")
+    backend = os.environ.get("BTF_DIST_BACKEND", "gloo")
+    exercise = os.environ.get("BTF_EXERCISE_EXCHANGE", "0")
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     for name in ("g2_c2_complete.npz", "g1_c1_heldout.npz"):
         g = load_golden(name)
@@ -57,6 +68,7 @@ def main():
         chains = []
         for shard in ((rank, world), None):
             np.random.seed(7)
+            os.environ["BTF_EXERCISE_EXCHANGE"] = exercise if shard is not None else "0"     # the plain chain: no collectives
             m = GaussianBayesianTensorFiltering(
                 N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
                 W_init=st["W"], V_init=st["V"], compat="exact", shard=shard, device=0, rng="device", device_seed=9,
@@ -79,6 +91,7 @@ def main():
     chains = []
     for shard in ((rank, world), None):
         np.random.seed(7)
+        os.environ["BTF_EXERCISE_EXCHANGE"] = exercise if shard is not None else "0"
         m = BinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
                                             W_init=st["W"], V_init=st["V"], compat="exact", shard=shard, device=0, rng="device",
                                             device_seed=9)

@@ -715,6 +715,28 @@ def test_two_ranks_share_one_gpu():
     assert out.stdout.count("SHARD_GPU_OK") == 2, out.stdout[-2000:]
 
 
+@pytest.mark.timeout(400)
+def test_rccl_exchange_with_one_rank_reproduces_the_plain_chain():
+    """The DEVICE collective path of sharded runs (functionalmf_amd/parallel.py: all_gather_into_tensor on the
+    context's own W / V buffers and the 8-byte all-reduce of the residual sum of squares, issued under
+    torch.cuda.ExternalStream(ctx stream); the nu2 draw split around the all-reduce, btf_draw_scalars which | 8 then
+    | 16) on real hardware: a one-rank RCCL ("nccl") group with BTF_EXERCISE_EXCHANGE=1 issues every collective of
+    an N-rank run.  Host-RNG half-sweeps against the oracle, then whole rng="device" sweeps (Gaussian complete,
+    Gaussian with held-out cells, Binomial): the chain with the exchanges in must equal the plain one - a collective
+    or a draw kernel running out of order on the stream would change it."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, BTF_DIST_BACKEND="nccl", BTF_EXERCISE_EXCHANGE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29583", os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=380)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("SHARD_GPU_OK") == 1, out.stdout[-2000:]
+
+
 def test_device_scalar_draws_have_the_right_conditionals(golden):
     """rng='device': nu2, sigma2 (btf_draw_scalars) and lam2, lam2_a (btf_draw_lam2) are drawn on
     the GPU.  Repeat each draw from a fixed state and compare with the analytic conditionals
