@@ -39,6 +39,8 @@ CONFIGS = {
     "c3": dict(N=512, M=256, T=64, R=4, K=5),
     "c5": dict(N=4096, M=1024, T=64, R=4, K=8),
     "c3k8": dict(N=512, M=256, T=64, R=4, K=8),      # tuning aid: C3 cells with C5's embedding size
+    "c3k10": dict(N=512, M=256, T=64, R=4, K=10),    # C3 cells with the reference's larger embedding (flutrends/benchmark.py:33)
+    "flu": dict(N=50, M=1, T=370, R=1, K=10),        # flutrends/benchmark.py:31-34: 50 states x 1 x 370 weeks, nembeds 10
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 METRIC = "Gibbs sweeps/sec (full W+V update) at (512,256,64) K=5; % HBM roofline"

@@ -145,7 +145,7 @@ def build(force=False, verbose=False, jobs=None):
     os.makedirs(OBJ_DIR, exist_ok=True)
     tag = os.path.splitext(os.path.basename(LIB_PATH))[0]
     base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function",
-            "-I", os.path.join(ROOT, "include")]
+            "-I", os.path.join(ROOT, "include")] + os.environ.get("BTF_BUILD_DEFS", "").split()   # A/B builds: -DBTF_... tuning macros
     units = [(SOURCES[0], os.path.join(OBJ_DIR, tag + "_abi.o"), [])]
     units += [(INST_SOURCE, os.path.join(OBJ_DIR, "%s_inst%d.o" % (tag, p)), ["-DBTF_INST_PART=%d" % p])
               for p in range(INST_PARTS)]

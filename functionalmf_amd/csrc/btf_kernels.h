@@ -36,6 +36,15 @@ namespace btf {
 #ifndef BTF_ACC_WAVES_WT
 #define BTF_ACC_WAVES_WT 12   // weighted modes, K <= 5: waves per workgroup
 #endif
+#ifndef BTF_ACC_WAVES_K10
+#define BTF_ACC_WAVES_K10 8   // complete data, K = 10: waves per workgroup
+#endif
+#ifndef BTF_ACC_UNR_K9
+#define BTF_ACC_UNR_K9 2      // complete data, K >= 9: rows in flight per wave
+#endif
+#ifndef BTF_ACC_ULDS_MINK
+#define BTF_ACC_ULDS_MINK 8   // complete data: from this K on the factor rows are staged in LDS (accum_kernel, ULDS)
+#endif
 constexpr int ACC_WAVES = BTF_ACC_WAVES;   // waves per workgroup
 constexpr int ACC_THREADS = ACC_WAVES * WAVE;
 constexpr int ACC_TILE = 2 * WAVE;      // outputs per workgroup along the lane axis
@@ -189,7 +198,20 @@ struct GramSide { const double* U; int Rdim; double* gpart; int nblocks; };
 // (complete data), two loads per row (statistic + byte counts / f64 weights) at 20-23 us, four (stale-weight
 // gathers) at 28-35 us.  A software-pipelined loop (BTF_ACC_PF_WT=1), 12 or 8 waves per workgroup for a larger
 // register budget: all equal or slower.
-__host__ __device__ constexpr int acc_waves(int K, int MODE) { return MODE >= 1 ? (K >= 6 ? 8 : BTF_ACC_WAVES_WT) : ACC_WAVES; }
+// (complete data at K = 10: the stream itself needs 40 VGPRs, but the eigen side task compiled into the same kernel
+//  spilled 7 under the 128-VGPR budget of 16 waves - 8 waves there, two workgroups per CU)
+__host__ __device__ constexpr int acc_waves(int K, int MODE) {
+  return MODE >= 1 ? (K >= 6 ? 8 : BTF_ACC_WAVES_WT) : (K >= 10 && ACC_WAVES > BTF_ACC_WAVES_K10 ? BTF_ACC_WAVES_K10 : ACC_WAVES);
+}
+// (A/B aid) occupancy hint of the K = 10 complete-data kernel: BTF_ACC_K10_EU waves per SIMD (0: none)
+#ifndef BTF_ACC_K10_EU
+#define BTF_ACC_K10_EU 0
+#endif
+#if BTF_ACC_K10_EU > 0
+#define BTF_ACC_EU_ATTR(K, MODE, WAVES) __attribute__((amdgpu_waves_per_eu((K) >= 10 && (MODE) == 0 ? BTF_ACC_K10_EU : 1, (K) >= 10 && (MODE) == 0 ? BTF_ACC_K10_EU : 8)))
+#else
+#define BTF_ACC_EU_ATTR(K, MODE, WAVES)
+#endif
 // outputs per lane: two adjacent ones (one 16-byte load per row and lane) wherever the K + K(K+1)/2 accumulator pairs
 // fit the register file; the weighted modes of K >= 9 (54 / 65 values: 216 / 260 VGPRs for the pairs alone) keep ONE
 // output per lane - the waves of a workgroup pair up over the two halves of the 128-column tile - and do not spill
@@ -203,16 +225,23 @@ __host__ __device__ constexpr int acc_opl(int K, int MODE) { return MODE >= 1 &&
 // 1-2 % faster with 3 (359 / 346 us against 361 / 353 us per launch at C5), short ones (C3: 32 rows per wave) slower.
 template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double, typename XT = double, int UNRV = 0,
           int OPL = acc_opl(K, MODE)>
-__global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
+__global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void accum_kernel(
     const XT* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
     int rows_per_block, EigSide side, EigSideCols sidec, TauSide tau, GramSide gram) {
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
-  constexpr int ACC_UNR = UNRV > 0 ? UNRV : (MODE >= 1 ? BTF_ACC_UNR_WT : BTF_ACC_UNR);
+  constexpr int ACC_UNR = UNRV > 0 ? UNRV : (MODE >= 1 ? BTF_ACC_UNR_WT : (K >= 9 ? BTF_ACC_UNR_K9 : BTF_ACC_UNR));
   constexpr int ACC_RG = (WAVES * WAVE / ACC_TILE) < 4 ? (WAVES * WAVE / ACC_TILE) : 4;
   __shared__ double red[ACC_WAVES][ACC_RG][ACC_TILE];
+  // ULDS: the factor rows U[r][:] of the workgroup's row range come in through LDS (one coalesced copy per block of
+  // ACC_UROWS rows, then a broadcast ds_read per row and wave) instead of scalar loads - for the long row ranges of
+  // C5-sized slabs at K >= 8 (the three-rows-in-flight instance): 353 / 346 -> 342 / 337 us per launch at C5.  Short
+  // ranges (C3-sized, 512 rows per workgroup) gain nothing (K = 8: 12.6 -> 13.1 us; K = 10: 18.7 us either way).
+  constexpr bool ULDS = MODE == 0 && K >= BTF_ACC_ULDS_MINK && UNRV == 3;
+  constexpr int ACC_UROWS_MAX = 512;
+  __shared__ double ush[ULDS ? ACC_UROWS_MAX * K : 1];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -319,6 +348,7 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
     if constexpr (OPL == 2) s1 = srcmap[col + 1];
   }
 
+  int ublk0 = r0;                                             // first row of the block of U staged in `ush` (ULDS)
   // (uk: the wave-uniform factor row - scalar loads issued WITH the vector loads, one wait for all of them)
   // FULL: every row of the group exists - no guards, one basic block (the guarded form is the tail's)
   // (OPL == 1: only the .x halves of the pairs are used)
@@ -328,7 +358,11 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
 #pragma unroll
     for (int u = 0; u < ACC_UNR; ++u) {
       const int r = rb + u * NWR;  // wave-uniform
-      {
+      if constexpr (ULDS) {
+        const double* up = ush + (size_t)((FULL ? r : min(r, r1 - 1)) - ublk0) * K;         // wave-uniform: broadcast reads
+#pragma unroll
+        for (int k = 0; k < K; ++k) R.uk[u][k] = up[k];
+      } else {
         const double* __restrict__ up = U + (size_t)(FULL ? r : min(r, r1 - 1)) * K;      // clamp: x/c are zero beyond r1
 #pragma unroll
         for (int k = 0; k < K; ++k) R.uk[u][k] = up[k];
@@ -402,7 +436,36 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
   constexpr bool PIPELINED = MODE >= 1 && BTF_ACC_PF_WT;      // (complete data: 5 FMAs per load, nothing to hide)
   const int full_end = r1 - (ACC_UNR - 1) * NWR;              // groups starting below it have all their rows
   int rb = r0 + wv;
-  if constexpr (PIPELINED) {
+  if constexpr (ULDS) {
+    // blocks of ACC_UROWS rows: copy the block's factor rows (contiguous: rows x K doubles, 16-byte aligned since the
+    // block starts at a multiple of 64 rows), then the waves stream its rows as below; STEP divides ACC_UROWS, so a
+    // wave's row sequence simply continues from block to block
+    constexpr int ACC_UROWS = (ACC_UROWS_MAX / STEP) * STEP;   // whole groups of rows; even (STEP is)
+    for (ublk0 = r0; ublk0 < r1; ublk0 += ACC_UROWS) {
+      const int bend = min(ublk0 + ACC_UROWS, r1);
+      if (ublk0 > r0) __syncthreads();                        // everybody is done with the previous block
+      {
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(U + (size_t)ublk0 * K);
+        double2* dst = reinterpret_cast<double2*>(ush);
+        const int n2 = (bend - ublk0) * K / 2;                // (an odd last double - K odd, odd row count - goes separately)
+        for (int i = threadIdx.x; i < n2; i += WAVES * WAVE) dst[i] = src[i];
+        if (((bend - ublk0) * K & 1) && threadIdx.x == 0) ush[(bend - ublk0) * K - 1] = U[(size_t)bend * K - 1];
+      }
+      __syncthreads();
+      const int bfull = min(full_end, bend - (ACC_UNR - 1) * NWR);
+      for (; rb < bfull; rb += STEP) {
+        Rows A;
+        load_rows(rb, A, std::true_type{});
+        compute(rb, A);
+      }
+      if (rb < bend) {                                         // the block's (= the range's: blocks before the last are whole) tail
+        Rows A;
+        load_rows(rb, A, std::false_type{});
+        compute(rb, A);
+        rb += STEP;
+      }
+    }
+  } else if constexpr (PIPELINED) {
     Rows A, B;
     bool more = rb < full_end;
     if (more) load_rows(rb, A, std::true_type{});
@@ -424,10 +487,12 @@ __global__ __launch_bounds__(WAVES * WAVE) void accum_kernel(
       compute(rb, A);
     }
   }
-  if (rb < r1) {
-    Rows A;
-    load_rows(rb, A, std::false_type{});
-    compute(rb, A);
+  if constexpr (!ULDS) {
+    if (rb < r1) {
+      Rows A;
+      load_rows(rb, A, std::false_type{});
+      compute(rb, A);
+    }
   }
 
   // cross-wave reduction through LDS, ACC_RG values per round, fixed order
@@ -758,6 +823,23 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     for (int v = 0; v < NVMAX; ++v) red[grp][v][lane] = part[v];
   }
   __syncthreads();
+  // Weighted rows of K = 6 and 8 leave WS_SPLIT (K + KK) = 216 / 176 values per row in LDS: wave 0 summing them all on
+  // its own kept two hundred loaded doubles alive next to the solve's registers (148 VGPRs spilled at K = 6).  There
+  // the waves first add the WS_SPLIT shares of every WS_SPLIT-th value each (same order: bit-identical sums), in place.
+#ifndef BTF_WS_TWO_LEVEL_MIN
+#define BTF_WS_TWO_LEVEL_MIN 160
+#endif
+  constexpr bool TWO_LEVEL = WEIGHTED && WS_SPLIT * (K + KK) > BTF_WS_TWO_LEVEL_MIN;
+  if constexpr (TWO_LEVEL) {
+    for (int v = grp; v < NV; v += WS_SPLIT) {
+      double s2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < WS_SPLIT; ++w) s2 += red[w][v][lane];
+      red[0][v][lane] = s2;
+    }
+    __syncthreads();
+  }
+  constexpr int NSH = TWO_LEVEL ? 1 : WS_SPLIT;          // shares wave 0 still has to add
   if (grp != 0) return;                      // wave 0 finishes: one lane per row
   const bool live = lane < RW && il < a.nl;
   const int i = a.row0 + (live ? il : 0);
@@ -767,7 +849,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
   for (int k = 0; k < K; ++k) {
     double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < WS_SPLIT; ++w) s += red[w][k][rr];
+    for (int w = 0; w < NSH; ++w) s += red[w][k][rr];
     m[k] = s * a.s;
   }
 #pragma unroll
@@ -775,7 +857,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     if constexpr (WEIGHTED) {
       double s = 0.0;
 #pragma unroll
-      for (int w = 0; w < WS_SPLIT; ++w) s += red[w][K + q][rr];
+      for (int w = 0; w < NSH; ++w) s += red[w][K + q][rr];
       Q[q] = s * a.s;
     } else {
       Q[q] = G[q];

@@ -376,3 +376,56 @@ def test_full_size_held_out_curves_vs_weighted_conditionals(sampler):
     perm = "spectral" if sampler == "spectral" else orc.perm_from_order(model.v_order(), K, T)
     orc.v_step(ost, Y, orc.trend_penalty(T, 2), perm=perm, z=zv, compat="exact", cols=cols)
     assert relerr(model.V[cols], ost["V"][cols]) < 1e-6
+
+
+# ---- K = 10 (a configuration the reference runs: flutrends/benchmark.py:33, `for nembeds in [5, 10]`) at C3 size ----
+@pytest.mark.parametrize("variant", ["complete", "missing"])
+def test_full_size_k10_half_sweeps(variant):
+    """(512,256,64,4) with nembeds = 10: the accumulation kernels of K = 10 (complete data: 8-wave workgroups; weighted:
+    one output per lane, 65 accumulators - the instances that spilled hundreds of VGPRs before round 3), w_solve
+    with 10 x 10 systems and the any-bandwidth V sampler (half-bandwidth 30).  W: every row against the weighted
+    conditional from the per-cell counts; V: a spread of columns against the oracle in the kernel's declared order."""
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    from oracle import btf_oracle as orc
+    K10 = 10
+    rs = np.random.RandomState(21)
+    Wt = rs.normal(size=(N, K10))
+    Wt[np.triu_indices(K10, 1)] = 0
+    Vt = 0.1 * np.cumsum(rs.normal(size=(M, T, K10)), axis=1)
+    Y = np.einsum("nk,mtk->nmt", Wt, Vt)[..., None] + rs.normal(0, 0.5, size=(N, M, T, R))
+    if variant == "missing":
+        Y[rs.rand(N, M) < 0.05] = np.nan
+        Y[rs.rand(N, M, T, R) < 0.05] = np.nan
+    st = dict(W=Wt + 0.1 * rs.normal(size=Wt.shape), V=Vt + 0.05 * rs.normal(size=Vt.shape), Tau2=rs.gamma(2.0, 0.5, size=(M, 3 * T - 1)),
+              lam2=0.2, sigma2=0.6, nu2=0.3)
+    st["W"][np.triu_indices(K10, 1)] = 0
+    model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K10, tf_order=2, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                            nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"],
+                                            compat="exact", sampler="banded")
+    np.random.seed(3)
+    zw = np.random.normal(size=K10 * (K10 + 1) // 2 + (N - K10) * K10)
+    zv = np.random.normal(size=(M, K10 * T))
+    np.random.seed(3)
+    model._resample_W(Y)
+    assert model.likelihood_form() == ("weighted" if variant == "missing" else "complete")
+    cnt = np.sum(~np.isnan(Y), axis=3).astype(float)
+    S1 = np.nansum(Y, axis=3)
+    Vf = st["V"].reshape(-1, K10)
+    c = cnt.reshape(N, -1) / st["nu2"]
+    m = (S1.reshape(N, -1) / st["nu2"]) @ Vf
+    W = st["W"].copy()
+    zpos = 0
+    for i in range(N):
+        d = min(i + 1, K10)
+        Q = (Vf[:, :d] * c[i][:, None]).T @ Vf[:, :d] + np.eye(d) / st["sigma2"]
+        L = np.linalg.cholesky(Q)
+        W[i, :d] = np.linalg.solve(Q, m[i, :d]) + np.linalg.solve(L.T, zw[zpos:zpos + d])
+        zpos += d
+    assert relerr(model.W, W) < 1e-10
+    np.random.seed(5)
+    model._v_normals = lambda: zv
+    model._resample_V(Y)
+    cols = [0, 1, 17, 100, 255]
+    ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in dict(st, W=W).items()}
+    orc.v_step(ost, Y, orc.trend_penalty(T, 2), perm=orc.perm_from_order(model.v_order(), K10, T), z=zv, compat="exact", cols=cols)
+    assert relerr(model.V[cols], ost["V"][cols]) < 1e-6

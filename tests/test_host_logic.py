@@ -174,3 +174,25 @@ def test_shard_plan_rejects_more_shards_than_the_padding_allows():
     from functionalmf_amd.parallel import ShardPlan
     with pytest.raises(ValueError):
         ShardPlan(1000, 1000, 0, 65)
+
+
+def test_no_vgpr_spills_in_the_hot_kernels():
+    """Code-object notes of the built library (scripts/kernel_notes.py: the NT_AMDGPU_METADATA note of every embedded
+    gfx950 ELF): the streaming accumulation, the W solve and the flat Polya-Gamma kernels must not spill VGPRs for any
+    supported nembeds (1..10) - K = 9 / 10 weighted accumulation, w_solve<6, weighted> and the K = 10 eigen side task
+    did before round 3."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("kernel_notes", os.path.join(ROOT, "scripts", "kernel_notes.py"))
+    kn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kn)
+    rows = kn.kernels()
+    assert len(rows) > 600
+    hot = [r for r in rows if any(t in r["mangled"] for t in ("accum_kernel", "w_solve_kernel", "pgx_tile_kernel", "pgx_kernel",
+                                                             "v_spectral_kernel", "v_banded_twist_kernel"))]
+    assert len(hot) > 150
+    bad = [(r["mangled"], r["vgpr_spill"]) for r in hot if r["vgpr_spill"]]
+    assert not bad, bad
+    ks = {int(m) for r in hot for m in __import__("re").findall(r"accum_kernelILi(\d+)E", r["mangled"])}
+    assert ks == set(range(1, 11)), ks
