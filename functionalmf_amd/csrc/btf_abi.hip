@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -115,6 +116,12 @@ struct btf_ctx {
   double* eig_cols = nullptr;                                         // [M][K + K*K + 8] per-column eigen-systems
   int* cv_dcols = nullptr; int cv_ndef = 0;                           // the columns that have deficient rows
   bool w_part_curve = false;                                          // the W-step partials were made in curve mode
+  // sharded runs, BTF_OPT_SPLIT_ACCUM: the chunks of the rank's own block of the fixed factor are accumulated right
+  // behind the kernel that drew it (no exchange needed), the rest behind the all-gather
+  bool split_accum = false;
+  bool w_local_done = false, v_local_done = false;                    // own-block chunks of the next W / V accumulation are in c->part
+  int w_local_rpb = 0, w_local_mode = 0, v_local_rpb = 0, v_local_mode = 0;
+  hipEvent_t ev_draw = nullptr, ev_join = nullptr;                    // behind the last draw kernel / the comm stream's tail
   bool tau_pending = false; unsigned long long tau_seed = 0; double tau_stability = 1e-6;   // btf_queue_Tau2
   bool lam_pending = false; unsigned long long lam_seed = 0; int lam_exact = 0;            // btf_queue_lam2
   unsigned long long sweep_w = 0, sweep_v = 0;
@@ -296,24 +303,26 @@ template <int K>
 void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const unsigned char* C8, const double* U,
                   const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr},
                   EigSideCols sidec = EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
-                  TauSide tau = TauSide{}, GramSide gram = GramSide{nullptr, 0, nullptr, 0}) {
+                  TauSide tau = TauSide{}, GramSide gram = GramSide{nullptr, 0, nullptr, 0},
+                  ChunkMap cm = ChunkMap{0, INT_MAX, 0}) {
+  // nch: the chunks THIS launch covers (all of them unless cm says otherwise)
   Prof p(c, kid);
   const int cpw = TAU_SIDE_CPW;
   dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 + eig_side_groups(sidec.ncols, acc_waves(K, mode)) : 0) +
             (tau.Tau2 ? (tau.M + cpw - 1) / cpw : 0) + (gram.gpart ? gram.nblocks : 0));   // (+ the side tasks' workgroups)
   const signed char* A8 = (mode >= 1 && !C8 && X == c->A_wT) ? c->A8_wT : ((mode >= 1 && !C8 && X == c->A_v) ? c->A8_v : nullptr);
   if (A8) {                    // Binomial pseudo-data as bytes (f64 weights)
-    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), double, signed char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
-    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), double, signed char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), double, signed char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), double, signed char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
     return;
   }
   if (mode >= 1 && C8) {       // byte weights (Gaussian replicate counts)
-    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
-    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
-  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
-  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
-  else if (rpb >= 2048) p.launch(accum_kernel<K, 0, acc_waves(K, 0), double, double, 3>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
-  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram);
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
+  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
+  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
+  else if (rpb >= 2048) p.launch(accum_kernel<K, 0, acc_waves(K, 0), double, double, 3>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
+  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
 }
 // Which Polya-Gamma launches a draw needs (pg_class_of): the flat exact kernel for the integer counts it takes
 // under the mode, the series kernel and / or the f64 Devroye kernel with a fractional part for the rest - each only
@@ -749,6 +758,8 @@ void btf_destroy(btf_ctx* c) {
     if (p) (void)hipFree(p);
   if (c->hyp) (void)hipFree(c->hyp);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (c->ev_draw) (void)hipEventDestroy(c->ev_draw);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -856,7 +867,7 @@ static int finish_data(btf_ctx* c) {
     if (rc2) return rc2;
   }
   c->have_data = true;
-  c->w_part_valid = false;
+  c->w_part_valid = false; c->w_local_done = c->v_local_done = false;
   return BTF_OK;
 }
 
@@ -981,7 +992,15 @@ int btf_set_W(btf_ctx* c, const double* W) {
   c->have_W = true;
   c->nb_L_valid = false;
   c->ngp_w = 0;
+  c->v_local_done = false;
   return BTF_OK;
+}
+int btf_set_gathered_W(btf_ctx* c, const double* W) {
+  if (!c) return BTF_EINVAL;
+  const bool keep = c->v_local_done;
+  const int rc = btf_set_W(c, W);
+  if (rc == BTF_OK) c->v_local_done = keep;       // the caller's own rows are unchanged: what was accumulated from them stands
+  return rc;
 }
 int btf_get_W(btf_ctx* c, double* W) {
   if (!c || !W) return BTF_EINVAL;
@@ -998,7 +1017,15 @@ int btf_set_V(btf_ctx* c, const double* V) {
   c->nb_L_valid = false;
   c->w_part_valid = false;
   c->ngp_v = 0;
+  c->w_local_done = false;
   return BTF_OK;
+}
+int btf_set_gathered_V(btf_ctx* c, const double* V) {
+  if (!c) return BTF_EINVAL;
+  const bool keep = c->w_local_done;
+  const int rc = btf_set_V(c, V);
+  if (rc == BTF_OK) c->w_local_done = keep;       // the caller's own columns are unchanged
+  return rc;
 }
 int btf_get_V(btf_ctx* c, double* V) {
   if (!c || !V) return BTF_EINVAL;
@@ -1095,7 +1122,7 @@ int btf_set_nu2(btf_ctx* c, double nu2) {
   return BTF_OK;
 }
 int btf_set_omega(btf_ctx* c, const double* omega_rows, const double* omega_cols) {
-  if (c) c->w_part_valid = false;   // the weights change
+  if (c) { c->w_part_valid = false; c->w_local_done = c->v_local_done = false; }   // the weights change
   if (!c || !omega_rows || !omega_cols) return BTF_EINVAL;
   if (!c->have_data || !c->binomial) return fail(c, BTF_ESTATE, "btf_set_omega needs binomial data");
   HIPCHK(c, hipSetDevice(c->dev));
@@ -1129,7 +1156,22 @@ namespace {
 // phase 1 of the W half-sweep: Gram / outer products of V and the streaming accumulation into c->part.
 // It depends on the data and on V only, so it can be queued ahead of the hyper-parameter draws
 // (btf_w_accum) and its partials also give the residual sum of squares (btf_draw_scalars, which & 4).
-int w_accum_phase(btf_ctx* c, int compat) {
+// the chunk range [c0, c1) of the rank's own block [lo, hi) of the reduction axis, if the chunking lines up with it
+struct SplitGeom { bool ok; int c0, c1; };
+SplitGeom split_geom(int lo, int hi, int Rdim, int rpb) {
+  SplitGeom g{false, 0, 0};
+  if (hi <= lo || hi - lo >= Rdim || rpb <= 0) return g;
+  if (lo % rpb != 0 || !(hi % rpb == 0 || hi == Rdim)) return g;
+  g.ok = true; g.c0 = lo / rpb; g.c1 = (hi + rpb - 1) / rpb;
+  return g;
+}
+bool split_applies(const btf_ctx* c) {
+  return c->split_accum && !c->binomial && !c->counts && !(c->nl == c->N && c->ml == c->M) && c->nl > 0 && c->ml > 0;
+}
+enum { ACC_ALL = 2, ACC_LOCAL = 0 };
+// part: ACC_ALL - whatever is still missing (every chunk, or the rest behind an ACC_LOCAL launch); ACC_LOCAL - only the
+// chunks of this rank's own columns of V, no side tasks (queued right behind the V draw, before the all-gather of V)
+int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL) {
   const int K = c->K, KK = c->KK, MT = c->M * c->T;
   const bool wt = lik_weighted(c), cv = c->weighted && !wt;
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_w && c->srcmap_w ? 2 : 1);
@@ -1139,6 +1181,21 @@ int w_accum_phase(btf_ctx* c, int compat) {
   const int nch = (MT + rpb - 1) / rpb;
   int rc;
   if ((rc = ensure_part(c, (size_t)nch * NV * c->ldw))) return rc;
+  const SplitGeom sg = split_applies(c) ? split_geom(c->col0 * c->T, (c->col0 + c->ml) * c->T, MT, rpb) : SplitGeom{false, 0, 0};
+  if (part == ACC_LOCAL) {
+    c->w_local_done = false;
+    if (!sg.ok || mode == 2) return BTF_OK;               // nothing queued ahead: the next call accumulates everything
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, rpb, sg.c1 - sg.c0,
+                                 EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
+                                 TauSide{}, GramSide{nullptr, 0, nullptr, 0}, ChunkMap{sg.c0, INT_MAX, 0}));
+    HIPCHK(c, hipGetLastError());
+    c->w_local_done = true; c->w_local_rpb = rpb; c->w_local_mode = mode;
+    return BTF_OK;
+  }
+  const bool rest_only = c->w_local_done && sg.ok && c->w_local_rpb == rpb && c->w_local_mode == mode;
+  c->w_local_done = false;
+  const ChunkMap cm = rest_only ? ChunkMap{0, sg.c0, sg.c1 - sg.c0} : ChunkMap{0, INT_MAX, 0};
+  const int nch_launch = rest_only ? nch - (sg.c1 - sg.c0) : nch;
   const bool whole = c->nl == c->N && c->ml == c->M;      // fused Grams cover all rows/columns only when unsharded
   bool use_gv = !wt && whole && c->fuse_gram && c->ngp_v > 0;
   if (cv && c->nl > 0) {                      // the per-column Grams V_j'V_j: from the sampler that drew V, or computed here
@@ -1160,8 +1217,8 @@ int w_accum_phase(btf_ctx* c, int compat) {
     }
     TauSide tau{};
     if (c->tau_pending && c->dev_scalars && c->have_chain) tau = tau_side_of(c, c->tau_seed, 1.0, c->tau_stability);
-    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, rpb, nch,
-                                 EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}, tau, gram));
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, rpb, nch_launch,
+                                 EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}, tau, gram, cm));
     c->tau_pending = false;
   } else if (c->tau_pending && c->dev_scalars && c->have_chain) {
     // a rank without rows (ceil chunks: N = 10 over 8 ranks leaves ranks 5-7 empty) has no accumulation launch to
@@ -1175,6 +1232,11 @@ int w_accum_phase(btf_ctx* c, int compat) {
   c->w_part_curve = cv;
   return BTF_OK;
 }
+}  // namespace
+
+namespace {
+int v_accum_local(btf_ctx* c, int compat);
+int mark_draw(btf_ctx* c);
 }  // namespace
 
 int btf_w_accum(btf_ctx* c, int compat) {
@@ -1192,6 +1254,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
   const bool wt = lik_weighted(c), cv = c->weighted && !wt;
   const int want_mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_w && c->srcmap_w ? 2 : 1);
   int rc;
+  c->v_local_done = false;                                 // W is about to change
   if (!(c->w_part_valid && c->w_part_mode == want_mode && c->w_part_curve == cv)) { if ((rc = w_accum_phase(c, compat))) return rc; }
   const int nch = c->w_part_nch;
   const bool use_gv = c->w_part_gv;
@@ -1229,6 +1292,10 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
   c->sweep_w++;
   c->nb_L_valid = false;
   HIPCHK(c, hipGetLastError());
+  if (split_applies(c)) {        // behind the W draw: mark it, then queue the own-rows chunks of the next V accumulation
+    if ((rc = mark_draw(c))) return rc;
+    return v_accum_local(c, compat);
+  }
   return BTF_OK;
 }
 
@@ -1313,11 +1380,51 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
   return BTF_OK;
 }
 
+namespace {
+// the own-rows chunks of the next V accumulation, queued right behind the W solve (before the all-gather of W)
+int v_accum_local(btf_ctx* c, int compat) {
+  c->v_local_done = false;
+  if (!split_applies(c)) return BTF_OK;
+  const int K = c->K, KK = c->KK;
+  const bool wt = lik_weighted(c);
+  const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_v && c->srcmap_v ? 2 : 1);
+  if (mode == 2) return BTF_OK;
+  const int NV = wt ? K + KK : K;
+  const int tiles = c->ldv / ACC_TILE;
+  const int rpb = pick_rpb(c->N, tiles, c->rpb_v, wt);
+  const int nch = (c->N + rpb - 1) / rpb;
+  const SplitGeom sg = split_geom(c->row0, c->row0 + c->nl, c->N, rpb);
+  if (!sg.ok) return BTF_OK;
+  int rc;
+  if ((rc = ensure_part(c, (size_t)nch * NV * c->ldv))) return rc;
+  K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb, sg.c1 - sg.c0,
+                               EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
+                               TauSide{}, GramSide{nullptr, 0, nullptr, 0}, ChunkMap{sg.c0, INT_MAX, 0}));
+  HIPCHK(c, hipGetLastError());
+  c->v_local_done = true; c->v_local_rpb = rpb; c->v_local_mode = mode;
+  return BTF_OK;
+}
+// the event the comm stream waits for: right behind the kernel that drew this rank's block
+int mark_draw(btf_ctx* c) {
+  if (!c->ev_draw) HIPCHK(c, hipEventCreateWithFlags(&c->ev_draw, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->ev_draw, c->stream));
+  return BTF_OK;
+}
+// behind the V draw: mark it, then queue the own-columns chunks of the next W accumulation
+int after_v_draw(btf_ctx* c, int compat) {
+  if (!split_applies(c)) return BTF_OK;
+  int rc;
+  if ((rc = mark_draw(c))) return rc;
+  return w_accum_phase(c, compat, ACC_LOCAL);
+}
+}  // namespace
+
 int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, double eps0, int attempts) {
   if (!c) return BTF_EINVAL;
   if (!c->have_data || !c->have_V || !c->have_W || !c->have_hyper) return fail(c, BTF_ESTATE, "set data, W, V and hyper-parameters first");
   if (attempts < 0) attempts = 0;
   HIPCHK(c, hipSetDevice(c->dev));
+  c->w_local_done = false;                                 // V is about to change
   const int K = c->K, KK = c->KK, T = c->T, n = T * K;
   const bool wt = lik_weighted(c), cv = c->weighted && !wt;
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_v && c->srcmap_v ? 2 : 1);
@@ -1356,7 +1463,14 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     EigSideCols sidec{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr};
     const bool cols_aside = choice == 3 && cv;
     if (cols_aside) sidec = EigSideCols{c->cv_dcols, c->cv_ndef, CurveLists{c->cv_cptr, c->cv_crow, c->cv_cdef}, c->W, 1.0 / c->R, c->eig_cols};
-    K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb, nch, side, sidec));
+    {
+      const SplitGeom sg = split_applies(c) ? split_geom(c->row0, c->row0 + c->nl, c->N, rpb) : SplitGeom{false, 0, 0};
+      const bool rest_only = c->v_local_done && sg.ok && c->v_local_rpb == rpb && c->v_local_mode == mode;
+      c->v_local_done = false;
+      const ChunkMap cm = rest_only ? ChunkMap{0, sg.c0, sg.c1 - sg.c0} : ChunkMap{0, INT_MAX, 0};
+      K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb,
+                                   rest_only ? nch - (sg.c1 - sg.c0) : nch, side, sidec, TauSide{}, GramSide{nullptr, 0, nullptr, 0}, cm));
+    }
     hipError_t e = hipSuccess;
     if (choice == 3) {
       // spectral sampler (complete data): K scalar banded systems per column in the eigen-basis of the Gram
@@ -1395,15 +1509,16 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       c->nb_L_valid = false;
       c->w_part_valid = false;
       HIPCHK(c, hipGetLastError());
-      return BTF_OK;
+      return after_v_draw(c, compat);
     }
     if ((rc = v_banded_dispatch(c, choice, dz, seed, nch, use_gw, eps0, attempts, c->V, false))) return rc;
   }
+  c->v_local_done = false;
   c->sweep_v++;
   c->nb_L_valid = false;
   c->w_part_valid = false;
   HIPCHK(c, hipGetLastError());
-  return BTF_OK;
+  return after_v_draw(c, compat);
 }
 
 // ------------------------------------------------------------------ elliptical slice sampling
@@ -1518,6 +1633,7 @@ int btf_ess_eval(btf_ctx* c, int what, double theta, int current, int link, doub
     Prof p(c, BTF_K_ESS);
     p.launch(ess_combine_kernel, dim3((unsigned)((d.n + 255) / 256)), dim3(256), 0, (const double*)c->essX0, (const double*)c->essNu,
              what == 0 ? c->W : c->V, d.n, 0, (const double*)c->ess_theta, (const int*)c->ess_done, 0);
+    c->w_local_done = c->v_local_done = false;
     if (what == 0) { c->ngp_w = 0; c->w_part_valid = false; } else { c->ngp_v = 0; c->w_part_valid = false; }
     c->nb_L_valid = false;
   }
@@ -1568,7 +1684,7 @@ int btf_ess_run(btf_ctx* c, int what, int link, int mode, const double* z, uint6
   HIPCHK(c, hipGetLastError());
   c->ess_last_chains = d.nchains;
   if (what == 0) c->ngp_w = 0; else c->ngp_v = 0;
-  c->w_part_valid = false;
+  c->w_part_valid = false; c->w_local_done = c->v_local_done = false;
   c->nb_L_valid = false;
   return BTF_OK;
 }
@@ -1759,7 +1875,7 @@ int btf_gass_commit(btf_ctx* c, int what, const double* theta, const int32_t* ke
   }
   HIPCHK(c, hipGetLastError());
   if (what == 0) c->ngp_w = 0; else c->ngp_v = 0;
-  c->w_part_valid = false; c->nb_L_valid = false;
+  c->w_part_valid = false; c->w_local_done = c->v_local_done = false; c->nb_L_valid = false;
   return BTF_OK;
 }
 
@@ -1776,7 +1892,7 @@ int btf_gass_select(btf_ctx* c, int what, uint64_t seed, int32_t* naccept_out) {
   }
   HIPCHK(c, hipGetLastError());
   if (what == 0) c->ngp_w = 0; else c->ngp_v = 0;
-  c->w_part_valid = false; c->nb_L_valid = false;
+  c->w_part_valid = false; c->w_local_done = c->v_local_done = false; c->nb_L_valid = false;
   if (naccept_out) {
     HIPCHK(c, hipMemcpyAsync(naccept_out, c->gs_nacc, (size_t)nch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     return check_status(c);
@@ -2092,7 +2208,7 @@ int btf_nb_loglik(btf_ctx* c, const double* R, const double* cand, const int32_t
 
 int btf_nb_set_rate(btf_ctx* c, const double* R, const int32_t* shared) {
   if (!c || !R || !shared) return BTF_EINVAL;
-  c->w_part_valid = false;
+  c->w_part_valid = false; c->w_local_done = c->v_local_done = false;
   if (!c->counts) return fail(c, BTF_ESTATE, "btf_nb_set_rate follows btf_set_data_counts");
   HIPCHK(c, hipSetDevice(c->dev));
   int rc;
@@ -2435,7 +2551,7 @@ int btf_sse(btf_ctx* c, double* sse, double* nobs) {
 
 int btf_pg_draw(btf_ctx* c, uint64_t seed) {
   if (!c) return BTF_EINVAL;
-  c->w_part_valid = false;          // the weights change
+  c->w_part_valid = false; c->w_local_done = c->v_local_done = false;          // the weights change
   if (!c->have_data || !c->binomial || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_pg_draw needs binomial data, W and V");
   HIPCHK(c, hipSetDevice(c->dev));
   const unsigned long long MT = (unsigned long long)c->M * c->T;
@@ -2793,10 +2909,14 @@ int btf_set_option(btf_ctx* c, int option, int value) {
       c->fuse_gram = value != 0;
       c->ngp_v = c->ngp_w = 0;
       return BTF_OK;
+    case BTF_OPT_SPLIT_ACCUM:
+      c->split_accum = value != 0;
+      c->w_local_done = c->v_local_done = false;
+      return BTF_OK;
     case BTF_OPT_CURVE_COUNTS:
       c->curve_opt = value != 0;
       c->ngp_v = c->ngp_w = 0;
-      c->w_part_valid = false;
+      c->w_part_valid = false; c->w_local_done = c->v_local_done = false;
       return BTF_OK;
     default:
       return fail(c, BTF_EINVAL, "unknown option");
@@ -2826,6 +2946,25 @@ int btf_set_draw_counters(btf_ctx* c, uint64_t w, uint64_t v) {
   const size_t rec = (size_t)c->K + (size_t)c->K * c->K + 8;
   if (c->eig) HIPCHK(c, hipMemsetAsync(c->eig, 0, rec * sizeof(double), c->stream));
   if (c->eig_cols) HIPCHK(c, hipMemsetAsync(c->eig_cols, 0, (size_t)c->M * rec * sizeof(double), c->stream));
+  return BTF_OK;
+}
+
+int btf_comm_fork(btf_ctx* c, void* comm_stream) {
+  if (!c || !comm_stream) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  int rc;
+  // sharded runs with BTF_OPT_SPLIT_ACCUM leave the event behind the draw kernel (work queued after it must not hold
+  // the exchange back); otherwise: everything queued so far
+  if (!(c->ev_draw && split_applies(c))) { if ((rc = mark_draw(c))) return rc; }
+  HIPCHK(c, hipStreamWaitEvent((hipStream_t)comm_stream, c->ev_draw, 0));
+  return BTF_OK;
+}
+int btf_comm_join(btf_ctx* c, void* comm_stream) {
+  if (!c || !comm_stream) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (!c->ev_join) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->ev_join, (hipStream_t)comm_stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
   return BTF_OK;
 }
 

@@ -186,6 +186,12 @@ constexpr int TAU_SIDE_CPW = 2;
 // solve kernel FOLLOWS: nblocks partial Grams of U's rows, one per side workgroup, consumed across the kernel boundary
 struct GramSide { const double* U; int Rdim; double* gpart; int nblocks; };
 
+// which chunks of the reduction axis a launch covers: its streaming workgroups are numbered over `count` logical
+// chunks, chunk c = base + (logical index) and a hole of `skip_n` chunks opens at `skip_at` (sharded runs: the chunks of
+// the rank's OWN block of the fixed factor are accumulated first - that block needs no exchange - and the rest in a
+// second launch behind the all-gather; both write their own slots of the partials).  {0, INT_MAX, 0}: every chunk.
+struct ChunkMap { int base, skip_at, skip_n; };
+
 // MODE 0: X only (complete data)
 // MODE 1: X, C and the outer products UU
 // MODE 2: as 1, but the precision weight of output l is read from output srcmap[l] of the
@@ -228,7 +234,7 @@ template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double,
 __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void accum_kernel(
     const XT* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
-    int rows_per_block, EigSide side, EigSideCols sidec, TauSide tau, GramSide gram) {
+    int rows_per_block, EigSide side, EigSideCols sidec, TauSide tau, GramSide gram, ChunkMap cm) {
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
@@ -326,7 +332,8 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
     b -= gram.nblocks;
   }
   const int ntiles = ld / ACC_TILE;
-  const int chunk = b / ntiles, tile = b - chunk * ntiles;
+  const int lchunk = b / ntiles, tile = b - lchunk * ntiles;
+  const int chunk = cm.base + lchunk + (cm.base + lchunk >= cm.skip_at ? cm.skip_n : 0);
   // OPL == 2: every wave covers the tile's 128 columns (two per lane) and takes every WAVES-th row.
   // OPL == 1: wave w covers the half (w & 1) of the tile, one column per lane, and takes every (WAVES/2)-th row.
   static_assert(OPL == 2 || (OPL == 1 && WAVES % 2 == 0), "outputs per lane");

@@ -93,7 +93,7 @@ class BayesianTensorFiltering(_BayesianModel):
                  force_psd_eps=1e-6,
                  force_psd_attempts=4,
                  compat="reference", rng="host", device=0, stream=None, shard=None, device_seed=0,
-                 sampler="auto",
+                 sampler="auto", overlap_exchange=True,
                  **kwargs):
         super().__init__(**kwargs)
         if compat not in _native.COMPAT:
@@ -111,16 +111,20 @@ class BayesianTensorFiltering(_BayesianModel):
         self._device_seed = int(device_seed)
         self._draws = 0
 
-        # Sharded runs exchange W / V through torch.distributed on the ctx's own stream (parallel.Exchange wraps it
-        # in a torch.cuda.ExternalStream and issues the collectives under it): the all-gather is ordered after
-        # the draw and the next half-sweep after the all-gather without touching torch's current stream.
+        # Sharded runs exchange W / V through torch.distributed (parallel.Exchange).  overlap_exchange (default): the
+        # all-gather of the freshly drawn block runs on a communication stream ordered behind the draw kernel
+        # (btf_comm_fork), while the ctx's stream already accumulates the chunks of the next half-sweep that reduce over
+        # this rank's own block (BTF_OPT_SPLIT_ACCUM); the rest of that accumulation waits for the gather (btf_comm_join).
+        # False: the collectives are issued under the ctx's own stream, one after the other (round 2).
         import os
         # device context first: without the HIP library / a GPU nothing below can run
         self._ctx = _native.Context(nrows, ncols, ndepth, nembeds, tf_order, device=device, stream=stream)
         self._plan = ShardPlan(nrows, ncols, *(shard if shard is not None else (0, 1)))
-        self._exchange = Exchange(self._plan, self._ctx)
+        self._exchange = Exchange(self._plan, self._ctx, overlap=bool(overlap_exchange))
         if self._plan.world > 1:
             self._ctx.call("btf_set_shard", *self._plan.mine())
+        if self._exchange.active and self._exchange.overlap:
+            self._ctx.call("btf_set_option", _native.OPT_SPLIT_ACCUM, 1)
         self.sampler = sampler
         self._ctx.call("btf_set_option", _native.OPT_SAMPLER,
                        _native.SAMPLERS[("spectral" if rng == "device" else "banded") if sampler == "auto" else sampler])

@@ -65,10 +65,11 @@ class _DevView:
 class Exchange:
     """The per-half-sweep exchange.  world == 1: no-ops."""
 
-    def __init__(self, plan, ctx=None, group=None):
+    def __init__(self, plan, ctx=None, group=None, overlap=True):
         self.plan, self.ctx, self.group = plan, ctx, group
+        self.overlap = overlap          # all-gathers on a communication stream of their own (see _gather_stream)
         self._Wt = self._Vt = None
-        self._tstream = None
+        self._tstream = self._cstream = None
         self.timing, self._events = False, {"all_gather_W": [], "all_gather_V": [], "all_reduce_sse": []}
         # BTF_EXERCISE_EXCHANGE=1: issue the collectives even in a 1-rank group (lets a 1-GPU box
         # run the exact RCCL call sequence of the sharded path)
@@ -90,9 +91,28 @@ class Exchange:
             self._tstream = torch.cuda.ExternalStream(self.ctx.stream_handle, device=torch.device("cuda", self.ctx.device))
         return self._tstream
 
-    def _timed(self, name, fn):
+    def _comm(self):
+        """The communication stream of the overlapped exchange: ordered behind the kernel that drew this rank's block
+        (btf_comm_fork) - NOT behind the own-block chunks of the next accumulation the ctx queues after it - and
+        joined back into the ctx's stream when the gather has been issued (btf_comm_join)."""
         import torch
-        with torch.cuda.stream(self._stream()):
+        if self._cstream is None:
+            self._cstream = torch.cuda.Stream(device=torch.device("cuda", self.ctx.device))
+        return self._cstream
+
+    def _gather(self, name, fn):
+        """One all-gather of the freshly drawn block: overlapped (own stream, fork / join against the ctx's) or in line."""
+        if not self.overlap:
+            return self._timed(name, fn)
+        import ctypes as C
+        comm = self._comm()
+        self.ctx.call("btf_comm_fork", C.c_void_p(comm.cuda_stream))
+        self._timed(name, fn, stream=comm)
+        self.ctx.call("btf_comm_join", C.c_void_p(comm.cuda_stream))
+
+    def _timed(self, name, fn, stream=None):
+        import torch
+        with torch.cuda.stream(stream if stream is not None else self._stream()):
             if self.timing:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -144,24 +164,24 @@ class Exchange:
             return
         if self._staged():
             N, M, T, K, _ = self.ctx.dims
-            return self._staged_gather("btf_get_W", "btf_set_W", (N, K), self.plan.row0, self.plan.nl, self.gather_rows_host)
+            return self._staged_gather("btf_get_W", "btf_set_gathered_W", (N, K), self.plan.row0, self.plan.nl, self.gather_rows_host)
         import torch.distributed as dist
         Wt, _ = self._views()
         K = self.ctx.dims[3]
         n = self.plan.row_chunk * K
-        self._timed("all_gather_W", lambda: dist.all_gather_into_tensor(Wt, Wt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group))
+        self._gather("all_gather_W", lambda: dist.all_gather_into_tensor(Wt, Wt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group))
 
     def after_V(self):
         if not self.active:
             return
         if self._staged():
             N, M, T, K, _ = self.ctx.dims
-            return self._staged_gather("btf_get_V", "btf_set_V", (M, T, K), self.plan.col0, self.plan.ml, self.gather_cols_host)
+            return self._staged_gather("btf_get_V", "btf_set_gathered_V", (M, T, K), self.plan.col0, self.plan.ml, self.gather_cols_host)
         import torch.distributed as dist
         _, Vt = self._views()
         _, _, T, K, _ = self.ctx.dims
         n = self.plan.col_chunk * T * K
-        self._timed("all_gather_V", lambda: dist.all_gather_into_tensor(Vt, Vt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group))
+        self._gather("all_gather_V", lambda: dist.all_gather_into_tensor(Vt, Vt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group))
 
     def all_reduce_sse(self):
         """Sum the rank-local residual sum of squares (device scalar slot 4, btf_dev_hyp) over the ranks, in place,

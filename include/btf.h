@@ -77,6 +77,12 @@ enum {
                                 (whole curves missing, as Y[:3,:3] = NaN in the reference's examples) run the
                                 complete-data kernels plus per-row / per-column corrections (same conditionals as the
                                 weighted form of factor.py:343-346, :388-391); 0: always the weighted form         */
+  BTF_OPT_SPLIT_ACCUM = 5,   /* sharded Gaussian contexts: 1 - the streaming accumulation of a half-sweep runs in two launches: the
+                                chunks that reduce over this rank's OWN block of the fixed factor (its columns of V for the W
+                                half-sweep, its rows of W for the V half-sweep) are queued right behind the kernel that drew
+                                that block - they need no exchange - and the remaining chunks by the next half-sweep call, behind
+                                the all-gather (btf_comm_fork / btf_comm_join order a communication stream against them).
+                                Same partial sums, same results.  0 (default): one launch.                              */
   BTF_OPT_PG_EXACT = 3       /* Polya-Gamma sampler of btf_pg_draw (what pypolyagamma's pgdrawv does at factor.py:459).
                                 0 (default): every integer trial count up to 32 by Devroye's exact alternating-series
                                 sampler, summed b times, as pypolyagamma does (flat per-lane work-queue kernels: f32
@@ -119,6 +125,16 @@ int btf_set_shard(btf_ctx* ctx, int row0, int nrows_local, int col0, int ncols_l
 void* btf_stream(btf_ctx* ctx); /* the hipStream_t every step function of this ctx enqueues on (the one passed
                                   to btf_create, or the private one): collectives on the ctx's buffers and event
                                   timing must be ordered against it */
+/* Ordering a communication stream (the one the all-gathers of W / V are issued on) against the ctx's stream:
+ * btf_comm_fork makes `comm_stream` wait for the kernel that drew this rank's block in the last half-sweep (not for work
+ * queued behind it: BTF_OPT_SPLIT_ACCUM); btf_comm_join makes the ctx's stream wait for everything queued on
+ * `comm_stream` so far.  hipStream_t handles; no host synchronisation. */
+int btf_comm_fork(btf_ctx* ctx, void* comm_stream);
+int btf_comm_join(btf_ctx* ctx, void* comm_stream);
+/* btf_set_W / btf_set_V for an exchange staged through the host: the caller's own block is unchanged, so chunks already
+ * accumulated from it (BTF_OPT_SPLIT_ACCUM) stay valid. */
+int btf_set_gathered_W(btf_ctx* ctx, const double* W);
+int btf_set_gathered_V(btf_ctx* ctx, const double* V);
 void* btf_dev_W(btf_ctx* ctx); /* device double[N][K]    */
 void* btf_dev_V(btf_ctx* ctx); /* device double[M][T][K] */
 

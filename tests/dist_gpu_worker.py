@@ -20,6 +20,75 @@ from oracle import btf_oracle as orc  # noqa: E402
 from functionalmf_amd.factor import GaussianBayesianTensorFiltering  # noqa: E402
 
 
+def split_section(rank, world):
+    """The overlapped exchange (BTF_OPT_SPLIT_ACCUM) on shapes whose chunking lines up with the shards: each half-sweep's
+    accumulation runs as two launches - the chunks of this rank's own block queued behind the previous draw, the rest
+    (a chunk map with a hole at the start, in the middle or at the end, by rank) behind the gather - and must give the
+    unsharded oracle's W and V; complete data and data with missing replicates (weighted accumulation), host normals;
+    then whole rng="device" sweeps against the plain one-launch path."""
+    from functionalmf_amd import _native
+    N, M, T, R, K = 192 * world, 8 * world, 64, 2, 3
+    rs = np.random.RandomState(11)
+    Wt = rs.normal(size=(N, K))
+    Wt[np.triu_indices(K, 1)] = 0
+    Vt = 0.1 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    Yc = np.einsum("nk,mtk->nmt", Wt, Vt)[..., None] + rs.normal(0, 0.5, size=(N, M, T, R))
+    Ym = Yc.copy()
+    Ym[rs.rand(N, M, T, R) < 0.1] = np.nan
+    Delta = orc.trend_penalty(T, 2)
+    st0 = dict(W=Wt + 0.1 * rs.normal(size=Wt.shape), V=Vt + 0.05 * rs.normal(size=Vt.shape), Tau2=rs.gamma(2.0, 0.5, size=(M, Delta.shape[0])),
+               lam2=0.2, sigma2=0.6, nu2=0.4)
+    st0["W"][np.triu_indices(K, 1)] = 0
+    for Y, form in ((Yc, "complete"), (Ym, "weighted")):
+        model = GaussianBayesianTensorFiltering(
+            N, M, T, nembeds=K, tf_order=2, sigma2_init=st0["sigma2"], lam2_init=st0["lam2"], nu2_init=st0["nu2"],
+            W_init=st0["W"], V_init=st0["V"], Tau2_init=st0["Tau2"], compat="exact", shard=(rank, world), device=0, sampler="banded")
+        model._ctx.call("btf_set_tuning", 64, 64)          # 64-row chunks: every shard is a whole number of them
+        ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st0.items()}
+        model._ctx.kernel_times()
+        for it in range(3):
+            np.random.seed(60 + it)
+            model._resample_W(Y)
+            model._resample_V(Y)
+            np.random.seed(60 + it)
+            orc.w_step(ost, Y)
+            orc.v_step(ost, Y, Delta, compat="exact", perm=orc.perm_from_order(model.v_order(), K, T))
+            ew = np.abs(model.W - ost["W"]).max() / np.abs(ost["W"]).max()
+            ev = np.abs(model.V - ost["V"]).max() / np.abs(ost["V"]).max()
+            assert ew < 1e-10 and ev < 1e-6, (form, it, ew, ev)
+            model.W, model.V = ost["W"], ost["V"]
+        assert model.likelihood_form() == form
+        # (the host pushes of W / V above drop what was queued ahead: the first accumulation of a pair runs whole.  Now
+        #  leave the state on the device: from the second half-sweep on every accumulation must be two launches)
+        model._ctx.kernel_times()
+        for it in range(2):
+            np.random.seed(70 + it)
+            model._resample_W(Y)
+            model._resample_V(Y)
+            np.random.seed(70 + it)
+            orc.w_step(ost, Y)
+            orc.v_step(ost, Y, Delta, compat="exact", perm=orc.perm_from_order(model.v_order(), K, T))
+        kt = model._ctx.kernel_times()
+        assert kt["w_accum"][1] == 4 and kt["v_accum"][1] == 4, kt       # W: whole + ahead, rest + ahead; V: ahead + rest, twice
+        ew = np.abs(model.W - ost["W"]).max() / np.abs(ost["W"]).max()
+        ev = np.abs(model.V - ost["V"]).max() / np.abs(ost["V"]).max()
+        assert ew < 1e-9 and ev < 1e-5, (form, ew, ev)
+        del model
+    chains = []
+    for overlap in (True, False):
+        np.random.seed(7)
+        m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=st0["sigma2"], lam2_init=st0["lam2"],
+                                            nu2_init=st0["nu2"], W_init=st0["W"], V_init=st0["V"], compat="exact", shard=(rank, world),
+                                            device=0, rng="device", device_seed=9, overlap_exchange=overlap)
+        m._ctx.call("btf_set_tuning", 64, 64)
+        for _ in range(4):
+            m.resample(Yc)
+        chains.append((m.W.copy(), m.V.copy(), float(m.nu2), float(m.sigma2), float(m.lam2)))
+        del m
+    a, b = chains
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:], "overlapped chain differs from the in-line one"
+
+
 def main():
     backend = os.environ.get("BTF_DIST_BACKEND", "gloo")
     exercise = os.environ.get("BTF_EXERCISE_EXCHANGE", "0")
@@ -30,6 +99,14 @@ def main():
     else:
         dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    sections = os.environ.get("BTF_DIST_SECTION", "base,split").split(",")
+    if "split" in sections and world > 1:
+        split_section(rank, world)
+    if "base" not in sections:
+        print("SHARD_GPU_OK rank", rank, flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     for name in ("g2_c2_complete.npz", "g1_c1_heldout.npz"):
         g = load_golden(name)
         N, M, T, R, K, tf = [int(x) for x in g["dims"]]

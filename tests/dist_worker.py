@@ -34,6 +34,20 @@ def main():
     orc.w_step(ref, Y, z=g["z_W"])
     assert W.shape == ref["W"].shape and np.array_equal(W, ref["W"]), np.abs(W - ref["W"]).max()
 
+    # ---- the overlapped exchange (BTF_OPT_SPLIT_ACCUM): the W half-sweep's sums over (j, t) split into the chunk of this
+    # rank's OWN columns of V - known before the all-gather of V - and the rest; the two parts add up to the whole
+    cnt_r, yb_r = orc.replicate_stats(rows)                        # (nl, M, T)
+    c = np.where(cnt_r > 0, cnt_r, 0.0)
+    s1 = np.where(cnt_r > 0, cnt_r * np.nan_to_num(yb_r), 0.0)
+    own = slice(plan.col0, plan.col0 + plan.ml)
+    rest = np.r_[0:plan.col0, plan.col0 + plan.ml:M]
+    Vst = state_from(g, "s0_")["V"]
+    m_all = np.einsum("nmt,mtk->nk", s1, Vst)
+    q_all = np.einsum("nmt,mtk,mtl->nkl", c, Vst, Vst)
+    m_two = np.einsum("nmt,mtk->nk", s1[:, own], Vst[own]) + np.einsum("nmt,mtk->nk", s1[:, rest], Vst[rest])
+    q_two = np.einsum("nmt,mtk,mtl->nkl", c[:, own], Vst[own], Vst[own]) + np.einsum("nmt,mtk,mtl->nkl", c[:, rest], Vst[rest], Vst[rest])
+    assert np.abs(m_two - m_all).max() <= 1e-12 * np.abs(m_all).max() and np.abs(q_two - q_all).max() <= 1e-12 * np.abs(q_all).max()
+
     # ---- V half-sweep: my columns only (exact mode: no stale source outside the shard)
     st["W"] = W
     full = dict(st, V=st["V"].copy())

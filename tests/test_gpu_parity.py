@@ -716,6 +716,24 @@ def test_two_ranks_share_one_gpu():
 
 
 @pytest.mark.timeout(400)
+def test_three_ranks_overlapped_exchange_split_accumulation():
+    """BTF_OPT_SPLIT_ACCUM on hardware with three ranks on cuda:0 (gloo control plane, exchange staged through the host):
+    rank 0's own block opens the chunk range, rank 1's sits in the middle (a chunk map with a hole), rank 2's closes it.
+    Every accumulation after the first runs as two launches and the half-sweeps equal the unsharded oracle; whole
+    rng="device" sweeps equal the one-launch path bit for bit (tests/dist_gpu_worker.py: split_section)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, BTF_DIST_SECTION="split")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+           "--master-addr", "127.0.0.1", "--master-port", "29585", os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=380)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("SHARD_GPU_OK") == 3, out.stdout[-2000:]
+
+
+@pytest.mark.timeout(400)
 def test_rccl_exchange_with_one_rank_reproduces_the_plain_chain():
     """The DEVICE collective path of sharded runs (functionalmf_amd/parallel.py: all_gather_into_tensor on the
     context's own W / V buffers and the 8-byte all-reduce of the residual sum of squares, issued under
