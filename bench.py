@@ -101,6 +101,11 @@ def parse_args(argv=None):
                     "(the default already draws integer counts up to 32 exactly)")
     ap.add_argument("--pg-series", action="store_true", help="binomial / negbinom: the approximate sum-of-gammas series for every count")
     ap.add_argument("--burn", type=int, default=10, help="full Gibbs sweeps before timing (leave the initial state)")
+    ap.add_argument("--as-rank", default=None, metavar="R/P", help="ONE GPU plays rank R of a P-GPU run of --config (default c5): its "
+                    "kernels on that rank's real slabs, every collective of the sharded step in a one-rank RCCL group at the full "
+                    "message size; adds a `projected` block (never `value`: that stays this GPU's own rate)")
+    ap.add_argument("--overlap", action="store_true", help="sharded runs: all-gathers on a communication stream, own-block chunks of the "
+                    "next accumulation ahead of them (BTF_OPT_SPLIT_ACCUM); default: collectives in line on the ctx's stream")
     ap.add_argument("--master-port", type=int, default=29533)
     return ap.parse_args(argv)
 
@@ -133,6 +138,13 @@ def main():
         local_rank = int(os.environ["BTF_FORCE_DEVICE"])
     args.gpus = world
     dry = os.environ.get("BTF_BENCH_DRY", "0") == "1"       # CPU rehearsal of the launch / timing / reporting plumbing
+    as_rank = None
+    if args.as_rank:
+        if world != 1:
+            sys.exit("--as-rank is a one-GPU rehearsal")
+        as_rank = tuple(int(x) for x in args.as_rank.split("/"))
+        if args.config is None:
+            args.config = "c5"
     if args.config is None:
         args.config = "c3" if (world == 1 or args.weak) else "c5"
     if args.steps is None:
@@ -140,7 +152,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    exercise = os.environ.get("BTF_EXERCISE_EXCHANGE", "0") == "1"
+    exercise = os.environ.get("BTF_EXERCISE_EXCHANGE", "0") == "1" or as_rank is not None
     backend = None
     if not dry:
         torch.cuda.set_device(local_rank)
@@ -168,8 +180,8 @@ def main():
 
     # ---- synthetic data: only this rank's two slabs are ever materialised -------------
     Vt = synth_V(1, M, T, K)
-    plan = ShardPlan(N, M, rank, world)
-    if world == 1:
+    plan = ShardPlan(N, M, *(as_rank if as_rank else (rank, world)))
+    if world == 1 and not as_rank:
         Y, _ = synth_rows(1, range(N), M, T, R, K, Vt)
         slabs = None
     else:
@@ -200,8 +212,9 @@ def main():
     np.random.seed(1)
     stream = torch.cuda.current_stream().cuda_stream or None     # null stream -> the ctx's own / a dedicated torch stream
     common = dict(nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, rng="device",
-                  compat="reference" if world == 1 else "exact", device=local_rank, stream=stream,
-                  shard=(rank, world) if world > 1 else None, device_seed=1, sampler=args.sampler)
+                  compat="reference" if (world == 1 and not as_rank) else "exact", device=local_rank, stream=stream,
+                  shard=as_rank if as_rank else ((rank, world) if world > 1 else None), device_seed=1, sampler=args.sampler,
+                  overlap_exchange=args.overlap, rehearse_rank=as_rank is not None)
     if args.variant == "binomial":
         model = BinomialBayesianTensorFiltering(N, M, T, pg_exact=(True if args.pg_exact else False if args.pg_series else None), **common)
     elif args.variant == "negbinom":
@@ -210,7 +223,7 @@ def main():
         model = GaussianBayesianTensorFiltering(N, M, T, nu2_init=1.0, **common)
     if args.rpb != [0, 0]:
         model._ctx.call("btf_set_tuning", args.rpb[0], args.rpb[1])
-    if world == 1:
+    if world == 1 and not as_rank:
         data = Y
     else:
         data = _SlabData(slabs, (N, M, T, R))
@@ -313,8 +326,8 @@ def main():
     # algorithmic bytes: the local slab of the linear statistic once per accumulation launch
     # (8 B/cell complete data; + a byte of replicate count with missing data; Binomial: f64 weights + the pseudo-data
     #  as one byte when the counts are integers, else as f64) - asked of the context, which knows what it streams
-    cells_local = (N // world if world > 1 else N) * M * T
-    cells_local_v = N * (M // world if world > 1 else M) * T
+    cells_local = plan.nl * M * T
+    cells_local_v = N * plan.ml * T
     form = model.likelihood_form()     # "curve_counts": held-out whole curves run the complete-data stream (no counts read)
     import ctypes as _C
     _b = _C.c_double()
@@ -370,13 +383,30 @@ def main():
     if world > 1 or exercise:
         out["config"].update({"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
                               "collective_us": coll})
+    if as_rank:
+        # What ONE rank of a P-GPU run does per step, measured on one GPU: its kernels on its real slabs and the RCCL call
+        # sequence (one-rank group: launch + local copy of the full message, no wire time).  The projection adds nothing for
+        # the wire (4.2 MB of V per step over 7 xGMI links of ~153 GB/s: a few us, overlapped with the own-block chunks)
+        # and assumes the ranks stay in step.  A rehearsal, not a measurement of P GPUs.
+        ref = same_config_one_gpu(args.config, "complete")
+        step_us = 1e3 * ms_step
+        out["config"]["workload"] += "; REHEARSAL of rank %d of %d on one GPU (row slab %d x %d, column slab %d x %d)" % (
+            as_rank[0], as_rank[1], plan.nl, M, N, plan.ml)
+        out["projected"] = {"what": "rank %d of %d: W+V step with both all-gathers (one-rank RCCL group, full message sizes)" % as_rank,
+                            "ranks": as_rank[1], "per_rank_step_us": round(step_us, 1),
+                            "projected_sweeps_per_s": round(1e6 / step_us, 1),
+                            "exchange": "overlapped (own-block chunks ahead of the all-gather)" if args.overlap else "in line",
+                            "collective_us": coll,
+                            "one_gpu_same_workload": ref,
+                            "projected_speedup_vs_one_gpu": round((1e6 / step_us) / ref["value"], 2) if ref else None,
+                            "not_measured": "wire time and skew between %d real ranks" % as_rank[1]}
     if world > 1:
         # the one-GPU figure of THIS workload (a `--gpus 1` run reports the headline C3 instead): strong scaling - the
         # whole fixed tensor on one GPU; weak - one rank's slab.  From the committed profile of that run, with its file.
         ref = same_config_one_gpu(args.config, "complete")      # (weak: args.config names one rank's slab)
         if ref is not None:
             out["config"]["one_gpu_same_workload"] = ref
-    if world == 1 and not args.no_cpu and args.variant not in ("binomial", "negbinom"):
+    if world == 1 and not as_rank and not args.no_cpu and args.variant not in ("binomial", "negbinom"):
         out["cpu_baseline"] = cpu_baseline(Y, model, cfg)
 
     if rank == 0:

@@ -304,8 +304,9 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
                   const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr},
                   EigSideCols sidec = EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
                   TauSide tau = TauSide{}, GramSide gram = GramSide{nullptr, 0, nullptr, 0},
-                  ChunkMap cm = ChunkMap{0, INT_MAX, 0}) {
+                  ChunkMap cm = ChunkMap{0, 0, INT_MAX, 0, 0}) {
   // nch: the chunks THIS launch covers (all of them unless cm says otherwise)
+  if (cm.row_end == 0) cm.row_end = Rdim;
   Prof p(c, kid);
   const int cpw = TAU_SIDE_CPW;
   dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 + eig_side_groups(sidec.ncols, acc_waves(K, mode)) : 0) +
@@ -1156,13 +1157,19 @@ namespace {
 // phase 1 of the W half-sweep: Gram / outer products of V and the streaming accumulation into c->part.
 // It depends on the data and on V only, so it can be queued ahead of the hyper-parameter draws
 // (btf_w_accum) and its partials also give the residual sum of squares (btf_draw_scalars, which & 4).
-// the chunk range [c0, c1) of the rank's own block [lo, hi) of the reduction axis, if the chunking lines up with it
-struct SplitGeom { bool ok; int c0, c1; };
-SplitGeom split_geom(int lo, int hi, int Rdim, int rpb) {
-  SplitGeom g{false, 0, 0};
-  if (hi <= lo || hi - lo >= Rdim || rpb <= 0) return g;
-  if (lo % rpb != 0 || !(hi % rpb == 0 || hi == Rdim)) return g;
-  g.ok = true; g.c0 = lo / rpb; g.c1 = (hi + rpb - 1) / rpb;
+// Split of an accumulation over the rank's own block [lo, hi) of the reduction axis: the REST launch covers the other
+// rows in chunks of rpb (slots 0 .. nch_r - 1; needs lo % rpb == 0 so that no chunk straddles the hole), the LOCAL launch
+// the own rows in chunks of rpb_l - sized to spread that eighth of the work over the whole chip, not over an eighth of
+// the workgroups - with slots nch_r .. nch_r + nch_l - 1.
+struct SplitGeom { bool ok; int lo, hi, rpb_l, nch_l, nch_r; };
+SplitGeom split_geom(int lo, int hi, int Rdim, int rpb, int tiles) {
+  SplitGeom g{false, lo, hi, 0, 0, 0};
+  if (hi <= lo || hi - lo >= Rdim || rpb <= 0 || lo % rpb != 0) return g;
+  g.ok = true;
+  g.nch_r = (Rdim - (hi - lo) + rpb - 1) / rpb;
+  long long rl = ((long long)(hi - lo) * tiles + 255) / 256;
+  g.rpb_l = std::min(rpb, std::max(64, round_up((int)rl, 64)));
+  g.nch_l = (hi - lo + g.rpb_l - 1) / g.rpb_l;
   return g;
 }
 bool split_applies(const btf_ctx* c) {
@@ -1181,21 +1188,23 @@ int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL) {
   const int nch = (MT + rpb - 1) / rpb;
   int rc;
   if ((rc = ensure_part(c, (size_t)nch * NV * c->ldw))) return rc;
-  const SplitGeom sg = split_applies(c) ? split_geom(c->col0 * c->T, (c->col0 + c->ml) * c->T, MT, rpb) : SplitGeom{false, 0, 0};
+  const SplitGeom sg = split_applies(c) ? split_geom(c->col0 * c->T, (c->col0 + c->ml) * c->T, MT, rpb, tiles) : SplitGeom{};
+  if (sg.ok) { if ((rc = ensure_part(c, (size_t)(sg.nch_r + sg.nch_l) * NV * c->ldw))) return rc; }
   if (part == ACC_LOCAL) {
     c->w_local_done = false;
     if (!sg.ok || mode == 2) return BTF_OK;               // nothing queued ahead: the next call accumulates everything
-    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, rpb, sg.c1 - sg.c0,
+    K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, sg.rpb_l, sg.nch_l,
                                  EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
-                                 TauSide{}, GramSide{nullptr, 0, nullptr, 0}, ChunkMap{sg.c0, INT_MAX, 0}));
+                                 TauSide{}, GramSide{nullptr, 0, nullptr, 0}, ChunkMap{sg.nch_r, sg.lo, INT_MAX, 0, sg.hi}));
     HIPCHK(c, hipGetLastError());
     c->w_local_done = true; c->w_local_rpb = rpb; c->w_local_mode = mode;
     return BTF_OK;
   }
   const bool rest_only = c->w_local_done && sg.ok && c->w_local_rpb == rpb && c->w_local_mode == mode;
   c->w_local_done = false;
-  const ChunkMap cm = rest_only ? ChunkMap{0, sg.c0, sg.c1 - sg.c0} : ChunkMap{0, INT_MAX, 0};
-  const int nch_launch = rest_only ? nch - (sg.c1 - sg.c0) : nch;
+  const ChunkMap cm = rest_only ? ChunkMap{0, 0, sg.lo, sg.hi - sg.lo, MT} : ChunkMap{0, 0, INT_MAX, 0, MT};
+  const int nch_launch = rest_only ? sg.nch_r : nch;
+  const int nch_total = rest_only ? sg.nch_r + sg.nch_l : nch;
   const bool whole = c->nl == c->N && c->ml == c->M;      // fused Grams cover all rows/columns only when unsharded
   bool use_gv = !wt && whole && c->fuse_gram && c->ngp_v > 0;
   if (cv && c->nl > 0) {                      // the per-column Grams V_j'V_j: from the sampler that drew V, or computed here
@@ -1228,7 +1237,7 @@ int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL) {
     c->tau_pending = false;
   }
   HIPCHK(c, hipGetLastError());
-  c->w_part_valid = true; c->w_part_mode = mode; c->w_part_nch = nch; c->w_part_rpb = rpb; c->w_part_gv = use_gv;
+  c->w_part_valid = true; c->w_part_mode = mode; c->w_part_nch = nch_total; c->w_part_rpb = rpb; c->w_part_gv = use_gv;
   c->w_part_curve = cv;
   return BTF_OK;
 }
@@ -1393,13 +1402,13 @@ int v_accum_local(btf_ctx* c, int compat) {
   const int tiles = c->ldv / ACC_TILE;
   const int rpb = pick_rpb(c->N, tiles, c->rpb_v, wt);
   const int nch = (c->N + rpb - 1) / rpb;
-  const SplitGeom sg = split_geom(c->row0, c->row0 + c->nl, c->N, rpb);
+  const SplitGeom sg = split_geom(c->row0, c->row0 + c->nl, c->N, rpb, tiles);
   if (!sg.ok) return BTF_OK;
   int rc;
-  if ((rc = ensure_part(c, (size_t)nch * NV * c->ldv))) return rc;
-  K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb, sg.c1 - sg.c0,
+  if ((rc = ensure_part(c, (size_t)std::max(nch, sg.nch_r + sg.nch_l) * NV * c->ldv))) return rc;
+  K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, sg.rpb_l, sg.nch_l,
                                EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
-                               TauSide{}, GramSide{nullptr, 0, nullptr, 0}, ChunkMap{sg.c0, INT_MAX, 0}));
+                               TauSide{}, GramSide{nullptr, 0, nullptr, 0}, ChunkMap{sg.nch_r, sg.lo, INT_MAX, 0, sg.hi}));
   HIPCHK(c, hipGetLastError());
   c->v_local_done = true; c->v_local_rpb = rpb; c->v_local_mode = mode;
   return BTF_OK;
@@ -1431,7 +1440,12 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
   const int NV = wt ? K + KK : K;
   const int tiles = c->ldv / ACC_TILE;
   const int rpb = pick_rpb(c->N, tiles, c->rpb_v, wt);
-  const int nch = (c->N + rpb - 1) / rpb;
+  // (the own-rows chunks may already be in the partials, queued behind the W draw: BTF_OPT_SPLIT_ACCUM)
+  const SplitGeom vsg = split_applies(c) ? split_geom(c->row0, c->row0 + c->nl, c->N, rpb, tiles) : SplitGeom{};
+  const bool v_rest_only = c->v_local_done && vsg.ok && c->v_local_rpb == rpb && c->v_local_mode == mode;
+  c->v_local_done = false;
+  const int nch_all = (c->N + rpb - 1) / rpb;
+  const int nch = v_rest_only ? vsg.nch_r + vsg.nch_l : nch_all;       // slots the sampler adds up
   int rc;
   if ((rc = ensure_part(c, (size_t)nch * NV * c->ldv))) return rc;
   const double* dz = nullptr;
@@ -1464,12 +1478,9 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     const bool cols_aside = choice == 3 && cv;
     if (cols_aside) sidec = EigSideCols{c->cv_dcols, c->cv_ndef, CurveLists{c->cv_cptr, c->cv_crow, c->cv_cdef}, c->W, 1.0 / c->R, c->eig_cols};
     {
-      const SplitGeom sg = split_applies(c) ? split_geom(c->row0, c->row0 + c->nl, c->N, rpb) : SplitGeom{false, 0, 0};
-      const bool rest_only = c->v_local_done && sg.ok && c->v_local_rpb == rpb && c->v_local_mode == mode;
-      c->v_local_done = false;
-      const ChunkMap cm = rest_only ? ChunkMap{0, sg.c0, sg.c1 - sg.c0} : ChunkMap{0, INT_MAX, 0};
+      const ChunkMap cm = v_rest_only ? ChunkMap{0, 0, vsg.lo, vsg.hi - vsg.lo, c->N} : ChunkMap{0, 0, INT_MAX, 0, c->N};
       K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb,
-                                   rest_only ? nch - (sg.c1 - sg.c0) : nch, side, sidec, TauSide{}, GramSide{nullptr, 0, nullptr, 0}, cm));
+                                   v_rest_only ? vsg.nch_r : nch_all, side, sidec, TauSide{}, GramSide{nullptr, 0, nullptr, 0}, cm));
     }
     hipError_t e = hipSuccess;
     if (choice == 3) {

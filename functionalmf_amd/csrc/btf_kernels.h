@@ -186,11 +186,13 @@ constexpr int TAU_SIDE_CPW = 2;
 // solve kernel FOLLOWS: nblocks partial Grams of U's rows, one per side workgroup, consumed across the kernel boundary
 struct GramSide { const double* U; int Rdim; double* gpart; int nblocks; };
 
-// which chunks of the reduction axis a launch covers: its streaming workgroups are numbered over `count` logical
-// chunks, chunk c = base + (logical index) and a hole of `skip_n` chunks opens at `skip_at` (sharded runs: the chunks of
-// the rank's OWN block of the fixed factor are accumulated first - that block needs no exchange - and the rest in a
-// second launch behind the all-gather; both write their own slots of the partials).  {0, INT_MAX, 0}: every chunk.
-struct ChunkMap { int base, skip_at, skip_n; };
+// Which rows of the reduction axis a launch covers, and where its partial sums go: logical chunk l of the launch takes
+// rows r0 .. min(r0 + rows_per_block, row_end) - 1 with r0 = row_base + l rows_per_block, moved up by `skip_rows` from
+// `skip_at` on (a hole), and writes slot slot_base + l of the partials.  Sharded runs (BTF_OPT_SPLIT_ACCUM): the rows of
+// the rank's OWN block of the fixed factor are accumulated first - that block needs no exchange - in chunks sized for
+// the whole chip, and the rest in a second launch behind the all-gather, around the hole; the consumers just add all
+// slots.  {0, 0, INT_MAX, 0, Rdim}: every row, slot = chunk.
+struct ChunkMap { int slot_base, row_base, skip_at, skip_rows, row_end; };
 
 // MODE 0: X only (complete data)
 // MODE 1: X, C and the outer products UU
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   }
   const int ntiles = ld / ACC_TILE;
   const int lchunk = b / ntiles, tile = b - lchunk * ntiles;
-  const int chunk = cm.base + lchunk + (cm.base + lchunk >= cm.skip_at ? cm.skip_n : 0);
+  const int chunk = cm.slot_base + lchunk;                  // slot of the partials
   // OPL == 2: every wave covers the tile's 128 columns (two per lane) and takes every WAVES-th row.
   // OPL == 1: wave w covers the half (w & 1) of the tile, one column per lane, and takes every (WAVES/2)-th row.
   static_assert(OPL == 2 || (OPL == 1 && WAVES % 2 == 0), "outputs per lane");
@@ -341,8 +343,9 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   const int half = OPL == 2 ? 0 : (wave & 1);
   const int wv = OPL == 2 ? wave : (wave >> 1);
   const size_t col = (size_t)tile * ACC_TILE + (OPL == 2 ? 2 * lane : 64 * half + lane);
-  const int r0 = chunk * rows_per_block;
-  const int r1 = min(r0 + rows_per_block, Rdim);
+  int r0 = cm.row_base + lchunk * rows_per_block;
+  if (r0 >= cm.skip_at) r0 += cm.skip_rows;
+  const int r1 = min(r0 + rows_per_block, cm.row_end);
 
   double acc[NV][OPL];
 #pragma unroll

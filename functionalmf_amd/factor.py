@@ -93,7 +93,7 @@ class BayesianTensorFiltering(_BayesianModel):
                  force_psd_eps=1e-6,
                  force_psd_attempts=4,
                  compat="reference", rng="host", device=0, stream=None, shard=None, device_seed=0,
-                 sampler="auto", overlap_exchange=True,
+                 sampler="auto", overlap_exchange=False, rehearse_rank=False,
                  **kwargs):
         super().__init__(**kwargs)
         if compat not in _native.COMPAT:
@@ -111,16 +111,20 @@ class BayesianTensorFiltering(_BayesianModel):
         self._device_seed = int(device_seed)
         self._draws = 0
 
-        # Sharded runs exchange W / V through torch.distributed (parallel.Exchange).  overlap_exchange (default): the
-        # all-gather of the freshly drawn block runs on a communication stream ordered behind the draw kernel
-        # (btf_comm_fork), while the ctx's stream already accumulates the chunks of the next half-sweep that reduce over
-        # this rank's own block (BTF_OPT_SPLIT_ACCUM); the rest of that accumulation waits for the gather (btf_comm_join).
-        # False: the collectives are issued under the ctx's own stream, one after the other (round 2).
+        # Sharded runs exchange W / V through torch.distributed (parallel.Exchange).  Default: the collectives are issued
+        # under the ctx's own stream, in line.  overlap_exchange=True: the all-gather of the freshly drawn block runs on a
+        # communication stream ordered behind the draw kernel (btf_comm_fork), while the ctx's stream already accumulates
+        # the chunks of the next half-sweep that reduce over this rank's own block (BTF_OPT_SPLIT_ACCUM); the rest of that
+        # accumulation waits for the gather (btf_comm_join).  Measured on one MI355X playing rank 0 of 8 at C5
+        # (bench.py --as-rank 0/8): the kernels get shorter (2 x 26 us against 57 us per accumulation) but the two
+        # cross-stream edges per half-sweep cost more than the own-block eighth hides - 190 us per step against 157 in
+        # line - so it stays opt-in until a run on 8 GPUs (longer, skewed gathers) says otherwise.
         import os
         # device context first: without the HIP library / a GPU nothing below can run
         self._ctx = _native.Context(nrows, ncols, ndepth, nembeds, tf_order, device=device, stream=stream)
         self._plan = ShardPlan(nrows, ncols, *(shard if shard is not None else (0, 1)))
-        self._exchange = Exchange(self._plan, self._ctx, overlap=bool(overlap_exchange))
+        # rehearse_rank: this process plays rank shard[0] of shard[1] alone (timing rehearsal, see parallel.Exchange)
+        self._exchange = Exchange(self._plan, self._ctx, overlap=bool(overlap_exchange), rehearse=bool(rehearse_rank))
         if self._plan.world > 1:
             self._ctx.call("btf_set_shard", *self._plan.mine())
         if self._exchange.active and self._exchange.overlap:

@@ -65,21 +65,29 @@ class _DevView:
 class Exchange:
     """The per-half-sweep exchange.  world == 1: no-ops."""
 
-    def __init__(self, plan, ctx=None, group=None, overlap=True):
+    def __init__(self, plan, ctx=None, group=None, overlap=True, rehearse=False):
         self.plan, self.ctx, self.group = plan, ctx, group
         self.overlap = overlap          # all-gathers on a communication stream of their own (see _gather_stream)
+        # rehearse: ONE process plays rank `plan.rank` of `plan.world` (bench.py --as-rank): its kernels run on that
+        # rank's real slabs, and every collective of the sharded step is issued in a one-rank group on scratch buffers
+        # of the full message size - the blocks of the other ranks in W / V are never refreshed, so the chain is not a
+        # sampler of anything; only the clock is read
+        self.rehearse = rehearse
         self._Wt = self._Vt = None
         self._tstream = self._cstream = None
         self.timing, self._events = False, {"all_gather_W": [], "all_gather_V": [], "all_reduce_sse": []}
         # BTF_EXERCISE_EXCHANGE=1: issue the collectives even in a 1-rank group (lets a 1-GPU box
         # run the exact RCCL call sequence of the sharded path)
         import os
-        self.active = plan.world > 1 or os.environ.get("BTF_EXERCISE_EXCHANGE", "0") == "1"
+        self.active = plan.world > 1 or rehearse or os.environ.get("BTF_EXERCISE_EXCHANGE", "0") == "1"
         if self.active:
             import torch.distributed as dist
             if not dist.is_initialized():
                 raise RuntimeError("shard=(rank, world) needs an initialised torch.distributed process group")
-            if dist.get_world_size(group) != plan.world or dist.get_rank(group) != plan.rank:
+            if rehearse:
+                if dist.get_world_size(group) != 1:
+                    raise RuntimeError("a rehearsal runs in a one-rank process group")
+            elif dist.get_world_size(group) != plan.world or dist.get_rank(group) != plan.rank:
                 raise RuntimeError("shard does not match the process group")
 
     # -- device path (RCCL) ----------------------------------------------------------
@@ -145,6 +153,17 @@ class Exchange:
             self._Vt = torch.as_tensor(_DevView(lib.btf_dev_V(self.ctx.h), (p.world * p.col_chunk * T * K,)), device=dev)
         return self._Wt, self._Vt
 
+    def _scratch(self, which):
+        """Rehearsal buffers: a one-rank all-gather moves out = in, so both have the size of the whole gathered factor."""
+        import torch
+        if getattr(self, "_scr", None) is None:
+            p, (N, M, T, K, _) = self.plan, self.ctx.dims
+            dev = torch.device("cuda", self.ctx.device)
+            nW, nV = p.world * p.row_chunk * K, p.world * p.col_chunk * T * K
+            self._scr = {"W": torch.zeros(nW, dtype=torch.float64, device=dev), "W_in": torch.zeros(nW, dtype=torch.float64, device=dev),
+                         "V": torch.zeros(nV, dtype=torch.float64, device=dev), "V_in": torch.zeros(nV, dtype=torch.float64, device=dev)}
+        return self._scr[which]
+
     def _staged(self):
         """True when the process group cannot move device memory (e.g. gloo): the exchange is then
         staged through the host (used to rehearse several ranks on one GPU; RCCL refuses that)."""
@@ -166,6 +185,8 @@ class Exchange:
             N, M, T, K, _ = self.ctx.dims
             return self._staged_gather("btf_get_W", "btf_set_gathered_W", (N, K), self.plan.row0, self.plan.nl, self.gather_rows_host)
         import torch.distributed as dist
+        if self.rehearse:
+            return self._gather("all_gather_W", lambda: dist.all_gather_into_tensor(self._scratch("W"), self._scratch("W_in"), group=self.group))
         Wt, _ = self._views()
         K = self.ctx.dims[3]
         n = self.plan.row_chunk * K
@@ -178,6 +199,8 @@ class Exchange:
             N, M, T, K, _ = self.ctx.dims
             return self._staged_gather("btf_get_V", "btf_set_gathered_V", (M, T, K), self.plan.col0, self.plan.ml, self.gather_cols_host)
         import torch.distributed as dist
+        if self.rehearse:
+            return self._gather("all_gather_V", lambda: dist.all_gather_into_tensor(self._scratch("V"), self._scratch("V_in"), group=self.group))
         _, Vt = self._views()
         _, _, T, K, _ = self.ctx.dims
         n = self.plan.col_chunk * T * K

@@ -3,11 +3,12 @@
 # rocprofv3 kernel stats and the two PMC passes (FETCH_SIZE / WRITE_SIZE need separate passes on gfx950: TCC
 # slots) of `bench.py --config <config> --variant <variant>`; then scripts/summarize_profiles.py <tag> <config> <variant>.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}; CFG=${2:-c3}; VAR=${3:-complete}; STEPS=${4:-100}
-NAME=${TAG}_${CFG}_${VAR}
+# EXTRA="--as-rank 0/8" SUFFIX=_rank0of8: further bench.py arguments and a suffix of the file stem
+TAG=${1:-r03}; CFG=${2:-c3}; VAR=${3:-complete}; STEPS=${4:-100}
+NAME=${TAG}_${CFG}_${VAR}${SUFFIX:-}
 export PYTHONUNBUFFERED=1
 cd /tmp && export TMPDIR=/tmp
-ARGS="--config $CFG --variant $VAR --no-cpu"
+ARGS="--config $CFG --variant $VAR --no-cpu ${EXTRA:-}"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$NAME -o $NAME --output-format csv -- python3 $R/bench.py $ARGS --steps $STEPS --warmup 10 > $R/gpurun_out/prof_$NAME.log 2>&1 || exit 1
 echo "stats pass done"
 timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch_$NAME -o $NAME --output-format csv -- python3 $R/bench.py $ARGS --steps 20 --warmup 2 --burn 2 > $R/gpurun_out/pmc_fetch_$NAME.log 2>&1 || exit 1

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/{prof,pmc_fetch,pmc_write}_<tag>_<config>_<variant> into profiles/.  Usage:
-   python scripts/summarize_profiles.py r02 c3 complete"""
+   python scripts/summarize_profiles.py r03 c3 complete [suffix]"""
 import collections, csv, json, os, shutil, sys
-tag, cfg, var = (sys.argv[1:4] + ["r02", "c3", "complete"][len(sys.argv) - 1:])[:3]
-name = "%s_%s_%s" % (tag, cfg, var)
+tag, cfg, var = (sys.argv[1:4] + ["r03", "c3", "complete"][len(sys.argv) - 1:])[:3]
+suffix = sys.argv[4] if len(sys.argv) > 4 else ""
+name = "%s_%s_%s%s" % (tag, cfg, var, suffix)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -36,6 +37,6 @@ if os.path.exists(sqdir):
 for k, d in pmc.items():
     f, w = d.get("FETCH_SIZE_KB_avg", 0.0), d.get("WRITE_SIZE_KB_avg", 0.0)
     d["hbm_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0
-json.dump(pmc, open(os.path.join(out, "%s_pmc_%s_%s.json" % (tag, cfg, var)), "w"), indent=1, sort_keys=True)
+json.dump(pmc, open(os.path.join(out, "%s_pmc_%s_%s%s.json" % (tag, cfg, var, suffix)), "w"), indent=1, sort_keys=True)
 for k, d in sorted(pmc.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch_corrected", 0.0))[:6]:
     print("%-60s %10.2f MB/launch" % (k[:60], d["hbm_bytes_per_launch_corrected"] / 1e6))

@@ -12,6 +12,7 @@ import sys
 import numpy as np
 import torch.distributed as dist
 
+OVERLAP = os.environ.get("BTF_DIST_OVERLAP", "0") == "1"      # base section: all-gathers on the communication stream
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -42,7 +43,8 @@ def split_section(rank, world):
     for Y, form in ((Yc, "complete"), (Ym, "weighted")):
         model = GaussianBayesianTensorFiltering(
             N, M, T, nembeds=K, tf_order=2, sigma2_init=st0["sigma2"], lam2_init=st0["lam2"], nu2_init=st0["nu2"],
-            W_init=st0["W"], V_init=st0["V"], Tau2_init=st0["Tau2"], compat="exact", shard=(rank, world), device=0, sampler="banded")
+            W_init=st0["W"], V_init=st0["V"], Tau2_init=st0["Tau2"], compat="exact", shard=(rank, world), device=0, sampler="banded",
+            overlap_exchange=True)
         model._ctx.call("btf_set_tuning", 64, 64)          # 64-row chunks: every shard is a whole number of them
         ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st0.items()}
         model._ctx.kernel_times()
@@ -85,8 +87,9 @@ def split_section(rank, world):
             m.resample(Yc)
         chains.append((m.W.copy(), m.V.copy(), float(m.nu2), float(m.sigma2), float(m.lam2)))
         del m
-    a, b = chains
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:], "overlapped chain differs from the in-line one"
+    a, b = chains                # (the own-block chunks have their own size: other partial sums, same totals up to rounding)
+    assert np.abs(a[0] - b[0]).max() / np.abs(b[0]).max() < 1e-8 and np.abs(a[1] - b[1]).max() / np.abs(b[1]).max() < 1e-6
+    assert all(abs(x - y) / abs(y) < 1e-8 for x, y in zip(a[2:], b[2:])), (a[2:], b[2:])
 
 
 def main():
@@ -113,7 +116,7 @@ def main():
         st = state_from(g, "s0_")
         model = GaussianBayesianTensorFiltering(
             N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
-            W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], compat="exact", shard=(rank, world), device=0)
+            W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], compat="exact", shard=(rank, world), device=0, overlap_exchange=OVERLAP)
         assert model._exchange.active and model._plan.world == world
         Delta = orc.trend_penalty(T, tf)
         ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
@@ -148,7 +151,7 @@ def main():
             os.environ["BTF_EXERCISE_EXCHANGE"] = exercise if shard is not None else "0"     # the plain chain: no collectives
             m = GaussianBayesianTensorFiltering(
                 N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
-                W_init=st["W"], V_init=st["V"], compat="exact", shard=shard, device=0, rng="device", device_seed=9,
+                W_init=st["W"], V_init=st["V"], compat="exact", shard=shard, device=0, rng="device", device_seed=9, overlap_exchange=OVERLAP,
                 # (held-out cells: a rank whose slabs happen to be complete would pick the spectral sampler where the
                 #  unsharded run - one weighted tensor - uses the banded one: same distribution, another square root)
                 sampler="auto" if name.startswith("g2") else "banded")
@@ -171,7 +174,7 @@ def main():
         os.environ["BTF_EXERCISE_EXCHANGE"] = exercise if shard is not None else "0"
         m = BinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
                                             W_init=st["W"], V_init=st["V"], compat="exact", shard=shard, device=0, rng="device",
-                                            device_seed=9)
+                                            device_seed=9, overlap_exchange=OVERLAP)
         for _ in range(2):
             m.resample((g["Ysucc"], g["Ntrials"]))
         chains.append((m.W.copy(), m.V.copy(), np.array(m.nu2).copy()))

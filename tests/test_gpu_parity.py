@@ -746,13 +746,14 @@ def test_rccl_exchange_with_one_rank_reproduces_the_plain_chain():
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, BTF_DIST_BACKEND="nccl", BTF_EXERCISE_EXCHANGE="1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
-           "--master-addr", "127.0.0.1", "--master-port", "29583", os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=380)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-    assert out.stdout.count("SHARD_GPU_OK") == 1, out.stdout[-2000:]
+    for overlap in ("0", "1"):      # collectives in line on the ctx's stream / on the communication stream (btf_comm_fork / _join)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, BTF_DIST_BACKEND="nccl", BTF_EXERCISE_EXCHANGE="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", BTF_DIST_OVERLAP=overlap, BTF_DIST_SECTION="base")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+               "--master-addr", "127.0.0.1", "--master-port", "29583", os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        assert out.stdout.count("SHARD_GPU_OK") == 1, out.stdout[-2000:]
 
 
 def test_device_scalar_draws_have_the_right_conditionals(golden):
