@@ -23,7 +23,7 @@ BTF_OK, BTF_EINVAL, BTF_EHIP, BTF_ENOTPD, BTF_ESTATE = 0, 1, 2, 3, 4
 COMPAT = {"reference": 0, "exact": 1}
 KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw", "nb_loglik",
                 "prior_band", "gram_eig", "hyper", "ess"]
-OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT, OPT_CURVE_COUNTS, OPT_SPLIT_ACCUM = 0, 1, 2, 3, 4, 5
+OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT, OPT_CURVE_COUNTS, OPT_SPLIT_ACCUM, OPT_FUSED_SWEEP = 0, 1, 2, 3, 4, 5, 6
 SAMPLERS = {"banded": 0, "spectral": 1, "chain": 2, "generic": 3, "banded_nopanel": 4}
 
 # every symbol include/btf.h declares: (name, restype, argtypes)
@@ -114,6 +114,7 @@ SIGNATURES = {
     "btf_set_draw_counters": (C.c_int, [_ctx, C.c_uint64, C.c_uint64]),
     "btf_get_accum_bytes_per_cell": (C.c_int, [_ctx, _c_dp]),
     "btf_get_V_sampler": (C.c_int, [_ctx, _c_ip]),
+    "btf_queue_scalars": (C.c_int, [_ctx, C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _c_ip]),
     "btf_comm_fork": (C.c_int, [_ctx, C.c_void_p]),
     "btf_comm_join": (C.c_int, [_ctx, C.c_void_p]),
     "btf_set_gathered_W": (C.c_int, [_ctx, _c_dp]),

@@ -123,6 +123,12 @@ struct btf_ctx {
   int w_local_rpb = 0, w_local_mode = 0, v_local_rpb = 0, v_local_mode = 0;
   hipEvent_t ev_draw = nullptr, ev_join = nullptr;                    // behind the last draw kernel / the comm stream's tail
   bool tau_pending = false; unsigned long long tau_seed = 0; double tau_stability = 1e-6;   // btf_queue_Tau2
+  // the four-launch sweep (BTF_OPT_FUSED_SWEEP): per-column residual parts left by the spectral V sampler, and a queued
+  // nu2 / sigma2 draw that the next W accumulation launch carries as a side workgroup (btf_queue_scalars)
+  bool fused_sweep = true;
+  double* sse_cols = nullptr; bool sse_cols_valid = false;
+  bool nu2_drawn_since_v = false;      // a device nu2 draw happened since the last V half-sweep: the caller runs full sweeps
+  bool sc_pending = false; unsigned long long sc_seed = 0; int sc_which = 0; double sc_prior[4] = {0, 0, 0, 0};
   bool lam_pending = false; unsigned long long lam_seed = 0; int lam_exact = 0;            // btf_queue_lam2
   unsigned long long sweep_w = 0, sweep_v = 0;
   bool profiling = false;
@@ -304,26 +310,27 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
                   const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr},
                   EigSideCols sidec = EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
                   TauSide tau = TauSide{}, GramSide gram = GramSide{nullptr, 0, nullptr, 0},
-                  ChunkMap cm = ChunkMap{0, 0, INT_MAX, 0, 0}) {
+                  ChunkMap cm = ChunkMap{0, 0, INT_MAX, 0, 0, 0}, SweepSide sw = SweepSide{}) {
   // nch: the chunks THIS launch covers (all of them unless cm says otherwise)
   if (cm.row_end == 0) cm.row_end = Rdim;
   Prof p(c, kid);
   const int cpw = TAU_SIDE_CPW;
-  dim3 grid((ld / ACC_TILE) * nch + (side.out ? 1 + eig_side_groups(sidec.ncols, acc_waves(K, mode)) : 0) +
-            (tau.Tau2 ? (tau.M + cpw - 1) / cpw : 0) + (gram.gpart ? gram.nblocks : 0));   // (+ the side tasks' workgroups)
+  cm.nside = (sw.sc.hyp ? 1 : 0) + (sw.lam.hyp ? 1 : 0) + (side.out ? 1 + eig_side_groups(sidec.ncols, acc_waves(K, mode)) : 0) +
+             (tau.Tau2 ? (tau.M + cpw - 1) / cpw : 0) + (gram.gpart ? gram.nblocks : 0);   // the side tasks' workgroups, in front
+  dim3 grid((ld / ACC_TILE) * nch + cm.nside);
   const signed char* A8 = (mode >= 1 && !C8 && X == c->A_wT) ? c->A8_wT : ((mode >= 1 && !C8 && X == c->A_v) ? c->A8_v : nullptr);
   if (A8) {                    // Binomial pseudo-data as bytes (f64 weights)
-    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), double, signed char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
-    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), double, signed char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), double, signed char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), double, signed char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
     return;
   }
   if (mode >= 1 && C8) {       // byte weights (Gaussian replicate counts)
-    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
-    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
-  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
-  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
-  else if (rpb >= 2048) p.launch(accum_kernel<K, 0, acc_waves(K, 0), double, double, 3>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
-  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm);
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+  else if (rpb >= 2048) p.launch(accum_kernel<K, 0, acc_waves(K, 0), double, double, 3>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
 }
 // Which Polya-Gamma launches a draw needs (pg_class_of): the flat exact kernel for the integer counts it takes
 // under the mode, the series kernel and / or the f64 Devroye kernel with a fractional part for the rest - each only
@@ -868,7 +875,7 @@ static int finish_data(btf_ctx* c) {
     if (rc2) return rc2;
   }
   c->have_data = true;
-  c->w_part_valid = false; c->w_local_done = c->v_local_done = false;
+  c->w_part_valid = false; c->w_local_done = c->v_local_done = false; c->sse_cols_valid = false;
   return BTF_OK;
 }
 
@@ -994,6 +1001,7 @@ int btf_set_W(btf_ctx* c, const double* W) {
   c->nb_L_valid = false;
   c->ngp_w = 0;
   c->v_local_done = false;
+  c->sse_cols_valid = false;
   return BTF_OK;
 }
 int btf_set_gathered_W(btf_ctx* c, const double* W) {
@@ -1019,6 +1027,7 @@ int btf_set_V(btf_ctx* c, const double* V) {
   c->w_part_valid = false;
   c->ngp_v = 0;
   c->w_local_done = false;
+  c->sse_cols_valid = false;
   return BTF_OK;
 }
 int btf_set_gathered_V(btf_ctx* c, const double* V) {
@@ -1123,7 +1132,7 @@ int btf_set_nu2(btf_ctx* c, double nu2) {
   return BTF_OK;
 }
 int btf_set_omega(btf_ctx* c, const double* omega_rows, const double* omega_cols) {
-  if (c) { c->w_part_valid = false; c->w_local_done = c->v_local_done = false; }   // the weights change
+  if (c) { c->w_part_valid = false; c->w_local_done = c->v_local_done = false; c->sse_cols_valid = false; }   // the weights change
   if (!c || !omega_rows || !omega_cols) return BTF_EINVAL;
   if (!c->have_data || !c->binomial) return fail(c, BTF_ESTATE, "btf_set_omega needs binomial data");
   HIPCHK(c, hipSetDevice(c->dev));
@@ -1195,14 +1204,14 @@ int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL) {
     if (!sg.ok || mode == 2) return BTF_OK;               // nothing queued ahead: the next call accumulates everything
     K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, sg.rpb_l, sg.nch_l,
                                  EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
-                                 TauSide{}, GramSide{nullptr, 0, nullptr, 0}, ChunkMap{sg.nch_r, sg.lo, INT_MAX, 0, sg.hi}));
+                                 TauSide{}, GramSide{nullptr, 0, nullptr, 0}, ChunkMap{sg.nch_r, sg.lo, INT_MAX, 0, sg.hi, 0}));
     HIPCHK(c, hipGetLastError());
     c->w_local_done = true; c->w_local_rpb = rpb; c->w_local_mode = mode;
     return BTF_OK;
   }
   const bool rest_only = c->w_local_done && sg.ok && c->w_local_rpb == rpb && c->w_local_mode == mode;
   c->w_local_done = false;
-  const ChunkMap cm = rest_only ? ChunkMap{0, 0, sg.lo, sg.hi - sg.lo, MT} : ChunkMap{0, 0, INT_MAX, 0, MT};
+  const ChunkMap cm = rest_only ? ChunkMap{0, 0, sg.lo, sg.hi - sg.lo, MT, 0} : ChunkMap{0, 0, INT_MAX, 0, MT, 0};
   const int nch_launch = rest_only ? sg.nch_r : nch;
   const int nch_total = rest_only ? sg.nch_r + sg.nch_l : nch;
   const bool whole = c->nl == c->N && c->ml == c->M;      // fused Grams cover all rows/columns only when unsharded
@@ -1226,8 +1235,16 @@ int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL) {
     }
     TauSide tau{};
     if (c->tau_pending && c->dev_scalars && c->have_chain) tau = tau_side_of(c, c->tau_seed, 1.0, c->tau_stability);
+    SweepSide sw{};
+    if (c->sc_pending) {                      // queued nu2 / sigma2 draw (btf_queue_scalars checked that it can ride here)
+      const int h = std::min(c->K, c->N);
+      const double nfree = (double)c->N * c->K - (double)h * (h - 1) / 2.0 - (double)(c->K - h) * c->N;   // factor.py:155-174
+      sw.sc = ScalarSide{c->sse_cols, c->M, c->ssw + c->sa2, c->nobs_global >= 0.0 ? c->nobs_global : c->nobs, c->W, c->N * c->K, nfree,
+                         c->sc_prior[0], c->sc_prior[1], c->sc_prior[2], c->sc_prior[3], c->sc_which, c->sc_seed, c->hyp};
+      c->sc_pending = false;
+    }
     K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, rpb, nch_launch,
-                                 EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}, tau, gram, cm));
+                                 EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}, tau, gram, cm, sw));
     c->tau_pending = false;
   } else if (c->tau_pending && c->dev_scalars && c->have_chain) {
     // a rank without rows (ceil chunks: N = 10 over 8 ranks leaves ranks 5-7 empty) has no accumulation launch to
@@ -1265,6 +1282,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
   int rc;
   c->v_local_done = false;                                 // W is about to change
   if (!(c->w_part_valid && c->w_part_mode == want_mode && c->w_part_curve == cv)) { if ((rc = w_accum_phase(c, compat))) return rc; }
+  if (c->sc_pending) return fail(c, BTF_ESTATE, "btf_queue_scalars must be followed by the W accumulation that carries it");
   const int nch = c->w_part_nch;
   const bool use_gv = c->w_part_gv;
   c->w_part_valid = false;                                 // consumed: W changes below
@@ -1300,6 +1318,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
   }
   c->sweep_w++;
   c->nb_L_valid = false;
+  c->sse_cols_valid = false;                               // W has changed: the residual parts are those of the old W
   HIPCHK(c, hipGetLastError());
   if (split_applies(c)) {        // behind the W draw: mark it, then queue the own-rows chunks of the next V accumulation
     if ((rc = mark_draw(c))) return rc;
@@ -1408,7 +1427,7 @@ int v_accum_local(btf_ctx* c, int compat) {
   if ((rc = ensure_part(c, (size_t)std::max(nch, sg.nch_r + sg.nch_l) * NV * c->ldv))) return rc;
   K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, sg.rpb_l, sg.nch_l,
                                EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
-                               TauSide{}, GramSide{nullptr, 0, nullptr, 0}, ChunkMap{sg.nch_r, sg.lo, INT_MAX, 0, sg.hi}));
+                               TauSide{}, GramSide{nullptr, 0, nullptr, 0}, ChunkMap{sg.nch_r, sg.lo, INT_MAX, 0, sg.hi, 0}));
   HIPCHK(c, hipGetLastError());
   c->v_local_done = true; c->v_local_rpb = rpb; c->v_local_mode = mode;
   return BTF_OK;
@@ -1434,6 +1453,8 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
   if (attempts < 0) attempts = 0;
   HIPCHK(c, hipSetDevice(c->dev));
   c->w_local_done = false;                                 // V is about to change
+  c->sse_cols_valid = false;
+  struct ResetFlag { bool& f; ~ResetFlag() { f = false; } } reset_nu2_flag{c->nu2_drawn_since_v};
   const int K = c->K, KK = c->KK, T = c->T, n = T * K;
   const bool wt = lik_weighted(c), cv = c->weighted && !wt;
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_v && c->srcmap_v ? 2 : 1);
@@ -1478,9 +1499,14 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     const bool cols_aside = choice == 3 && cv;
     if (cols_aside) sidec = EigSideCols{c->cv_dcols, c->cv_ndef, CurveLists{c->cv_cptr, c->cv_crow, c->cv_cdef}, c->W, 1.0 / c->R, c->eig_cols};
     {
-      const ChunkMap cm = v_rest_only ? ChunkMap{0, 0, vsg.lo, vsg.hi - vsg.lo, c->N} : ChunkMap{0, 0, INT_MAX, 0, c->N};
+      const ChunkMap cm = v_rest_only ? ChunkMap{0, 0, vsg.lo, vsg.hi - vsg.lo, c->N, 0} : ChunkMap{0, 0, INT_MAX, 0, c->N, 0};
+      SweepSide sw{};
+      if (c->lam_pending && c->dev_scalars && c->lsum && c->have_chain) {     // a queued lam2 | rest draw no scalar launch took
+        sw.lam = LamSide{c->lsum, c->M, (double)c->nD * c->M * c->K + 1.0, c->lam_exact, c->lam_seed, c->hyp};
+        c->lam_pending = false;
+      }
       K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb,
-                                   v_rest_only ? vsg.nch_r : nch_all, side, sidec, TauSide{}, GramSide{nullptr, 0, nullptr, 0}, cm));
+                                   v_rest_only ? vsg.nch_r : nch_all, side, sidec, TauSide{}, GramSide{nullptr, 0, nullptr, 0}, cm, sw));
     }
     hipError_t e = hipSuccess;
     if (choice == 3) {
@@ -1499,6 +1525,13 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
         sa.cv = CurveLists{c->cv_cptr, c->cv_crow, c->cv_cdef}; sa.cv_W = c->W;
         sa.gpart = side.gpart; sa.ngp = side.ngp; sa.eig_cols = c->eig_cols;
         sa.eig_cols_ready = cols_aside ? 1 : 0;
+      }
+      c->sse_cols_valid = false;
+      // (only inside full sweeps - a nu2 draw since the last V half-sweep: a loop of bare W + V steps does not pay for it)
+      if (c->fused_sweep && whole && !cv && mode == 0 && !c->binomial && c->dev_scalars && c->nu2_drawn_since_v) {
+        if (!c->sse_cols) { if ((rc = dev_alloc(c, &c->sse_cols, (size_t)c->M))) return rc; }
+        sa.sse_out = c->sse_cols;
+        c->sse_cols_valid = true;             // (as of the end of this launch: W as it stands, V as drawn here)
       }
       const bool emit = whole && c->fuse_gram &&
                         (size_t)c->ml * KK + 16 * KK <= ws_gram_stage(K, false);
@@ -1644,7 +1677,7 @@ int btf_ess_eval(btf_ctx* c, int what, double theta, int current, int link, doub
     Prof p(c, BTF_K_ESS);
     p.launch(ess_combine_kernel, dim3((unsigned)((d.n + 255) / 256)), dim3(256), 0, (const double*)c->essX0, (const double*)c->essNu,
              what == 0 ? c->W : c->V, d.n, 0, (const double*)c->ess_theta, (const int*)c->ess_done, 0);
-    c->w_local_done = c->v_local_done = false;
+    c->w_local_done = c->v_local_done = false; c->sse_cols_valid = false;
     if (what == 0) { c->ngp_w = 0; c->w_part_valid = false; } else { c->ngp_v = 0; c->w_part_valid = false; }
     c->nb_L_valid = false;
   }
@@ -1695,7 +1728,7 @@ int btf_ess_run(btf_ctx* c, int what, int link, int mode, const double* z, uint6
   HIPCHK(c, hipGetLastError());
   c->ess_last_chains = d.nchains;
   if (what == 0) c->ngp_w = 0; else c->ngp_v = 0;
-  c->w_part_valid = false; c->w_local_done = c->v_local_done = false;
+  c->w_part_valid = false; c->w_local_done = c->v_local_done = false; c->sse_cols_valid = false;
   c->nb_L_valid = false;
   return BTF_OK;
 }
@@ -1886,7 +1919,7 @@ int btf_gass_commit(btf_ctx* c, int what, const double* theta, const int32_t* ke
   }
   HIPCHK(c, hipGetLastError());
   if (what == 0) c->ngp_w = 0; else c->ngp_v = 0;
-  c->w_part_valid = false; c->w_local_done = c->v_local_done = false; c->nb_L_valid = false;
+  c->w_part_valid = false; c->w_local_done = c->v_local_done = false; c->sse_cols_valid = false; c->nb_L_valid = false;
   return BTF_OK;
 }
 
@@ -1903,7 +1936,7 @@ int btf_gass_select(btf_ctx* c, int what, uint64_t seed, int32_t* naccept_out) {
   }
   HIPCHK(c, hipGetLastError());
   if (what == 0) c->ngp_w = 0; else c->ngp_v = 0;
-  c->w_part_valid = false; c->w_local_done = c->v_local_done = false; c->nb_L_valid = false;
+  c->w_part_valid = false; c->w_local_done = c->v_local_done = false; c->sse_cols_valid = false; c->nb_L_valid = false;
   if (naccept_out) {
     HIPCHK(c, hipMemcpyAsync(naccept_out, c->gs_nacc, (size_t)nch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     return check_status(c);
@@ -1935,8 +1968,12 @@ int btf_gibbs_sweeps(btf_ctx* c, int n, uint64_t seed_base, uint64_t draws0, int
     const uint64_t d = seed_base + draws0 + 5ULL * (uint64_t)s;
     if ((rc = btf_queue_Tau2(c, d + 1, stability))) return rc;
     if ((rc = btf_queue_lam2(c, d + 2, compat))) return rc;
+    // four launches when the previous sweep's V sampler left the residual parts behind (BTF_OPT_FUSED_SWEEP): nu2 and
+    // sigma2 ride in the W accumulation launch, lam2 in the V accumulation launch; six otherwise (first sweep, weighted data)
+    int32_t queued = 0;
+    if ((rc = btf_queue_scalars(c, d + 3, 3, nu2_a, nu2_b, sigma2_a, sigma2_b, &queued))) return rc;
     if ((rc = btf_w_accum(c, compat))) return rc;
-    if ((rc = btf_draw_scalars(c, d + 3, 7, nu2_a, nu2_b, sigma2_a, sigma2_b))) return rc;
+    if (!queued) { if ((rc = btf_draw_scalars(c, d + 3, 7, nu2_a, nu2_b, sigma2_a, sigma2_b))) return rc; }
     if ((rc = btf_resample_W(c, nullptr, d + 4, compat))) return rc;
     if ((rc = btf_resample_V(c, nullptr, d + 5, compat, eps0, attempts))) return rc;
   }
@@ -2219,7 +2256,7 @@ int btf_nb_loglik(btf_ctx* c, const double* R, const double* cand, const int32_t
 
 int btf_nb_set_rate(btf_ctx* c, const double* R, const int32_t* shared) {
   if (!c || !R || !shared) return BTF_EINVAL;
-  c->w_part_valid = false; c->w_local_done = c->v_local_done = false;
+  c->w_part_valid = false; c->w_local_done = c->v_local_done = false; c->sse_cols_valid = false;
   if (!c->counts) return fail(c, BTF_ESTATE, "btf_nb_set_rate follows btf_set_data_counts");
   HIPCHK(c, hipSetDevice(c->dev));
   int rc;
@@ -2467,6 +2504,7 @@ int btf_draw_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double 
   // of squares into the device scalar HYP_SSE and stop; 16 = draw from HYP_SSE (all-reduced by the caller in between)
   const int phase = (which & 8) ? 1 : ((which & 16) ? 2 : 0);
   if ((which & 1) && (!c->have_data || c->binomial)) return fail(c, BTF_ESTATE, "the scalar nu2 draw needs Gaussian data");
+  if (which & 1) c->nu2_drawn_since_v = true;
   if (!c->have_W || ((which & 1) && !c->have_V)) return fail(c, BTF_ESTATE, "set W and V first");
   HIPCHK(c, hipSetDevice(c->dev));
   size_t nb = 0;
@@ -2511,6 +2549,30 @@ int btf_draw_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double 
     if (with_lam) c->lam_pending = false;
   }
   HIPCHK(c, hipGetLastError());
+  return BTF_OK;
+}
+
+namespace {
+// can the next W accumulation launch carry nu2 | rest / sigma2 | rest as a side workgroup?
+bool scalars_can_ride(const btf_ctx* c, int which) {
+  if (!c->fused_sweep || !c->dev_scalars || c->binomial || c->counts || !c->have_data || !c->have_W || !c->have_V) return false;
+  if (c->nl != c->N || c->ml != c->M || c->nl < 1) return false;
+  if (c->w_part_valid) return false;                      // the accumulation has already been launched
+  if (lik_weighted(c) || c->weighted) return false;       // complete data: the residual identity of the spectral sampler
+  if ((which & 1) && !(c->sse_cols && c->sse_cols_valid)) return false;
+  return (which & 3) != 0;
+}
+}  // namespace
+
+int btf_queue_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double nu2_b, double sigma2_a, double sigma2_b, int32_t* queued) {
+  if (!c || !queued) return BTF_EINVAL;
+  *queued = 0;
+  if (!c->dev_scalars) return fail(c, BTF_ESTATE, "enable device-resident scalars first");
+  if (!scalars_can_ride(c, which)) return BTF_OK;         // the caller draws them with btf_draw_scalars instead
+  c->sc_pending = true; c->sc_seed = seed; c->sc_which = which & 3;
+  if (which & 1) c->nu2_drawn_since_v = true;
+  c->sc_prior[0] = nu2_a; c->sc_prior[1] = nu2_b; c->sc_prior[2] = sigma2_a; c->sc_prior[3] = sigma2_b;
+  *queued = 1;
   return BTF_OK;
 }
 
@@ -2562,7 +2624,7 @@ int btf_sse(btf_ctx* c, double* sse, double* nobs) {
 
 int btf_pg_draw(btf_ctx* c, uint64_t seed) {
   if (!c) return BTF_EINVAL;
-  c->w_part_valid = false; c->w_local_done = c->v_local_done = false;          // the weights change
+  c->w_part_valid = false; c->w_local_done = c->v_local_done = false; c->sse_cols_valid = false;          // the weights change
   if (!c->have_data || !c->binomial || !c->have_W || !c->have_V) return fail(c, BTF_ESTATE, "btf_pg_draw needs binomial data, W and V");
   HIPCHK(c, hipSetDevice(c->dev));
   const unsigned long long MT = (unsigned long long)c->M * c->T;
@@ -2920,14 +2982,18 @@ int btf_set_option(btf_ctx* c, int option, int value) {
       c->fuse_gram = value != 0;
       c->ngp_v = c->ngp_w = 0;
       return BTF_OK;
+    case BTF_OPT_FUSED_SWEEP:
+      c->fused_sweep = value != 0;
+      c->sse_cols_valid = false;
+      return BTF_OK;
     case BTF_OPT_SPLIT_ACCUM:
       c->split_accum = value != 0;
-      c->w_local_done = c->v_local_done = false;
+      c->w_local_done = c->v_local_done = false; c->sse_cols_valid = false;
       return BTF_OK;
     case BTF_OPT_CURVE_COUNTS:
       c->curve_opt = value != 0;
       c->ngp_v = c->ngp_w = 0;
-      c->w_part_valid = false; c->w_local_done = c->v_local_done = false;
+      c->w_part_valid = false; c->w_local_done = c->v_local_done = false; c->sse_cols_valid = false;
       return BTF_OK;
     default:
       return fail(c, BTF_EINVAL, "unknown option");
@@ -2953,6 +3019,8 @@ int btf_set_draw_counters(btf_ctx* c, uint64_t w, uint64_t v) {
   // The spectral sampler refines the previous sweep's eigenvectors; a chain continued from a checkpoint has none.
   // Forget them here, so that the chain that goes on (checkpoint() calls this too) and the restored one both start
   // from a cold eigen-solve: the same basis bit for bit, also inside a cluster of near-equal eigenvalues.
+  // Likewise the residual parts the V sampler left for the next nu2 draw (BTF_OPT_FUSED_SWEEP): both take the six-launch sweep once.
+  c->sse_cols_valid = false;
   HIPCHK(c, hipSetDevice(c->dev));
   const size_t rec = (size_t)c->K + (size_t)c->K * c->K + 8;
   if (c->eig) HIPCHK(c, hipMemsetAsync(c->eig, 0, rec * sizeof(double), c->stream));

@@ -12,7 +12,7 @@
 namespace btf {
 
 #define BTF_ACC_ARGS(XT, CT) \
-  (const XT*, const CT*, const double*, const int*, double*, int, int, int, EigSide, EigSideCols, TauSide, GramSide, ChunkMap)
+  (const XT*, const CT*, const double*, const int*, double*, int, int, int, EigSide, EigSideCols, TauSide, GramSide, ChunkMap, SweepSide)
 #define BTF_ACCUM_SET(P, K)                                                                              \
   P void accum_kernel<K, 0> BTF_ACC_ARGS(double, double);                                                \
   P void accum_kernel<K, 0, acc_waves(K, 0), double, double, 3> BTF_ACC_ARGS(double, double);            \

@@ -192,7 +192,22 @@ struct GramSide { const double* U; int Rdim; double* gpart; int nblocks; };
 // the rank's OWN block of the fixed factor are accumulated first - that block needs no exchange - in chunks sized for
 // the whole chip, and the rest in a second launch behind the all-gather, around the hole; the consumers just add all
 // slots.  {0, 0, INT_MAX, 0, Rdim}: every row, slot = chunk.
-struct ChunkMap { int slot_base, row_base, skip_at, skip_rows, row_end; };
+struct ChunkMap { int slot_base, row_base, skip_at, skip_rows, row_end; int nside; };     // nside: side workgroups in front (set by launch_accum)
+
+// nu2 | rest and sigma2 | rest as ONE side workgroup of the W accumulation launch (full sweeps, rng="device", complete
+// Gaussian data): the residual sum of squares comes from the per-column parts the spectral V sampler left behind at the
+// end of the previous sweep (sse_cols: sum_t R v'W'Wv - 2 v.m with the W and V that still stand) plus the constants of
+// the data, sum W^2 from W itself; w_solve - the next kernel - reads the two draws.  Same Philox streams as
+// scalars_kernel.  hyp == nullptr: no such workgroup.
+struct ScalarSide {
+  const double* sse_cols; int M; double sconst, nobs;
+  const double* W; int NK; double nfree;
+  double nu2_a, nu2_b, sig_a, sig_b; int which; unsigned long long seed; double* hyp;
+};
+// lam2 | rest (and lam2_a) as a side workgroup of the V accumulation launch: it needs the column sums the Tau2 chain left
+// in the W accumulation launch; the V sampler - the next kernel - reads the draw.  hyp == nullptr: none.
+struct LamSide { const double* lsum; int M; double shape; int exact; unsigned long long seed; double* hyp; };
+struct SweepSide { ScalarSide sc; LamSide lam; };
 
 // MODE 0: X only (complete data)
 // MODE 1: X, C and the outer products UU
@@ -224,6 +239,8 @@ __host__ __device__ constexpr int acc_waves(int K, int MODE) {
 // fit the register file; the weighted modes of K >= 9 (54 / 65 values: 216 / 260 VGPRs for the pairs alone) keep ONE
 // output per lane - the waves of a workgroup pair up over the two halves of the 128-column tile - and do not spill
 __host__ __device__ constexpr int acc_opl(int K, int MODE) { return MODE >= 1 && K >= 9 ? 1 : 2; }
+template <int NW> __device__ void sweep_scalar_side(const ScalarSide& sc, double* red);
+template <int NW> __device__ void sweep_lam_side(const LamSide& lm, double* red);
 
 // CT: storage type of the weights C: double (Binomial: the Polya-Gamma draws) or unsigned char (Gaussian data with
 // missing replicates: C is the replicate count 0..R, 1 byte instead of 8 per cell: 9 instead of 16 B/cell)
@@ -236,7 +253,7 @@ template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double,
 __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void accum_kernel(
     const XT* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
-    int rows_per_block, EigSide side, EigSideCols sidec, TauSide tau, GramSide gram, ChunkMap cm) {
+    int rows_per_block, EigSide side, EigSideCols sidec, TauSide tau, GramSide gram, ChunkMap cm, SweepSide sw) {
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
@@ -255,6 +272,16 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // grid: one workgroup per (tile, chunk), linear; with a side task one more in front of them
   int b = blockIdx.x;
+  // (one scalar test keeps the streaming workgroups clear of the side tasks' arguments)
+  if (b < cm.nside) {
+  if (sw.sc.hyp) {
+    if (b == 0) { sweep_scalar_side<WAVES>(sw.sc, &red[0][0][0]); return; }
+    b -= 1;
+  }
+  if (sw.lam.hyp) {
+    if (b == 0) { sweep_lam_side<WAVES>(sw.lam, &red[0][0][0]); return; }
+    b -= 1;
+  }
   if (side.out) {
     // side task (spectral V sampler): the first workgroup is dispatched first; one wave of it solves the K x K
     // eigenproblem of the Gram beside the stream, its other waves leave at once
@@ -333,6 +360,9 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
     }
     b -= gram.nblocks;
   }
+  return;                                                    // (not reached: cm.nside counts exactly the side workgroups)
+  }
+  b -= cm.nside;
   const int ntiles = ld / ACC_TILE;
   const int lchunk = b / ntiles, tile = b - lchunk * ntiles;
   const int chunk = cm.slot_base + lchunk;                  // slot of the partials
@@ -2139,6 +2169,61 @@ static __global__ __launch_bounds__(256) void lam2_kernel(const double* __restri
                                                    unsigned long long seed, double* __restrict__ hyp) {
   __shared__ double red[4];
   lam2_draw(lsum, M, shape, exact, seed, hyp, red);
+}
+
+// the same draws as side workgroups of the accumulation launches (NW waves; fixed-order reductions: lane-strided partial
+// sums, wave butterflies, the waves' sums in order)
+template <int NW>
+__device__ inline double side_block_sum(double x, double* red) {
+  x = wave_sum(x);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) s += red[w];
+  __syncthreads();
+  return s;
+}
+template <int NW>
+__device__ void sweep_scalar_side(const ScalarSide& sc, double* red) {
+  double sse = 0.0, wsq = 0.0;
+  if (sc.which & 1) {
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < sc.M; j += NW * WAVE) acc += sc.sse_cols[j];
+    sse = side_block_sum<NW>(acc, red) + sc.sconst;
+  }
+  if (sc.which & 2) {
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < sc.NK; e += NW * WAVE) { const double w = sc.W[e]; acc = fma(w, w, acc); }
+    wsq = side_block_sum<NW>(acc, red);
+  }
+  if ((sc.which & 1) && threadIdx.x == 0) {
+    CellRng g(sc.seed, (unsigned long long)HYP_NU2);
+    sc.hyp[HYP_SSE] = sse;
+    sc.hyp[HYP_NU2] = (sc.nu2_b + 0.5 * sse) / gamma_mt(sc.nu2_a + 0.5 * sc.nobs, g);
+  }
+  if ((sc.which & 2) && threadIdx.x == 64) {
+    CellRng g(sc.seed, (unsigned long long)HYP_SIGMA2);
+    sc.hyp[HYP_WSQ] = wsq;
+    sc.hyp[HYP_SIGMA2] = (sc.sig_b + 0.5 * wsq) / gamma_mt(sc.sig_a + 0.5 * sc.nfree, g);
+  }
+}
+template <int NW>
+__device__ void sweep_lam_side(const LamSide& lm, double* red) {
+  double rate;
+  if (lm.exact) {
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < lm.M; j += NW * WAVE) acc += lm.lsum[j];
+    rate = 1.0 / lm.hyp[HYP_LAM2A] + 0.5 * side_block_sum<NW>(acc, red);
+  } else {
+    rate = 0.5 * lm.lsum[lm.M - 1];
+  }
+  if (threadIdx.x == 0) {
+    CellRng g(lm.seed, (unsigned long long)HYP_LAM2);
+    const double lam2 = fmax(1e-5, rate / gamma_mt(0.5 * lm.shape, g));
+    lm.hyp[HYP_LAM2] = lam2;
+    lm.hyp[HYP_LAM2A] = (1.0 / lam2 + 1.0) / g.expo();
+  }
 }
 
 // ============================================================================

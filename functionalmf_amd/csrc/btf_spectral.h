@@ -58,6 +58,10 @@ struct VSpecArgs {
   // of ITS Gram  W'W - sum_i (1 - c_ij / R) w_i w_i'  here (warm-started from its own previous solution in eig_cols)
   CurveLists cv; const double* cv_W; const double* gpart; int ngp; double* eig_cols;
   int eig_cols_ready;                    // 1: the accumulation launch's side tasks already solved the curve columns
+  // [ml] this column's part of the residual sum of squares with the W that stands and the V just drawn:
+  // sum_t (R v_t' W'W v_t - 2 v_t . m_t), m the raw mean part of the partials - what nu2 | rest of the NEXT sweep needs
+  // (besides the constants of the data), so that sweep spends no launch on it; nullptr: not wanted (complete data only)
+  double* sse_out;
 };
 
 // Elimination order inside one system (the order the build declares for this sampler; z[j][k*T + i]
@@ -440,6 +444,8 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
   stamp[4] = __builtin_amdgcn_s_memtime();
   // ---- rotate back, write V[j] (depth-major), Gram share ---------------------------------------------
   double* xout = mraw;
+  double sse_acc = 0.0;
+  const double inv_s2 = -2.0 / a.s;
   for (int idx = tid; idx < n; idx += VS_THREADS) {
     const int t = idx / K, k = idx - t * K;
     const int pos = t < nl ? t : (t < nl + ns ? nl + nr + (t - nl) : nl + (T - 1 - t));
@@ -447,6 +453,16 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
     for (int kk = 0; kk < K; ++kk) s = fma(Ush[k * K + kk], rec[(size_t)(kk * T + pos) * RS + S + 1], s);
     xout[idx] = s;
     a.V[(size_t)jg * n + idx] = s;
+    if (a.sse_out) {     // in the eigen-basis: R lambda_k x~^2 - 2 x~ m~  (mt holds s U'm)
+      const double xt = rec[(size_t)(k * T + pos) * RS + S + 1];
+      sse_acc = fma(xt, fma(a.Rrep * gsh[k], xt, inv_s2 * mt[k * Tp + t]), sse_acc);
+    }
+  }
+  if (a.sse_out) {       // fixed order: wave butterflies, then the four waves' sums
+    const double v = wave_sum(sse_acc);
+    if ((tid & 63) == 0) flag[2 + wave] = v;
+    __syncthreads();
+    if (tid == 0) a.sse_out[j] = (flag[2] + flag[3]) + (flag[4] + flag[5]);
   }
   if (a.gout) {
     __syncthreads();

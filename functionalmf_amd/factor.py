@@ -864,9 +864,20 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
                             self._push_scalars()
                             self._ctx.call("btf_queue_lam2", lam_seed, _native.COMPAT[self.compat])
                             self._lam2_drawn, self._lsum_on_device = True, False
+                # four-launch sweep: when the previous V half-sweep left the residual parts behind, nu2 / sigma2 ride in
+                # the W accumulation launch (btf_queue_scalars) and a queued lam2 in the V accumulation launch
+                seed = self._next_seed()
+                queued = ctypes.c_int32(0)
+                if not self._exchange.active:
+                    self._ctx.call("btf_queue_scalars", seed, which & 3, float(self.nu2_a), float(self.nu2_b),
+                                   float(self.sigma2_a), float(self.sigma2_b), ctypes.byref(queued))
                 self._ctx.call("btf_w_accum", _native.COMPAT[self.compat])
+                if queued.value:
+                    self._sc_dev_new = True
+                    return
                 which |= 4
-            seed = self._next_seed()
+            else:
+                seed = self._next_seed()
             if self._exchange.active:      # this rank's share -> all-reduce of one device double -> identical draws
                 self._ctx.call("btf_draw_scalars", seed, (which & 5) | 8, float(self.nu2_a), float(self.nu2_b),
                                float(self.sigma2_a), float(self.sigma2_b))
@@ -876,7 +887,6 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
                            float(self.sigma2_a), float(self.sigma2_b))
             self._sc_dev_new = True
             return
-        import ctypes
         sse, nobs = ctypes.c_double(), ctypes.c_double()
         if getattr(self, "_sse_queued", False) and not (self._W_host_new or self._V_host_new):
             self._sse_queued = False

@@ -77,6 +77,12 @@ enum {
                                 (whole curves missing, as Y[:3,:3] = NaN in the reference's examples) run the
                                 complete-data kernels plus per-row / per-column corrections (same conditionals as the
                                 weighted form of factor.py:343-346, :388-391); 0: always the weighted form         */
+  BTF_OPT_FUSED_SWEEP = 6,   /* 1 (default): full sweeps with device-resident scalars on complete Gaussian data run as FOUR launches -
+                                the spectral V sampler leaves every column's part of the residual sum of squares behind, nu2 | rest
+                                and sigma2 | rest of the next sweep ride in its W accumulation launch as a side workgroup
+                                (btf_queue_scalars), lam2 | rest in the V accumulation launch (btf_queue_lam2) - instead of six
+                                (a residual reduction and a scalar-draw launch between W accumulation and W solve).  Same
+                                conditionals, same Philox streams; the sums are formed in another order (rounding).  0: six.   */
   BTF_OPT_SPLIT_ACCUM = 5,   /* sharded Gaussian contexts: 1 - the streaming accumulation of a half-sweep runs in two launches: the
                                 chunks that reduce over this rank's OWN block of the fixed factor (its columns of V for the W
                                 half-sweep, its rows of W for the V half-sweep) are queued right behind the kernel that drew
@@ -202,6 +208,14 @@ int btf_queue_Tau2(btf_ctx* ctx, uint64_t seed, double stability);
 /* ... and the NEXT drawing btf_draw_scalars launch also draws lam2 | rest (a second workgroup of that launch; the
  * lam2-rate terms must be on the device by then: a Tau2 update queued with btf_queue_Tau2, or btf_resample_Tau2). */
 int btf_queue_lam2(btf_ctx* ctx, uint64_t seed, int compat);
+/* (if no btf_draw_scalars launch takes it, the V accumulation launch of the next btf_resample_V carries it as a side workgroup)
+ * nu2 | rest (which & 1) and sigma2 | rest (which & 2) as a side workgroup of the NEXT W accumulation launch (btf_w_accum /
+ * btf_resample_W): possible on complete Gaussian data, unsharded, when the spectral V sampler of the previous half-sweep left
+ * the per-column residual parts behind (BTF_OPT_FUSED_SWEEP) and nothing has touched W or V since.  *queued = 1: queued, the
+ * W solve of this sweep will read the new values; 0: not possible now - draw them with btf_draw_scalars.  Replaces the
+ * residual pass of factor.py:411-416 and the two gamma draws of genlasso.py:160-164 / factor.py:130-132. */
+int btf_queue_scalars(btf_ctx* ctx, uint64_t seed, int which, double nu2_a, double nu2_b, double sigma2_a, double sigma2_b,
+                      int32_t* queued);
 
 /* n whole Gibbs sweeps (nu2, sigma2, Tau2 chain, lam2, W, V: GaussianBTF.resample, factor.py:306-311 over :112-128)
  * queued by one call: scalar-noise Gaussian data, device-resident scalars, unsharded.  Seeds: sweep s uses

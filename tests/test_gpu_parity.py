@@ -1797,6 +1797,56 @@ def test_c_driven_sweeps_walk_the_python_driven_chain(golden, name, monkeypatch)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("compat", ["reference", "exact"])
+def test_four_launch_sweep_walks_the_six_launch_chain(golden, compat):
+    """BTF_OPT_FUSED_SWEEP (include/btf.h): from the second sweep on a full device sweep on complete Gaussian data is four
+    launches - nu2 | rest and sigma2 | rest ride in the W accumulation launch, fed by the per-column residual parts the
+    spectral V sampler left behind; lam2 | rest rides in the V accumulation launch - instead of six.  Same conditionals,
+    same Philox streams: the chains coincide up to the rounding of differently grouped sums (factor.py:306-311, :411-416,
+    :130-153 on the device).  The residual parts themselves are checked against the oracle's residual sum of squares."""
+    import ctypes
+    from oracle import btf_oracle as orc
+    from functionalmf_amd import _native
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    g = golden("g2_c2_complete.npz")
+    N, M, T, R, K, tf = [int(x) for x in g["dims"]]
+    st = state_from(g, "s0_")
+
+    def make(fused):
+        np.random.seed(11)
+        m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                            nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], rng="device", device_seed=5, compat=compat)
+        m._ctx.call("btf_set_option", _native.OPT_FUSED_SWEEP, 1 if fused else 0)
+        return m
+    a, b = make(True), make(False)
+    a.resample(g["Y"]); b.resample(g["Y"])                  # the first sweep has no residual parts yet: six launches both
+    for m, want in ((a, 4), (b, 6)):
+        m._ctx.kernel_times()
+        m.resample_sweeps(g["Y"], 5)
+        kt = m._ctx.kernel_times()
+        assert sum(v[1] for v in kt.values()) == 5 * want, kt
+    for x, y, tol in ((a.W, b.W, 1e-8), (a.V, b.V, 1e-6), (a.Tau2, b.Tau2, 1e-6)):
+        assert relerr(np.asarray(x), np.asarray(y)) < tol
+    for x, y in ((a.nu2, b.nu2), (a.sigma2, b.sigma2), (a.lam2, b.lam2)):
+        assert abs(x - y) / abs(y) < 1e-8, (x, y)
+    # the Python-driven sweep takes the same decisions: bit-identical to the C-driven one
+    c, d = make(True), make(True)
+    for _ in range(4):
+        c.resample(g["Y"])
+    d.resample_sweeps(g["Y"], 4)
+    assert np.array_equal(c.W, d.W) and np.array_equal(c.V, d.V) and (c.nu2, c.sigma2, c.lam2) == (d.nu2, d.sigma2, d.lam2)
+    # the residual sum of squares the next nu2 draw would use = the oracle's, for the state as it stands
+    a.sync()
+    sc = np.zeros(8)
+    a._ctx.call("btf_get_scalars", _native.dptr(sc))          # HYP_SSE of the last draw: the state BEFORE the last W, V
+    stn = dict(W=a.W.copy(), V=a.V.copy(), nu2=float(a.nu2))
+    a.resample(g["Y"])
+    a._ctx.call("btf_get_scalars", _native.dptr(sc))
+    sse, n = orc.sse_and_count(stn, g["Y"])
+    assert abs(sc[4] - sse) / sse < 1e-10, (sc[4], sse)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ntrials", [4, 150, 2.5])
 def test_binomial_pseudo_data_bytes_and_fallback(ntrials):
     """Integer counts up to 127 stream the pseudo-data kappa = Y - N/2 as one byte per cell (9 B/cell); larger or
