@@ -115,6 +115,7 @@ SIGNATURES = {
     "btf_get_accum_bytes_per_cell": (C.c_int, [_ctx, _c_dp]),
     "btf_get_V_sampler": (C.c_int, [_ctx, _c_ip]),
     "btf_queue_scalars": (C.c_int, [_ctx, C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _c_ip]),
+    "btf_host_selftest": (C.c_int, []),
     "btf_comm_fork": (C.c_int, [_ctx, C.c_void_p]),
     "btf_comm_join": (C.c_int, [_ctx, C.c_void_p]),
     "btf_set_gathered_W": (C.c_int, [_ctx, _c_dp]),
@@ -166,7 +167,7 @@ def build(force=False, verbose=False, jobs=None):
     jobs = jobs or max(1, min(len(units), os.cpu_count() or 1))
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         objs = list(pool.map(compile_unit, units))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + os.environ.get("BTF_LINK_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -239,14 +239,13 @@ void build_delta_dense(int T, int tf, std::vector<double>& Delta, int& nD) {
     for (int c = 0; c < T; ++c) Delta[(size_t)r * T + c] = rows[r][c];
 }
 
-int build_stencil(btf_ctx* c) {
-  const int T = c->T, tf = c->TF, D1 = tf + 2;
-  std::vector<double> Delta;
-  int nD = 0;
-  build_delta_dense(T, tf, Delta, nD);
-  c->nD = nD;
-  std::vector<int> ptr(T * D1 + 1, 0), row;
-  std::vector<double> coef;
+// the Delta'.Delta stencil per (t, d) as CSR over the penalty rows: pure host code (btf_host_selftest walks it under the
+// host sanitizers, scripts/asan_host.sh)
+void stencil_csr(int T, int tf, const std::vector<double>& Delta, int nD, std::vector<int>& ptr, std::vector<int>& row,
+                 std::vector<double>& coef) {
+  const int D1 = tf + 2;
+  ptr.assign((size_t)T * D1 + 1, 0);
+  row.clear(); coef.clear();
   for (int t = 0; t < T; ++t)
     for (int d = 0; d < D1; ++d) {
       if (t + d < T)
@@ -256,6 +255,16 @@ int build_stencil(btf_ctx* c) {
         }
       ptr[t * D1 + d + 1] = (int)row.size();
     }
+}
+int build_stencil(btf_ctx* c) {
+  const int T = c->T, tf = c->TF, D1 = tf + 2;
+  std::vector<double> Delta;
+  int nD = 0;
+  build_delta_dense(T, tf, Delta, nD);
+  c->nD = nD;
+  std::vector<int> ptr, row;
+  std::vector<double> coef;
+  stencil_csr(T, tf, Delta, nD, ptr, row, coef);
   {  // Delta itself, CSR by row (device Tau2 update)
     std::vector<int> rp(nD + 1, 0), rc;
     std::vector<double> rv;
@@ -455,13 +464,12 @@ hipError_t launch_vbanded_twist(btf_ctx* c, const VBandArgs& a, size_t lds_bytes
 // same-depth-block entries come from the Gram block(s) Ql, the tf+1 prior couplings from the prior band P
 // (btf_banded_twist.h, "assemble the two bands").  Padded to a multiple of the workgroup size with reads of
 // P[0] written to a dummy word.
-int make_fill_table(btf_ctx* c, bool weighted) {
-  const int key = weighted ? 1 : 0;
-  if (c->fill_tab && c->fill_key == key) return BTF_OK;
-  const int T = c->T, K = c->K, TF = c->TF, KK = c->KK, D1 = TF + 2, n = T * K;
+// band assembly program of the twisted kernel, [n][4] = {dst, src, diag-src or -1, 0} in LDS word offsets: pure host code
+void fill_table_host(int T, int K, int TF, bool weighted, std::vector<int>& tab) {
+  const int KK = tri(K), D1 = TF + 2, n = T * K;
   const TwLayout W = tw_layout(T, K, TF, weighted ? 1 : 0);
   const int R1 = W.L.R1, nl = W.nl, nr = W.nr, nL = W.nL;
-  std::vector<int> tab;
+  tab.clear();
   auto put = [&](int dst, int src, int dia) { tab.push_back(dst); tab.push_back(src); tab.push_back(dia); tab.push_back(0); };
   for (int i = 0; i < nL; ++i) {                       // left view: column i (global g = i), entry (g+aa, g)
     const int t = i / K, k = i - t * K;
@@ -478,6 +486,12 @@ int make_fill_table(btf_ctx* c, bool weighted) {
       if (gc - d * K >= nl) put(W.R.band + m * R1 + d * K, W.P + (tc - d) * D1 + d, -1);
   }
   while ((tab.size() / 4) % VT_THREADS) put(W.L.dummy + 1, W.P, -1);
+}
+int make_fill_table(btf_ctx* c, bool weighted) {
+  const int key = weighted ? 1 : 0;
+  if (c->fill_tab && c->fill_key == key) return BTF_OK;
+  std::vector<int> tab;
+  fill_table_host(c->T, c->K, c->TF, weighted, tab);
   int rc;
   if ((rc = dev_alloc(c, &c->fill_tab, tab.size()))) return rc;
   HIPCHK(c, hipMemcpy(c->fill_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -3045,6 +3059,95 @@ int btf_comm_join(btf_ctx* c, void* comm_stream) {
   HIPCHK(c, hipEventRecord(c->ev_join, (hipStream_t)comm_stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
   return BTF_OK;
+}
+
+// Host-only self-test: walks every piece of index arithmetic the host side feeds to the kernels - penalty matrix and
+// stencil tables, the LDS layouts of the three V samplers, the band assembly program, elimination orders, row / chunk
+// geometry of the (split) accumulation, Polya-Gamma sampler classes - over a grid of shapes, checking bounds and
+// coverage.  No HIP call: it runs on a CPU-only box, and under the host sanitizers (scripts/asan_host.sh builds the
+// library's host side with -fsanitize=address,undefined and runs this).  Returns 0, or the source line of the first
+// failed check.
+int btf_host_selftest(void) {
+#define ST_CHECK(cond) do { if (!(cond)) return __LINE__; } while (0)
+  const int Ts[] = {4, 6, 7, 12, 16, 33, 64, 65, 370};
+  for (int T : Ts)
+    for (int tf = 0; tf <= 3; ++tf) {
+      std::vector<double> Delta;
+      int nD = 0;
+      build_delta_dense(T, tf, Delta, nD);
+      ST_CHECK(nD > 0 && (size_t)nD * T == Delta.size());
+      std::vector<int> ptr, row;
+      std::vector<double> coef;
+      stencil_csr(T, tf, Delta, nD, ptr, row, coef);
+      ST_CHECK(ptr.size() == (size_t)T * (tf + 2) + 1 && ptr.front() == 0 && (size_t)ptr.back() == row.size() && row.size() == coef.size());
+      for (size_t e = 0; e + 1 < ptr.size(); ++e) ST_CHECK(ptr[e] <= ptr[e + 1]);
+      for (int r : row) ST_CHECK(r >= 0 && r < nD);
+      for (int K = 1; K <= 10; ++K) {
+        const int n = T * K, S = tf + 1;
+        {   // spectral sampler: pivot order is a permutation, layout offsets increase
+          std::vector<int> seen(T, 0);
+          for (int i = 0; i < T; ++i) { const int d = spectral_depth_of_pivot(i, T, S); ST_CHECK(d >= 0 && d < T); seen[d]++; }
+          for (int v : seen) ST_CHECK(v == 1);
+          const VsLayout L = vs_layout(T, K, tf, nD);
+          const int offs[] = {L.U, L.g, L.itau, L.P, L.Pm, L.mraw, L.mt, L.mtm, L.zz, L.rec, L.win, L.gs, L.flag, L.eG, L.eo, L.esc, L.total};
+          for (size_t i = 0; i + 1 < sizeof(offs) / sizeof(int); ++i) ST_CHECK(offs[i] >= 0 && offs[i] < offs[i + 1]);
+        }
+        if (twist_ok(T, K, tf)) {
+          for (int wt = 0; wt <= 1; ++wt) {
+            const TwLayout W = tw_layout(T, K, tf, wt);
+            ST_CHECK(W.nl + W.nr + W.ns == n && W.total > 0);
+            std::vector<int> seen(n, 0);
+            for (int i = 0; i < n; ++i) { const int g = twist_order(i, n, W.nl, W.nr); ST_CHECK(g >= 0 && g < n); seen[g]++; }
+            for (int v : seen) ST_CHECK(v == 1);
+            if (tw_lds_bytes(T, K, tf, wt) <= 160 * 1024) {
+              std::vector<int> tab;
+              fill_table_host(T, K, tf, wt != 0, tab);
+              ST_CHECK(!tab.empty() && tab.size() % (4 * VT_THREADS) == 0);
+              for (size_t e = 0; e < tab.size(); e += 4) {
+                ST_CHECK(tab[e] >= 0 && tab[e] < W.total && tab[e + 1] >= 0 && tab[e + 1] < W.total);
+                ST_CHECK(tab[e + 2] >= -1 && tab[e + 2] < W.total);
+              }
+            }
+          }
+        }
+        const VbLayout L = vb_layout(T, K, tf, 1);
+        ST_CHECK(L.total > 0 && L.band >= 0 && L.rhs > L.band && L.dummy + 64 * 9 + 8 <= L.total);
+        for (int i = 0; i + 1 < 8; ++i) ST_CHECK(w_z_offset(i + 1, K) - w_z_offset(i, K) == std::min(i + 1, K));
+      }
+    }
+  // rows per workgroup and the split of an accumulation around a rank's own block: every row exactly once
+  const int Rs[] = {64, 512, 576, 1536, 4096, 16384, 65536}, tilesv[] = {1, 4, 64};
+  for (int Rdim : Rs)
+    for (int tiles : tilesv)
+      for (int wt = 0; wt <= 1; ++wt)
+        for (int world = 2; world <= 8; world *= 2)
+          for (int rank = 0; rank < world; ++rank) {
+            const int rpb = pick_rpb(Rdim, tiles, 0, wt != 0);
+            ST_CHECK(rpb >= 64 && rpb % 64 == 0);
+            const int chunk = (Rdim + world - 1) / world, lo = std::min(rank * chunk, Rdim), hi = std::min(lo + chunk, Rdim);
+            const SplitGeom g = split_geom(lo, hi, Rdim, rpb, tiles);
+            if (!g.ok) continue;
+            std::vector<int> cover(Rdim, 0);
+            auto walk = [&](ChunkMap cm, int rp, int nch) {
+              for (int l = 0; l < nch; ++l) {
+                int r0 = cm.row_base + l * rp;
+                if (r0 >= cm.skip_at) r0 += cm.skip_rows;
+                const int r1 = std::min(r0 + rp, cm.row_end);
+                for (int r = r0; r < r1; ++r) { if (r < 0 || r >= Rdim) return false; cover[r]++; }
+              }
+              return true;
+            };
+            ST_CHECK(walk(ChunkMap{g.nch_r, g.lo, INT_MAX, 0, g.hi, 0}, g.rpb_l, g.nch_l));
+            ST_CHECK(walk(ChunkMap{0, 0, g.lo, g.hi - g.lo, Rdim, 0}, rpb, g.nch_r));
+            for (int v : cover) ST_CHECK(v == 1);
+          }
+  // which Polya-Gamma sampler takes a count
+  ST_CHECK(pg_class_of(0.0, PG_MODE_DEFAULT) == PG_CLASS_NONE && pg_class_of(4.0, PG_MODE_DEFAULT) == PG_CLASS_FLAT);
+  ST_CHECK(pg_class_of(33.0, PG_MODE_DEFAULT) == PG_CLASS_SERIES && pg_class_of(33.0, PG_MODE_EXACT_ALL) == PG_CLASS_FLAT);
+  ST_CHECK(pg_class_of(2.5, PG_MODE_EXACT_ALL) == PG_CLASS_FRAC && pg_class_of(2.0, PG_MODE_SERIES_ALL) == PG_CLASS_SERIES);
+  ST_CHECK(pg_class_of(200.0, PG_MODE_EXACT_ALL) == PG_CLASS_NORMAL);
+#undef ST_CHECK
+  return 0;
 }
 
 int btf_get_accum_bytes_per_cell(btf_ctx* c, double* bytes) {

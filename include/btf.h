@@ -348,6 +348,10 @@ int btf_pg_batch(int device, int64_t n, const double* b, const double* psi, uint
 int btf_pg_batch_mode(int device, int64_t n, const double* b, const double* psi, uint64_t seed, int mode, double* out);
 
 int btf_sync(btf_ctx* ctx); /* waits; returns BTF_ENOTPD if a step failed since the last sync */
+/* Host-only self-test of the index arithmetic behind the kernels' tables, LDS layouts, elimination orders and chunk maps
+ * (no GPU, no HIP call): 0, or the source line of the first failed check.  scripts/asan_host.sh runs it on a build of the
+ * host side with -fsanitize=address,undefined (the reference has no native code to sanitise; SURVEY section 5 aux). */
+int btf_host_selftest(void);
 
 /* ---- structured-Gaussian sampler (the fast_mvn equivalent, stand-alone) ----
  * Batched draw  x_b = Q_b^-1 mu_b + L_b^-T z_b,  L_b L_b' = Q_b (+ jitter), for

@@ -1797,6 +1797,42 @@ def test_c_driven_sweeps_walk_the_python_driven_chain(golden, name, monkeypatch)
 
 
 @pytest.mark.gpu
+def test_in_place_edit_of_a_few_cells_is_noticed(golden):
+    """The reference re-reads Y every half-sweep (factor.py:329-330); the build uploads it once.  A few cells set to NaN in
+    place after the first sweep slip past the 64-point fingerprint; the periodic hash of the whole array
+    (data_check_seconds) must catch them, warn and re-upload, after which the half-sweep equals one on a fresh model."""
+    import warnings
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    g = golden("g2_c2_complete.npz")
+    N, M, T, R, K, tf = [int(x) for x in g["dims"]]
+    st = state_from(g, "s0_")
+    Y = g["Y"].copy()
+
+    def make():
+        return GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                               nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"])
+    a = make()
+    a.data_check_seconds = 0.0
+    np.random.seed(3)
+    a._resample_W(Y)
+    Y[5:8, 3:5] = np.nan                                   # 6 curves of 2048: the fingerprint does not see them
+    a.W = st["W"]
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        np.random.seed(3)
+        a._resample_W(Y)
+    assert any("modified in place" in str(w.message) for w in wl)
+    b = make()
+    np.random.seed(3)
+    b._resample_W(Y)
+    assert np.array_equal(a.W, b.W)
+    with warnings.catch_warnings(record=True) as wl:       # nothing changed: no warning, no upload
+        warnings.simplefilter("always")
+        a._resample_W(Y)
+    assert not wl
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("compat", ["reference", "exact"])
 def test_four_launch_sweep_walks_the_six_launch_chain(golden, compat):
     """BTF_OPT_FUSED_SWEEP (include/btf.h): from the second sweep on a full device sweep on complete Gaussian data is four

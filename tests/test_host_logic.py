@@ -196,3 +196,19 @@ def test_no_vgpr_spills_in_the_hot_kernels():
     assert not bad, bad
     ks = {int(m) for r in hot for m in __import__("re").findall(r"accum_kernelILi(\d+)E", r["mangled"])}
     assert ks == set(range(1, 11)), ks
+
+
+def test_host_selftest_of_tables_layouts_and_chunk_maps():
+    """btf_host_selftest (include/btf.h): the host-made stencil tables, LDS layouts, elimination orders, band assembly
+    program and (split) accumulation chunk maps over a grid of shapes - no GPU involved."""
+    from functionalmf_amd import _native
+    assert _native.load().btf_host_selftest() == 0
+
+
+@pytest.mark.timeout(900)
+def test_host_side_under_address_and_ub_sanitizers():
+    """scripts/asan_host.sh: the same self-test on a build whose host side carries AddressSanitizer and
+    UndefinedBehaviorSanitizer (device code unchanged; CPU only - GPU sanitizers are not available on this pool)."""
+    out = subprocess.run(["bash", os.path.join(ROOT, "scripts", "asan_host.sh")], capture_output=True, text=True, timeout=850)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "btf_host_selftest: 0" in out.stdout and "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
