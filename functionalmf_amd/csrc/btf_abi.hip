@@ -127,6 +127,7 @@ struct btf_ctx {
   // nu2 / sigma2 draw that the next W accumulation launch carries as a side workgroup (btf_queue_scalars)
   bool fused_sweep = true;
   double* sse_cols = nullptr; bool sse_cols_valid = false;
+  double* vs_rec = nullptr; size_t vs_rec_elems = 0;       // HBM scratch of the spectral sampler's pivot records (long depth axes)
   bool nu2_drawn_since_v = false;      // a device nu2 draw happened since the last V half-sweep: the caller runs full sweeps
   bool sc_pending = false; unsigned long long sc_seed = 0; int sc_which = 0; double sc_prior[4] = {0, 0, 0, 0};
   bool lam_pending = false; unsigned long long lam_seed = 0; int lam_exact = 0;            // btf_queue_lam2
@@ -524,7 +525,8 @@ hipError_t dispatch_vbanded_twist(btf_ctx* c, const VBandArgs& a, int bw, size_t
 // which sampler a V half-sweep of this context will use: 3 spectral, 2 twisted, 1 single chain (LDS), -1 generic
 int banded_choice_for(const btf_ctx* c, bool wt, bool allow_spectral) {
   const int bw = (c->TF + 1) * c->K;
-  if (allow_spectral && c->sampler == BTF_SAMPLER_SPECTRAL && !wt && !c->binomial && c->st_dense_ok && vs_lds_bytes(c->T, c->K, c->TF, c->nD) <= 160 * 1024) return 3;
+  if (allow_spectral && c->sampler == BTF_SAMPLER_SPECTRAL && !wt && !c->binomial && c->st_dense_ok &&
+      vs_lds_bytes(c->T, c->K, c->TF, c->nD, true) <= 160 * 1024) return 3;        // (pivot records in LDS, or in HBM scratch for long depth axes)
   if (c->sampler == BTF_SAMPLER_GENERIC || bw < 3) return -1;
   if (c->sampler != BTF_SAMPLER_CHAIN && twist_ok(c->T, c->K, c->TF) && tw_lds_bytes(c->T, c->K, c->TF, wt) <= 160 * 1024) return 2;
   if (vb_fast_lds_bytes(c->T, c->K, c->TF, wt) <= 158 * 1024) return 1;
@@ -541,16 +543,16 @@ bool curve_on(const btf_ctx* c) {
 // does the likelihood part run its weighted form (per-cell weights streamed, per-depth Gram blocks)?
 bool lik_weighted(const btf_ctx* c) { return c->weighted && !curve_on(c); }
 int banded_choice(const btf_ctx* c, bool allow_spectral = true) { return banded_choice_for(c, lik_weighted(c), allow_spectral); }
-template <int S>
+template <int S, bool RG>
 hipError_t launch_vspectral(btf_ctx* c, const VSpecArgs& a, size_t lds_bytes) {
   static std::atomic<unsigned long long> attr_set{0};      // one bit per device: the attribute is per device
   if (!dev_flag_is_set(attr_set, c->dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)v_spectral_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)v_spectral_kernel<S, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     dev_flag_set(attr_set, c->dev);
   }
   Prof p(c, BTF_K_V_BANDED);
-  p.launch(v_spectral_kernel<S>, dim3(a.ml), dim3(VS_THREADS), lds_bytes, a);
+  p.launch(v_spectral_kernel<S, RG>, dim3(a.ml), dim3(VS_THREADS), lds_bytes, a);
   return hipSuccess;
 }
 template <int K>
@@ -771,7 +773,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->A8_wT, c->A8_v, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_llp, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->A8_wT, c->A8_v, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_llp, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val, c->sse_cols, c->vs_rec};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
@@ -1555,12 +1557,22 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
       }
       c->ngp_v = emit ? c->ml : 0;
       c->ngp_w = 0;
-      const size_t sl = vs_lds_bytes(T, K, c->TF, c->nD);
-      switch (c->TF + 1) {
-        case 1: e = launch_vspectral<1>(c, sa, sl); break;
-        case 2: e = launch_vspectral<2>(c, sa, sl); break;
-        case 3: e = launch_vspectral<3>(c, sa, sl); break;
-        default: e = launch_vspectral<4>(c, sa, sl); break;
+      const bool rg = vs_lds_bytes(T, K, c->TF, c->nD, false) > 160 * 1024;     // long depth axis: pivot records in HBM scratch
+      if (rg) {
+        const size_t need = (size_t)c->ml * n * (c->TF + 3);
+        if (need > c->vs_rec_elems) { if ((rc = dev_alloc(c, &c->vs_rec, need))) return rc; c->vs_rec_elems = need; }
+        sa.rec_g = c->vs_rec;
+      }
+      const size_t sl = vs_lds_bytes(T, K, c->TF, c->nD, rg);
+      switch ((c->TF + 1) * 2 + (rg ? 1 : 0)) {
+        case 2: e = launch_vspectral<1, false>(c, sa, sl); break;
+        case 3: e = launch_vspectral<1, true>(c, sa, sl); break;
+        case 4: e = launch_vspectral<2, false>(c, sa, sl); break;
+        case 5: e = launch_vspectral<2, true>(c, sa, sl); break;
+        case 6: e = launch_vspectral<3, false>(c, sa, sl); break;
+        case 7: e = launch_vspectral<3, true>(c, sa, sl); break;
+        case 8: e = launch_vspectral<4, false>(c, sa, sl); break;
+        default: e = launch_vspectral<4, true>(c, sa, sl); break;
       }
       HIPCHK(c, e);
       c->sweep_v++;

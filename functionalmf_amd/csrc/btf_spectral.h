@@ -62,6 +62,7 @@ struct VSpecArgs {
   // sum_t (R v_t' W'W v_t - 2 v_t . m_t), m the raw mean part of the partials - what nu2 | rest of the NEXT sweep needs
   // (besides the constants of the data), so that sweep spends no launch on it; nullptr: not wanted (complete data only)
   double* sse_out;
+  double* rec_g;                         // [ml][T K (S+2)] HBM scratch for the pivot records (v_spectral_kernel<S, true>), else nullptr
 };
 
 // Elimination order inside one system (the order the build declares for this sampler; z[j][k*T + i]
@@ -86,7 +87,9 @@ struct VsLayout {      // LDS offsets in doubles
   int U, g, itau, P, Pm, mraw, mt, mtm, zz, rec, win, gs, flag, eG, eo, esc, total;
   int Tp, RS;
 };
-__host__ __device__ inline VsLayout vs_layout(int T, int K, int TF, int nD) {
+// rec_global: the pivot records (n (S+2) doubles, the largest piece) live in HBM scratch instead - long depth axes
+// (the reference's flu data: T = 370, K = 10: 148 KB of records alone) keep the spectral split that way
+__host__ __device__ inline VsLayout vs_layout(int T, int K, int TF, int nD, bool rec_global = false) {
   VsLayout L;
   const int S = TF + 1, n = T * K;
   L.Tp = T + S + 1;
@@ -102,7 +105,7 @@ __host__ __device__ inline VsLayout vs_layout(int T, int K, int TF, int nD) {
   L.mt = o; o += K * L.Tp;         // rotated right-hand sides, k-major, zero padded
   L.mtm = o; o += K * L.Tp;        // ... mirrored
   L.zz = o; o += n;
-  L.rec = o; o += n * L.RS;
+  L.rec = o; if (!rec_global) o += n * L.RS;
   L.win = o; o += 2 * K * (S * (S + 1) + S);   // the two chains' windows at the separator
   L.gs = o; o += VS_THREADS;       // Gram-share scratch: at most 16 groups of KK <= 256 doubles
   L.flag = o; o += 8;
@@ -112,8 +115,8 @@ __host__ __device__ inline VsLayout vs_layout(int T, int K, int TF, int nD) {
   L.total = o;
   return L;
 }
-__host__ __device__ inline size_t vs_lds_bytes(int T, int K, int TF, int nD) {
-  return (size_t)vs_layout(T, K, TF, nD).total * sizeof(double);
+__host__ __device__ inline size_t vs_lds_bytes(int T, int K, int TF, int nD, bool rec_global = false) {
+  return (size_t)vs_layout(T, K, TF, nD, rec_global).total * sizeof(double);
 }
 
 // One elimination chain: LDL' of  A = g I + P  (half-bandwidth S) from one end, the forward substitution of
@@ -194,7 +197,7 @@ __device__ __forceinline__ void spectral_backward(double* __restrict__ rec, int 
   }
 }
 
-template <int S>
+template <int S, bool RG = false>
 __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
   if (a.hyp) {
     if (a.hyp_noise) { a.s = 1.0 / a.hyp[HYP_NU2]; a.sR = a.s * a.Rrep; }
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
   const int K = a.K, T = a.T, n = T * K, KK = tri(K);
   constexpr int D1 = S + 1, RS = S + 2, WN = S * (S + 1) + S;
   constexpr int MAXE = VS_MAXE;
-  const VsLayout L = vs_layout(T, K, a.TF, a.nD);
+  const VsLayout L = vs_layout(T, K, a.TF, a.nD, RG);
   const int Tp = L.Tp;
   int nl, nr, ns;
   spectral_split(T, S, nl, nr, ns);
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
   double* mt = lds + L.mt;
   double* mtm = lds + L.mtm;
   double* zz = lds + L.zz;
-  double* rec = lds + L.rec;
+  double* rec = RG ? a.rec_g + (size_t)j * n * RS : lds + L.rec;
   double* win = lds + L.win;
   double* flag = lds + L.flag;
   long long stamp[6];
