@@ -216,11 +216,15 @@ struct SweepSide { ScalarSide sc; LamSide lam; };
 //         stale cached weights (factor.py:349 and :394-401)
 // waves per workgroup: 16 wherever the accumulators fit 128 VGPRs (1024-thread launch bound);
 // the weighted modes of K >= 6 would spill there and run with 8 waves (256-VGPR budget).
-// Measured (round 2, C3, profiles/README.md): the weighted modes are bound by the number of vector-memory
-// INSTRUCTIONS per row, not by occupancy or by the fused multiply-adds - one 1-KiB load per row runs at 11.5 us
-// (complete data), two loads per row (statistic + byte counts / f64 weights) at 20-23 us, four (stale-weight
-// gathers) at 28-35 us.  A software-pipelined loop (BTF_ACC_PF_WT=1), 12 or 8 waves per workgroup for a larger
-// register budget: all equal or slower.
+// Where the weighted launches stand (round 3, C3, PMC passes in profiles/README.md): complete data issues 0.94 M VALU
+// instructions per launch and takes 10.9 us (6.1 TB/s of the 67.1 MB statistic); byte counts (MODE 1) issue 4.28 M -
+// 65 per wave and row of 128 cells: 2 x (20 FMA + 5 products) + conversions - which is 7 us of f64 issue spread over
+// all SIMDs, beside 12.3 us of HBM time for the 75.5 MB at the complete-data rate; the launch takes 15.3 us.  A wave
+// alternates "loads in flight" and "130 dependent-free FMAs", and at 121 VGPRs (the accumulator pairs alone are 80)
+// three waves per SIMD overlap the two only partly.  Tried, A/B in one gpurun call each: software-pipelined rows
+// (BTF_ACC_PF_WT=1: spills), 8 / 16 waves, four rows in flight (round 2: all equal or slower), one output per lane at
+// K = 5 for twice the waves (BTF_ACC_OPL1_MINK=5: byte counts 14.5 / 14.9 us, but f64 weights 25.7 / 23.4 against
+// 19.0 / 19.2 - not shipped).  MODE 2 adds two scalar gathers of the stale source's weight per lane and row.
 // (complete data at K = 10: the stream itself needs 40 VGPRs, but the eigen side task compiled into the same kernel
 //  spilled 7 under the 128-VGPR budget of 16 waves - 8 waves there, two workgroups per CU)
 __host__ __device__ constexpr int acc_waves(int K, int MODE) {
@@ -238,7 +242,10 @@ __host__ __device__ constexpr int acc_waves(int K, int MODE) {
 // outputs per lane: two adjacent ones (one 16-byte load per row and lane) wherever the K + K(K+1)/2 accumulator pairs
 // fit the register file; the weighted modes of K >= 9 (54 / 65 values: 216 / 260 VGPRs for the pairs alone) keep ONE
 // output per lane - the waves of a workgroup pair up over the two halves of the 128-column tile - and do not spill
-__host__ __device__ constexpr int acc_opl(int K, int MODE) { return MODE >= 1 && K >= 9 ? 1 : 2; }
+#ifndef BTF_ACC_OPL1_MINK
+#define BTF_ACC_OPL1_MINK 9
+#endif
+__host__ __device__ constexpr int acc_opl(int K, int MODE) { return MODE >= 1 && K >= BTF_ACC_OPL1_MINK ? 1 : 2; }
 template <int NW> __device__ void sweep_scalar_side(const ScalarSide& sc, double* red);
 template <int NW> __device__ void sweep_lam_side(const LamSide& lm, double* red);
 
