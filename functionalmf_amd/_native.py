@@ -116,6 +116,7 @@ SIGNATURES = {
     "btf_get_V_sampler": (C.c_int, [_ctx, _c_ip]),
     "btf_queue_scalars": (C.c_int, [_ctx, C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _c_ip]),
     "btf_host_selftest": (C.c_int, []),
+    "btf_set_likelihood_param": (C.c_int, [_ctx, C.c_int, C.c_double]),
     "btf_comm_fork": (C.c_int, [_ctx, C.c_void_p]),
     "btf_comm_join": (C.c_int, [_ctx, C.c_void_p]),
     "btf_set_gathered_W": (C.c_int, [_ctx, _c_dp]),

@@ -74,6 +74,7 @@ struct btf_ctx {
   double* gs_thetas = nullptr; int* gs_ntheta = nullptr; double* gs_ll = nullptr; double* gs_llp = nullptr; size_t gs_llp_elems = 0; double* gs_hh = nullptr; double* gs_cur = nullptr;
   int* gs_nacc = nullptr; double* gs_u = nullptr;
   int gs_chains = 0, gs_what = -1, gs_link = 0;
+  double lik_par[ESS_FAM_COUNT] = {0, 0, 0, 1.0, 1.0};     // parameter per likelihood family (btf_set_likelihood_param)
   long long* dbg = nullptr;
   double* pband = nullptr;
   double* Ta = nullptr; double* Tb = nullptr; double* Tc = nullptr; double* lsum = nullptr;   // horseshoe+ chain (device mode)
@@ -570,25 +571,27 @@ template <int K>
 void launch_ess_ll(btf_ctx* c, int what, int mode, int link, int nbx) {
   Prof p(c, BTF_K_ESS);
   const double Rc = (double)c->R;
+  const LikFam lf{link, c->lik_par[link]};                 // `link` is the likelihood family (ESS_FAM_*)
+  const int tl = ess_link_of(link);                        // the kernel instantiation that evaluates it
   const unsigned char* c8v = c->C8_v; const unsigned char* c8w = c->C8_wT;
   if (what == 1 && mode == 1) {      // per-column chains: W layout
     dim3 grid(nbx, c->M);
 #define ESS_COLS(LINK_)                                                                                                   \
     if (c8w) p.launch(poisson_ll_cols_kernel<K, LINK_, unsigned char>, grid, dim3(ESS_THREADS), 0, (const double*)c->A_wT, c8w, Rc, \
-                      (const double*)c->W, (const double*)c->V, 0, c->N, c->ldw, 0, c->T, (const int*)c->ess_done, c->ess_part);   \
+                      (const double*)c->W, (const double*)c->V, 0, c->N, c->ldw, 0, c->T, (const int*)c->ess_done, c->ess_part, lf);   \
     else p.launch(poisson_ll_cols_kernel<K, LINK_, double>, grid, dim3(ESS_THREADS), 0, (const double*)c->A_wT, (const double*)c->C_wT, Rc, \
-                  (const double*)c->W, (const double*)c->V, 0, c->N, c->ldw, 0, c->T, (const int*)c->ess_done, c->ess_part);
-    if (link == ESS_LINK_LOG) { ESS_COLS(ESS_LINK_LOG) } else { ESS_COLS(ESS_LINK_IDENTITY) }
+                  (const double*)c->W, (const double*)c->V, 0, c->N, c->ldw, 0, c->T, (const int*)c->ess_done, c->ess_part, lf);
+    if (tl == ESS_LINK_LOG) { ESS_COLS(ESS_LINK_LOG) } else if (tl == ESS_LINK_IDENTITY) { ESS_COLS(ESS_LINK_IDENTITY) } else { ESS_COLS(ESS_LINK_GENERIC) }
 #undef ESS_COLS
   } else {
     dim3 grid(nbx, c->N);
     const int per_row = (what == 0 && mode == 1) ? 1 : 0;
 #define ESS_ROWS(LINK_)                                                                                                   \
     if (c8v) p.launch(poisson_ll_rows_kernel<K, LINK_, unsigned char>, grid, dim3(ESS_THREADS), 0, (const double*)c->A_v, c8v, Rc,  \
-                      (const double*)c->W, (const double*)c->V, 0, c->M * c->T, c->ldv, (size_t)0, (const int*)c->ess_done, per_row, c->ess_part); \
+                      (const double*)c->W, (const double*)c->V, 0, c->M * c->T, c->ldv, (size_t)0, (const int*)c->ess_done, per_row, c->ess_part, lf); \
     else p.launch(poisson_ll_rows_kernel<K, LINK_, double>, grid, dim3(ESS_THREADS), 0, (const double*)c->A_v, (const double*)c->C_v, Rc, \
-                  (const double*)c->W, (const double*)c->V, 0, c->M * c->T, c->ldv, (size_t)0, (const int*)c->ess_done, per_row, c->ess_part);
-    if (link == ESS_LINK_LOG) { ESS_ROWS(ESS_LINK_LOG) } else { ESS_ROWS(ESS_LINK_IDENTITY) }
+                  (const double*)c->W, (const double*)c->V, 0, c->M * c->T, c->ldv, (size_t)0, (const int*)c->ess_done, per_row, c->ess_part, lf);
+    if (tl == ESS_LINK_LOG) { ESS_ROWS(ESS_LINK_LOG) } else if (tl == ESS_LINK_IDENTITY) { ESS_ROWS(ESS_LINK_IDENTITY) } else { ESS_ROWS(ESS_LINK_GENERIC) }
 #undef ESS_ROWS
   }
 }
@@ -1608,7 +1611,7 @@ int ess_alloc(btf_ctx* c) {
   return BTF_OK;
 }
 int ess_check(btf_ctx* c, int what, int link) {
-  if (what < 0 || what > 1 || link < 0 || link > 1) return fail(c, BTF_EINVAL, "bad elliptical-slice arguments");
+  if (what < 0 || what > 1 || link < 0 || link >= ESS_FAM_COUNT) return fail(c, BTF_EINVAL, "bad elliptical-slice arguments");
   if (!c->have_data || c->binomial || !c->have_W || !c->have_V || !c->have_hyper)
     return fail(c, BTF_ESTATE, "elliptical slice sampling needs count data (btf_set_data_gaussian statistics), W, V and hyper-parameters");
   if (c->nl != c->N || c->ml != c->M) return fail(c, BTF_ESTATE, "elliptical slice sampling needs an unsharded context");
@@ -1799,14 +1802,18 @@ int gass_eval_launch(btf_ctx* c, int what, int link) {
   a.nsplit = nsplit;
   Prof p(c, BTF_K_ESS);
   const dim3 grid(nch, nsplit);
+  a.lf = LikFam{link, c->lik_par[link]};
+  const int tl = ess_link_of(link);
   if (what == 0) {
     a.F = c->V; a.A = c->A_v; a.C8 = c->C8_v; a.Cd = c->C_v; a.ld = c->ldv;
-    if (link == ESS_LINK_LOG) p.launch(gass_eval_kernel<ESS_LINK_LOG, true>, grid, dim3(GASS_THREADS), 0, a);
-    else p.launch(gass_eval_kernel<ESS_LINK_IDENTITY, true>, grid, dim3(GASS_THREADS), 0, a);
+    if (tl == ESS_LINK_LOG) p.launch(gass_eval_kernel<ESS_LINK_LOG, true>, grid, dim3(GASS_THREADS), 0, a);
+    else if (tl == ESS_LINK_IDENTITY) p.launch(gass_eval_kernel<ESS_LINK_IDENTITY, true>, grid, dim3(GASS_THREADS), 0, a);
+    else p.launch(gass_eval_kernel<ESS_LINK_GENERIC, true>, grid, dim3(GASS_THREADS), 0, a);
   } else {
     a.F = c->W; a.A = c->A_wT; a.C8 = c->C8_wT; a.Cd = c->C_wT; a.ld = c->ldw;
-    if (link == ESS_LINK_LOG) p.launch(gass_eval_kernel<ESS_LINK_LOG, false>, grid, dim3(GASS_THREADS), 0, a);
-    else p.launch(gass_eval_kernel<ESS_LINK_IDENTITY, false>, grid, dim3(GASS_THREADS), 0, a);
+    if (tl == ESS_LINK_LOG) p.launch(gass_eval_kernel<ESS_LINK_LOG, false>, grid, dim3(GASS_THREADS), 0, a);
+    else if (tl == ESS_LINK_IDENTITY) p.launch(gass_eval_kernel<ESS_LINK_IDENTITY, false>, grid, dim3(GASS_THREADS), 0, a);
+    else p.launch(gass_eval_kernel<ESS_LINK_GENERIC, false>, grid, dim3(GASS_THREADS), 0, a);
   }
   if (nsplit > 1)
     hipLaunchKernelGGL(gass_ll_sum_kernel, dim3((nch * GASS_MAXC + 255) / 256), dim3(256), 0, c->stream, (const double*)c->gs_llp, nsplit,
@@ -2003,6 +2010,13 @@ int btf_gibbs_sweeps(btf_ctx* c, int n, uint64_t seed_base, uint64_t draws0, int
     if ((rc = btf_resample_W(c, nullptr, d + 4, compat))) return rc;
     if ((rc = btf_resample_V(c, nullptr, d + 5, compat, eps0, attempts))) return rc;
   }
+  return BTF_OK;
+}
+
+int btf_set_likelihood_param(btf_ctx* c, int family, double par) {
+  if (!c || family < 0 || family >= ESS_FAM_COUNT || !(par == par)) return fail(c, BTF_EINVAL, "bad likelihood family / parameter");
+  if ((family == ESS_FAM_GAUSSIAN || family == ESS_FAM_NEGBIN_LOGIT) && !(par > 0.0)) return fail(c, BTF_EINVAL, "the parameter must be positive");
+  c->lik_par[family] = par;
   return BTF_OK;
 }
 

@@ -492,6 +492,77 @@ __device__ inline void banded_unit_backward_blk(double* lds, const VbLayout L, i
   }
 }
 
+// ---- back-substitution with the sequential part reduced to one mat-vec per 16 columns (band stride 16, bw <= 15) ----
+// x = L^-T w in blocks of 16 columns: block b at column c = 16 b couples only to block b+1 (bw < 16), with
+//   T_b[i][j] = L[c+i, c+j]  (unit lower triangular)   and   N_b[i][j] = L[c+16+i, c+j]  (non-zero for i < j), so
+//   x_b = T_b^-T (w_b - N_b' x_{b+1}) = y_b - M_b x_{b+1},     y_b = T_b^-T w_b,   M_b = T_b^-T N_b'.
+// y_b and the 16 columns of M_b are 17 independent 16-step triangular solves per block that ALL blocks of both views do
+// at once (backpar16_prepare: every thread of the workgroup takes one or two of them, results back in place - M_b over the
+// block's own band storage, y_b over w_b), which leaves one dependent 16 x 16 mat-vec per block for the chain
+// (backpar16_chain: ~60 instructions per 16 columns against ~10 per column for banded_unit_backward_blk).
+// T_b^-T is formed implicitly, solve by solve; its conditioning is that of a 16 x 16 piece of the factor (<= sqrt cond Q).
+__device__ inline void backpar16_prepare(double* lds, const VbLayout LA, int nbA, const VbLayout LB, int nbB, int tid, int nthreads) {
+  constexpr int MAXT = 2;
+  const int ntask = (nbA + nbB) * 17;
+  double s[MAXT][16];
+  int dst[MAXT], dstep[MAXT], dmask[MAXT];
+#pragma unroll
+  for (int u = 0; u < MAXT; ++u) {
+    const int t = tid + u * nthreads;
+    const bool has = t < ntask;
+    const int tt = has ? t : 0;
+    const int blk = tt / 17, cl = tt - blk * 17;
+    const bool inA = blk < nbA;
+    const int c = 16 * (inA ? blk : blk - nbA);
+    const int band0 = (inA ? LA.band : LB.band) + c * 16, rhs0 = (inA ? LA.rhs : LB.rhs) + c;
+    double r[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      // column cl of N_b' (entry j: N_b[cl][j], non-zero for j > cl), or the right-hand side w_b for cl == 16
+      const int a = cl == 16 ? rhs0 + j : band0 + j * 16 + (j > cl ? 16 + cl - j : 0);
+      const double v = lds[a];
+      r[j] = (cl == 16 || j > cl) ? v : 0.0;
+    }
+#pragma unroll
+    for (int j = 15; j >= 0; --j) {        // T_b' s = r, unit upper triangular: s_j = r_j - sum_{i > j} T_b[i][j] s_i
+      double acc = r[j];
+#pragma unroll
+      for (int i = j + 1; i < 16; ++i) acc = fma(-lds[band0 + j * 16 + (i - j)], s[u][i], acc);
+      s[u][j] = acc;
+    }
+    // where the results go: y_b over w_b; column cl of M_b into the block's own storage, entry M_b[j][cl] at word
+    // cl * 16 + ((j + cl) & 15) - the chain's lane j then reads M_b[j][i], i fixed, at consecutive words (no bank
+    // conflict; rows of 16 doubles at stride 16 would put all sixteen lanes on one bank), and so do these writes.
+    // Tasks beyond the list park theirs in the thread's private dummy word.
+    dst[u] = !has ? LA.dummy + 64 + (tid & 63) : (cl == 16 ? rhs0 : band0 + cl * 16);
+    dstep[u] = !has || cl == 16 ? 0 : cl;                  // word (j + dstep) & dmask of the destination
+    dmask[u] = !has ? 0 : (cl == 16 ? 31 : 15);
+  }
+  __syncthreads();                         // every solve has read its block before any block is overwritten
+#pragma unroll
+  for (int u = 0; u < MAXT; ++u)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) lds[dst[u] + ((j + dstep[u]) & dmask[u])] = s[u][j];
+  __syncthreads();
+}
+// the chain of one view (one wave; lanes 16.. repeat lanes 0..15): x_b = y_b - M_b x_{b+1}, top block first
+__device__ inline void backpar16_chain(double* lds, const VbLayout L, int nb) {
+  const int j = threadIdx.x & 15;
+  double xprev = 0.0;
+  for (int b = nb - 1; b >= 0; --b) {
+    const int c = 16 * b;
+    const double* Mb = lds + L.band + c * 16;
+    double m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = Mb[i * 16 + ((j + i) & 15)];      // M_b[j][i] (the swizzle of backpar16_prepare)
+    double acc = lds[L.rhs + c + j];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc = fma(-m[i], bcast_lane(xprev, i), acc);
+    xprev = acc;
+    lds[L.rhs + c + j] = acc;
+  }
+}
+
 // dispatch on bw (wave-uniform); false if no blocked variant exists for this band width
 template <bool ROW16>
 __device__ inline bool banded_unit_backward_auto(double* lds, const VbLayout L, int n, int bw) {

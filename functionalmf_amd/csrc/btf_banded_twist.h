@@ -22,6 +22,9 @@
 namespace btf {
 
 constexpr int VT_THREADS = 256;
+#ifndef BTF_TWIST_BACKPAR
+#define BTF_TWIST_BACKPAR 0       // 1: parallel block solves + one mat-vec per 16 columns (backpar16_*): measured 19.6 k cycles against 16.2 k for the column-by-column routine (round 3) - kept for A/B, not shipped
+#endif
 
 struct TwLayout {
   VbLayout L, R, S;      // left chain, right chain, separator: views for the shared routines
@@ -506,8 +509,16 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   }
   __syncthreads();
   stamp[4] = __builtin_amdgcn_s_memtime();
-  if (wave == 0) banded_unit_backward_auto<ROW16>(lds, W.L, nL, bw);
-  else if (wave == 1) banded_unit_backward_auto<ROW16>(lds, W.R, nR, bw);
+  if (ROW16 && BTF_TWIST_BACKPAR) {
+    // (band stride 16: the 2 x 11 blocks' triangular solves in parallel, then one mat-vec per block and chain)
+    const int nbL = (nL + 15) / 16, nbR = (nR + 15) / 16;
+    backpar16_prepare(lds, W.L, nbL, W.R, nbR, tid, VT_THREADS);
+    if (wave == 0) backpar16_chain(lds, W.L, nbL);
+    else if (wave == 1) backpar16_chain(lds, W.R, nbR);
+  } else {
+    if (wave == 0) banded_unit_backward_auto<ROW16>(lds, W.L, nL, bw);
+    else if (wave == 1) banded_unit_backward_auto<ROW16>(lds, W.R, nR, bw);
+  }
   __syncthreads();
   stamp[5] = __builtin_amdgcn_s_memtime();
   // ---- write V[j] (depth-major), Gram share --------------------------------------------------

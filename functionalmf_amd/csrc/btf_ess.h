@@ -22,7 +22,21 @@
 
 namespace btf {
 
-enum { ESS_LINK_LOG = 0, ESS_LINK_IDENTITY = 1 };
+// Likelihood families of the slice samplers, all functions of the hoisted statistics (S1 = sum_r y, cnt = observed
+// replicates) and the linear predictor eta = w.v; the state-independent normalising terms are left to the caller:
+//   0 Poisson, log link       S1 eta - cnt exp(eta)
+//   1 Poisson, identity link  S1 log(eta) - cnt eta                    (-inf where eta <= 0)
+//   2 Bernoulli / Binomial, logit link (S1 successes of cnt trials)   S1 eta - cnt softplus(eta)
+//   3 Gaussian, identity link, known variance (par = 1 / variance)    par (S1 eta - cnt eta^2 / 2)
+//   4 Negative-Binomial, logit link, known rate (par = r)             S1 eta - (S1 + cnt r) softplus(eta)
+// Families 0 and 1 have kernels of their own (table-based exp / log); 2..4 share the ESS_LINK_GENERIC instantiation,
+// which takes the family and its parameter at run time (libm exp / log1p: one evaluation is still one pass).
+enum { ESS_LINK_LOG = 0, ESS_LINK_IDENTITY = 1, ESS_LINK_GENERIC = 2 };
+enum { ESS_FAM_POISSON_LOG = 0, ESS_FAM_POISSON_IDENTITY = 1, ESS_FAM_BERNOULLI_LOGIT = 2, ESS_FAM_GAUSSIAN = 3, ESS_FAM_NEGBIN_LOGIT = 4,
+       ESS_FAM_COUNT = 5 };
+struct LikFam { int fam; double par; };
+__host__ __device__ constexpr int ess_link_of(int fam) { return fam <= ESS_FAM_POISSON_IDENTITY ? fam : ESS_LINK_GENERIC; }
+__device__ __forceinline__ double softplus(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 constexpr int ESS_THREADS = 256;
 
 // prior draw of W: N(0, sigma2) on the free entries (lower triangle of the leading K rows, everything below),
@@ -59,10 +73,15 @@ static __global__ void ess_combine_kernel(const double* __restrict__ x0, const d
 
 // (log_tab / exp_tab: table-based double-precision log and exp, btf_device.h)
 template <int LINK>
-__device__ __forceinline__ double poisson_term(double s1, double cnt, double eta, const double2* __restrict__ ltab) {
+__device__ __forceinline__ double poisson_term(double s1, double cnt, double eta, const double2* __restrict__ ltab, LikFam lf = LikFam{0, 0.0}) {
   if (!(cnt > 0.0)) return 0.0;
   if constexpr (LINK == ESS_LINK_LOG) return fma(s1, eta, -cnt * exp_tab(eta, ltab));
-  else return eta > 0.0 ? fma(s1, log_tab(eta, ltab), -cnt * eta) : -INFINITY;
+  else if constexpr (LINK == ESS_LINK_IDENTITY) return eta > 0.0 ? fma(s1, log_tab(eta, ltab), -cnt * eta) : -INFINITY;
+  else {
+    if (lf.fam == ESS_FAM_GAUSSIAN) return lf.par * eta * fma(-0.5 * cnt, eta, s1);
+    const double sp = softplus(eta);
+    return lf.fam == ESS_FAM_BERNOULLI_LOGIT ? fma(s1, eta, -cnt * sp) : fma(s1, eta, -fma(cnt, lf.par, s1) * sp);
+  }
 }
 
 // Poisson log-likelihood of the local rows, lanes along (j,t) (V layout): part[i][bx] = sum over the block's cells of
@@ -71,13 +90,13 @@ template <int K, int LINK, typename CT>
 __global__ __launch_bounds__(ESS_THREADS) void poisson_ll_rows_kernel(
     const double* __restrict__ A, const CT* __restrict__ Cx, double Rc, const double* __restrict__ W,
     const double* __restrict__ V, int row0, int ncols, int ld, size_t col0, const int* __restrict__ done, int per_row,
-    double* __restrict__ part) {
+    double* __restrict__ part, LikFam lf) {
   __shared__ double red[ESS_THREADS / WAVE];
   __shared__ double2 ltab[LOGTAB_N];
   const int i = blockIdx.y;
   if (per_row && done[i]) return;
   if (!per_row && done[0]) return;
-  if constexpr (LINK != ESS_LINK_LOG) log_table_build(ltab); else exp_table_build(ltab);
+  if constexpr (LINK == ESS_LINK_IDENTITY) log_table_build(ltab); else if constexpr (LINK == ESS_LINK_LOG) exp_table_build(ltab);
   __syncthreads();
   double w[K];
 #pragma unroll
@@ -90,7 +109,7 @@ __global__ __launch_bounds__(ESS_THREADS) void poisson_ll_rows_kernel(
     for (int k = 0; k < K; ++k) eta = fma(w[k], v[k], eta);
     const double s1 = A[(size_t)i * ld + l];
     const double cnt = Cx ? (double)Cx[(size_t)i * ld + l] : Rc;
-    s += poisson_term<LINK>(s1, cnt, eta, ltab);
+    s += poisson_term<LINK>(s1, cnt, eta, ltab, lf);
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -108,12 +127,12 @@ template <int K, int LINK, typename CT>
 __global__ __launch_bounds__(ESS_THREADS) void poisson_ll_cols_kernel(
     const double* __restrict__ A, const CT* __restrict__ Cx, double Rc, const double* __restrict__ W,
     const double* __restrict__ V, int row0, int nl, int ld, int col0, int T, const int* __restrict__ done,
-    double* __restrict__ part) {
+    double* __restrict__ part, LikFam lf) {
   __shared__ double red[ESS_THREADS / WAVE];
   __shared__ double2 ltab[LOGTAB_N];
   const int j = blockIdx.y;
   if (done[j]) return;
-  if constexpr (LINK != ESS_LINK_LOG) log_table_build(ltab); else exp_table_build(ltab);
+  if constexpr (LINK == ESS_LINK_IDENTITY) log_table_build(ltab); else if constexpr (LINK == ESS_LINK_LOG) exp_table_build(ltab);
   __syncthreads();
   double s = 0.0;
   for (int i = blockIdx.x * ESS_THREADS + threadIdx.x; i < nl; i += gridDim.x * ESS_THREADS) {
@@ -127,7 +146,7 @@ __global__ __launch_bounds__(ESS_THREADS) void poisson_ll_cols_kernel(
       for (int k = 0; k < K; ++k) eta = fma(w[k], v[k], eta);
       const size_t o = ((size_t)j * T + t) * ld + i;
       const double cnt = Cx ? (double)Cx[o] : Rc;
-      s += poisson_term<LINK>(A[o], cnt, eta, ltab);
+      s += poisson_term<LINK>(A[o], cnt, eta, ltab, lf);
     }
   }
   s = wave_sum(s);

@@ -260,6 +260,7 @@ struct GassEvalArgs {
   int N, M, T, K, ld;
   const double* thetas; const int* ntheta; double* ll;   // [nchains][GASS_MAXC] (nsplit == 1) or partial sums [nchains][nsplit][GASS_MAXC]
   int nsplit;                                           // workgroups per chain (blockIdx.y): tiles dealt round-robin
+  LikFam lf;                                            // likelihood family and parameter (ESS_LINK_GENERIC)
 };
 
 template <int LINK, bool ROWS>
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(GASS_THREADS) void gass_eval_kernel(GassEvalArgs a)
   __shared__ double e0s[GASS_CT], e1s[GASS_CT], s1s[GASS_CT], cns[GASS_CT];
   __shared__ double red[GASS_THREADS / WAVE][GASS_MAXC];
   __shared__ double2 ltab[LOGTAB_N];
-  if constexpr (LINK != ESS_LINK_LOG) log_table_build(ltab); else exp_table_build(ltab);      // (the tile loop's first barrier publishes it)
+  if constexpr (LINK == ESS_LINK_IDENTITY) log_table_build(ltab); else if constexpr (LINK == ESS_LINK_LOG) exp_table_build(ltab);      // (the tile loop's first barrier publishes it)
   const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, K = a.K, T = a.T;
   const int nth = a.ntheta[ch];
   const double th0 = lane < nth ? a.thetas[(size_t)ch * GASS_MAXC + lane] : 0.0;
@@ -308,8 +309,8 @@ __global__ __launch_bounds__(GASS_THREADS) void gass_eval_kernel(GassEvalArgs a)
     const int lim = min(GASS_CT, ncell - base);
     for (int e = wave; e < lim; e += GASS_THREADS / WAVE) {
       const double d0 = e0s[e], d1 = e1s[e], sv = s1s[e], cv = cns[e];
-      acc0 += poisson_term<LINK>(sv, cv, fma(c0, d0, s0 * d1), ltab);
-      acc1 += poisson_term<LINK>(sv, cv, fma(c1, d0, s1 * d1), ltab);
+      acc0 += poisson_term<LINK>(sv, cv, fma(c0, d0, s0 * d1), ltab, a.lf);
+      acc1 += poisson_term<LINK>(sv, cv, fma(c1, d0, s1 * d1), ltab, a.lf);
     }
   }
   red[wave][lane] = acc0;

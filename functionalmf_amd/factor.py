@@ -1189,7 +1189,11 @@ class NonconjugateBayesianTensorFiltering(BayesianTensorFiltering):
         "poisson" / "poisson_log"   counts y ~ Poisson(exp(w.v))
         "poisson_identity"          counts y ~ Poisson(w.v), zero likelihood where w.v <= 0
                                     (the likelihood of examples/poisson_tensor_filtering.py:26-37)
-    data: counts (N,M,T) or (N,M,T,R), NaN = missing.
+        "bernoulli_logit"           y in {0, 1} ~ Bernoulli(ilogit(w.v))      (scipy.stats.bernoulli.logpmf)
+        "gaussian"                  y ~ N(w.v, likelihood_param)              (likelihood_param: the variance)
+        "negbin_logit"              y ~ NB(likelihood_param, 1 - ilogit(w.v)) (scipy.stats.nbinom; likelihood_param: the rate r)
+    - all functions of the hoisted per-cell statistics (sum and count of the observed replicates).
+    data: (N,M,T) or (N,M,T,R), NaN = missing.
 
     ess = "joint" (default): ONE slice over all of W, then one over all of V, as the reference; with rng="host" the
           normals and uniforms come from the global legacy numpy generator in the reference's order, so a seeded
@@ -1198,9 +1202,9 @@ class NonconjugateBayesianTensorFiltering(BayesianTensorFiltering):
           the other factor, as in the reference's constrained model (factor.py:665-720) - all brackets shrinking
           in lockstep on the device; mixes faster than the joint slice, whose step shrinks with the dimension."""
 
-    LINKS = {"poisson": 0, "poisson_log": 0, "poisson_identity": 1}
+    LINKS = {"poisson": 0, "poisson_log": 0, "poisson_identity": 1, "bernoulli_logit": 2, "gaussian": 3, "negbin_logit": 4}
 
-    def __init__(self, nrows, ncols, ndepth, loglikelihood, ess="joint", ess_max_rounds=40, **kwargs):
+    def __init__(self, nrows, ncols, ndepth, loglikelihood, ess="joint", ess_max_rounds=40, likelihood_param=None, **kwargs):
         if callable(loglikelihood) or loglikelihood not in self.LINKS:
             raise NotImplementedError("loglikelihood must name a device likelihood %s: the slice loop evaluates it on "
                                       "the GPU, there is no host path for a Python callback" % sorted(self.LINKS))
@@ -1213,6 +1217,13 @@ class NonconjugateBayesianTensorFiltering(BayesianTensorFiltering):
             raise ValueError("ess='rows' draws its uniforms on the device: use rng='device'")
         self.loglikelihood = loglikelihood
         self._link = self.LINKS[loglikelihood]
+        if self._link in (3, 4):
+            if likelihood_param is None or not likelihood_param > 0:
+                raise ValueError("loglikelihood=%r needs likelihood_param > 0 (the variance / the rate)" % loglikelihood)
+            self.likelihood_param = float(likelihood_param)
+            self._ctx.call("btf_set_likelihood_param", self._link, 1.0 / self.likelihood_param if self._link == 3 else self.likelihood_param)
+        else:
+            self.likelihood_param = None
         self.ess, self.ess_max_rounds = ess, int(ess_max_rounds)
         self.ess_evaluations = 0          # likelihood evaluations of the last host-driven slice (diagnostic)
         self._ll_const = 0.0
@@ -1227,10 +1238,21 @@ class NonconjugateBayesianTensorFiltering(BayesianTensorFiltering):
         rows, cols = self._plan.slabs(Y4)
         self._ctx.call("btf_set_data_gaussian", _native.dptr(rows), _native.dptr(cols), int(Y4.shape[3]))
         obs = ~np.isnan(Y4)
-        self._ll_const = -float(gammaln(np.where(obs, Y4, 0.0) + 1.0)[obs].sum())     # - sum lgamma(y+1): state-independent
+        y = np.where(obs, Y4, 0.0)
+        # the state-independent part of the log-likelihood (the device kernels leave it out)
+        if self._link <= 1:
+            self._ll_const = -float(gammaln(y + 1.0)[obs].sum())                      # - sum lgamma(y+1)
+        elif self._link == 2:
+            self._ll_const = 0.0
+        elif self._link == 3:
+            s2 = self.likelihood_param
+            self._ll_const = -float(0.5 * (y[obs] ** 2).sum() / s2 + 0.5 * obs.sum() * np.log(2 * np.pi * s2))
+        else:
+            r = self.likelihood_param
+            self._ll_const = float((gammaln(y + r) - gammaln(r) - gammaln(y + 1.0))[obs].sum())
 
     def log_likelihood(self, data):
-        """Poisson log-likelihood of the current state (what the reference's callback returns)."""
+        """Log-likelihood of the current state (what the reference's callback returns), normalising terms included."""
         import ctypes
         self._bind_data(data)
         self._push_state()

@@ -386,7 +386,12 @@ int btf_mvn_dense(int device, int batch, int n, const double* A, int form, const
  * likelihood over the statistics btf_set_data_gaussian hoisted (counts y, NaN = missing):
  *   link 0  Poisson, log link:       sum_cells  S1 (w.v) - cnt exp(w.v)
  *   link 1  Poisson, identity link:  sum_cells  S1 log(w.v) - cnt (w.v),  -inf where w.v <= 0
- * (the state-independent term - sum lgamma(y+1) is left to the caller).  what: 0 = W, 1 = V.  Unsharded contexts.
+ *   link 2  Bernoulli / Binomial, logit link (S1 successes of cnt trials):  S1 (w.v) - cnt log(1 + exp(w.v))
+ *   link 3  Gaussian, identity link, known variance s2 (parameter 1/s2):     (S1 (w.v) - cnt (w.v)^2 / 2) / s2
+ *   link 4  Negative-Binomial, logit link, known rate r (parameter r):      S1 (w.v) - (S1 + cnt r) log(1 + exp(w.v))
+ * - every one a function of the hoisted statistics S1 = sum_r y, cnt = observed replicates; the state-independent terms
+ * (- sum lgamma(y+1), the Gaussian's - sum y^2 / 2 s2 - n log(2 pi s2) / 2, the Negative-Binomial's log binomial
+ * coefficients) are left to the caller.  Parameters: btf_set_likelihood_param.  what: 0 = W, 1 = V.  Unsharded contexts.
  *
  * Host-driven form (rng="host": the uniforms come from the caller's generator, so a seeded chain walks the
  * reference's path): btf_ess_begin saves the current state x0 and draws nu (z: the normals of
@@ -400,6 +405,7 @@ int btf_mvn_dense(int device, int batch, int n, const double* A, int form, const
  * mode 1: one slice per row of W (resp. per column of V) - the rows are conditionally independent given V - all
  * brackets shrinking in lockstep, one proposal per row per round.  btf_ess_info (synchronises): chains that used up
  * max_rounds (they keep the current state) and the log-likelihood the first chain ended on.                      */
+int btf_set_likelihood_param(btf_ctx* ctx, int link, double parameter);   /* links 3 (1 / variance) and 4 (rate); > 0 */
 int btf_ess_begin(btf_ctx* ctx, int what, const double* z, uint64_t seed, double eps0, int attempts);
 int btf_ess_eval(btf_ctx* ctx, int what, double theta, int current, int link, double* ll);
 int btf_ess_run(btf_ctx* ctx, int what, int link, int mode, const double* z, uint64_t seed, int max_rounds,
@@ -408,8 +414,8 @@ int btf_ess_info(btf_ctx* ctx, int32_t* unfinished, double* ll_first);
 
 /* ---- generalized analytic slice sampling (gass.py:13-130) for the constrained non-conjugate model
  * (ConstrainedNonconjugateBayesianTensorFiltering._resample_W / _resample_V, factor.py:665-855): every row of W (what = 0)
- * or every column of V (what = 1) is one chain, all chains advance together.  Likelihood: the device Poisson likelihoods
- * of btf_ess_* (link 0 = log, 1 = identity) on the statistics of btf_set_data_gaussian.  Unsharded contexts.
+ * or every column of V (what = 1) is one chain, all chains advance together.  Likelihood: the device likelihoods
+ * of btf_ess_* (links 0..4) on the statistics of btf_set_data_gaussian.  Unsharded contexts.
  *
  * btf_gass_set_constraints: cons [J][T+1], row q = (Cons_q, bound_q): every curve tau_ij = (w_i . v_jt)_t must satisfy
  *   Cons_q . tau_ij >= bound_q (the reference's `Constraints`, factor.py:910); row_cons [nrc][K+1]: fixed constraints on

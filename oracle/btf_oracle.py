@@ -1095,7 +1095,36 @@ def poisson_loglik(W, V, Y, link="log"):
     return float(term.sum())
 
 
-def nonconjugate_w_step(st, Y, link="log", z=None, info=None):
+def family_loglik(W, V, Y, family, param=None):
+    """Log-likelihoods a user of the reference would pass to NonconjugateBayesianTensorFiltering as callbacks
+    (factor.py:567-570 takes any `loglikelihood(W, V, data)`), for the families the build evaluates on the device,
+    eta = w.v per cell, summed over the observed replicates (NaN = missing), normalising terms included:
+      "bernoulli_logit"  y in {0, 1}:  y eta - log(1 + e^eta)                      (scipy.stats.bernoulli.logpmf(y, ilogit(eta)))
+      "gaussian"         norm.logpdf(y, eta, sqrt(param)), param = the variance
+      "negbin_logit"     nbinom.logpmf(y, param, 1 - ilogit(eta)), param = the rate r"""
+    from scipy.special import gammaln
+    eta = np.einsum("nk,mtk->nmt", W, V)[..., None]
+    Y4 = Y[..., None] if Y.ndim == 3 else Y
+    obs = ~np.isnan(Y4)
+    y = np.where(obs, Y4, 0.0)
+    sp = np.logaddexp(0.0, eta)                             # softplus
+    if family == "bernoulli_logit":
+        term = y * eta - sp
+    elif family == "gaussian":
+        term = -0.5 * (y - eta) ** 2 / param - 0.5 * np.log(2 * np.pi * param)
+    elif family == "negbin_logit":
+        term = gammaln(y + param) - gammaln(param) - gammaln(y + 1.0) + y * eta - (y + param) * sp
+    else:
+        raise ValueError(family)
+    return float(np.where(obs, term, 0.0).sum())
+
+
+def nc_loglik(W, V, Y, link, param=None):
+    """dispatcher: the Poisson links of poisson_loglik, or a family of family_loglik"""
+    return poisson_loglik(W, V, Y, link) if link in ("log", "identity") else family_loglik(W, V, Y, link, param)
+
+
+def nonconjugate_w_step(st, Y, link="log", z=None, info=None, param=None):
     """factor.py:572-581: prior sample of the packed W (precision I/sigma2: nu = sqrt(sigma2) z), one elliptical
     slice over all of it with the full-tensor likelihood."""
     W, V = st["W"], st["V"]
@@ -1105,13 +1134,13 @@ def nonconjugate_w_step(st, Y, link="log", z=None, info=None):
     nu = np.sqrt(st["sigma2"]) * np.asarray(z)
 
     def ll(vec, _):
-        return poisson_loglik(unpack_W(vec, np.zeros_like(W)), V, Y, link)
+        return nc_loglik(unpack_W(vec, np.zeros_like(W)), V, Y, link, param)
     new, _ = elliptical_slice(cur, nu, ll, info=info)
     unpack_W(new, W)
     return W
 
 
-def nonconjugate_v_step(st, Y, Delta, link="log", perm="depth", z=None, info=None):
+def nonconjugate_v_step(st, Y, Delta, link="log", perm="depth", z=None, info=None, param=None):
     """factor.py:583-590: prior sample of the packed V (block-diagonal precision I_K (x) Delta' Lambda_j Delta per
     column, k-major, factor.py:176-195; drawn column by column in the declared order `perm`), one elliptical
     slice over all of V."""
@@ -1134,7 +1163,7 @@ def nonconjugate_v_step(st, Y, Delta, link="log", perm="depth", z=None, info=Non
 
     def ll(vec, _):
         Vp = np.stack([vec[j * n:(j + 1) * n].reshape(K, T).T for j in range(M)])
-        return poisson_loglik(W, Vp, Y, link)
+        return nc_loglik(W, Vp, Y, link, param)
     new, _ = elliptical_slice(cur, nu, ll, info=info)
     for j in range(M):
         V[j] = new[j * n:(j + 1) * n].reshape(K, T).T

@@ -1319,6 +1319,44 @@ def test_nonconjugate_joint_slice_walks_the_reference_path(golden, link):
     assert relerr(model.V, g[tag + "V_after"]) < 1e-6
 
 
+@pytest.mark.parametrize("family", ["bernoulli_logit", "gaussian", "negbin_logit"])
+def test_nonconjugate_other_likelihoods_walk_the_reference_path(golden, family):
+    """The device likelihoods beyond Poisson (include/btf.h, links 2..4): rng="host", the chain must land where the
+    reference's NonconjugateBayesianTensorFiltering landed with the matching scipy.stats callback (fixture g11, made by
+    the reference itself: tests/golden/make_golden_lik.py), after the same number of likelihood evaluations; then whole
+    device-RNG slices (joint and per row / per column) leave a finite log-likelihood."""
+    from oracle import btf_oracle as orc
+    from functionalmf_amd.factor import NonconjugateBayesianTensorFiltering
+    g = golden("g11_likelihoods.npz")
+    tag = "lk_%s_" % family
+    N, M, T, R, K, tf = [int(x) for x in g[tag + "dims"]]
+    par = None if np.isnan(g[tag + "param"]) else float(g[tag + "param"])
+    st = {k: (float(g[tag + "s0_" + k]) if k in ("lam2", "sigma2") else g[tag + "s0_" + k].copy()) for k in ("W", "V", "Tau2", "lam2", "sigma2")}
+    Y = g[tag + "Y"]
+    model = NonconjugateBayesianTensorFiltering(N, M, T, family, likelihood_param=par, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"],
+                                                lam2_init=st["lam2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"])
+    ll0 = model.log_likelihood(Y)
+    assert abs(ll0 - float(g[tag + "ll0"])) < 1e-9 * abs(ll0), (ll0, float(g[tag + "ll0"]))
+    np.random.seed(int(g[tag + "seeds"][0]))
+    model._resample_W(Y)
+    assert model.ess_evaluations == int(g[tag + "W_nev"])
+    assert relerr(model.W, g[tag + "W_after"]) < 1e-10
+    np.random.seed(int(g[tag + "seeds"][1]))
+    model._resample_V(Y)
+    assert model.ess_evaluations == int(g[tag + "V_nev"])
+    assert relerr(model.V, g[tag + "V_after"]) < 1e-6
+    assert abs(model.log_likelihood(Y) - orc.family_loglik(model.W, model.V, Y, family, par)) < 1e-9 * abs(ll0)
+    for ess in ("joint", "rows"):
+        np.random.seed(4)            # (no Tau2_init: with it the reference - and the build - have no horseshoe+ levels to update, quirk Q6)
+        m2 = NonconjugateBayesianTensorFiltering(N, M, T, family, likelihood_param=par, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"],
+                                                 lam2_init=st["lam2"], W_init=st["W"], V_init=st["V"], rng="device", ess=ess)
+        l0 = m2.log_likelihood(Y)
+        for _ in range(30):
+            m2.resample(Y)
+        l1 = m2.log_likelihood(Y)
+        assert np.isfinite(l1) and l1 > l0 - 0.5 * abs(l0), (ess, l0, l1)
+
+
 @pytest.mark.parametrize("ess", ["joint", "rows"])
 def test_nonconjugate_device_slices_stay_on_the_slice_and_recover_rates(ess):
     """rng="device": every update must leave the log-likelihood finite; the per-row / per-column slices must find the
@@ -1745,6 +1783,40 @@ def test_gass_device_chain_stays_feasible_and_fits(golden):
     assert model.log_likelihood(Y) > ll0
     fit = acc / n
     assert np.corrcoef(fit.ravel(), rate.ravel())[0, 1] > 0.9
+
+
+@pytest.mark.gpu
+def test_gass_with_a_gaussian_likelihood_keeps_monotone_curves_and_fits():
+    """The constrained model with another device likelihood (link 3, Gaussian with known variance): monotone curves
+    observed with noise.  Every state keeps every curve monotone, and the posterior mean recovers the curves."""
+    from functionalmf_amd.factor import ConstrainedNonconjugateBayesianTensorFiltering
+    rs = np.random.RandomState(13)
+    N, M, T, R, K = 20, 8, 12, 3, 3
+    Wt = rs.gamma(2.0, 0.4, size=(N, K))
+    Vt = np.cumsum(rs.gamma(1.0, 0.15, size=(M, T, K)), axis=1)
+    curve = np.einsum("nk,mtk->nmt", Wt, Vt)
+    Y = curve[..., None] + rs.normal(0, 0.3, size=(N, M, T, R))
+    Y[:2, :2] = np.nan
+    Cons = np.zeros((T - 1, T + 1))                                        # monotone (a Gaussian mean may be negative)
+    Cons[np.arange(T - 1), np.arange(T - 1)] = -1.0
+    Cons[np.arange(T - 1), np.arange(1, T)] = 1.0
+    np.random.seed(5)
+    model = ConstrainedNonconjugateBayesianTensorFiltering(N, M, T, "gaussian", Cons, likelihood_param=0.09, nembeds=K, tf_order=0,
+                                                           sigma2_init=1.0, lam2_init=0.1, W_init=Wt * 0 + 0.5,
+                                                           V_init=np.repeat(np.linspace(0.1, 1.0, T)[None, :, None], M, axis=0).repeat(K, axis=2),
+                                                           rng="device", device_seed=3)
+    ll0 = model.log_likelihood(Y)
+    acc, n = 0.0, 0
+    for it in range(300):
+        model.resample(Y)
+        if it % 25 == 24 or it >= 200:
+            tau = np.einsum("nk,mtk->nmt", model.W, model.V)
+            assert (np.einsum("qt,nmt->nmq", Cons[:, :-1], tau) >= Cons[:, -1] - 1e-9).all(), it
+        if it >= 150:
+            acc = acc + np.einsum("nk,mtk->nmt", model.W, model.V)
+            n += 1
+    assert model.log_likelihood(Y) > ll0
+    assert np.corrcoef((acc / n).ravel(), curve.ravel())[0, 1] > 0.9
 
 
 @pytest.mark.gpu

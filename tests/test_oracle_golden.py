@@ -371,6 +371,29 @@ def test_nonconjugate_joint_slice_steps_vs_reference(golden, link):
     assert relerr(st["V"], g[tag + "V_after"]) < 1e-9 and info["evaluations"] == int(g[tag + "V_nev"])
 
 
+@pytest.mark.parametrize("family", ["bernoulli_logit", "gaussian", "negbin_logit"])
+def test_nonconjugate_steps_with_other_likelihoods_vs_reference(golden, family):
+    """The reference's NonconjugateBayesianTensorFiltering run with scipy.stats callbacks for a Bernoulli-logit, a
+    Gaussian and a Negative-Binomial-logit likelihood (tests/golden/make_golden_lik.py): the oracle's family_loglik equals
+    the callback's value, and its slice steps land on the reference's states after the same number of evaluations."""
+    g = golden("g11_likelihoods.npz")
+    tag = "lk_%s_" % family
+    N, M, T, R, K, tf = [int(x) for x in g[tag + "dims"]]
+    par = None if np.isnan(g[tag + "param"]) else float(g[tag + "param"])
+    st = {k: (float(g[tag + "s0_" + k]) if k in ("lam2", "sigma2") else g[tag + "s0_" + k].copy()) for k in ("W", "V", "Tau2", "lam2", "sigma2")}
+    Y = g[tag + "Y"]
+    ll0 = orc.family_loglik(st["W"], st["V"], Y, family, par)
+    assert abs(ll0 - float(g[tag + "ll0"])) < 1e-10 * abs(ll0)
+    Delta = orc.trend_penalty(T, tf)
+    info = {}
+    np.random.seed(int(g[tag + "seeds"][0]))
+    orc.nonconjugate_w_step(st, Y, link=family, info=info, param=par)
+    assert relerr(st["W"], g[tag + "W_after"]) < 1e-12 and info["evaluations"] == int(g[tag + "W_nev"])
+    np.random.seed(int(g[tag + "seeds"][1]))
+    orc.nonconjugate_v_step(st, Y, Delta, link=family, perm="twist", info=info, param=par)
+    assert relerr(st["V"], g[tag + "V_after"]) < 1e-9 and info["evaluations"] == int(g[tag + "V_nev"])
+
+
 # ---- constrained non-conjugate model: the reference's own worker functions (make_golden_gass.py) ----
 def _gass_case(golden):
     g = golden("g10_gass.npz")
