@@ -296,6 +296,22 @@ def main():
     if os.environ.get("BTF_BENCH_DEBUG") == "1" and rank == 0:
         for k in ("w_accum", "w_solve", "v_accum", "v_banded"):
             print("blocks %s: %s" % (k, ["%.2f" % (1e3 * blk[k][0] / max(blk[k][1], 1)) for blk in blocks]), file=sys.stderr)
+    if os.environ.get("BTF_ACC_STAMPS_OUT") and rank == 0:      # diagnostic builds (-DBTF_ACC_STAMPS, scripts/acc_stamps.sh)
+        import ctypes as C
+        lib = model._ctx.lib
+        lib.btf_debug_acc_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        dump = {}
+        for name, half in (("w", lambda: model._resample_W(data)), ("v", lambda: model._resample_V(data))):
+            buf = np.zeros((8192, 4), dtype=np.int64)
+            for _ in range(3):
+                (model._resample_V(data) if name == "w" else model._resample_W(data))
+                fence()
+                lib.btf_debug_acc_stamps(model._ctx.h, buf.ctypes.data_as(C.POINTER(C.c_longlong)))      # (reads and clears)
+                half()
+                fence()
+            lib.btf_debug_acc_stamps(model._ctx.h, buf.ctypes.data_as(C.POINTER(C.c_longlong)))
+            dump[name] = buf
+        np.savez(os.environ["BTF_ACC_STAMPS_OUT"], **dump)
     kt = {}
     for k in blocks[0]:
         avgs = sorted(blk[k][0] / blk[k][1] for blk in blocks if blk[k][1] > 0)

@@ -34,6 +34,7 @@ struct EvPair { hipEvent_t a, b; int kid; };
 struct btf_ctx {
   int N = 0, M = 0, T = 0, K = 0, TF = 0, nD = 0, KK = 0;
   int dev = 0;
+  int ncu = 256;                     // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int row0 = 0, nl = 0, col0 = 0, ml = 0;
@@ -76,6 +77,9 @@ struct btf_ctx {
   int gs_chains = 0, gs_what = -1, gs_link = 0;
   double lik_par[ESS_FAM_COUNT] = {0, 0, 0, 1.0, 1.0};     // parameter per likelihood family (btf_set_likelihood_param)
   long long* dbg = nullptr;
+#ifdef BTF_ACC_STAMPS
+  long long* acc_stamps = nullptr;
+#endif
   double* pband = nullptr;
   double* Ta = nullptr; double* Tb = nullptr; double* Tc = nullptr; double* lsum = nullptr;   // horseshoe+ chain (device mode)
   int* dr_ptr = nullptr; int* dr_col = nullptr; double* dr_val = nullptr;                   // Delta, CSR by row
@@ -316,6 +320,12 @@ int build_stencil(btf_ctx* c) {
 }
 
 // ---- templated launch tables -------------------------------------------------
+// rows per workgroup from which the complete-data stream keeps three rows in flight per wave (and, K >= 8, stages the
+// factor rows in LDS); BTF_UNR3_RPB overrides it for A/B runs
+inline int unr3_min_rpb() {
+  static const int v = [] { const char* e = std::getenv("BTF_UNR3_RPB"); return e ? std::atoi(e) : 2048; }();
+  return v;
+}
 template <int K>
 void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const unsigned char* C8, const double* U,
                   const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr},
@@ -324,6 +334,9 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
                   ChunkMap cm = ChunkMap{0, 0, INT_MAX, 0, 0, 0}, SweepSide sw = SweepSide{}) {
   // nch: the chunks THIS launch covers (all of them unless cm says otherwise)
   if (cm.row_end == 0) cm.row_end = Rdim;
+#ifdef BTF_ACC_STAMPS
+  cm.stamps = c->acc_stamps;
+#endif
   Prof p(c, kid);
   const int cpw = TAU_SIDE_CPW;
   cm.nside = (sw.sc.hyp ? 1 : 0) + (sw.lam.hyp ? 1 : 0) + (side.out ? 1 + eig_side_groups(sidec.ncols, acc_waves(K, mode)) : 0) +
@@ -340,7 +353,7 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
     else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
   } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
   else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
-  else if (rpb >= 2048) p.launch(accum_kernel<K, 0, acc_waves(K, 0), double, double, 3>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+  else if (rpb >= unr3_min_rpb()) p.launch(accum_kernel<K, 0, acc_waves(K, 0), double, double, 3>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
   else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
 }
 // Which Polya-Gamma launches a draw needs (pg_class_of): the flat exact kernel for the integer counts it takes
@@ -642,7 +655,9 @@ int ensure_z(btf_ctx* c, size_t elems) {
   return BTF_OK;
 }
 
-int pick_rpb(int Rdim, int tiles, int user, bool weighted) {
+// `slots`: workgroups of the accumulation kernel the chip holds at once (one 12- or 16-wave workgroup per CU at its
+// 121-128 VGPRs; 0 = unknown), `reserve`: side workgroups the launch will put in front of the streaming ones.
+int pick_rpb(int Rdim, int tiles, int user, bool weighted, int slots = 0, int reserve = 0) {
   // rows per workgroup (a multiple of 64): enough workgroups to fill the chip twice over when the problem is that
   // large, but never fewer rows than pay for a workgroup's prologue and its share of the partials - measured at
   // C3 (scripts/ab_rpb.sh): complete data 512 rows (128 workgroups: W 11.5 us, V 12.8 -> 11.2 us, and w_solve
@@ -652,7 +667,33 @@ int pick_rpb(int Rdim, int tiles, int user, bool weighted) {
   long long rpb = ((long long)Rdim * tiles + want_wgs - 1) / want_wgs;
   rpb = std::max<long long>(rpb, weighted ? 256 : 512);
   rpb = std::min<long long>(rpb, std::max(Rdim, 1));
-  return std::max(128, round_up((int)rpb, 64));
+  rpb = std::max(128, round_up((int)rpb, 64));
+  // One round.  A launch of one to two rounds of workgroups (a rank's slab of a sharded run: 256 streaming workgroups
+  // + 32 Gram side workgroups, or 512 + 1) ends in a round that is mostly tail: every CU holds ONE workgroup, the side
+  // workgroups keep theirs for 10-25 us, and the streaming workgroups they displace start late and finish alone, at
+  // the rate of a few lone CUs (scripts/acc_stamps.sh: 57 us for a 268 MB slab whose workgroups stream at 7 TB/s
+  // while they all run).  So when the launch can fit the chip in one round - side workgroups included - it does.
+  static const bool fit = [] { const char* e = std::getenv("BTF_FIT_ROUND"); return !e || std::atoi(e) != 0; }();
+  if (fit && slots > 0) {
+    const long long nch = (Rdim + rpb - 1) / rpb, total = nch * tiles + reserve;
+    const long long nch1 = (slots - reserve) / std::max(tiles, 1);
+    if (total > slots && total <= 2LL * slots + reserve && nch1 >= 1) {
+      const long long r1 = round_up((int)((Rdim + nch1 - 1) / nch1), 64);
+      if (r1 >= rpb) rpb = r1;
+    }
+  }
+  return (int)rpb;
+}
+inline int acc_slots(const btf_ctx* c, int K, int mode) { return c->ncu * std::max(1, 16 / acc_waves(K, mode)); }
+// upper bounds of the side workgroups the two accumulation launches put in front (launch_accum counts them exactly)
+inline int w_side_reserve(const btf_ctx* c, bool wt) {
+  const bool whole = c->nl == c->N && c->ml == c->M;
+  const bool gram_side = !wt && !(whole && c->fuse_gram && c->ngp_v > 0) && !c->weighted;
+  return (gram_side ? 32 : 0) + (c->tau_pending && c->dev_scalars && c->have_chain ? (c->ml + TAU_SIDE_CPW - 1) / TAU_SIDE_CPW : 0) +
+         (c->sc_pending ? 1 : 0);
+}
+inline int v_side_reserve(const btf_ctx* c, bool wt) {
+  return 1 + (c->weighted && !wt ? (c->cv_ndef + 3) / 4 : 0) + (c->lam_pending ? 1 : 0);
 }
 
 // upload a host slab and turn it into the padded device layouts
@@ -746,6 +787,7 @@ int btf_create(btf_ctx** out, int nrows, int ncols, int ndepth, int nembeds, int
   c->row0 = 0; c->nl = nrows; c->col0 = 0; c->ml = ncols;
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) { g_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete c; return BTF_EHIP; }
+  { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->ncu = n; }
   if (stream) { c->stream = (hipStream_t)stream; }
   else {
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -1212,7 +1254,7 @@ int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL) {
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_w && c->srcmap_w ? 2 : 1);
   const int NV = wt ? K + KK : K;
   const int tiles = c->ldw / ACC_TILE;
-  const int rpb = pick_rpb(MT, tiles, c->rpb_w, wt);
+  const int rpb = pick_rpb(MT, tiles, c->rpb_w, wt, acc_slots(c, K, mode), w_side_reserve(c, wt));
   const int nch = (MT + rpb - 1) / rpb;
   int rc;
   if ((rc = ensure_part(c, (size_t)nch * NV * c->ldw))) return rc;
@@ -1438,7 +1480,7 @@ int v_accum_local(btf_ctx* c, int compat) {
   if (mode == 2) return BTF_OK;
   const int NV = wt ? K + KK : K;
   const int tiles = c->ldv / ACC_TILE;
-  const int rpb = pick_rpb(c->N, tiles, c->rpb_v, wt);
+  const int rpb = pick_rpb(c->N, tiles, c->rpb_v, wt, acc_slots(c, K, mode), v_side_reserve(c, wt));
   const int nch = (c->N + rpb - 1) / rpb;
   const SplitGeom sg = split_geom(c->row0, c->row0 + c->nl, c->N, rpb, tiles);
   if (!sg.ok) return BTF_OK;
@@ -1479,7 +1521,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_v && c->srcmap_v ? 2 : 1);
   const int NV = wt ? K + KK : K;
   const int tiles = c->ldv / ACC_TILE;
-  const int rpb = pick_rpb(c->N, tiles, c->rpb_v, wt);
+  const int rpb = pick_rpb(c->N, tiles, c->rpb_v, wt, acc_slots(c, K, mode), v_side_reserve(c, wt));
   // (the own-rows chunks may already be in the partials, queued behind the W draw: BTF_OPT_SPLIT_ACCUM)
   const SplitGeom vsg = split_applies(c) ? split_geom(c->row0, c->row0 + c->nl, c->N, rpb, tiles) : SplitGeom{};
   const bool v_rest_only = c->v_local_done && vsg.ok && c->v_local_rpb == rpb && c->v_local_mode == mode;
@@ -2982,6 +3024,21 @@ int btf_kernel_times(btf_ctx* c, double* ms_total, int64_t* launches) {
   return BTF_OK;
 }
 
+#ifdef BTF_ACC_STAMPS
+// diagnostic builds only: the accumulation workgroups' wall-clock stamps of the LAST launch, [8192][4]
+extern "C" int btf_debug_acc_stamps(btf_ctx* c, long long* out) {
+  if (!c) return BTF_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!c->acc_stamps) {
+    int rc = dev_alloc(c, &c->acc_stamps, (size_t)8192 * 4);
+    if (rc) return rc;
+  }
+  HIPCHK(c, hipMemcpy(out, c->acc_stamps, sizeof(long long) * 8192 * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemset(c->acc_stamps, 0, sizeof(long long) * 8192 * 4));
+  return BTF_OK;
+}
+#endif
 // diagnostic (not in btf.h): phase stamps of the fast banded kernel, [ncols_local][6] shader clocks
 extern "C" int btf_debug_stamps(btf_ctx* c, long long* out) {
   if (!c) return BTF_EINVAL;
@@ -3167,6 +3224,15 @@ int btf_host_selftest(void) {
             ST_CHECK(walk(ChunkMap{0, 0, g.lo, g.hi - g.lo, Rdim, 0}, rpb, g.nch_r));
             for (int v : cover) ST_CHECK(v == 1);
           }
+  // one-round fitting of the accumulation launch: a rank's slabs of C5 / 8 (tiles x chunks + side workgroups <= CUs)
+  {
+    const int rw = pick_rpb(65536, 4, 0, false, 256, 32), rv = pick_rpb(4096, 64, 0, false, 256, 1);
+    ST_CHECK(rw % 64 == 0 && rv % 64 == 0);
+    ST_CHECK(4 * ((65536 + rw - 1) / rw) + 32 <= 256 && 4 * ((65536 + rw - 1) / rw) + 32 > 192);
+    ST_CHECK(64 * ((4096 + rv - 1) / rv) + 1 <= 256);
+    ST_CHECK(pick_rpb(16384, 4, 0, false, 256, 0) == 512 && pick_rpb(512, 128, 0, false, 256, 1) == 512);   // C3: untouched
+    ST_CHECK(pick_rpb(65536, 4, 0, false, 0, 0) == 1024);                                                       // unknown chip: the old rule
+  }
   // which Polya-Gamma sampler takes a count
   ST_CHECK(pg_class_of(0.0, PG_MODE_DEFAULT) == PG_CLASS_NONE && pg_class_of(4.0, PG_MODE_DEFAULT) == PG_CLASS_FLAT);
   ST_CHECK(pg_class_of(33.0, PG_MODE_DEFAULT) == PG_CLASS_SERIES && pg_class_of(33.0, PG_MODE_EXACT_ALL) == PG_CLASS_FLAT);

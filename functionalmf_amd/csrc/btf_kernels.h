@@ -146,6 +146,54 @@ __device__ __forceinline__ void gram_pass_wave(RowFn row_of, int ebeg, int eend,
   if constexpr (PASS + 1 < GramPasses<K>::NP) gram_pass_wave<K, PASS + 1>(row_of, ebeg, eend, estep, out);
 }
 
+// The Gram of a tall factor on the matrix cores (side tasks, K <= 16): one v_mfma_f64_16x16x4_f64 per four rows with
+// a == b - lane l holds U[4 g + (l >> 4)][l & 15] (zero beyond K or the last row), so every row group costs one load
+// and one MFMA per wave and the 16 x 16 result comes out summed over the wave's rows: no cross-lane reduction at all
+// (the register form above ends in K(K+1)/2 six-step shuffles per wave - 25 us for a side workgroup of 16 waves at
+// K = 8, which kept its CU from the stream for half the launch on a rank's slab, round 3).  acc: row (l >> 4) + 4 i,
+// column l & 15 in element i.  Groups g0 .. g1-1, eight loads in flight.
+typedef double gram_f64x4 __attribute__((ext_vector_type(4)));
+template <int K>
+__device__ __forceinline__ void gram_mfma_groups(const double* __restrict__ U, int Rdim, int g0, int g1, gram_f64x4& acc) {
+  static_assert(K <= 16, "one 16 x 16 tile");
+  const int lane = threadIdx.x & 63, sub = lane >> 4, k = lane & 15;
+  constexpr int UN = 8;
+  for (int g = g0; g < g1; g += UN) {
+    double x[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int r = 4 * (g + u) + sub;
+      x[u] = (k < K && g + u < g1 && r < Rdim) ? U[(size_t)r * K + k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], x[u], acc, 0, 0, 0);
+  }
+}
+// the whole workgroup: NW waves split the row groups [0, ceil(Rdim / 4)) of this workgroup's share (block b of nb) into
+// contiguous runs, then the NW tiles are added in a fixed order; out[lidx(p, q)], q <= p < K (packed lower triangle).
+// scr: NW * 256 doubles of LDS.  No barrier after the last write.
+template <int K, int NW>
+__device__ __forceinline__ void gram_mfma_block(const double* __restrict__ U, int Rdim, int b, int nb, double* scr, double* out) {
+  static_assert(NW >= 4, "256 threads write the tile out");
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int G = (Rdim + 3) >> 2;
+  const int per = (G + nb * NW - 1) / (nb * NW);
+  const int g0 = min(G, (b * NW + wave) * per), g1 = min(G, g0 + per);
+  gram_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  gram_mfma_groups<K>(U, Rdim, g0, g1, acc);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) scr[wave * 256 + ((lane >> 4) + 4 * i) * 16 + (lane & 15)] = acc[i];
+  __syncthreads();
+  if ((int)threadIdx.x < 256) {
+    const int p = threadIdx.x >> 4, q = threadIdx.x & 15;
+    if (p < K && q <= p) {
+      double t = 0.0;
+      for (int w = 0; w < NW; ++w) t += scr[w * 256 + threadIdx.x];
+      out[lidx(p, q)] = t;
+    }
+  }
+}
+
 // one-wave form (side tasks: a wave per column): lane l takes entries e0 + l, + 64, ...;
 // out[q] = sum_{i in D(col)} (R - c_i,col) w_i[p] w_i[p'] (the caller scales and subtracts)
 template <int K>
@@ -192,7 +240,12 @@ struct GramSide { const double* U; int Rdim; double* gpart; int nblocks; };
 // the rank's OWN block of the fixed factor are accumulated first - that block needs no exchange - in chunks sized for
 // the whole chip, and the rest in a second launch behind the all-gather, around the hole; the consumers just add all
 // slots.  {0, 0, INT_MAX, 0, Rdim}: every row, slot = chunk.
-struct ChunkMap { int slot_base, row_base, skip_at, skip_rows, row_end; int nside; };     // nside: side workgroups in front (set by launch_accum)
+struct ChunkMap {
+  int slot_base, row_base, skip_at, skip_rows, row_end; int nside;     // nside: side workgroups in front (set by launch_accum)
+#ifdef BTF_ACC_STAMPS
+  long long* stamps;       // diagnostic builds: [8192][4] wall-clock stamps of the streaming workgroups
+#endif
+};
 
 // nu2 | rest and sigma2 | rest as ONE side workgroup of the W accumulation launch (full sweeps, rng="device", complete
 // Gaussian data): the residual sum of squares comes from the per-column parts the spectral V sampler left behind at the
@@ -255,6 +308,13 @@ template <int NW> __device__ void sweep_lam_side(const LamSide& lm, double* red)
 // integer counts (2 kappa in -127..127 stored, 1 byte instead of 8 per cell: 9 instead of 16 B/cell with f64 weights)
 // UNRV: rows in flight per wave; 0 = the build's default (2).  Long row ranges per workgroup (C5-sized slabs) stream
 // 1-2 % faster with 3 (359 / 346 us against 361 / 353 us per launch at C5), short ones (C3: 32 rows per wave) slower.
+#ifdef BTF_ACC_STAMPS     // diagnostic builds (scripts/acc_stamps.sh): wall-clock stamps (100 MHz) of every streaming workgroup
+#define ACC_STAMP(i) do { if (threadIdx.x == 0 && b < 4096 && cm.stamps) cm.stamps[b * 4 + (i)] = wall_clock64(); } while (0)
+#define ACC_SIDE_STAMP(i) do { if (threadIdx.x == 0 && cm.stamps) cm.stamps[(4096 + blockIdx.x) * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define ACC_STAMP(i) do { } while (0)
+#define ACC_SIDE_STAMP(i) do { } while (0)
+#endif
 template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double, typename XT = double, int UNRV = 0,
           int OPL = acc_opl(K, MODE)>
 __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void accum_kernel(
@@ -299,28 +359,20 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       // the whole workgroup sums the Gram partials (one round of loads, whatever their number); then workgroup 0's
       // first wave solves the shared Gram, and in the others wave w takes curve column (b-1) TPW + w: its own Gram,
       // its own (warm-started) eigen-system
-      double* sc = &red[0][0][0];
-      double* gsum = sc + TPW * EIG_LDS_DOUBLES;                 // [64]
+      // LDS: [gsum 64][gown TPW x 64][sc: the eigen-solvers' scratch; before they start, the Gram reduction's]
+      double* gsum = &red[0][0][0];                              // [64]
       double* gown = gsum + 64;                                  // [TPW][64]
-      double* rsc = gown + TPW * 64;                             // reduce_gram's scratch: <= blockDim doubles
-      static_assert(TPW * EIG_LDS_DOUBLES + 64 + TPW * 64 + ACC_WAVES * WAVE <= ACC_WAVES * ACC_RG * ACC_TILE, "side task scratch");
+      double* sc = gown + TPW * 64;                              // [TPW][EIG_LDS_DOUBLES]
+      double* rsc = sc;                                          // reduce_gram: <= blockDim doubles; gram_mfma_block: 256 per wave
+      static_assert(64 + TPW * 64 + TPW * EIG_LDS_DOUBLES <= ACC_WAVES * ACC_RG * ACC_TILE, "side task scratch");
+      static_assert(64 + TPW * 64 + ACC_WAVES * 256 <= ACC_WAVES * ACC_RG * ACC_TILE, "side task Gram scratch");
       static_assert(tri(EIG_MAXK) <= 64, "side task Gram slots");
       const int t = (b - 1) * TPW + wave;
       const bool task = b > 0 && wave < TPW && t < sidec.ncols;
       const int col = task ? sidec.cols[t] : 0;
       if (task) curve_column_sum_wave<K>(sidec.cv, sidec.W, col, gown + wave * 64);    // (its loads fly with reduce_gram's)
       if (side.Usrc) {         // (sharded runs: W has just been all-gathered, nobody summed its Gram)
-        gram_pass_wave<K, 0>([&](int r, double (&u)[K], double& d) {
-          d = 1.0;
-#pragma unroll
-          for (int k = 0; k < K; ++k) u[k] = side.Usrc[(size_t)r * K + k];
-        }, (int)threadIdx.x, side.nrows, WAVES * WAVE, rsc + wave * KK);
-        __syncthreads();
-        if ((int)threadIdx.x < KK) {
-          double t2 = 0.0;
-          for (int w = 0; w < ACC_WAVES; ++w) t2 += rsc[w * KK + threadIdx.x];
-          gsum[threadIdx.x] = t2;
-        }
+        gram_mfma_block<K, WAVES>(side.Usrc, side.nrows, 0, 1, rsc, gsum);
         __syncthreads();
       } else {
         reduce_gram(side.gpart, side.ngp, KK, 1.0, rsc, gsum);
@@ -351,18 +403,11 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   if (gram.gpart) {
     if (b < gram.nblocks) {
       // rows b, b + nblocks*threads, ... (strided like gram_kernel), K(K+1)/2 sums per thread, fixed-order reduction
-      double* scr = &red[0][0][0];                              // [ACC_WAVES][KK]
-      gram_pass_wave<K, 0>([&](int r, double (&u)[K], double& d) {
-        d = 1.0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) u[k] = gram.U[(size_t)r * K + k];
-      }, b * (WAVES * WAVE) + (int)threadIdx.x, gram.Rdim, gram.nblocks * (WAVES * WAVE), scr + wave * KK);
-      __syncthreads();
-      if ((int)threadIdx.x < KK) {
-        double t = 0.0;
-        for (int w = 0; w < ACC_WAVES; ++w) t += scr[w * KK + threadIdx.x];
-        gram.gpart[(size_t)b * KK + threadIdx.x] = t;
-      }
+      // this block's share of the rows on the matrix cores (gram_mfma_block), fixed-order reduction over the waves
+      ACC_SIDE_STAMP(0);
+      static_assert(ACC_WAVES * 256 <= ACC_WAVES * ACC_RG * ACC_TILE, "Gram side scratch");
+      gram_mfma_block<K, WAVES>(gram.U, gram.Rdim, b, gram.nblocks, &red[0][0][0], gram.gpart + (size_t)b * KK);
+      ACC_SIDE_STAMP(3);
       return;
     }
     b -= gram.nblocks;
@@ -370,6 +415,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   return;                                                    // (not reached: cm.nside counts exactly the side workgroups)
   }
   b -= cm.nside;
+  ACC_STAMP(0);
   const int ntiles = ld / ACC_TILE;
   const int lchunk = b / ntiles, tile = b - lchunk * ntiles;
   const int chunk = cm.slot_base + lchunk;                  // slot of the partials
@@ -499,6 +545,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
         if (((bend - ublk0) * K & 1) && threadIdx.x == 0) ush[(bend - ublk0) * K - 1] = U[(size_t)bend * K - 1];
       }
       __syncthreads();
+      if (ublk0 == r0) ACC_STAMP(1);
       const int bfull = min(full_end, bend - (ACC_UNR - 1) * NWR);
       for (; rb < bfull; rb += STEP) {
         Rows A;
@@ -542,6 +589,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
     }
   }
 
+  ACC_STAMP(2);
   // cross-wave reduction through LDS, ACC_RG values per round, fixed order
   const int tv = threadIdx.x >> 7;   // value slot 0..3
   const int tc = threadIdx.x & 127;  // column inside the tile
@@ -563,6 +611,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
     }
     __syncthreads();
   }
+  ACC_STAMP(3);
 }
 
 // ============================================================================

@@ -1,0 +1,34 @@
+"""Diagnostic: timeline of the accumulation workgroups (libbtf built with -DBTF_ACC_STAMPS; bench.py with
+BTF_ACC_STAMPS_OUT=file.npz writes the stamps of one W and one V accumulation launch).  100 MHz wall clock."""
+import sys
+import numpy as np
+
+d = np.load(sys.argv[1])
+for name in d.files:
+    s = d[name].astype(np.float64)
+    side = s[4096:]
+    side = side[side[:, 3] > 0]
+    s = s[:4096]
+    s = s[s[:, 3] > 0]
+    if len(side):
+        o = side[:, 0].min()
+        print("%s side workgroups: %d; start %.1f..%.1f us, pass done +%.1f, barrier +%.1f, end +%.1f (medians, from their start); last end %.1f"
+              % (name, len(side), 0.0, (side[:, 0].max() - o) / 100, np.median(side[:, 1] - side[:, 0]) / 100,
+                 np.median(side[:, 2] - side[:, 0]) / 100, np.median(side[:, 3] - side[:, 0]) / 100, (side[:, 3].max() - o) / 100))
+    if not len(s):
+        continue
+    t0 = s[:, 0].min()
+    s = (s - t0) / 100.0          # us
+    n = len(s)
+    print("%s accumulation: %d workgroups, span %.1f us" % (name, n, s[:, 3].max()))
+    q = lambda a: "min %.1f  p10 %.1f  med %.1f  p90 %.1f  max %.1f" % (a.min(), np.percentile(a, 10), np.median(a), np.percentile(a, 90), a.max())
+    print("  start           ", q(s[:, 0]))
+    if (s[:, 1] > 0).all():
+        print("  first U block in", q(s[:, 1] - s[:, 0]))
+    print("  stream (wave 0) ", q(s[:, 2] - s[:, 0]))
+    print("  epilogue        ", q(s[:, 3] - s[:, 2]))
+    print("  end             ", q(s[:, 3]))
+    # bandwidth-idle estimate: how many workgroups are streaming at each 1-us tick
+    ticks = np.arange(0, s[:, 3].max() + 1, 2.0)
+    live = [(int(((s[:, 0] <= t) & (s[:, 2] > t)).sum())) for t in ticks]
+    print("  streaming workgroups every 2 us:", live)
