@@ -296,6 +296,17 @@ def main():
     if os.environ.get("BTF_BENCH_DEBUG") == "1" and rank == 0:
         for k in ("w_accum", "w_solve", "v_accum", "v_banded"):
             print("blocks %s: %s" % (k, ["%.2f" % (1e3 * blk[k][0] / max(blk[k][1], 1)) for blk in blocks]), file=sys.stderr)
+    if os.environ.get("BTF_BENCH_DEBUG") == "1" and rank == 0 and model.v_sampler() == "spectral":
+        import ctypes as C
+        eg = np.zeros(K + K * K + 8)
+        fn = model._ctx.lib.btf_debug_eig
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        sw = []
+        for _ in range(8):
+            step()
+            if fn(model._ctx.h, eg.ctypes.data_as(C.POINTER(C.c_double))) == 0:
+                sw.append(int(eg[K + K * K]))
+        print("eigen side task: Jacobi sweeps of 8 solves (0 = warm refinement) %s; eigenvalues %s" % (sw, np.array2string(eg[:K], precision=4)), file=sys.stderr)
     if os.environ.get("BTF_ACC_STAMPS_OUT") and rank == 0:      # diagnostic builds (-DBTF_ACC_STAMPS, scripts/acc_stamps.sh)
         import ctypes as C
         lib = model._ctx.lib

@@ -3024,6 +3024,16 @@ int btf_kernel_times(btf_ctx* c, double* ms_total, int64_t* launches) {
   return BTF_OK;
 }
 
+// diagnostic (not in btf.h): the shared eigen-system as the side task left it, K + K*K + 8 doubles
+// ([K + K*K]: Jacobi sweeps of the last solve, 0 = the warm refinement converged)
+extern "C" int btf_debug_eig(btf_ctx* c, double* out) {
+  if (!c || !out) return BTF_EINVAL;
+  if (!c->eig) return fail(c, BTF_ESTATE, "no eigen-system yet");
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, c->eig, ((size_t)c->K + c->K * c->K + 8) * sizeof(double), hipMemcpyDeviceToHost));
+  return BTF_OK;
+}
 #ifdef BTF_ACC_STAMPS
 // diagnostic builds only: the accumulation workgroups' wall-clock stamps of the LAST launch, [8192][4]
 extern "C" int btf_debug_acc_stamps(btf_ctx* c, long long* out) {

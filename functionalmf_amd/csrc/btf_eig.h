@@ -40,10 +40,24 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// k = 0 .. K-1: unrolled when K is a compile-time constant (KC > 0), the plain loop otherwise
+template <int KC, class F>
+__device__ __forceinline__ void eig_for(int K, F f) {
+  if constexpr (KC > 0) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k) f(k);
+  } else {
+    for (int k = 0; k < K; ++k) f(k);
+  }
+}
 // gsrc: `ngp` packed-lower partial Grams [ngp][K(K+1)/2] summed in block order.  lane = threadIdx.x & 63 of the
 // calling wave (all 64 lanes must call).
-__device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, int K, double* __restrict__ out,
+// KC > 0: K known at compile time (the callers inside kernels templated on it) - the K-long inner products unroll and
+// their LDS reads go out together; a lone wave otherwise pays one LDS round trip per term (K = 10, warm path: ~20 us).
+template <int KC = 0>
+__device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, int Krt, double* __restrict__ out,
                                      double* __restrict__ scratch, bool warm_ok = true) {
+  const int K = KC > 0 ? KC : Krt;
   __builtin_amdgcn_s_setprio(3);       // beside a streaming kernel: win the issue arbitration, the stream waits on memory anyway
   const int lane = threadIdx.x & 63;
   const int KK = tri(K), K2 = K * K;
@@ -96,21 +110,29 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
       double R0 = 0.0, R1 = 0.0;
       {
         double t0 = 0.0, t1 = 0.0, q0 = 0.0, q1 = 0.0;
-        if (h0) for (int k = 0; k < K; ++k) { const double xc = X[k * K + c0]; t0 = fma(Ab0[r0 * K + k], xc, t0); q0 = fma(X[k * K + r0], xc, q0); }
-        if (h1) for (int k = 0; k < K; ++k) { const double xc = X[k * K + c1]; t1 = fma(Ab0[r1 * K + k], xc, t1); q1 = fma(X[k * K + r1], xc, q1); }
+        if (h0) {
+          eig_for<KC>(K, [&](int k) { const double xc = X[k * K + c0]; t0 = fma(Ab0[r0 * K + k], xc, t0); q0 = fma(X[k * K + r0], xc, q0); });
+        }
+        if (h1) {
+          eig_for<KC>(K, [&](int k) { const double xc = X[k * K + c1]; t1 = fma(Ab0[r1 * K + k], xc, t1); q1 = fma(X[k * K + r1], xc, q1); });
+        }
         if (h0) { Ab1[e0] = t0; R0 = (r0 == c0 ? 1.0 : 0.0) - q0; }
         if (h1) { Ab1[e1] = t1; R1 = (r1 == c1 ? 1.0 : 0.0) - q1; }
       }
       wave_lds_sync();
       // S = X'T (registers); eigenvalue estimates from the diagonal
       double S0 = 0.0, S1 = 0.0;
-      if (h0) for (int k = 0; k < K; ++k) S0 = fma(X[k * K + r0], Ab1[k * K + c0], S0);
-      if (h1) for (int k = 0; k < K; ++k) S1 = fma(X[k * K + r1], Ab1[k * K + c1], S1);
+      if (h0) {
+        eig_for<KC>(K, [&](int k) { S0 = fma(X[k * K + r0], Ab1[k * K + c0], S0); });
+      }
+      if (h1) {
+        eig_for<KC>(K, [&](int k) { S1 = fma(X[k * K + r1], Ab1[k * K + c1], S1); });
+      }
       if (h0 && r0 == c0) lamv[r0] = S0 / (1.0 - R0);
       if (h1 && r1 == c1) lamv[r1] = S1 / (1.0 - R1);
       wave_lds_sync();
       double lmax = 0.0;
-      for (int k = 0; k < K; ++k) lmax = fmax(lmax, fabs(lamv[k]));
+      eig_for<KC>(K, [&](int k) { lmax = fmax(lmax, fabs(lamv[k])); });
       // error of this iterate: off-diagonal of S and all of R, relative to the largest eigenvalue
       float err = 0.0f;
       if (h0) err = fmaxf(err, (float)fmax(r0 == c0 ? 0.0 : fabs(S0), lmax * fabs(R0)));
@@ -133,8 +155,16 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
       }
       wave_lds_sync();
       // X <- X + X E
-      if (h0) { double x = X[e0]; for (int k = 0; k < K; ++k) x = fma(X[r0 * K + k], Ab1[k * K + c0], x); Xn[e0] = x; }
-      if (h1) { double x = X[e1]; for (int k = 0; k < K; ++k) x = fma(X[r1 * K + k], Ab1[k * K + c1], x); Xn[e1] = x; }
+      if (h0) {
+        double x = X[e0];
+        eig_for<KC>(K, [&](int k) { x = fma(X[r0 * K + k], Ab1[k * K + c0], x); });
+        Xn[e0] = x;
+      }
+      if (h1) {
+        double x = X[e1];
+        eig_for<KC>(K, [&](int k) { x = fma(X[r1 * K + k], Ab1[k * K + c1], x); });
+        Xn[e1] = x;
+      }
       xcur ^= 1;
       wave_lds_sync();
       if (last) { refined = true; break; }
@@ -232,16 +262,16 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
   if (lane < K) {
     const double lam = lamv[lane];
     int rank = 0;
-    for (int i = 0; i < K; ++i) {
+    eig_for<KC>(K, [&](int i) {
       const double li = lamv[i];
       if (li < lam || (li == lam && i < lane)) ++rank;
-    }
+    });
     int bigr = 0;
     double bv = 0.0;
-    for (int r = 0; r < K; ++r) {
+    eig_for<KC>(K, [&](int r) {
       const double v = fabs(U[r * K + lane]);
       if (v > bv) { bv = v; bigr = r; }
-    }
+    });
     const double sgn = U[bigr * K + lane] < 0.0 ? -1.0 : 1.0;
     out[rank] = lam;
     for (int r = 0; r < K; ++r) out[K + r * K + rank] = sgn * U[r * K + lane];

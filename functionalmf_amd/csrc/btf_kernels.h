@@ -157,7 +157,7 @@ template <int K>
 __device__ __forceinline__ void gram_mfma_groups(const double* __restrict__ U, int Rdim, int g0, int g1, gram_f64x4& acc) {
   static_assert(K <= 16, "one 16 x 16 tile");
   const int lane = threadIdx.x & 63, sub = lane >> 4, k = lane & 15;
-  constexpr int UN = 8;
+  constexpr int UN = K >= 9 ? 4 : 8;                        // (K >= 9: the 128-VGPR kernels have no room for eight)
   for (int g = g0; g < g1; g += UN) {
     double x[UN];
 #pragma unroll
@@ -367,6 +367,9 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       static_assert(64 + TPW * 64 + TPW * EIG_LDS_DOUBLES <= ACC_WAVES * ACC_RG * ACC_TILE, "side task scratch");
       static_assert(64 + TPW * 64 + ACC_WAVES * 256 <= ACC_WAVES * ACC_RG * ACC_TILE, "side task Gram scratch");
       static_assert(tri(EIG_MAXK) <= 64, "side task Gram slots");
+      // (the unrolled eigen-solver needs registers: two matrix elements per lane from K = 9 on, which the 128-VGPR
+      //  budget of a 16-wave workgroup does not have beside the stream's - there K stays a run-time value)
+      constexpr int EIG_KC = (K <= 8 || WAVES <= 8) ? K : 0;
       const int t = (b - 1) * TPW + wave;
       const bool task = b > 0 && wave < TPW && t < sidec.ncols;
       const int col = task ? sidec.cols[t] : 0;
@@ -378,11 +381,11 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
         reduce_gram(side.gpart, side.ngp, KK, 1.0, rsc, gsum);
       }
       if (b == 0) {
-        if (wave == 0) gram_eig_wave(gsum, 1, K, side.out, sc);
+        if (wave == 0) gram_eig_wave<EIG_KC>(gsum, 1, K, side.out, sc);
       } else if (task) {
         if (lane < KK) gown[wave * 64 + lane] = fma(-sidec.inv_R, gown[wave * 64 + lane], gsum[lane]);
         wave_lds_sync();
-        gram_eig_wave(gown + wave * 64, 1, K, sidec.eig_cols + (size_t)col * (K + K * K + 8), sc + wave * EIG_LDS_DOUBLES);
+        gram_eig_wave<EIG_KC>(gown + wave * 64, 1, K, sidec.eig_cols + (size_t)col * (K + K * K + 8), sc + wave * EIG_LDS_DOUBLES);
       }
 #endif
       return;
