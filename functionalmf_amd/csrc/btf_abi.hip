@@ -675,11 +675,14 @@ int pick_rpb(int Rdim, int tiles, int user, bool weighted, int slots = 0, int re
   // while they all run).  So when the launch can fit the chip in one round - side workgroups included - it does.
   static const bool fit = [] { const char* e = std::getenv("BTF_FIT_ROUND"); return !e || std::atoi(e) != 0; }();
   if (fit && slots > 0) {
+    // (cost model: rounds x rows per workgroup; only a strict gain moves the rule - the weighted launches at C3 are
+    //  issue-bound and want all 256 CUs: 2 x 128 workgroups of 256 rows beat 128 of 512, 15.4 against 21.3 us)
     const long long nch = (Rdim + rpb - 1) / rpb, total = nch * tiles + reserve;
+    const long long rounds = (total + slots - 1) / slots;
     const long long nch1 = (slots - reserve) / std::max(tiles, 1);
-    if (total > slots && total <= 2LL * slots + reserve && nch1 >= 1) {
+    if (rounds >= 2 && rounds <= 3 && nch1 >= 1) {
       const long long r1 = round_up((int)((Rdim + nch1 - 1) / nch1), 64);
-      if (r1 >= rpb) rpb = r1;
+      if (r1 < rounds * rpb) rpb = r1;
     }
   }
   return (int)rpb;
@@ -693,7 +696,8 @@ inline int w_side_reserve(const btf_ctx* c, bool wt) {
          (c->sc_pending ? 1 : 0);
 }
 inline int v_side_reserve(const btf_ctx* c, bool wt) {
-  return 1 + (c->weighted && !wt ? (c->cv_ndef + 3) / 4 : 0) + (c->lam_pending ? 1 : 0);
+  const bool spectral = banded_choice(c) == 3;               // the eigen side tasks ride with the spectral sampler only
+  return (spectral ? 1 + (c->weighted && !wt ? (c->cv_ndef + 3) / 4 : 0) : 0) + (c->lam_pending ? 1 : 0);
 }
 
 // upload a host slab and turn it into the padded device layouts

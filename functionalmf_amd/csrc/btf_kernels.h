@@ -606,6 +606,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       }
     }
     __syncthreads();
+    if constexpr (!ULDS) { if (g == 0) ACC_STAMP(1); }         // (diagnostic builds: every wave has finished its rows)
     if (tv < ACC_RG && g + tv < NV) {
       double s = 0.0;
 #pragma unroll

@@ -23,8 +23,10 @@ for name in d.files:
     print("%s accumulation: %d workgroups, span %.1f us" % (name, n, s[:, 3].max()))
     q = lambda a: "min %.1f  p10 %.1f  med %.1f  p90 %.1f  max %.1f" % (a.min(), np.percentile(a, 10), np.median(a), np.percentile(a, 90), a.max())
     print("  start           ", q(s[:, 0]))
-    if (s[:, 1] > 0).all():
+    if (s[:, 1] > 0).all() and (s[:, 1] < s[:, 2]).all():
         print("  first U block in", q(s[:, 1] - s[:, 0]))
+    elif (s[:, 1] > 0).all():
+        print("  last wave - wave 0", q(s[:, 1] - s[:, 2]), " (all waves at the first barrier of the epilogue)")
     print("  stream (wave 0) ", q(s[:, 2] - s[:, 0]))
     print("  epilogue        ", q(s[:, 3] - s[:, 2]))
     print("  end             ", q(s[:, 3]))
