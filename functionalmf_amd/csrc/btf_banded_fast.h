@@ -245,7 +245,8 @@ __device__ inline bool banded_ldl_forward(double* lds, const VbLayout L, int n, 
 //     exactly like the two-column chain of banded_ldl_forward;
 //   * the 16 x 16 trailing window, rows / columns c+4 .. c+19, is the MFMA accumulator: element (i,j) sits
 //     in register i/4, lane 16 (i%4) + j, so  D = C - Y V'  with  A[i][k] = L[c+4+i, c+k]  (lane (k,i)) and
-//     B[k][j] = unscaled column entry (lane (k,j)) - both re-read from LDS in exactly that lane order;
+//     B[k][j] = unscaled column entry (lane (k,j)) - both formed from the panel's registers by one in-row DPP shift per
+//     lane group (p4_operand; round 3: they used to be stored and re-read in that lane order, an LDS round trip on the chain);
 //   * column 15 of the window (matrix column c+19) is never touched by a panel at c (reach c+18), so it
 //     carries the right-hand side instead: lanes with j == 15 address rhs[c+4+i], and B[k][15] = u_k (the
 //     panel's finished rhs entries, a 4 x 4 forward substitution on wave-uniform values): the forward
@@ -262,6 +263,22 @@ __device__ __forceinline__ double row_shl_zero(double v) {       // lane i <- la
   return __hiloint2double(hi, lo);
 }
 
+// rows (16-lane groups) named by the mask RM <- lane i+S of v inside the row (0 beyond it); the other rows keep `old`
+template <int S, int RM>
+__device__ __forceinline__ double row_shl_into(double old, double v) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x100 + S, RM, 0xF, true);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x100 + S, RM, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// the MFMA operand of lane (k = g, j): column k of the panel, entry 4 + j - k (zero past entry 15) - the four panel
+// columns are replicated in every lane group, so this is one in-row shift per group, no LDS round trip
+__device__ __forceinline__ double p4_operand(double c0, double c1, double c2, double c3) {
+  double x = row_shl_zero<4>(c0);
+  x = row_shl_into<3, 0x2>(x, c1);
+  x = row_shl_into<2, 0x4>(x, c2);
+  return row_shl_into<1, 0x8>(x, c3);
+}
+
 template <int NPL>
 __device__ inline bool banded_ldl_forward_p4(double* lds, const VbLayout L, int n, int bw, int n_elim) {
   constexpr int R1 = 16;             // band stride (L.R1 == 16): columns of bw + 1 <= 16 words, zero beyond
@@ -269,12 +286,10 @@ __device__ inline bool banded_ldl_forward_p4(double* lds, const VbLayout L, int 
   const int g = lane >> 4, j = lane & 15;
   if (n_elim < 0) n_elim = n;
   const int npan = n_elim / 4;
-  const int zero = 8 * (L.dummy + 64 * 9);                    // never written
   // uniform-stride addresses (all lanes valid; the four lane groups hold / store identical copies)
   int cl = 8 * (L.band + j);                                   // column c+q, entry j       at +128 q
   int ia = 8 * L.invd;                                         // invd[c+q]                 at +8 q
   int ra = 8 * L.rhs;                                          // rhs[c+q]                  at +8 q
-  const int va = 8 * (L.vs4 + j);                              // vs4[q][j]                 at +128 q
   // window (accumulator) addresses: register r, lane (g,j) <-> element (4r+g, j)
   int ca[4], cs[4];
 #pragma unroll
@@ -284,12 +299,9 @@ __device__ inline bool banded_ldl_forward_p4(double* lds, const VbLayout L, int 
     else if (i >= j) { ca[r] = 8 * (L.band + (4 + j) * R1 + (i - j)); cs[r] = 4 * R1 * 8; }     // A[c+4+i, c+4+j]
     else { ca[r] = 8 * (L.dummy + 64 * (1 + r) + lane); cs[r] = 0; }                            // upper triangle: unused
   }
-  // MFMA operands: lane (k = g, i|j = j)
-  const bool aval = 4 + j - g <= 15;
-  int aa = aval ? 8 * (L.band + g * R1 + (4 + j - g)) : zero;                  // L[c+4+i, c+k] = band[(c+k) R1 + 4+i-k]
-  const int as = aval ? 4 * R1 * 8 : 0;
-  int ba = j == 15 ? 8 * (L.rhs + g) : (aval ? 8 * (L.vs4 + g * R1 + (4 + j - g)) : zero);
-  const int bs = j == 15 ? 32 : 0;
+  // MFMA operands: lane (k = g, i|j = j), built from the panel's registers (p4_operand); column 15 of B carries the
+  // panel's finished rhs entries u_k: one-hot lane masks (lane 16 k + 15) blend them in
+  const double m15_0 = lane == 15 ? 1.0 : 0.0, m15_1 = lane == 31 ? 1.0 : 0.0, m15_2 = lane == 47 ? 1.0 : 0.0, m15_3 = lane == 63 ? 1.0 : 0.0;
   bool bad = false;
   for (int pnl = 0; pnl < npan; ++pnl) {
     // ---- loads: panel columns first (the pivot chain waits for nothing else), then the panel's rhs entries
@@ -301,7 +313,6 @@ __device__ inline bool banded_ldl_forward_p4(double* lds, const VbLayout L, int 
     W[0] = ldsr(lds, ca[0]); W[1] = ldsr(lds, ca[1]); W[2] = ldsr(lds, ca[2]); W[3] = ldsr(lds, ca[3]);
     // ---- pivot 0
     const double p0 = bcast_first(C0);
-    bad |= !(p0 > 0.0);
     const double i0 = rcp_nr(p0);
     const double Y0 = C0 * i0;
     const double y01 = bcast_lane(Y0, 1), y02 = bcast_lane(Y0, 2), y03 = bcast_lane(Y0, 3);
@@ -310,7 +321,6 @@ __device__ inline bool banded_ldl_forward_p4(double* lds, const VbLayout L, int 
     C3 = fma(-row_shl_zero<3>(C0), y03, C3);
     // ---- pivot 1
     const double p1 = bcast_first(C1);
-    bad |= !(p1 > 0.0);
     const double i1 = rcp_nr(p1);
     const double Y1 = C1 * i1;
     const double y11 = bcast_lane(Y1, 1), y12 = bcast_lane(Y1, 2);
@@ -318,14 +328,12 @@ __device__ inline bool banded_ldl_forward_p4(double* lds, const VbLayout L, int 
     C3 = fma(-row_shl_zero<2>(C1), y12, C3);
     // ---- pivot 2
     const double p2 = bcast_first(C2);
-    bad |= !(p2 > 0.0);
     const double i2 = rcp_nr(p2);
     const double Y2 = C2 * i2;
     const double y21 = bcast_lane(Y2, 1);
     C3 = fma(-row_shl_zero<1>(C2), y21, C3);
     // ---- pivot 3
     const double p3 = bcast_first(C3);
-    bad |= !(p3 > 0.0);
     const double i3 = rcp_nr(p3);
     const double Y3 = C3 * i3;
     // ---- the panel's rhs entries (wave-uniform 4 x 4 forward substitution)
@@ -335,17 +343,26 @@ __device__ inline bool banded_ldl_forward_p4(double* lds, const VbLayout L, int 
     const double u3 = fma(-y21, u2, fma(-y12, u1, fma(-y03, u0, r3)));
     // ---- stores: L columns (in place), unscaled columns, 1/D, finished rhs
     ldsw(lds, cl, Y0); ldsw(lds, cl + 128, Y1); ldsw(lds, cl + 256, Y2); ldsw(lds, cl + 384, Y3);
-    ldsw(lds, va, C0); ldsw(lds, va + 128, C1); ldsw(lds, va + 256, C2); ldsw(lds, va + 384, C3);
     ldsw(lds, ia, i0); ldsw(lds, ia + 8, i1); ldsw(lds, ia + 16, i2); ldsw(lds, ia + 24, i3);
     ldsw(lds, ra, u0); ldsw(lds, ra + 8, u1); ldsw(lds, ra + 16, u2); ldsw(lds, ra + 24, u3);
     // ---- trailing window: W -= Y V'  (column 15: rhs[c+4+i] -= sum_k L[c+4+i, c+k] u_k)
-    const double A = ldsr(lds, aa);
-    const double B = ldsr(lds, ba);
+    const double A = p4_operand(Y0, Y1, Y2, Y3);
+    const double B = fma(m15_3, u3, fma(m15_2, u2, fma(m15_1, u1, fma(m15_0, u0, p4_operand(C0, C1, C2, C3)))));
     W = __builtin_amdgcn_mfma_f64_16x16x4f64(-A, B, W, 0, 0, 0);
     ldsw(lds, ca[0], W[0]); ldsw(lds, ca[1], W[1]); ldsw(lds, ca[2], W[2]); ldsw(lds, ca[3], W[3]);
-    cl += 4 * R1 * 8; ia += 32; ra += 32; aa += as; ba += bs;
+    cl += 4 * R1 * 8; ia += 32; ra += 32;
 #pragma unroll
     for (int r = 0; r < 4; ++r) ca[r] += cs[r];
+  }
+  // ---- every pivot of the panels positive?  Read off their stored reciprocals, once, after the chain (a compare and an
+  //      s_or per pivot on the chain otherwise): p <= 0 or NaN leaves 1/p <= 0, inf or NaN
+  {
+    bool bad_l = false;
+    for (int e = lane; e < 4 * npan; e += WAVE) {
+      const double iv = lds[L.invd + e];
+      bad_l |= !(iv > 0.0 && iv < __builtin_huge_val());
+    }
+    bad = __ballot(bad_l) != 0ULL;
   }
   // ---- leftover pivots (and the flush of the register-resident columns) on a view shifted by 4 npan
   VbLayout L2 = L;

@@ -88,8 +88,18 @@ __host__ __device__ inline int twist_order(int i, int n, int nl, int nr) {
   return nl + (i - nl - nr);
 }
 
-template <int NPL, bool ROW16>
+// pairs-per-lane count and band stride of a (K, tf) shape (what dispatch_vbanded_twist derives at run time)
+__host__ __device__ constexpr int tw_npl(int K, int TF) {
+  const int bw = (TF + 1) * K, np = ((bw - 1) * (bw - 2) / 2 + WAVE - 1) / WAVE;
+  return np < 1 ? 1 : np;
+}
+__host__ __device__ constexpr bool tw_row16(int K, int TF) { return (TF + 1) * K <= 15; }
+
+// KC > 0: nembeds and the trend-filter order as compile-time constants (the instances of BTF_TWIST_SET for the reference's
+// default tf_order = 2): the setup's address arithmetic folds - 234 -> 109 spilled SGPRs, 37.0 -> 35.2 us at C3
+template <int NPL, bool ROW16, int KC = 0, int TFC = 0>
 __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a, int K) {
+  if constexpr (KC > 0) { K = KC; a.TF = TFC; }
   vband_load_hyp(a);
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
