@@ -562,16 +562,16 @@ bool curve_on(const btf_ctx* c) {
 // does the likelihood part run its weighted form (per-cell weights streamed, per-depth Gram blocks)?
 bool lik_weighted(const btf_ctx* c) { return c->weighted && !curve_on(c); }
 int banded_choice(const btf_ctx* c, bool allow_spectral = true) { return banded_choice_for(c, lik_weighted(c), allow_spectral); }
-template <int S, bool RG>
+template <int S, bool RG, int KC = 0>
 hipError_t launch_vspectral(btf_ctx* c, const VSpecArgs& a, size_t lds_bytes) {
   static std::atomic<unsigned long long> attr_set{0};      // one bit per device: the attribute is per device
   if (!dev_flag_is_set(attr_set, c->dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)v_spectral_kernel<S, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)v_spectral_kernel<S, RG, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     dev_flag_set(attr_set, c->dev);
   }
   Prof p(c, BTF_K_V_BANDED);
-  p.launch(v_spectral_kernel<S, RG>, dim3(a.ml), dim3(VS_THREADS), lds_bytes, a);
+  p.launch(v_spectral_kernel<S, RG, KC>, dim3(a.ml), dim3(VS_THREADS), lds_bytes, a);
   return hipSuccess;
 }
 template <int K>
@@ -1623,7 +1623,14 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
         case 3: e = launch_vspectral<1, true>(c, sa, sl); break;
         case 4: e = launch_vspectral<2, false>(c, sa, sl); break;
         case 5: e = launch_vspectral<2, true>(c, sa, sl); break;
-        case 6: e = launch_vspectral<3, false>(c, sa, sl); break;
+        case 6:                                  // tf_order = 2, records in LDS: the instances with nembeds compiled in
+          switch (K) {
+#define VS_FIXED(KV) case KV: e = launch_vspectral<3, false, KV>(c, sa, sl); break
+            VS_FIXED(1); VS_FIXED(2); VS_FIXED(3); VS_FIXED(4); VS_FIXED(5); VS_FIXED(6); VS_FIXED(7); VS_FIXED(8); VS_FIXED(9); VS_FIXED(10);
+#undef VS_FIXED
+            default: e = launch_vspectral<3, false>(c, sa, sl); break;
+          }
+          break;
         case 7: e = launch_vspectral<3, true>(c, sa, sl); break;
         case 8: e = launch_vspectral<4, false>(c, sa, sl); break;
         default: e = launch_vspectral<4, true>(c, sa, sl); break;

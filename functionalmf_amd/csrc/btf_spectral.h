@@ -197,7 +197,9 @@ __device__ __forceinline__ void spectral_backward(double* __restrict__ rec, int 
   }
 }
 
-template <int S, bool RG = false>
+// KC > 0: nembeds as a compile-time constant (instances for the reference's default tf_order = 2): the K-long rotations by
+// the eigenvectors unroll instead of paying an LDS round trip per term - 13.5 -> 12.2 us at C3
+template <int S, bool RG = false, int KC = 0>
 __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
   if (a.hyp) {
     if (a.hyp_noise) { a.s = 1.0 / a.hyp[HYP_NU2]; a.sR = a.s * a.Rrep; }
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = blockIdx.x, jg = a.col0 + j;
-  const int K = a.K, T = a.T, n = T * K, KK = tri(K);
+  const int K = KC > 0 ? KC : a.K, T = a.T, n = T * K, KK = tri(K);
   constexpr int D1 = S + 1, RS = S + 2, WN = S * (S + 1) + S;
   constexpr int MAXE = VS_MAXE;
   const VsLayout L = vs_layout(T, K, a.TF, a.nD, RG);
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
     reduce_gram(a.gpart, a.ngp, KK, 1.0, lds + L.gs, Gl);                       // W'W (ends with a barrier)
     curve_column_gram(a.cv, a.cv_W, jg, K, KK, 1.0 / a.Rrep, Gl, lds + L.esc, EIG_LDS_DOUBLES);
     __syncthreads();
-    if (wave == 0) gram_eig_wave(Gl, 1, K, eo, lds + L.esc);
+    if (wave == 0) gram_eig_wave<KC>(Gl, 1, K, eo, lds + L.esc);
     __syncthreads();
     for (int idx = tid; idx < ne; idx += VS_THREADS) {
       const double v = eo[idx];
