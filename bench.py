@@ -365,6 +365,21 @@ def main():
     acc_us = 1e3 * acc_ms / max(acc_n, 1)
     alg_bytes = bpc * 0.5 * (cells_local + cells_local_v)
     achieved = alg_bytes / (acc_us * 1e-6) / 1e9 if acc_us > 0 else 0.0
+    # the same W+V step with the reference-reproducible V sampler (`sampler="banded"`: P'L^-T of a declared ordering,
+    # the mode that can walk a seeded reference chain) beside the spectral one the headline uses
+    banded_per_s = None
+    if model.v_sampler() == "spectral" and world == 1 and not as_rank and args.sampler == "auto":
+        model._ctx.call("btf_set_option", _native.OPT_SAMPLER, _native.SAMPLERS["banded"])
+        nb = max(20, min(args.steps, 200))
+        for _ in range(10):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(nb):
+            step()
+        fence()
+        banded_per_s = nb / (time.perf_counter() - t0)
+        model._ctx.call("btf_set_option", _native.OPT_SAMPLER, _native.SAMPLERS["spectral"])
     b_wv = bpc * (cells_local + cells_local_v)                     # B_WV of SURVEY 8(d), per GPU
     if args.variant in ("binomial", "negbinom"):                   # + the PG draw: trials in, omega out (48 B/cell in all)
         b_wv += 16.0 * cells_local
@@ -392,7 +407,8 @@ def main():
                    "median_ms_per_step": round(float(np.median(per_step_ms)), 4), "median_over_steps": int(nmed),
                    "burn_in_sweeps": args.burn,
                    "full_resample_sweeps_per_s": round(full_per_s, 2),
-                   "v_sampler": sampler, "likelihood_form": form,
+                   "v_sampler": sampler, "banded_sweeps_per_s": None if banded_per_s is None else round(banded_per_s, 2),
+                   "likelihood_form": form,
                    "parallelism": "rows(W)/cols(V) x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "accum_kernel (w_accum + v_accum launches)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
