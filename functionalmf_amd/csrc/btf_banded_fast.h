@@ -580,6 +580,32 @@ __device__ inline void backpar16_chain(double* lds, const VbLayout L, int nb) {
   }
 }
 
+// the same chain on the matrix cores: the mat-vec M_b x_{b+1} as four v_mfma_f64_16x16x4 (A = four columns of M_b, B = four
+// entries of x_{b+1} repeated along the 16 result columns).  The accumulator of block b - element r of lane (g, .) =
+// x_b[4 r + g] - IS the B operand of block b-1 (lane (k, .) of sub-step m wants x[4 m + k]): no lane movement at all
+// between blocks, four dependent MFMAs per 16 columns.
+__device__ inline void backpar16_chain_mfma(double* lds, const VbLayout L, int nb) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  v4f64_t x = {0.0, 0.0, 0.0, 0.0};
+  for (int b = nb - 1; b >= 0; --b) {
+    const int c = 16 * b;
+    const double* Mb = lds + L.band + c * 16;
+    double A[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { const int i = 4 * m + g; A[m] = Mb[i * 16 + ((j + i) & 15)]; }      // M_b[j][i] (backpar16_prepare's swizzle)
+    v4f64_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = lds[L.rhs + c + 4 * r + g];                                      // y_b
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[m], x[m], acc, 0, 0, 0);
+    x = acc;
+    if (j == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[L.rhs + c + 4 * r + g] = acc[r];
+    }
+  }
+}
+
 // dispatch on bw (wave-uniform); false if no blocked variant exists for this band width
 template <bool ROW16>
 __device__ inline bool banded_unit_backward_auto(double* lds, const VbLayout L, int n, int bw) {

@@ -23,7 +23,11 @@ namespace btf {
 
 constexpr int VT_THREADS = 256;
 #ifndef BTF_TWIST_BACKPAR
-#define BTF_TWIST_BACKPAR 0       // 1: parallel block solves + one mat-vec per 16 columns (backpar16_*): measured 19.6 k cycles against 16.2 k for the column-by-column routine (round 3) - kept for A/B, not shipped
+#define BTF_TWIST_BACKPAR 0       // 1: parallel block solves (backpar16_prepare) + four MFMAs per 16 columns on the chain (backpar16_chain_mfma).
+                                  // Round 3: the chain itself shrinks to ~2 k cycles, but the 2 x 11 x 17 triangular solves of the prepare
+                                  // phase cost ~18 k (LDS-latency-bound) against 14.4 k for the whole column-by-column routine; hiding
+                                  // them under the forward chain (two idle waves) would need 27 k of the chain's 43 k cycles and still
+                                  // leave the blocks next to the separator on the critical path - kept for A/B, not shipped
 #endif
 
 struct TwLayout {
@@ -523,8 +527,8 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     // (band stride 16: the 2 x 11 blocks' triangular solves in parallel, then one mat-vec per block and chain)
     const int nbL = (nL + 15) / 16, nbR = (nR + 15) / 16;
     backpar16_prepare(lds, W.L, nbL, W.R, nbR, tid, VT_THREADS);
-    if (wave == 0) backpar16_chain(lds, W.L, nbL);
-    else if (wave == 1) backpar16_chain(lds, W.R, nbR);
+    if (wave == 0) backpar16_chain_mfma(lds, W.L, nbL);
+    else if (wave == 1) backpar16_chain_mfma(lds, W.R, nbR);
   } else {
     if (wave == 0) banded_unit_backward_auto<ROW16>(lds, W.L, nL, bw);
     else if (wave == 1) banded_unit_backward_auto<ROW16>(lds, W.R, nR, bw);
