@@ -413,7 +413,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "accum_kernel (w_accum + v_accum launches)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": pmc_traffic(args.config, args.variant) if world == 1 else None,
+                     "traffic": pmc_traffic(args.config, args.variant, "_rank%dof%d" % as_rank if as_rank else "") if world == 1 else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(acc_us, 2),
                      "timing": "hipExtLaunchKernelGGL start/stop events of each accumulation dispatch, %d steps (median of five block averages)" % nprof,
                      "whole_step_bytes": b_wv,
@@ -545,12 +545,13 @@ def same_config_one_gpu(config, variant):
         return None
 
 
-def pmc_traffic(config, variant):
+def pmc_traffic(config, variant, suffix=""):
     """HBM bytes per accumulation launch from a committed rocprofv3 PMC pass OF THIS WORKLOAD
-    (profiles/r*_pmc_<config>_<variant>.json: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
-    MI355X_MICROARCH.md applied); None if no such profile is committed (never another workload's figure)."""
+    (profiles/r*_pmc_<config>_<variant><suffix>.json: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+    MI355X_MICROARCH.md applied; suffix "_rank0of8" for a rehearsed rank's slabs); None if no such profile is committed
+    (never another workload's figure)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_%s.json" % (config, variant))))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_%s%s.json" % (config, variant, suffix))))
     if not files:
         return None
     try:
