@@ -5,6 +5,7 @@
 #include "btf_kernels.h"
 #include "btf_banded_fast.h"
 #include "btf_banded_twist.h"
+#include "btf_banded_chunk.h"
 #include "btf_spectral.h"
 #include "btf_gass.h"
 #include "btf_instances.h"      // the large kernel families: extern templates, compiled in btf_instances.hip
@@ -77,6 +78,7 @@ struct btf_ctx {
   int gs_chains = 0, gs_what = -1, gs_link = 0;
   double lik_par[ESS_FAM_COUNT] = {0, 0, 0, 1.0, 1.0};     // parameter per likelihood family (btf_set_likelihood_param)
   long long* dbg = nullptr;
+  double* vc_scratch = nullptr; size_t vc_scratch_elems = 0;     // factor records of the chunked chain sampler
 #ifdef BTF_ACC_STAMPS
   long long* acc_stamps = nullptr;
 #endif
@@ -461,6 +463,44 @@ hipError_t dispatch_vbanded_fast(btf_ctx* c, const VBandArgs& a, int bw, size_t 
   *handled = false;
   return hipSuccess;
 }
+// the chunked single chain (btf_banded_chunk.h): bands that do not fit LDS in one piece
+template <int NPL>
+hipError_t launch_vbanded_chunk(btf_ctx* c, const VBandArgs& a, size_t lds_bytes, int CH) {
+  static std::atomic<unsigned long long> attr_set{0};      // one bit per device: the attribute is per device
+  if (!dev_flag_is_set(attr_set, c->dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)v_banded_chunk_kernel<NPL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    dev_flag_set(attr_set, c->dev);
+  }
+  Prof p(c, BTF_K_V_BANDED);
+  p.launch(v_banded_chunk_kernel<NPL>, dim3(a.ml), dim3(VB_THREADS), lds_bytes, a, c->K, CH);
+  return hipSuccess;
+}
+constexpr size_t VC_LDS_BUDGET = 158 * 1024;
+inline int vc_npl(int bw) { return std::max(1, ((bw - 1) * (bw - 2) / 2 + WAVE - 1) / WAVE); }
+// columns per chunk of the chunked chain for this context, 0 if it does not apply
+inline int vc_chunk_for(const btf_ctx* c, bool wt) {
+  const int bw = (c->TF + 1) * c->K;
+  if (bw < 3 || vc_npl(bw) > 8) return 0;
+  return vc_pick_chunk(c->T, c->K, c->TF, wt ? 1 : 0, VC_LDS_BUDGET);
+}
+hipError_t dispatch_vbanded_chunk(btf_ctx* c, const VBandArgs& a, int bw, int CH, bool wt, bool* handled) {
+  const size_t lds_bytes = vc_lds_bytes(c->T, c->K, c->TF, wt ? 1 : 0, CH);
+  *handled = true;
+  switch (vc_npl(bw)) {
+    case 1: return launch_vbanded_chunk<1>(c, a, lds_bytes, CH);
+    case 2: return launch_vbanded_chunk<2>(c, a, lds_bytes, CH);
+    case 3: return launch_vbanded_chunk<3>(c, a, lds_bytes, CH);
+    case 4: return launch_vbanded_chunk<4>(c, a, lds_bytes, CH);
+    case 5: return launch_vbanded_chunk<5>(c, a, lds_bytes, CH);
+    case 6: return launch_vbanded_chunk<6>(c, a, lds_bytes, CH);
+    case 7: return launch_vbanded_chunk<7>(c, a, lds_bytes, CH);
+    case 8: return launch_vbanded_chunk<8>(c, a, lds_bytes, CH);
+    default: break;
+  }
+  *handled = false;
+  return hipSuccess;
+}
 template <int NPL, bool ROW16, int KC = 0, int TFC = 0>
 hipError_t launch_vbanded_twist(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
   static std::atomic<unsigned long long> attr_set{0};      // one bit per device: the attribute is per device
@@ -541,7 +581,8 @@ hipError_t dispatch_vbanded_twist(btf_ctx* c, const VBandArgs& a, int bw, size_t
   *handled = false;
   return hipSuccess;
 }
-// which sampler a V half-sweep of this context will use: 3 spectral, 2 twisted, 1 single chain (LDS), -1 generic
+// which sampler a V half-sweep of this context will use: 3 spectral, 2 twisted, 1 single chain (LDS), 4 single chain in
+// chunks (band too large for LDS in one piece), -1 generic
 int banded_choice_for(const btf_ctx* c, bool wt, bool allow_spectral) {
   const int bw = (c->TF + 1) * c->K;
   if (allow_spectral && c->sampler == BTF_SAMPLER_SPECTRAL && !wt && !c->binomial && c->st_dense_ok &&
@@ -549,6 +590,7 @@ int banded_choice_for(const btf_ctx* c, bool wt, bool allow_spectral) {
   if (c->sampler == BTF_SAMPLER_GENERIC || bw < 3) return -1;
   if (c->sampler != BTF_SAMPLER_CHAIN && twist_ok(c->T, c->K, c->TF) && tw_lds_bytes(c->T, c->K, c->TF, wt) <= 160 * 1024) return 2;
   if (vb_fast_lds_bytes(c->T, c->K, c->TF, wt) <= 158 * 1024) return 1;
+  if (c->sampler != BTF_SAMPLER_GENERIC && vc_chunk_for(c, wt) > 0) return 4;
   return -1;
 }
 // curve-structured counts are handled as complete data plus corrections when nothing is stale, the per-column
@@ -557,7 +599,8 @@ bool curve_on(const btf_ctx* c) {
   if (!c->curve || !c->curve_opt || c->binomial || !c->weighted || c->stale_w || c->stale_v) return false;
   if (c->nl != c->N || c->ml != c->M) return false;
   if ((size_t)c->ml * c->KK + 16 * c->KK > ws_gram_stage(c->K, false)) return false;
-  return banded_choice_for(c, false, true) >= 2;
+  const int ch = banded_choice_for(c, false, true);       // (spectral or twisted: the samplers that take the per-column Gram)
+  return ch == 2 || ch == 3;
 }
 // does the likelihood part run its weighted form (per-cell weights streamed, per-depth Gram blocks)?
 bool lik_weighted(const btf_ctx* c) { return c->weighted && !curve_on(c); }
@@ -1470,8 +1513,23 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
     e = dispatch_vbanded_twist(c, a, bw, tw_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
   }
   HIPCHK(c, e);
-  if (fast && !handled) e = dispatch_vbanded_fast(c, a, bw, vb_fast_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
+  if (fast && !handled && vb_fast_lds_bytes(T, K, c->TF, wt ? 1 : 0) <= 158 * 1024)
+    e = dispatch_vbanded_fast(c, a, bw, vb_fast_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
   HIPCHK(c, e);
+  if (fast && !handled) {
+    const int CH = vc_chunk_for(c, wt);
+    if (CH > 0) {
+      const size_t stride = vc_scratch_stride(T, K, c->TF);
+      if (!c->vc_scratch || c->vc_scratch_elems < (size_t)c->ml * stride) {
+        if ((rc = dev_alloc(c, &c->vc_scratch, (size_t)c->ml * stride))) return rc;
+        c->vc_scratch_elems = (size_t)c->ml * stride;
+      }
+      VBandArgs ac = a;
+      ac.gband = c->vc_scratch; ac.gband_stride = stride;     // the factor record of every column (btf_banded_chunk.h)
+      e = dispatch_vbanded_chunk(c, ac, bw, CH, wt, &handled);
+      HIPCHK(c, e);
+    }
+  }
   if (!handled) { a.gout = nullptr; if (!prior_only) c->ngp_v = 0; }
   if (!handled) { K_SWITCH(K, e = launch_vbanded<KT>(c, a, lds_bytes)); }
   HIPCHK(c, e);
@@ -3282,7 +3340,7 @@ int btf_get_V_sampler(btf_ctx* c, int32_t* which) {
   if (!c || !which) return BTF_EINVAL;
   const int ch = banded_choice(c);
   *which = ch == 3 ? BTF_SAMPLER_SPECTRAL : (ch == 2 ? (c->sampler == BTF_SAMPLER_BANDED_NOPANEL ? BTF_SAMPLER_BANDED_NOPANEL : BTF_SAMPLER_BANDED)
-                                                     : (ch == 1 ? BTF_SAMPLER_CHAIN : BTF_SAMPLER_GENERIC));
+                                                     : (ch == 1 || ch == 4 ? BTF_SAMPLER_CHAIN : BTF_SAMPLER_GENERIC));
   return BTF_OK;
 }
 

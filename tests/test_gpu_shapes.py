@@ -193,25 +193,59 @@ def test_bw15_indefinite_column_is_reported_and_jitter_recovers(variant):
     assert np.isfinite(m.V).all()
 
 
+@pytest.mark.parametrize("sampler", ["banded", "generic"])
 @pytest.mark.parametrize("weighted", [False, True])
-def test_long_depth_axis_band_in_hbm_scratch(weighted):
+def test_long_depth_axis_band_in_hbm_scratch(weighted, sampler):
     """K*T = 3700 (the size of the reference's flu-trends application: flutrends/, 370 weeks x 10 embeddings):
-    the block-banded factor does not fit the 160 KB of LDS, so the any-size kernel keeps the band in HBM scratch
-    and only the vectors on chip.  One column block against the oracle from identical state and normals."""
+    the block-banded factor does not fit the 160 KB of LDS.  Default: the chunked chain (btf_banded_chunk.h) - the band is
+    assembled and eliminated ~200 columns at a time in LDS, the finished factor columns parked in HBM; sampler="generic":
+    the any-size kernel with the whole band in HBM scratch.  One column block against the oracle from identical state and
+    normals, both ways."""
     from functionalmf_amd.factor import GaussianBayesianTensorFiltering
     from oracle import btf_oracle as orc
     N, M, T, R, K, tf = 12, 2, 370, 2, 10, 2
     Y, st = make_case(N, M, T, R, K, tf, weighted, seed=77)
     model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
-                                            nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], sampler="banded")
+                                            nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], sampler=sampler)
     np.random.seed(5)
     zv = np.random.normal(size=(M, K * T))
     np.random.seed(5)
     model._resample_V(Y)
-    assert model.v_sampler() == "generic"
+    assert model.v_sampler() == ("chain" if sampler == "banded" else "generic")
     ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
     orc.v_step(ost, Y, orc.trend_penalty(T, tf), z=zv, perm=orc.perm_from_order(model.v_order(), K, T))
     assert relerr(model.V, ost["V"]) < 1e-8
+
+
+@pytest.mark.parametrize("N,M,T,R,K,tf,missing", [
+    (20, 5, 64, 2, 10, 2, True),      # C3's depth, nembeds 10, weighted: 640 x 31 band, two chunks
+    (20, 5, 64, 2, 9, 2, True),
+    (20, 5, 64, 2, 10, 2, False),     # complete data, sampler="banded" (the spectral sampler is the default there)
+    (20, 3, 64, 1, 8, 3, True),       # bw 32: the widest band the chain kernels take
+    (15, 3, 150, 2, 6, 2, True),      # 900 x 19
+    (15, 2, 41, 2, 10, 2, True),      # the last chunk shorter than the others
+])
+def test_chunked_chain_matches_oracle_and_the_any_size_kernel(N, M, T, R, K, tf, missing):
+    """Bands that do not fit LDS in one piece (weighted data from nembeds 8 at C3's depth): the chunked chain draws the
+    same depth-major x = Q^-1 mu + L^-T D^-1/2 z as the any-size kernel it replaces - and as the oracle."""
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    from oracle import btf_oracle as orc
+    Y, st = make_case(N, M, T, R, K, tf, missing, seed=N * 31 + K)
+    out = {}
+    for sampler in ("banded", "generic"):
+        model = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                                nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], sampler=sampler)
+        np.random.seed(5)
+        model._resample_V(Y)
+        assert model.v_sampler() == ("chain" if sampler == "banded" else "generic")
+        assert list(model.v_order()) == list(range(K * T))
+        out[sampler] = model.V.copy()
+    np.random.seed(5)
+    zv = np.random.normal(size=(M, K * T))
+    ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    orc.v_step(ost, Y, orc.trend_penalty(T, tf), z=zv, perm="depth")
+    assert relerr(out["banded"], ost["V"]) < 1e-8
+    assert relerr(out["banded"], out["generic"]) < 1e-9
 
 
 @pytest.mark.parametrize("N,M,T,R,K,tf", [(2100, 3, 5, 2, 2, 1), (9, 40, 64, 1, 3, 2), (2300, 36, 64, 1, 8, 2)])
