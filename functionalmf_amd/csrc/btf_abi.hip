@@ -355,6 +355,10 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
     else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
   } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
   else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+  else if (K >= 10 && ACC_WAVES != acc_waves(10, 0) && !side.out && rpb < unr3_min_rpb()) {
+    // nembeds 10: a launch without eigen side tasks (the W half-sweep's) takes the 16-wave instance
+    if constexpr (K >= 10) p.launch(accum_kernel<K, 0, ACC_WAVES>, grid, dim3(ACC_WAVES * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+  }
   else if (rpb >= unr3_min_rpb()) p.launch(accum_kernel<K, 0, acc_waves(K, 0), double, double, 3>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
   else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
 }

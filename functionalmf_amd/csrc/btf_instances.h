@@ -23,6 +23,12 @@ namespace btf {
   P void accum_kernel<K, 1, acc_waves(K, 1), double, signed char> BTF_ACC_ARGS(signed char, double);     \
   P void accum_kernel<K, 2, acc_waves(K, 2), double, signed char> BTF_ACC_ARGS(signed char, double);
 
+// nembeds 10, complete data: the W launch (no eigen side task, whose unrolled form is what needs the 8-wave register budget)
+// runs 16 waves per workgroup like the smaller K: 16.7 -> 13.3 us at (512,256,64), 5.0 TB/s (not the three-rows-in-flight
+// form of long row ranges: two spilled VGPRs at 16 waves - it stays with 8)
+#define BTF_ACCUM_K10W_SET(P)                                                                            \
+  P void accum_kernel<10, 0, ACC_WAVES> BTF_ACC_ARGS(double, double);
+
 #define BTF_WSOLVE_SET(P, K)                                                                             \
   P void w_solve_kernel<K, false, 8>(WSolveArgs);  P void w_solve_kernel<K, true, 8>(WSolveArgs);        \
   P void w_solve_kernel<K, false, 16>(WSolveArgs); P void w_solve_kernel<K, true, 16>(WSolveArgs);       \
@@ -69,6 +75,7 @@ constexpr int BTF_INST_PARTS = 8;
 #ifndef BTF_INST_PART
 #define BTF_X extern template __global__
 BTF_FOR_K(BTF_ACCUM_SET, BTF_X)
+BTF_ACCUM_K10W_SET(BTF_X)
 BTF_FOR_K(BTF_WSOLVE_SET, BTF_X)
 BTF_FOR_K(BTF_PG_SET, BTF_X)
 BTF_FOR_K(BTF_NB_SET, BTF_X)
@@ -77,7 +84,7 @@ BTF_TWIST_SET(BTF_X)
 #else
 #define BTF_D template __global__
 #if BTF_INST_PART == 0
-BTF_ACCUM_SET(BTF_D, 10) BTF_ACCUM_SET(BTF_D, 4)
+BTF_ACCUM_SET(BTF_D, 10) BTF_ACCUM_K10W_SET(BTF_D) BTF_ACCUM_SET(BTF_D, 4)
 #elif BTF_INST_PART == 1
 BTF_ACCUM_SET(BTF_D, 9) BTF_ACCUM_SET(BTF_D, 5)
 #elif BTF_INST_PART == 2
