@@ -524,33 +524,43 @@ hipError_t launch_vbanded_twist(btf_ctx* c, const VBandArgs& a, size_t lds_bytes
 // (btf_banded_twist.h, "assemble the two bands").  Padded to a multiple of the workgroup size with reads of
 // P[0] written to a dummy word.
 // band assembly program of the twisted kernel, [n][4] = {dst, src, diag-src or -1, 0} in LDS word offsets: pure host code
-void fill_table_host(int T, int K, int TF, bool weighted, std::vector<int>& tab) {
+// wmode: 0 complete data (one shared block), 1 weighted (per-depth blocks staged in LDS), 2 weighted, blocks fetched from
+// the partials: source -2 - (q T + t)
+void fill_table_host(int T, int K, int TF, int wmode, std::vector<int>& tab) {
   const int KK = tri(K), D1 = TF + 2, n = T * K;
-  const TwLayout W = tw_layout(T, K, TF, weighted ? 1 : 0);
+  const bool weighted = wmode != 0;
+  const TwLayout W = tw_layout(T, K, TF, wmode);
+  auto qsrc = [&](int t, int q) { return wmode == 2 ? -2 - (q * T + t) : W.Ql + (weighted ? t * KK : 0) + q; };
   const int R1 = W.L.R1, nl = W.nl, nr = W.nr, nL = W.nL;
   tab.clear();
   auto put = [&](int dst, int src, int dia) { tab.push_back(dst); tab.push_back(src); tab.push_back(dia); tab.push_back(0); };
   for (int i = 0; i < nL; ++i) {                       // left view: column i (global g = i), entry (g+aa, g)
     const int t = i / K, k = i - t * K;
     for (int aa = 0; aa < K - k; ++aa)
-      if (i + aa < nL) put(W.L.band + i * R1 + aa, W.Ql + (weighted ? t * KK : 0) + lidx(k + aa, k), aa == 0 ? W.P + t * D1 : -1);
+      if (i + aa < nL) put(W.L.band + i * R1 + aa, qsrc(t, lidx(k + aa, k)), aa == 0 ? W.P + t * D1 : -1);
     for (int d = 1; d < D1; ++d)
       if (t + d < T && i + d * K < nL) put(W.L.band + i * R1 + d * K, W.P + t * D1 + d, -1);
   }
   for (int m = 0; m < nr; ++m) {                       // right view: mirrored column m (global gc = n-1-m), entry (gc, gc-aa)
     const int gc = n - 1 - m, tc = gc / K, kc = gc - tc * K;
     for (int aa = 0; aa <= kc; ++aa)
-      if (gc - aa >= nl) put(W.R.band + m * R1 + aa, W.Ql + (weighted ? tc * KK : 0) + lidx(kc, kc - aa), aa == 0 ? W.P + tc * D1 : -1);
+      if (gc - aa >= nl) put(W.R.band + m * R1 + aa, qsrc(tc, lidx(kc, kc - aa)), aa == 0 ? W.P + tc * D1 : -1);
     for (int d = 1; d < D1; ++d)
       if (gc - d * K >= nl) put(W.R.band + m * R1 + d * K, W.P + (tc - d) * D1 + d, -1);
   }
   while ((tab.size() / 4) % VT_THREADS) put(W.L.dummy + 1, W.P, -1);
 }
+// how the twisted kernel holds the likelihood blocks of this context: 0 / 1 / 2 as fill_table_host's wmode; -1: does not fit
+inline int twist_wmode(const btf_ctx* c, bool wt) {
+  if (tw_lds_bytes(c->T, c->K, c->TF, wt ? 1 : 0) <= 160 * 1024) return wt ? 1 : 0;
+  if (wt && tw_lds_bytes(c->T, c->K, c->TF, 2) <= 160 * 1024) return 2;
+  return -1;
+}
 int make_fill_table(btf_ctx* c, bool weighted) {
-  const int key = weighted ? 1 : 0;
+  const int key = twist_wmode(c, weighted);
   if (c->fill_tab && c->fill_key == key) return BTF_OK;
   std::vector<int> tab;
-  fill_table_host(c->T, c->K, c->TF, weighted, tab);
+  fill_table_host(c->T, c->K, c->TF, key, tab);
   int rc;
   if ((rc = dev_alloc(c, &c->fill_tab, tab.size()))) return rc;
   HIPCHK(c, hipMemcpy(c->fill_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -592,7 +602,7 @@ int banded_choice_for(const btf_ctx* c, bool wt, bool allow_spectral) {
   if (allow_spectral && c->sampler == BTF_SAMPLER_SPECTRAL && !wt && !c->binomial && c->st_dense_ok &&
       vs_lds_bytes(c->T, c->K, c->TF, c->nD, true) <= 160 * 1024) return 3;        // (pivot records in LDS, or in HBM scratch for long depth axes)
   if (c->sampler == BTF_SAMPLER_GENERIC || bw < 3) return -1;
-  if (c->sampler != BTF_SAMPLER_CHAIN && twist_ok(c->T, c->K, c->TF) && tw_lds_bytes(c->T, c->K, c->TF, wt) <= 160 * 1024) return 2;
+  if (c->sampler != BTF_SAMPLER_CHAIN && twist_ok(c->T, c->K, c->TF) && twist_wmode(c, wt) >= 0) return 2;
   if (vb_fast_lds_bytes(c->T, c->K, c->TF, wt) <= 158 * 1024) return 1;
   if (c->sampler != BTF_SAMPLER_GENERIC && vc_chunk_for(c, wt) > 0) return 4;
   return -1;
@@ -1514,7 +1524,8 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
   if (choice == 2) {
     if ((rc = make_fill_table(c, wt))) return rc;
     a.fill = c->fill_tab; a.nfill = c->fill_n;
-    e = dispatch_vbanded_twist(c, a, bw, tw_lds_bytes(T, K, c->TF, wt ? 1 : 0), &handled);
+    a.ql_global = twist_wmode(c, wt) == 2 ? 1 : 0;
+    e = dispatch_vbanded_twist(c, a, bw, tw_lds_bytes(T, K, c->TF, twist_wmode(c, wt)), &handled);
   }
   HIPCHK(c, e);
   if (fast && !handled && vb_fast_lds_bytes(T, K, c->TF, wt ? 1 : 0) <= 158 * 1024)
@@ -3272,7 +3283,7 @@ int btf_host_selftest(void) {
             for (int v : seen) ST_CHECK(v == 1);
             if (tw_lds_bytes(T, K, tf, wt) <= 160 * 1024) {
               std::vector<int> tab;
-              fill_table_host(T, K, tf, wt != 0, tab);
+              fill_table_host(T, K, tf, wt, tab);
               ST_CHECK(!tab.empty() && tab.size() % (4 * VT_THREADS) == 0);
               for (size_t e = 0; e < tab.size(); e += 4) {
                 ST_CHECK(tab[e] >= 0 && tab[e] < W.total && tab[e + 1] >= 0 && tab[e + 1] < W.total);

@@ -75,7 +75,10 @@ __host__ __device__ inline TwLayout tw_layout(int T, int K, int TF, int weighted
   W.m0 = o; o += n;
   W.zs = o; o += n;
   W.P = o; o += T * D1;
-  W.Ql = o; o += weighted ? T * KK : KK;
+  // weighted == 2: the per-depth likelihood blocks are NOT staged in LDS - the band assembly program fetches each of them
+  // from the accumulation partials where it needs it (fill entries with a negative source) - for the shapes whose
+  // T K(K+1)/2 blocks are what keeps the layout from fitting (nembeds 8 at 64 depths: 180 -> 162 KB)
+  W.Ql = o; o += weighted == 1 ? T * KK : (weighted == 2 ? 0 : KK);
   W.flag = o; o += 8;
   W.itau = o; o += (TF + 2) * T;            // 1 / (lam2 Tau2_jr) per penalty row (at most (tf+2) T rows)
   W.total = o;
@@ -115,7 +118,8 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   const int j = blockIdx.x, jg = a.col0 + j;
   const int KK = tri(K), T = a.T, n = T * K, D1 = a.TF + 2, bw = (a.TF + 1) * K, R1 = bw <= 15 ? 16 : bw + 1;   // = tw_layout's stride
   const int NV = a.weighted ? K + KK : K;
-  const TwLayout W = tw_layout(T, K, a.TF, a.weighted);
+  const bool ql_global = a.weighted && a.ql_global;          // (see tw_layout: weighted == 2)
+  const TwLayout W = tw_layout(T, K, a.TF, a.weighted ? (ql_global ? 2 : 1) : 0);
   const int nl = W.nl, nr = W.nr, ns = W.ns, nL = W.nL, nR = W.nR;
   double* m0 = lds + W.m0;
   double* zs = lds + W.zs;
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   const bool g_early = !a.weighted && gram_early_ok(a.ngp, KK);     // Gram partials: fetched now, summed below
   if (g_early) reduce_gram_fetch(a.gpart, a.ngp, KK, gx);
   // per-depth likelihood blocks of weighted data, element e = q*T + t (see the general loop below)
-  const bool ql_now = a.weighted && n <= 2 * VT_THREADS && T * KK <= 4 * VT_THREADS;
+  const bool ql_now = a.weighted && !ql_global && n <= 2 * VT_THREADS && T * KK <= 4 * VT_THREADS;
   const double* qp[4];
   int qdst[4];
   bool qhas[4];
@@ -284,6 +288,8 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   if (ql_now) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) if (qhas[u]) Ql[qdst[u]] = qacc[u] * a.s;
+  } else if (ql_global) {
+    // (nothing staged: the assembly reads the blocks from the partials)
   } else if (a.weighted) {
     // per-depth likelihood blocks: element e = q*T + t, so that consecutive lanes read consecutive depths of one
     // Gram entry (coalesced 8-B words; the scatter to Ql[t*KK + q] is on the LDS side), four elements' chunks in
@@ -368,10 +374,15 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     if (a.fill) {
       // table-driven: every entry is an independent LDS read -> write (the loops below did one dependent
       // read -> write per column and trip, eleven trips per view, with one wave per SIMD to hide it)
+      // a negative source -2 - (q T + t) names entry q of depth t's likelihood block in the partials (ql_global)
+      auto from_partials = [&](int src) -> double {
+        const int e = -2 - src, q = e / T, t = e - q * T;
+        return chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t) * a.s;
+      };
       double val[FILL_REG];
 #pragma unroll
       for (int u = 0; u < FILL_REG; ++u) {
-        val[u] = lds[fsrc[u]];
+        val[u] = fsrc[u] >= 0 ? lds[fsrc[u]] : from_partials(fsrc[u]);
         if (fdia[u] >= 0) val[u] += lds[fdia[u]] + shift;
       }
 #pragma unroll
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
         const int e = u * VT_THREADS + tid;
         const int4 f = reinterpret_cast<const int4*>(a.fill)[e];
         const int dst = f.x, src = f.y, dia = f.z;
-        double v = lds[src];
+        double v = src >= 0 ? lds[src] : from_partials(src);
         if (dia >= 0) v += lds[dia] + shift;
         lds[dst] = v;
       }

@@ -1096,6 +1096,7 @@ struct VBandArgs {
   int panel4;          // 1: panelised MFMA factorisation where it applies (bw == 15)
   const int* fill;     // band assembly program of the twisted kernel: [nfill][4] = {dst, src, diag-src or -1, 0} (LDS word offsets)
   int nfill;           // multiple of the workgroup size (padded with writes to a dummy word)
+  int ql_global;       // twisted kernel, weighted data: 1 = likelihood blocks fetched from the partials by the assembly program, not staged in LDS
   CurveLists cv;       // curve-structured counts: deficient rows of every column (global column index), or ptr == nullptr
   const double* cv_W;  // the factor W (rows of the rank-one terms)
   const int* st_drow; const double* st_dcoef;   // the stencil with VS_MAXE fixed slots per (t,d): the twisted kernel builds

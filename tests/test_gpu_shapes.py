@@ -61,6 +61,8 @@ CASES = [
     (40, 9, 12, 3, 5, 2, "curves"), # whole / thinned curves missing: complete-data kernels plus corrections
     (600, 5, 8, 2, 3, 1, "curves"),
     (23, 70, 9, 2, 8, 2, "curves"), # more deficient columns than one side workgroup takes; K = 8
+    (20, 3, 64, 2, 8, 2, True),     # K = 8 at C3's depth, weighted: the twisted layout fits only without the staged likelihood blocks
+    (20, 3, 64, 2, 7, 2, True),     # ... K = 7: fits with them
     (31, 6, 9, 1, 4, 2, "curves"),  # 3-D input: counts 0 / 1
 ]
 
