@@ -250,6 +250,47 @@ def test_chunked_chain_matches_oracle_and_the_any_size_kernel(N, M, T, R, K, tf,
     assert relerr(out["banded"], out["generic"]) < 1e-9
 
 
+def test_chunked_chain_jitter_retries_and_failure():
+    """The chunked chain restarts from its first chunk when a pivot fails: a column made indefinite must be rescued by
+    the same cumulative jitter schedule as the any-size kernel (same retries, same draw), a grossly indefinite one
+    reported with its index, and the context usable afterwards."""
+    import ctypes as C
+    from functionalmf_amd._native import NotPositiveDefiniteError
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    N, M, T, R, K, tf = 20, 4, 64, 2, 10, 2
+    Y, st = make_case(N, M, T, R, K, tf, True, seed=91)
+
+    def run(sampler, tau_entry):
+        m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                            nu2_init=st["nu2"], W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"].copy(),
+                                            sampler=sampler, force_psd_eps=10.0, force_psd_attempts=4)
+        m.Tau2[2, 150] = tau_entry                      # a penalty row in the second chunk of column 2
+        np.random.seed(3)
+        m._resample_V(Y)
+        return m
+
+    tries = {}
+    out = {}
+    for sampler in ("banded", "generic"):
+        m = run(sampler, -0.05)                         # 1 / (lam2 Tau2) = -67 on a few diagonal entries: shift 10 fails, 110 rescues
+        m.sync()
+        assert m.v_sampler() == ("chain" if sampler == "banded" else "generic")
+        t = np.zeros(M, dtype=np.int32)
+        m._ctx.call("btf_get_V_attempts", t.ctypes.data_as(C.POINTER(C.c_int32)))
+        tries[sampler], out[sampler] = t.copy(), m.V.copy()
+    assert tries["banded"][2] >= 1 and (tries["banded"] == tries["generic"]).all()
+    assert relerr(out["banded"], out["generic"]) < 1e-8
+    m = run("banded", -1e-6)                            # hopeless: every retry fails
+    with pytest.raises(NotPositiveDefiniteError) as e:
+        m.sync()
+    assert e.value.index == 2
+    m.Tau2 = st["Tau2"].copy()
+    np.random.seed(3)
+    m._resample_V(Y)
+    m.sync()
+    assert np.isfinite(m.V).all()
+
+
 @pytest.mark.parametrize("N,M,T,R,K,tf", [(2100, 3, 5, 2, 2, 1), (9, 40, 64, 1, 3, 2), (2300, 36, 64, 1, 8, 2)])
 def test_long_row_ranges_per_workgroup(N, M, T, R, K, tf):
     """Row ranges of >= 2048 rows per workgroup take the three-rows-in-flight build of the complete-data accumulation
