@@ -2269,7 +2269,9 @@ int nb_upload_rate(btf_ctx* c, const double* R, const double* cand, const int32_
 
 int btf_set_data_counts(btf_ctx* c, const double* counts, int nreps) {
   if (!c || !counts || nreps < 1) return fail(c, BTF_EINVAL, "bad data arguments");
-  if (c->nl != c->N || c->ml != c->M) return fail(c, BTF_EINVAL, "count data need an unsharded context");
+  // Sharded contexts take the WHOLE count tensor too (8.6 GB at C5 against 288 GB of HBM): the rate update needs all of it
+  // and every rank computes it, like the other hyper-parameters; the augmented Binomial model - pseudo-data, trial counts,
+  // Polya-Gamma weights - is kept for the rank's two slabs only (nb_trials_kernel).
   HIPCHK(c, hipSetDevice(c->dev));
   const int MT = c->M * c->T;
   const size_t cells = (size_t)c->N * MT;
@@ -2277,8 +2279,8 @@ int btf_set_data_counts(btf_ctx* c, const double* counts, int nreps) {
   c->pg_has_small = c->pg_has_big = c->pg_has_frac = true;      // pseudo-trial counts change with the rate: every pass
   if (c->C8_wT) { (void)hipFree(c->C8_wT); c->C8_wT = nullptr; }
   if (c->C8_v) { (void)hipFree(c->C8_v); c->C8_v = nullptr; }
-  c->ldw = round_up(c->N, ACC_TILE);
-  c->ldv = round_up(MT, ACC_TILE);
+  c->ldw = round_up(std::max(c->nl, 1), ACC_TILE);
+  c->ldv = round_up(std::max(c->ml * c->T, 1), ACC_TILE);
   int rc;
   if ((rc = dev_alloc(c, &c->nb_data, cells * nreps))) return rc;
   if ((rc = dev_alloc(c, &c->nb_S, cells))) return rc;
@@ -2439,7 +2441,7 @@ int btf_nb_set_rate(btf_ctx* c, const double* R, const int32_t* shared) {
     Prof p(c, BTF_K_STATS);
     p.launch(nb_trials_kernel, dim3((MT + 63) / 64, (c->N + 63) / 64), dim3(256), 0, (const double*)c->nb_S,
              (const double*)c->nb_cnt, (const double*)c->nb_R, sr[0], sr[1], sr[2], c->N, MT, c->T, c->ldv, c->ldw, c->A_v,
-             c->B_v, c->A_wT, c->B_wT);
+             c->B_v, c->A_wT, c->B_wT, c->row0, c->nl, c->col0 * c->T, c->ml * c->T);
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));      // R is a borrowed host buffer
@@ -2521,7 +2523,7 @@ int btf_nb_mh(btf_ctx* c, uint64_t seed, int nsteps, double rpropstdev, double r
     Prof p(c, BTF_K_STATS);
     p.launch(nb_trials_kernel, dim3((MT + 63) / 64, (c->N + 63) / 64), dim3(256), 0, (const double*)c->nb_S,
              (const double*)c->nb_cnt, (const double*)c->nb_R, sr[0], sr[1], sr[2], c->N, MT, c->T, c->ldv, c->ldw, c->A_v,
-             c->B_v, c->A_wT, c->B_wT);
+             c->B_v, c->A_wT, c->B_wT, c->row0, c->nl, c->col0 * c->T, c->ml * c->T);
   }
   HIPCHK(c, hipGetLastError());
   if (R_in) HIPCHK(c, hipStreamSynchronize(c->stream));      // borrowed host buffer

@@ -2461,11 +2461,15 @@ static __global__ void nb_stats_kernel(const double* __restrict__ data, int Rr, 
 }
 
 // 64 x 64 tiles of the (N, MT) cell grid: V layout written directly, W layout through an LDS transpose
+// (sharded contexts hold the WHOLE count tensor - the rate update is a function of all of it and is computed by every rank,
+//  like the other hyper-parameters - and only their two slabs of the augmented model: rows row0 .. row0+nl-1 go to the
+//  transposed layout, columns jt_lo .. jt_lo+jt_n-1 of the (j,t) axis to the other)
 static __global__ __launch_bounds__(256) void nb_trials_kernel(const double* __restrict__ S, const double* __restrict__ cnt,
                                                        const double* __restrict__ Rv, long long sr0, long long sr1,
                                                        long long sr2, int N, int MT, int T, int ldv, int ldw,
                                                        double* __restrict__ Av, double* __restrict__ Bv,
-                                                       double* __restrict__ AwT, double* __restrict__ BwT) {
+                                                       double* __restrict__ AwT, double* __restrict__ BwT,
+                                                       int row0, int nl, int jt_lo, int jt_n) {
   __shared__ double ta[64][65], tb[64][65];
   const int col = threadIdx.x & 63;
   const int rgrp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2482,8 +2486,10 @@ static __global__ __launch_bounds__(256) void nb_trials_kernel(const double* __r
         b = s + n * Rv[(long long)i * sr0 + (long long)j * sr1 + (long long)t * sr2];
         a = s - 0.5 * b;
       }
-      Av[(size_t)i * ldv + jt] = a;
-      Bv[(size_t)i * ldv + jt] = b;
+      if (jt >= jt_lo && jt < jt_lo + jt_n) {
+        Av[(size_t)i * ldv + (jt - jt_lo)] = a;
+        Bv[(size_t)i * ldv + (jt - jt_lo)] = b;
+      }
     }
     ta[r][col] = a; tb[r][col] = b;
   }
@@ -2491,9 +2497,9 @@ static __global__ __launch_bounds__(256) void nb_trials_kernel(const double* __r
   const int i = i0 + col;
   for (int q = 0; q < 16; ++q) {
     const int c = rgrp + 4 * q, jj = jt0 + c;
-    if (jj < MT && i < N) {
-      AwT[(size_t)jj * ldw + i] = ta[col][c];
-      BwT[(size_t)jj * ldw + i] = tb[col][c];
+    if (jj < MT && i >= row0 && i < row0 + nl) {
+      AwT[(size_t)jj * ldw + (i - row0)] = ta[col][c];
+      BwT[(size_t)jj * ldw + (i - row0)] = tb[col][c];
     }
   }
 }

@@ -1040,8 +1040,9 @@ class NegativeBinomialBayesianTensorFiltering(BinomialBayesianTensorFiltering):
     def __init__(self, nrows, ncols, ndepth, R_true=None, R_init=None, nmetropolis=30, rpropstdev=0.1,
                  rstdev=1, rdims=(0, 1, 2), **kwargs):
         super().__init__(nrows, ncols, ndepth, **kwargs)
-        if self._plan.world > 1:
-            raise NotImplementedError("NegativeBinomialBayesianTensorFiltering: unsharded runs only")
+        # (sharded runs: every rank uploads the WHOLE count tensor - the rate update is a function of all of it and every
+        #  rank computes it, from the same streams, like the other hyper-parameters; the augmented Binomial model is kept
+        #  for the rank's two slabs only: btf_set_data_counts)
         self._shared = tuple(sorted(int(d) for d in (rdims if rdims is not None else ())))
         self.rdims = [3] + list(self._shared[::-1])                      # factor.py:485
         self.nmetropolis, self.rpropstdev, self.rstdev = nmetropolis, rpropstdev, rstdev

@@ -173,7 +173,10 @@ int btf_set_stale_sources(btf_ctx* ctx, const int32_t* src_row, const int32_t* s
  * p = ilogit(clip(w.v,-10,10)), NaN observations dropped.  Synchronises.  When R is shared
  * along (cols, depth) and every count is an integer < 1024 the sum is evaluated from per-row
  * count histograms (built once at upload) and one pass per sweep for sum cnt*log(1-p): an MH
- * step then reads 8 KB per row instead of the count tensor.                               */
+ * step then reads 8 KB per row instead of the count tensor.
+ * Sharded contexts (btf_set_shard) pass the WHOLE (nrows, ncols, ndepth, nreps) tensor as well: the rate
+ * update is a function of all of it and every rank computes it (same streams, same result), while
+ * the augmented Binomial model is kept for the rank's row and column slabs only.              */
 int btf_set_data_counts(btf_ctx* ctx, const double* counts, int nreps);
 int btf_nb_loglik(btf_ctx* ctx, const double* R, const double* cand, const int32_t* shared3, double* ll);
 int btf_nb_set_rate(btf_ctx* ctx, const double* R, const int32_t* shared3);

@@ -182,6 +182,35 @@ def main():
     a, b = chains
     assert np.abs(a[2] - b[2]).max() / np.abs(b[2]).max() < 1e-12          # the same Polya-Gamma draws, cell by cell
     assert np.abs(a[0] - b[0]).max() / np.abs(b[0]).max() < 1e-7 and np.abs(a[1] - b[1]).max() / np.abs(b[1]).max() < 1e-5
+    # ---- Negative-Binomial counts sharded: every rank holds the whole count tensor (the rate update is a function of all of
+    # it and is computed by every rank from the same Philox streams, like the other hyper-parameters); the augmented Binomial
+    # model - pseudo-data, Polya-Gamma weights, W and V half-sweeps - lives on the rank's two slabs.  Rates per row (the
+    # sharing pattern of examples/negbinom_tensor_filtering.py: the one-launch MH loop) and per cell (the stepwise loop).
+    from functionalmf_amd.factor import NegativeBinomialBayesianTensorFiltering
+    rs = np.random.RandomState(11)
+    N, M, T, K, tf = 18, 7, 9, 3, 1
+    cnts = rs.poisson(3.0, size=(N, M, T, 2)).astype(float)
+    cnts[rs.rand(N, M, T, 2) < 0.1] = np.nan
+    W0, V0 = 0.3 * rs.normal(size=(N, K)), 0.3 * rs.normal(size=(M, T, K))
+    W0[np.triu_indices(N, 1, K)] = 0
+    for rdims in ((1, 2), ()):
+        chains = []
+        for shard in ((rank, world), None):
+            np.random.seed(7)
+            os.environ["BTF_EXERCISE_EXCHANGE"] = exercise if shard is not None else "0"
+            m = NegativeBinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=0.7, lam2_init=0.2, W_init=W0.copy(),
+                                                        V_init=V0.copy(), rdims=rdims, nmetropolis=5, compat="exact", shard=shard, device=0,
+                                                        rng="device", device_seed=9, overlap_exchange=OVERLAP)
+            for _ in range(2):
+                m.resample(cnts)
+            with np.errstate(divide="ignore"):
+                om = np.where(np.isfinite(m.nu2), 1.0 / np.array(m.nu2), 0.0)      # (unobserved cells: weight 0, nu2 = inf)
+            chains.append((m.W.copy(), m.V.copy(), np.array(m.R).copy(), om))
+            del m
+        a, b = chains
+        assert np.abs(a[2] - b[2]).max() / np.abs(b[2]).max() < 1e-9, ("R", rdims)
+        assert np.abs(a[3] - b[3]).max() / np.abs(b[3]).max() < 1e-9, ("omega", rdims)
+        assert np.abs(a[0] - b[0]).max() / np.abs(b[0]).max() < 1e-7 and np.abs(a[1] - b[1]).max() / np.abs(b[1]).max() < 1e-5, rdims
     print("SHARD_GPU_OK rank", rank, flush=True)
     dist.barrier()
     dist.destroy_process_group()
