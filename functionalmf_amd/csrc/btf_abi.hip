@@ -2503,10 +2503,17 @@ int btf_nb_mh(btf_ctx* c, uint64_t seed, int nsteps, double rpropstdev, double r
       hipLaunchKernelGGL(nb_mh_step_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_out, gp, 1, 1, c->nb_R,
                          c->nb_C, rpropstdev, rstdev, sidx, (unsigned long long)seed);
     }
-  } else
+  }
+  // one rate per row: the rows' chains are independent - the whole loop in one launch, a workgroup per row
+  const bool rows_fused = !single && !scalar && nR == (size_t)c->N && !(stepwise_env && stepwise_env[0] == '1');
+  if (rows_fused) {
+    Prof p(c, BTF_K_NB);
+    p.launch(nb_mh_rows_kernel, dim3(c->N), dim3(256), 0, (const double*)c->nb_Hd, (const double*)c->nb_L, optr, (const double*)c->nb_oval,
+             c->nb_R, c->nb_C, rpropstdev, rstdev, nsteps, (unsigned long long)seed, std::min(c->nb_ymax + 1, (int)NB_TAB));
+  } else if (!single)
   hipLaunchKernelGGL(nb_mh_step_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_out, c->N, (int)nR, scalar, c->nb_R,
                      c->nb_C, rpropstdev, rstdev, -1, (unsigned long long)seed);
-  for (int sidx = 0; !single && sidx < nsteps; ++sidx) {
+  for (int sidx = 0; !single && !rows_fused && sidx < nsteps; ++sidx) {
     {
       Prof p(c, BTF_K_NB);
       p.launch(nb_hist_loglik_kernel, dim3(c->N), dim3(256), 0, (const double*)c->nb_Hd, (const double*)c->nb_L,

@@ -2656,6 +2656,64 @@ static __global__ __launch_bounds__(256) void nb_mh_step_kernel(const double* __
   }
 }
 
+// The whole random-walk MH loop for one rate PER ROW (rdims = (1,2), the sharing pattern of the reference's example), in one
+// launch: the chains of different rows do not interact, so workgroup b runs row b's nsteps steps by itself - its histogram
+// row in registers, the table of sum_{k<y} log((c+k)/(r+k)) rebuilt per step up to the largest count of the data, the
+// accept / propose arithmetic of nb_mh_step_kernel on thread 0 (same Philox stream: element b, two blocks per step) -
+// instead of two launches per step.  Same sums in the same order as nb_hist_loglik_kernel + nb_mh_step_kernel: the
+// chains are bit-identical (BTF_NB_MH_STEPWISE=1 keeps the stepwise form for the test).
+static __global__ __launch_bounds__(256) void nb_mh_rows_kernel(const double* __restrict__ Hd, const double* __restrict__ L,
+                                                        const int* __restrict__ optr, const double* __restrict__ oval,
+                                                        double* __restrict__ Rv, double* __restrict__ Cv, double rpropstdev,
+                                                        double rstdev, int nsteps, unsigned long long seed, int ymax) {
+  __shared__ double tab[NB_TAB];
+  __shared__ double wsum[4];
+  __shared__ double red[4];
+  __shared__ double rc[2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double h[NB_TAB / 256];
+#pragma unroll
+  for (int q = 0; q < NB_TAB / 256; ++q) h[q] = Hd[(size_t)b * NB_TAB + tid + 256 * q];
+  const int e0 = optr ? optr[b] : 0, e1 = optr ? optr[b + 1] : 0;
+  const double Lb = L[b];
+  if (tid == 0) {          // step -1: propose only
+    CellRng g(seed, (unsigned long long)b);
+    g.ctr = 0ull;
+    const double r = Rv[b];
+    rc[0] = r;
+    rc[1] = exp(log(r) + rpropstdev * g.normal());
+  }
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const double r = rc[0], c = rc[1];
+    nb_build_table(r, c, tab, wsum, ymax);               // (ends with a barrier: everybody has read rc)
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NB_TAB / 256; ++q) acc = fma(h[q], tab[tid + 256 * q], acc);
+    if (e1 > e0) {
+      const double base = lgamma_diff(r, c);
+      for (int e = e0 + tid; e < e1; e += 256) acc += lgamma_diff(oval[e] + c, oval[e] + r) + base;
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      const double ll = red[0] + red[1] + red[2] + red[3] + (c - r) * Lb;
+      CellRng g(seed, (unsigned long long)b);
+      g.ctr = 2ull * (unsigned long long)(step + 1);
+      const double lr = log(r), lc = log(c);
+      const double prior = (lr * lr - lc * lc) / (2.0 * rstdev * rstdev);
+      const double prob = exp(fmin(fmax(prior + ll, -10.0), 1.0));
+      double rn = r;
+      if (g.uniform() <= prob && c > 1.0) rn = c;
+      rc[0] = rn;
+      rc[1] = exp(log(rn) + rpropstdev * g.normal());
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { Rv[b] = rc[0]; Cv[b] = rc[1]; }
+}
+
 // Single shared rate, more outliers than one workgroup should take: the per-step likelihood ratio as gridDim.x
 // partial sums (workgroup g: logarithm k = 256 g + tid of the suffix-sum form, and its chunk of the outlier list;
 // workgroup 0 adds (c - r) * sum L) - nb_mh_step_kernel then sums them as it sums per-row values.

@@ -2093,6 +2093,40 @@ def test_log_link_exponential_is_accurate_to_double_precision():
     assert np.all(np.abs(cur - ref) <= tol), (np.abs(cur - ref) / tol).max()
 
 
+@pytest.mark.parametrize("noutliers", [0, 40])
+def test_negbinom_per_row_rates_mh_loop_in_one_launch_equals_the_stepwise_loop(monkeypatch, noutliers):
+    """rdims = (1,2) (one rate per row, examples/negbinom_tensor_filtering.py): the rows' chains do not interact, so
+    btf_nb_mh runs the whole loop in one launch, a workgroup per row; BTF_NB_MH_STEPWISE=1 keeps the two launches per
+    step.  Same Philox streams, same sums in the same order: the chains of rates are identical."""
+    from functionalmf_amd.factor import NegativeBinomialBayesianTensorFiltering
+    rs = np.random.RandomState(35)
+    N, M, T, Rr, K = 37, 9, 11, 2, 3
+    Wt = 0.7 * rs.normal(size=(N, K))
+    Vt = 0.3 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    P = 1 / (1 + np.exp(-np.einsum("nk,mtk->nmt", Wt, Vt)))
+    data = rs.negative_binomial(4.0, 1 - P[..., None].repeat(Rr, -1)).astype(float)
+    flat = data.reshape(-1)
+    if noutliers:
+        flat[rs.choice(flat.size, noutliers, replace=False)] += 1500.0 + rs.randint(0, 700, size=noutliers)
+    data[0, :2] = np.nan
+    chains = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BTF_NB_MH_STEPWISE", mode)
+        np.random.seed(4)
+        model = NegativeBinomialBayesianTensorFiltering(N, M, T, nembeds=K, W_true=Wt, V_true=Vt, sigma2_true=1.0,
+                                                        lam2_true=0.1, Tau2_true=np.ones((M, 3 * T - 1)),
+                                                        rdims=(1, 2), nmetropolis=7, rng="device", device_seed=11)
+        model._bind_data(data)
+        out = []
+        for _ in range(12):
+            model._resample_R(data)
+            out.append(np.asarray(model.R).reshape(-1).copy())
+        assert getattr(model, "_mh_on_device", True)
+        chains[mode] = np.array(out)
+    assert len(set(np.round(chains["0"][:, 3], 9))) > 3          # the chains move
+    assert np.array_equal(chains["0"], chains["1"])
+
+
 def test_negbinom_single_rate_partial_sum_launch_with_wide_count_range(monkeypatch):
     """The per-step partial-sum launch of the single-rate MH loop with counts across the whole 1024-entry table (several
     workgroups take the suffix-sum form) and a few thousand counts beyond it (their chunks spread over the workgroups):
