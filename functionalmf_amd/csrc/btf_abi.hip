@@ -3284,7 +3284,7 @@ int btf_host_selftest(void) {
           for (size_t i = 0; i + 1 < sizeof(offs) / sizeof(int); ++i) ST_CHECK(offs[i] >= 0 && offs[i] < offs[i + 1]);
         }
         if (twist_ok(T, K, tf)) {
-          for (int wt = 0; wt <= 1; ++wt) {
+          for (int wt = 0; wt <= 2; ++wt) {      // 2: weighted, likelihood blocks fetched from the partials (sources < -1)
             const TwLayout W = tw_layout(T, K, tf, wt);
             ST_CHECK(W.nl + W.nr + W.ns == n && W.total > 0);
             std::vector<int> seen(n, 0);
@@ -3295,7 +3295,10 @@ int btf_host_selftest(void) {
               fill_table_host(T, K, tf, wt, tab);
               ST_CHECK(!tab.empty() && tab.size() % (4 * VT_THREADS) == 0);
               for (size_t e = 0; e < tab.size(); e += 4) {
-                ST_CHECK(tab[e] >= 0 && tab[e] < W.total && tab[e + 1] >= 0 && tab[e + 1] < W.total);
+                ST_CHECK(tab[e] >= 0 && tab[e] < W.total && tab[e + 1] < W.total);
+                if (wt < 2) ST_CHECK(tab[e + 1] >= 0);
+                else ST_CHECK(tab[e + 1] >= 0 || (-2 - tab[e + 1] >= 0 && -2 - tab[e + 1] < T * tri(K)));
+                if (wt == 2 && tab[e + 1] >= 0) ST_CHECK(tab[e + 1] < W.Ql || tab[e + 1] >= W.flag);     // no source inside the (empty) block area
                 ST_CHECK(tab[e + 2] >= -1 && tab[e + 2] < W.total);
               }
             }
@@ -3303,6 +3306,16 @@ int btf_host_selftest(void) {
         }
         const VbLayout L = vb_layout(T, K, tf, 1);
         ST_CHECK(L.total > 0 && L.band >= 0 && L.rhs > L.band && L.dummy + 64 * 9 + 8 <= L.total);
+        // chunked chain: the chunk the budget allows fits it, leaves room for two band widths, and its layout is ordered
+        for (int wt = 0; wt <= 1; ++wt) {
+          const int bwc = (tf + 1) * K, ch = vc_pick_chunk(T, K, tf, wt, VC_LDS_BUDGET);
+          if (ch > 0) {
+            ST_CHECK(ch >= 2 * bwc + 2 && ch <= n && vc_lds_bytes(T, K, tf, wt, ch) <= VC_LDS_BUDGET);
+            const VcLayout C = vc_layout(T, K, tf, wt, ch);
+            ST_CHECK(C.V.band == 0 && C.V.rhs > C.V.band + C.V.npad * C.V.R1 && C.V.invd > C.V.rhs && C.m0 > C.V.dummy && C.zs == C.m0 + n);
+            ST_CHECK(C.Ql > C.P && C.flag > C.Ql && C.xk > C.flag && C.total == C.xk + 64 && C.VC == ch + bwc && C.QT * K >= C.VC + K);
+          }
+        }
         for (int i = 0; i + 1 < 8; ++i) ST_CHECK(w_z_offset(i + 1, K) - w_z_offset(i, K) == std::min(i + 1, K));
       }
     }
