@@ -2492,6 +2492,18 @@ int btf_nb_mh(btf_ctx* c, uint64_t seed, int nsteps, double rpropstdev, double r
     // (instead of one workgroup per row, each rebuilding the same table), then the decision kernel
     const int gparts = std::max((c->nb_ymax + 255) / 256, std::min(1024, (c->nb_nout + 255) / 256));      // ~ one outlier per thread
     const int gp = std::max(1, gparts);
+    const bool merged = !(stepwise_env && stepwise_env[0] == '2');      // BTF_NB_MH_STEPWISE=2 (test hook): two launches per step
+    if (merged) {
+      // one launch per step: the decision of the previous step rides at the top of the next partial-sum launch
+      if (need_out < (size_t)2 * gp + 4) { if ((rc = dev_alloc(c, &c->nb_out, (size_t)2 * gp + 4))) return rc; c->nb_out_elems = (size_t)2 * gp + 4; }
+      double* pa = c->nb_out, *pb = c->nb_out + gp, *rcb = c->nb_out + 2 * gp;
+      for (int l = 0; l <= nsteps; ++l) {
+        Prof p(c, BTF_K_NB);
+        p.launch(nb_scalar_step_kernel, dim3(gp), dim3(256), 0, (const double*)c->nb_G, c->nb_ymax, (const double*)(c->nb_L + c->N),
+                 (const double*)c->nb_oval, c->nb_nout, c->nb_R, c->nb_C, rcb, (const double*)((l & 1) ? pa : pb), (l & 1) ? pb : pa,
+                 rpropstdev, rstdev, l, nsteps, (unsigned long long)seed);
+      }
+    } else {
     hipLaunchKernelGGL(nb_mh_step_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_out, gp, 1, 1, c->nb_R,
                        c->nb_C, rpropstdev, rstdev, -1, (unsigned long long)seed);
     for (int sidx = 0; sidx < nsteps; ++sidx) {
@@ -2502,6 +2514,7 @@ int btf_nb_mh(btf_ctx* c, uint64_t seed, int nsteps, double rpropstdev, double r
       }
       hipLaunchKernelGGL(nb_mh_step_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->nb_out, gp, 1, 1, c->nb_R,
                          c->nb_C, rpropstdev, rstdev, sidx, (unsigned long long)seed);
+    }
     }
   }
   // one rate per row: the rows' chains are independent - the whole loop in one launch, a workgroup per row

@@ -2739,6 +2739,68 @@ static __global__ __launch_bounds__(256) void nb_scalar_part_kernel(const double
   if (tid == 0) part[g] = red[0] + red[1] + red[2] + red[3] + (g == 0 ? (c - r) * Ltot[0] : 0.0);
 }
 
+// The same loop with ONE launch per step: launch l first takes the decision of step l-1 from the previous launch's partial
+// sums (every workgroup by itself - same numbers, same result: the sum, the accept test and the proposal exactly as
+// nb_mh_step_kernel forms them) and then forms its share of the ratio for the new (r, c).  The pair (r, c) is double-buffered
+// (rc[l & 1] read, rc[(l + 1) & 1] written by workgroup 0) so that a late workgroup never reads a pair already replaced;
+// l = 0: propose only; l = nsteps: decision only, rate and pending candidate go back to Rv / Cv.
+static __global__ __launch_bounds__(256) void nb_scalar_step_kernel(const double* __restrict__ Gs, int ymax,
+                                                            const double* __restrict__ Ltot, const double* __restrict__ oval,
+                                                            int nout, double* __restrict__ Rv, double* __restrict__ Cv,
+                                                            double* __restrict__ rcbuf, const double* __restrict__ part_prev,
+                                                            double* __restrict__ part_out, double rpropstdev, double rstdev,
+                                                            int l, int nsteps, unsigned long long seed) {
+  __shared__ double red[4];
+  __shared__ double rc[2];
+  const int tid = threadIdx.x, g = blockIdx.x, gp = gridDim.x;
+  const double* src = rcbuf + 2 * (l & 1);
+  double lls = 0.0;
+  if (l >= 1) {
+    double acc = 0.0;
+    for (int i = tid; i < gp; i += 256) acc += part_prev[i];
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    lls = red[0] + red[1] + red[2] + red[3];
+  }
+  if (tid == 0) {
+    CellRng gen(seed, 0ull);
+    gen.ctr = 2ull * (unsigned long long)l;                  // step = l - 1: two Philox blocks per step
+    double r = l == 0 ? Rv[0] : src[0];
+    if (l >= 1) {
+      const double c = src[1];
+      const double lr = log(r), lc = log(c);
+      const double prior = (lr * lr - lc * lc) / (2.0 * rstdev * rstdev);
+      const double prob = exp(fmin(fmax(prior + lls, -10.0), 1.0));
+      if (gen.uniform() <= prob && c > 1.0) r = c;
+    }
+    rc[0] = r;
+    rc[1] = exp(log(r) + rpropstdev * gen.normal());
+    if (g == 0) {
+      double* dst = rcbuf + 2 * ((l + 1) & 1);
+      dst[0] = rc[0]; dst[1] = rc[1];
+      if (l == nsteps) { Rv[0] = rc[0]; Cv[0] = rc[1]; }
+    }
+  }
+  __syncthreads();
+  if (l == nsteps) return;
+  const double r = rc[0], c = rc[1];
+  double acc = 0.0;
+  const int k = g * 256 + tid;
+  if (k < ymax) acc = Gs[k] * log((c + k) / (r + k));
+  const int chunk = (nout + gp - 1) / gp;
+  const int e0 = g * chunk, e1 = min(e0 + chunk, nout);
+  if (e1 > e0) {
+    const double base = lgamma_diff(r, c);
+    for (int e = e0 + tid; e < e1; e += 256) acc += lgamma_diff(oval[e] + c, oval[e] + r) + base;
+  }
+  acc = wave_sum(acc);
+  __syncthreads();                                           // (red is read above by every thread)
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) part_out[g] = red[0] + red[1] + red[2] + red[3] + (g == 0 ? (c - r) * Ltot[0] : 0.0);
+}
+
 // The whole random-walk MH loop for ONE rate shared by every cell (rdims = (0,1,2), the reference's default), in one
 // launch by one workgroup: with a single rate the likelihood ratio needs only the histogram of all counts, as its
 // suffix sums Gs[k] = #{observations > k}, k < ymax:  sum_y H[y] sum_{k<y} log((c+k)/(r+k)) = sum_k Gs[k] log((c+k)/(r+k))

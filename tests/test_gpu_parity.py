@@ -2142,7 +2142,7 @@ def test_negbinom_single_rate_partial_sum_launch_with_wide_count_range(monkeypat
     nout = int((data >= 1024).sum())
     assert 256 < nout < data.size // 8 and data[data < 1024].max() > 768, (nout, data[data < 1024].max())
     chains = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):     # 0: one launch per step (decision merged into the next partial-sum launch); 2: two; 1: per row
         monkeypatch.setenv("BTF_NB_MH_STEPWISE", mode)
         np.random.seed(4)
         model = NegativeBinomialBayesianTensorFiltering(N, M, T, nembeds=K, W_true=Wt, V_true=Vt, sigma2_true=1.0,
@@ -2156,3 +2156,4 @@ def test_negbinom_single_rate_partial_sum_launch_with_wide_count_range(monkeypat
         chains[mode] = np.array(out)
     assert len(set(np.round(chains["0"], 9))) > 3
     np.testing.assert_allclose(chains["0"], chains["1"], rtol=1e-9)
+    assert np.array_equal(chains["0"], chains["2"])          # same sums in the same order
