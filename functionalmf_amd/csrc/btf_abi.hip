@@ -749,7 +749,11 @@ int pick_rpb(int Rdim, int tiles, int user, bool weighted, int slots = 0, int re
   }
   return (int)rpb;
 }
-inline int acc_slots(const btf_ctx* c, int K, int mode) { return c->ncu * std::max(1, 16 / acc_waves(K, mode)); }
+// (w_launch: the W half-sweep's launches carry no eigen side task and run the 16-wave instance at nembeds 10 too)
+inline int acc_slots(const btf_ctx* c, int K, int mode, bool w_launch = false) {
+  const int waves = (w_launch && mode == 0 && K >= 10) ? ACC_WAVES : acc_waves(K, mode);
+  return c->ncu * std::max(1, 16 / waves);
+}
 // upper bounds of the side workgroups the two accumulation launches put in front (launch_accum counts them exactly)
 inline int w_side_reserve(const btf_ctx* c, bool wt) {
   const bool whole = c->nl == c->N && c->ml == c->M;
@@ -1320,7 +1324,7 @@ int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL) {
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_w && c->srcmap_w ? 2 : 1);
   const int NV = wt ? K + KK : K;
   const int tiles = c->ldw / ACC_TILE;
-  const int rpb = pick_rpb(MT, tiles, c->rpb_w, wt, acc_slots(c, K, mode), w_side_reserve(c, wt));
+  const int rpb = pick_rpb(MT, tiles, c->rpb_w, wt, acc_slots(c, K, mode, true), w_side_reserve(c, wt));
   const int nch = (MT + rpb - 1) / rpb;
   int rc;
   if ((rc = ensure_part(c, (size_t)nch * NV * c->ldw))) return rc;
