@@ -374,15 +374,11 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
     if (a.fill) {
       // table-driven: every entry is an independent LDS read -> write (the loops below did one dependent
       // read -> write per column and trip, eleven trips per view, with one wave per SIMD to hide it)
-      // a negative source -2 - (q T + t) names entry q of depth t's likelihood block in the partials (ql_global)
-      auto from_partials = [&](int src) -> double {
-        const int e = -2 - src, q = e / T, t = e - q * T;
-        return chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t) * a.s;
-      };
+      if (!ql_global) {
       double val[FILL_REG];
 #pragma unroll
       for (int u = 0; u < FILL_REG; ++u) {
-        val[u] = fsrc[u] >= 0 ? lds[fsrc[u]] : from_partials(fsrc[u]);
+        val[u] = lds[fsrc[u]];
         if (fdia[u] >= 0) val[u] += lds[fdia[u]] + shift;
       }
 #pragma unroll
@@ -391,9 +387,27 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
         const int e = u * VT_THREADS + tid;
         const int4 f = reinterpret_cast<const int4*>(a.fill)[e];
         const int dst = f.x, src = f.y, dia = f.z;
-        double v = src >= 0 ? lds[src] : from_partials(src);
+        double v = lds[src];
         if (dia >= 0) v += lds[dia] + shift;
         lds[dst] = v;
+      }
+      } else {
+      // likelihood blocks not staged (tw_layout, weighted == 2): a negative source -2 - (q T + t) names entry q of depth
+      // t's block in the accumulation partials - summed here, chunk by chunk, where it is written (a path of its own: the
+      // loads in the unrolled form above cost the common case 3.5 us of registers and code)
+      for (int u = 0; u < nfe; ++u) {
+        const int e = u * VT_THREADS + tid;
+        const int4 f = reinterpret_cast<const int4*>(a.fill)[e];
+        const int dst = f.x, src = f.y, dia = f.z;
+        double v;
+        if (src >= 0) v = lds[src];
+        else {
+          const int ge = -2 - src, q = ge / T, t = ge - q * T;
+          v = chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t) * a.s;
+        }
+        if (dia >= 0) v += lds[dia] + shift;
+        lds[dst] = v;
+      }
       }
     } else
     {

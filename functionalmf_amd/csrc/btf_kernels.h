@@ -325,7 +325,13 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
   constexpr int ACC_UNR = UNRV > 0 ? UNRV : (MODE >= 1 ? BTF_ACC_UNR_WT : (K >= 9 ? BTF_ACC_UNR_K9 : BTF_ACC_UNR));
-  constexpr int ACC_RG = (WAVES * WAVE / ACC_TILE) < 4 ? (WAVES * WAVE / ACC_TILE) : 4;
+  // values per round of the cross-wave reduction: as many as the workgroup has 128-thread slots for and 96 KB of LDS hold
+  // (16 waves: 6, 12 waves: 6, 8 waves: 4), never more than there are - K = 5 complete data (5 values) reduces in one round
+  // instead of two, the weighted modes (20 values, 12 waves) in four instead of five; at least the old four (side-task scratch)
+  constexpr int ACC_RGT = WAVES * WAVE / ACC_TILE, ACC_RGL = (96 * 1024) / (WAVES * ACC_TILE * 8);
+  constexpr int ACC_RG0 = ACC_RGT < 4 ? ACC_RGT : 4;
+  constexpr int ACC_RGW = ACC_RGT < ACC_RGL ? (ACC_RGT < NV ? ACC_RGT : NV) : (ACC_RGL < NV ? ACC_RGL : NV);
+  constexpr int ACC_RG = ACC_RGW > ACC_RG0 ? ACC_RGW : ACC_RG0;
   __shared__ double red[ACC_WAVES][ACC_RG][ACC_TILE];
   // ULDS: the factor rows U[r][:] of the workgroup's row range come in through LDS (one coalesced copy per block of
   // ACC_UROWS rows, then a broadcast ds_read per row and wave) instead of scalar loads - for the long row ranges of
