@@ -1693,6 +1693,17 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
         const size_t need = (size_t)c->ml * n * (c->TF + 3);
         if (need > c->vs_rec_elems) { if ((rc = dev_alloc(c, &c->vs_rec, need))) return rc; c->vs_rec_elems = need; }
         sa.rec_g = c->vs_rec;
+        // long depth axes: the prior band of every column by prior_band_kernel (one thread per entry) instead of six
+        // stencil walks per thread inside the sampler
+        const int TD1 = T * (c->TF + 2);
+        if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; }
+        {
+          Prof p(c, BTF_K_PRIOR);
+          p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
+                   (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
+                   (const double*)(c->dev_scalars ? c->hyp : nullptr));
+        }
+        sa.pband = c->pband;
       }
       const size_t sl = vs_lds_bytes(T, K, c->TF, c->nD, rg);
       switch ((c->TF + 1) * 2 + (rg ? 1 : 0)) {
@@ -1708,7 +1719,14 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
             default: e = launch_vspectral<3, false>(c, sa, sl); break;
           }
           break;
-        case 7: e = launch_vspectral<3, true>(c, sa, sl); break;
+        case 7:                                  // tf_order = 2, records in HBM scratch (long depth axes): nembeds compiled in as well
+          switch (K) {
+#define VS_FIXED(KV) case KV: e = launch_vspectral<3, true, KV>(c, sa, sl); break
+            VS_FIXED(1); VS_FIXED(2); VS_FIXED(3); VS_FIXED(4); VS_FIXED(5); VS_FIXED(6); VS_FIXED(7); VS_FIXED(8); VS_FIXED(9); VS_FIXED(10);
+#undef VS_FIXED
+            default: e = launch_vspectral<3, true>(c, sa, sl); break;
+          }
+          break;
         case 8: e = launch_vspectral<4, false>(c, sa, sl); break;
         default: e = launch_vspectral<4, true>(c, sa, sl); break;
       }

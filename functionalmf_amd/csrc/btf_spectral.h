@@ -63,6 +63,7 @@ struct VSpecArgs {
   // (besides the constants of the data), so that sweep spends no launch on it; nullptr: not wanted (complete data only)
   double* sse_out;
   double* rec_g;                         // [ml][T K (S+2)] HBM scratch for the pivot records (v_spectral_kernel<S, true>), else nullptr
+  const double* pband;                   // [ml][T][S+1] prior band formed by prior_band_kernel (long depth axes), or nullptr: the kernel forms it
 };
 
 // Elimination order inside one system (the order the build declares for this sampler; z[j][k*T + i]
@@ -259,8 +260,33 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
     }
   }
   // 1 / (lam2 Tau2[j, r]) once per penalty row (the diagonal matrix of factor.py:404)
-  for (int idx = tid; idx < a.nD; idx += VS_THREADS) itau[idx] = 1.0 / (a.lam2 * a.Tau2[(size_t)jg * a.nD + idx]);
-  {
+  if constexpr (RG) {
+    for (int i0 = tid; i0 < a.nD; i0 += 8 * VS_THREADS) {   // (long depth axes: eight loads in flight; nD = 1109 at the flu shape)
+      double tv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int idx = i0 + u * VS_THREADS; if (idx < a.nD) tv[u] = a.Tau2[(size_t)jg * a.nD + idx]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int idx = i0 + u * VS_THREADS; if (idx < a.nD) itau[idx] = 1.0 / (a.lam2 * tv[u]); }
+    }
+  } else {
+    for (int idx = tid; idx < a.nD; idx += VS_THREADS) itau[idx] = 1.0 / (a.lam2 * a.Tau2[(size_t)jg * a.nD + idx]);
+  }
+  if (RG && a.nch == 1) {
+    // long depth axes, one chunk (few rows): eight elements' loads in flight per thread instead of two
+    for (int b0 = tid; b0 < n; b0 += 8 * VS_THREADS) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = b0 + u * VS_THREADS;
+        if (e < n) { const int k = e / T, t = e - k * T; v[u] = a.part[(size_t)k * a.ld + (size_t)j * T + t]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = b0 + u * VS_THREADS;
+        if (e < n) { const int k = e / T, t = e - k * T; mraw[t * K + k] = 0.0 + v[u]; }
+      }
+    }
+  } else {
     const size_t st = (size_t)K * a.ld;
     for (int e0 = tid; e0 < n; e0 += 2 * VS_THREADS) {       // element e = k*T + t: coalesced along t
       const int e1 = e0 + VS_THREADS;
@@ -311,8 +337,28 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
     if (idx == pidx) {
 #pragma unroll
       for (int u = 0; u < MAXE; ++u) if (u < scnt) s = fma(scf[u], itau[srow[u]], s);
-    } else if (idx < T * D1) {
+    } else if (RG && idx < T * D1 && a.pband) {
+      s = a.pband[(size_t)j * T * D1 + idx];               // (long depth axes: prior_band_kernel formed the band, all entries in parallel)
+    } else if (!RG && idx < T * D1) {
       for (int e = a.st_ptr[idx]; e < a.st_ptr[idx + 1]; ++e) s = fma(a.st_coef[e], itau[a.st_row[e]], s);
+    } else if (idx < T * D1) {
+      // (long depth axes: the fixed-slot stencil again - MAXE independent loads per entry, zero coefficients in the unused
+      //  slots - instead of a CSR walk whose loads depend on one another: 28 k -> cycles of this phase at T = 370)
+      int rw[MAXE];
+      double cf[MAXE];
+#pragma unroll
+      for (int u = 0; u < MAXE; u += 4) {
+        const int4 r4 = *reinterpret_cast<const int4*>(a.st_drow + (size_t)idx * MAXE + u);
+        rw[u] = r4.x; rw[u + 1] = r4.y; rw[u + 2] = r4.z; rw[u + 3] = r4.w;
+      }
+#pragma unroll
+      for (int u = 0; u < MAXE; u += 2) {
+        const double2 c2 = *reinterpret_cast<const double2*>(a.st_dcoef + (size_t)idx * MAXE + u);
+        cf[u] = c2.x; cf[u + 1] = c2.y;
+      }
+      const int cnt = a.st_ptr[idx + 1] - a.st_ptr[idx];
+#pragma unroll
+      for (int u = 0; u < MAXE; ++u) if (u < cnt) s = fma(cf[u], itau[rw[u]], s);
     }
     P[idx] = s;
     const int t = idx / D1, d = idx - t * D1;
@@ -414,23 +460,54 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
   }
   stamp[3] = __builtin_amdgcn_s_memtime();
   // ---- w = D^-1 u + D^-1/2 z  (pivot order) -----------------------------------------------------------
-  for (int idx = tid; idx < n; idx += VS_THREADS) {
-    const double iv = rec[idx * RS + S];
-    rec[idx * RS + S + 1] = fma(rec[idx * RS + S + 1], iv, zz[idx] * sqrt(iv));
+  {
+    // (records in HBM - RG - pay a global round trip per batch: sixteen records per thread and batch)
+    constexpr int WB = RG ? 16 : 1;
+    for (int i0 = tid; i0 < n; i0 += WB * VS_THREADS) {
+      double iv[WB], w[WB];
+#pragma unroll
+      for (int u = 0; u < WB; ++u) {
+        const int idx = i0 + u * VS_THREADS;
+        if (idx < n) { iv[u] = rec[(size_t)idx * RS + S]; w[u] = rec[(size_t)idx * RS + S + 1]; }
+      }
+#pragma unroll
+      for (int u = 0; u < WB; ++u) {
+        const int idx = i0 + u * VS_THREADS;
+        if (idx < n) rec[(size_t)idx * RS + S + 1] = fma(w[u], iv[u], zz[idx] * sqrt(iv[u]));
+      }
+    }
   }
   __syncthreads();
-  if (wave == 0) {
-    double x[S + 1];
+  double x[S + 1];
 #pragma unroll
-    for (int d = 0; d <= S; ++d) x[d] = 0.0;
+  for (int d = 0; d <= S; ++d) x[d] = 0.0;
+  if (wave == 0) {
     if (ns > 0 && tid < K) {                              // separator: S x S unit upper solve
       double* srec = rec + (size_t)(tid * T + nl + nr) * RS;
+      if constexpr (RG) {                                  // (records in HBM: all of the separator's fetched first)
+        double sl[S][S], sw[S];
 #pragma unroll
-      for (int c = S - 1; c >= 0; --c) {
-        double acc = srec[c * RS + S + 1];
+        for (int c = 0; c < S; ++c) {
+          sw[c] = srec[c * RS + S + 1];
 #pragma unroll
-        for (int d = 1; d <= S; ++d) if (c + d < S) acc = fma(-srec[c * RS + d - 1], srec[(c + d) * RS + S + 1], acc);
-        srec[c * RS + S + 1] = acc;
+          for (int d = 1; d <= S; ++d) sl[c][d - 1] = c + d < S ? srec[c * RS + d - 1] : 0.0;
+        }
+#pragma unroll
+        for (int c = S - 1; c >= 0; --c) {
+          double acc = sw[c];
+#pragma unroll
+          for (int d = 1; d <= S; ++d) if (c + d < S) acc = fma(-sl[c][d - 1], sw[c + d], acc);
+          sw[c] = acc;
+          srec[c * RS + S + 1] = acc;
+        }
+      } else {
+#pragma unroll
+        for (int c = S - 1; c >= 0; --c) {
+          double acc = srec[c * RS + S + 1];
+#pragma unroll
+          for (int d = 1; d <= S; ++d) if (c + d < S) acc = fma(-srec[c * RS + d - 1], srec[(c + d) * RS + S + 1], acc);
+          srec[c * RS + S + 1] = acc;
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -442,6 +519,75 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
 #pragma unroll
         for (int d = 1; d <= S; ++d) x[d] = srec[(side ? S - d : d - 1) * RS + S + 1];
       }
+      if constexpr (!RG) spectral_backward<S>(rec + (size_t)(k * T + (side ? nl : 0)) * RS, side ? nr : nl, x);
+    }
+  }
+  if constexpr (RG) {
+    // Records in HBM: the back-substitution would pay a global round trip per pivot (the loads do not depend on the data,
+    // but only four are in flight: 185 pivots cost ~50 us at the flu shape).  The other three waves stage the records of
+    // the next CHB pivots of every chain in LDS (the normals' area is free by now; chunk q+1 while wave 0 consumes chunk
+    // q) - the chain reads LDS only, its results go out as plain stores.  One barrier per chunk.
+    const int nchains = nr > 0 ? 2 * K : K, nmax = nl > nr ? nl : nr;
+    // (staging area: the mirrored right-hand sides and the normals, contiguous in the layout and both dead by now)
+    const int room = K * Tp + n;
+    int CHB = (room / (2 * nchains) - 1) / RS;
+    CHB = CHB > 48 ? 48 : CHB;
+    if (CHB >= 2) {
+      const int cst = CHB * RS + 1, tot = nchains * cst;             // (odd chain stride: the chains' lanes on different banks)
+      double* stage = mtm;
+      // chunk q of chain c: pivots i_hi = nc - 1 - q CHB down to i_lo = max(i_hi - CHB + 1, 0) - one contiguous span of the
+      // records, copied as it lies (ascending i; the chain walks it backwards): no index arithmetic per word
+      auto load_chunk = [&](int q, int t0, int nthreads) {
+        double* dst = stage + (q & 1) * tot;
+        for (int c0 = 0; c0 < nchains; c0 += 4) {                    // four chains' spans in flight per thread
+          double v[4][2];
+          int len[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u;
+            len[u] = 0;
+            if (c < nchains) {
+              const int side = c >= K ? 1 : 0, k = c - side * K, ihi = (side ? nr : nl) - 1 - q * CHB;
+              if (ihi >= 0) {
+                const int ilo = ihi - CHB + 1 > 0 ? ihi - CHB + 1 : 0;
+                len[u] = (ihi - ilo + 1) * RS;
+                const double* src = rec + (size_t)(k * T + (side ? nl : 0) + ilo) * RS;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) if (t0 + w * nthreads < len[u]) v[u][w] = src[t0 + w * nthreads];
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) if (t0 + w * nthreads < len[u]) dst[(c0 + u) * cst + t0 + w * nthreads] = v[u][w];
+        }
+      };
+      const int nq = (nmax + CHB - 1) / CHB;
+      __syncthreads();                                               // (w and the separator's x are in place; zz is dead)
+      load_chunk(0, tid, VS_THREADS);
+      __syncthreads();
+      for (int q = 0; q < nq; ++q) {
+        if (wave != 0) { if (q + 1 < nq) load_chunk(q + 1, tid - WAVE, VS_THREADS - WAVE); }
+        else if (tid < nchains) {
+          const int side = tid >= K ? 1 : 0, k = tid - side * K, nc = side ? nr : nl;
+          double* rc = rec + (size_t)(k * T + (side ? nl : 0)) * RS;
+          const int ihi = nc - 1 - q * CHB, ilo = ihi - CHB + 1 > 0 ? ihi - CHB + 1 : 0;
+          const double* st = stage + (q & 1) * tot + tid * cst - (size_t)ilo * RS;      // st[i RS + f]: record of pivot i
+          for (int i = ihi; i >= ilo; --i) {
+            double acc = st[i * RS + S + 1];
+#pragma unroll
+            for (int d = S; d >= 1; --d) acc = fma(-st[i * RS + d - 1], x[d], acc);
+#pragma unroll
+            for (int d = S; d >= 2; --d) x[d] = x[d - 1];
+            x[1] = acc;
+            rc[(size_t)i * RS + S + 1] = acc;
+          }
+        }
+        __syncthreads();
+      }
+    } else if (wave == 0 && tid < nchains) {
+      const int side = tid >= K ? 1 : 0, k = tid - side * K;
       spectral_backward<S>(rec + (size_t)(k * T + (side ? nl : 0)) * RS, side ? nr : nl, x);
     }
   }
@@ -451,15 +597,32 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
   double* xout = mraw;
   double sse_acc = 0.0;
   const double inv_s2 = -2.0 / a.s;
+  // the solution in the eigen-basis, x~[k T + pivot]: slot S+1 of the records - copied to LDS first when the records live
+  // in HBM (sixteen loads in flight per thread; the mirrored right-hand sides' area is free), so that the rotation below
+  // reads LDS either way
+  const double* xs = rec + S + 1;
+  constexpr int xstride = RG ? 1 : RS;
+  if constexpr (RG) {
+    double* xl = mtm;                                      // K Tp >= n doubles
+    for (int i0 = tid; i0 < n; i0 += 16 * VS_THREADS) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const int e = i0 + u * VS_THREADS; if (e < n) v[u] = rec[(size_t)e * RS + S + 1]; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const int e = i0 + u * VS_THREADS; if (e < n) xl[e] = v[u]; }
+    }
+    __syncthreads();
+    xs = xl;
+  }
   for (int idx = tid; idx < n; idx += VS_THREADS) {
     const int t = idx / K, k = idx - t * K;
     const int pos = t < nl ? t : (t < nl + ns ? nl + nr + (t - nl) : nl + (T - 1 - t));
     double s = 0.0;
-    for (int kk = 0; kk < K; ++kk) s = fma(Ush[k * K + kk], rec[(size_t)(kk * T + pos) * RS + S + 1], s);
+    for (int kk = 0; kk < K; ++kk) s = fma(Ush[k * K + kk], xs[(size_t)(kk * T + pos) * xstride], s);
     xout[idx] = s;
     a.V[(size_t)jg * n + idx] = s;
     if (a.sse_out) {     // in the eigen-basis: R lambda_k x~^2 - 2 x~ m~  (mt holds s U'm)
-      const double xt = rec[(size_t)(k * T + pos) * RS + S + 1];
+      const double xt = xs[(size_t)(k * T + pos) * xstride];
       sse_acc = fma(xt, fma(a.Rrep * gsh[k], xt, inv_s2 * mt[k * Tp + t]), sse_acc);
     }
   }

@@ -7,7 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from functionalmf_amd.factor import GaussianBayesianTensorFiltering
 from bench import synth_rows, synth_V
 
-N, M, T, R, K = 512, 256, 64, 4, 5
+from bench import CONFIGS
+_cfg = CONFIGS[os.environ.get("CFG", "c3")]      # CFG=c3 (default) | c3k10 | flu | ...
+N, M, T, R, K = _cfg["N"], _cfg["M"], _cfg["T"], _cfg["R"], _cfg["K"]
 Vt = synth_V(1, M, T, K)
 Y, _ = synth_rows(1, range(N), M, T, R, K, Vt)
 if os.environ.get("BTF_HELDOUT"):
