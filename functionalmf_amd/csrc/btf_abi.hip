@@ -72,6 +72,7 @@ struct btf_ctx {
   double* ess_part = nullptr; size_t ess_part_elems = 0; int ess_last_chains = 0;
   // generalized analytic slice sampling (btf_gass_*): constraints, per-chain grids / candidates / likelihoods
   double* gs_cons = nullptr; double* gs_cc = nullptr; double* gs_rc = nullptr; int gs_J = 0, gs_nrc = 0;
+  int* gs_cptr = nullptr; int* gs_cidx = nullptr; double* gs_cval = nullptr; int gs_cnnz = 0;     // the constraint matrix by its non-zeros
   double* gs_av = nullptr; unsigned char* gs_mask = nullptr; int* gs_info = nullptr;
   double* gs_thetas = nullptr; int* gs_ntheta = nullptr; double* gs_ll = nullptr; double* gs_llp = nullptr; size_t gs_llp_elems = 0; double* gs_hh = nullptr; double* gs_cur = nullptr;
   int* gs_nacc = nullptr; double* gs_u = nullptr;
@@ -888,7 +889,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->A8_wT, c->A8_v, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_llp, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val, c->sse_cols, c->vs_rec};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->A8_wT, c->A8_v, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_llp, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val, c->sse_cols, c->vs_rec, c->vc_scratch, c->gs_cptr, c->gs_cidx, c->gs_cval};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
@@ -1989,6 +1990,25 @@ int btf_gass_set_constraints(btf_ctx* c, const double* cons, int J, const double
   if ((rc = dev_alloc(c, &c->gs_cons, A.size()))) return rc;
   if ((rc = dev_alloc(c, &c->gs_cc, cc.size()))) return rc;
   HIPCHK(c, hipMemcpy(c->gs_cons, A.data(), A.size() * sizeof(double), hipMemcpyHostToDevice));
+  {   // the non-zeros of the constraint matrix, row by row in ascending depth (the column analysis walks them when they are few)
+    std::vector<int> ptr((size_t)J + 1, 0), idx;
+    std::vector<double> val;
+    for (int q = 0; q < J; ++q) {
+      for (int t = 0; t < T; ++t) if (A[(size_t)q * T + t] != 0.0) { idx.push_back(t); val.push_back(A[(size_t)q * T + t]); }
+      ptr[(size_t)q + 1] = (int)idx.size();
+    }
+    c->gs_cnnz = 0;
+    // used when it fits the dense matrix's LDS area and saves at least half of the work
+    if (!idx.empty() && (size_t)3 * idx.size() + (size_t)J + 4 <= (size_t)2 * J * T && 2 * idx.size() <= (size_t)J * T) {
+      if ((rc = dev_alloc(c, &c->gs_cptr, ptr.size()))) return rc;
+      if ((rc = dev_alloc(c, &c->gs_cidx, idx.size()))) return rc;
+      if ((rc = dev_alloc(c, &c->gs_cval, val.size()))) return rc;
+      HIPCHK(c, hipMemcpy(c->gs_cptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(c->gs_cidx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(c->gs_cval, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice));
+      c->gs_cnnz = (int)idx.size();
+    }
+  }
   HIPCHK(c, hipMemcpy(c->gs_cc, cc.data(), cc.size() * sizeof(double), hipMemcpyHostToDevice));
   if ((rc = dev_alloc(c, &c->gs_av, (size_t)c->M * J * K))) return rc;
   if (c->gs_rc) { (void)hipFree(c->gs_rc); c->gs_rc = nullptr; }
@@ -2028,6 +2048,7 @@ int btf_gass_begin(btf_ctx* c, int what, int link, const double* z, const double
   }
   GassArgs a{};
   a.X0 = c->essX0; a.Nu = c->essNu; a.Cons = c->gs_cons; a.Cc = c->gs_cc; a.J = c->gs_J;
+  if (c->gs_cnnz > 0) { a.cs_ptr = c->gs_cptr; a.cs_idx = c->gs_cidx; a.cs_val = c->gs_cval; a.cs_nnz = c->gs_cnnz; }
   a.AV = c->gs_av; a.Rc = c->gs_rc; a.nrc = what == 0 ? c->gs_nrc : 0; a.W = c->W;
   a.N = c->N; a.M = c->M; a.T = c->T; a.K = c->K;
   a.vmask = c->gs_mask; a.info = c->gs_info; a.pick = pick_ngrid > 0 ? 1 : 0; a.ngrid = pick_ngrid;
