@@ -81,6 +81,7 @@ SIGNATURES = {
                                         C.c_int, _c_dp, _c_dp]),
     "btf_collect_begin": (C.c_int, [_ctx, C.c_int]),
     "btf_collect": (C.c_int, [_ctx, C.c_int]),
+    "btf_collect_schedule": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int]),
     "btf_collect_end": (C.c_int, [_ctx, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
     "btf_collect_summary": (C.c_int, [_ctx, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp]),
     "btf_sync": (C.c_int, [_ctx]),

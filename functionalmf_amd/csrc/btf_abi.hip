@@ -110,6 +110,7 @@ struct btf_ctx {
   bool pg_has_small = true, pg_has_big = true, pg_has_frac = true;
   // on-device sample collection (run_gibbs, rng="device"): [nsamp] slots of W, V, Tau2 and the scalars
   double* smp_W = nullptr; double* smp_V = nullptr; double* smp_T = nullptr; double* smp_s = nullptr; int smp_n = 0;
+  int col_every = 0, col_slot = 0, col_count = 0;       // btf_collect_schedule: btf_gibbs_sweeps keeps every col_every-th state
   double* hyp = nullptr;        // device-resident scalars [HYP_COUNT] (nu2, sigma2, lam2, lam2_a, ...)
   bool dev_scalars = false;     // kernels read nu2 / sigma2 / lam2 from hyp instead of the host copies
   double* pin_hyp = nullptr;
@@ -2183,6 +2184,11 @@ int btf_gibbs_sweeps(btf_ctx* c, int n, uint64_t seed_base, uint64_t draws0, int
     if (!queued) { if ((rc = btf_draw_scalars(c, d + 3, 7, nu2_a, nu2_b, sigma2_a, sigma2_b))) return rc; }
     if ((rc = btf_resample_W(c, nullptr, d + 4, compat))) return rc;
     if ((rc = btf_resample_V(c, nullptr, d + 5, compat, eps0, attempts))) return rc;
+    if (c->col_every > 0 && --c->col_count == 0) {        // btf_collect_schedule: keep this state
+      if ((rc = btf_collect(c, c->col_slot++))) return rc;
+      c->col_count = c->col_every;
+      if (c->col_slot >= c->smp_n) c->col_every = 0;
+    }
   }
   return BTF_OK;
 }
@@ -2622,10 +2628,19 @@ int btf_collect(btf_ctx* c, int slot) {
   if (!c->have_W || !c->have_V || !c->have_hyper) return fail(c, BTF_ESTATE, "nothing to collect yet");
   HIPCHK(c, hipSetDevice(c->dev));
   const size_t nW = (size_t)c->N * c->K, nV = (size_t)c->M * c->T * c->K, nT = (size_t)c->M * c->nD;
-  HIPCHK(c, hipMemcpyAsync(c->smp_W + slot * nW, c->W, nW * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->smp_V + slot * nV, c->V, nV * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->smp_T + slot * nT, c->Tau2, nT * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  if (c->hyp) HIPCHK(c, hipMemcpyAsync(c->smp_s + (size_t)slot * HYP_COUNT, c->hyp, HYP_COUNT * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  const size_t tot = nW + nV + nT + (c->hyp ? HYP_COUNT : 0);
+  const unsigned blocks = (unsigned)std::min<size_t>(2048, (tot + 255) / 256);
+  hipLaunchKernelGGL(collect_kernel, dim3(blocks), dim3(256), 0, c->stream, (const double*)c->W, nW, (const double*)c->V, nV,
+                     (const double*)c->Tau2, nT, (const double*)c->hyp, c->hyp ? (int)HYP_COUNT : 0, c->smp_W + slot * nW,
+                     c->smp_V + slot * nV, c->smp_T + slot * nT, c->smp_s + (size_t)slot * HYP_COUNT);
+  HIPCHK(c, hipGetLastError());
+  return BTF_OK;
+}
+
+int btf_collect_schedule(btf_ctx* c, int every, int first_slot, int countdown) {
+  if (!c || every < 0 || first_slot < 0 || countdown < 0 || (every > 0 && (countdown < 1 || first_slot >= c->smp_n)))
+    return fail(c, BTF_EINVAL, "bad collection schedule");
+  c->col_every = every; c->col_slot = first_slot; c->col_count = countdown;
   return BTF_OK;
 }
 

@@ -2510,6 +2510,21 @@ static __global__ __launch_bounds__(256) void nb_trials_kernel(const double* __r
   }
 }
 
+// one kept state of the chain into its slot of the sample store: W, V, Tau2 and the device-resident scalars in ONE launch
+// (four hipMemcpyAsync device-to-device copies cost ~70 us per kept sample at C3 - more than the sweep that produced it)
+static __global__ __launch_bounds__(256) void collect_kernel(const double* __restrict__ W, size_t nW, const double* __restrict__ V,
+                                                     size_t nV, const double* __restrict__ Tau2, size_t nT,
+                                                     const double* __restrict__ hyp, int nh, double* __restrict__ sW,
+                                                     double* __restrict__ sV, double* __restrict__ sT, double* __restrict__ ss) {
+  const size_t tot = nW + nV + nT + (size_t)nh;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+    if (i < nW) sW[i] = W[i];
+    else if (i < nW + nV) sV[i - nW] = V[i - nW];
+    else if (i < nW + nV + nT) sT[i - nW - nV] = Tau2[i - nW - nV];
+    else ss[i - nW - nV - nT] = hyp[i - nW - nV - nT];
+  }
+}
+
 // ---- count histograms: when R is shared along (j,t) the MH log-likelihood ratio of row i is
 //        sum_y H[i][y] * tab_y(R_i, c_i) + (c_i - R_i) * L[i],
 //      H[i][y] = number of observed replicates in row i equal to y (data only: built once at upload),

@@ -592,16 +592,21 @@ class BayesianTensorFiltering(_BayesianModel):
         if self._sweeps_on_device():
             # whole sweeps queued by the C side (btf_gibbs_sweeps): the same chain as the loop below, without a
             # Python round trip per step
-            done = 0
-            for kept in range(nsamples):
-                target = nburn + kept * nthin + 1
-                while done < target:
-                    n = min(target - done, max(1, print_freq - done % print_freq)) if verbose else target - done
-                    if verbose and done % print_freq == 0:
-                        print('\tStep {}'.format(done))
-                    self.resample_sweeps(data, n)
-                    done += n
-                self._ctx.call("btf_collect", kept)
+            # Python round trip per step; the kept states (the first after nburn + 1 sweeps, then every nthin-th) are copied
+            # into their slots by the same C call (btf_collect_schedule) - one call per block of sweeps, not per sample
+            done, total = 0, nburn + (nsamples - 1) * nthin + 1
+            scheduled = False
+            while done < total:
+                if not scheduled and done >= nburn:
+                    self._ctx.call("btf_collect_schedule", int(nthin), 0, 1)
+                    scheduled = True
+                limit = total if scheduled else nburn
+                n = min(limit - done, max(1, print_freq - done % print_freq)) if verbose else limit - done
+                if verbose and done % print_freq == 0:
+                    print('\tStep {}'.format(done))
+                self.resample_sweeps(data, n)
+                done += n
+            self._ctx.call("btf_collect_schedule", 0, 0, 0)
         else:
             for step in range(nburn + nthin * nsamples):
                 if verbose and step % print_freq == 0:

@@ -459,12 +459,17 @@ int btf_posterior_summary(int device, int nsamples, int nrows, int ncols, int nd
 /* ---- on-device sample collection (rng="device"; replaces the per-sample copies of
  * genlasso.py:51-65) ---------------------------------------------------------------------
  * btf_collect_begin allocates nsamples slots for W, V, Tau2 and the device-resident scalars;
- * btf_collect(slot) queues device-to-device copies of the current state (no synchronisation);
+ * btf_collect(slot) queues one copy kernel for the current state (no synchronisation);
  * btf_collect_end downloads the first nsamples slots (W (S,N,K), V (S,M,T,K), Tau2 (S,M,nD),
  * scalars (S,8): nu2, sigma2, lam2, lam2_a, ...; any may be NULL) and synchronises;
  * btf_collect_summary is btf_posterior_summary on the collected samples, without an upload.   */
 int btf_collect_begin(btf_ctx* ctx, int nsamples);
 int btf_collect(btf_ctx* ctx, int slot);
+/* Let btf_gibbs_sweeps keep states by itself: after `countdown` more sweeps the state goes to slot first_slot, then every
+ * `every`-th sweep to the next slot, until the slots of btf_collect_begin are full (genlasso.py:52-60: the samples kept
+ * after burn-in, every nthin-th sweep).  every = 0 switches the schedule off.  One C call per block of sweeps instead of
+ * one per kept sample.                                                                                               */
+int btf_collect_schedule(btf_ctx* ctx, int every, int first_slot, int countdown);
 int btf_collect_end(btf_ctx* ctx, int nsamples, double* W, double* V, double* Tau2, double* scalars8);
 int btf_collect_summary(btf_ctx* ctx, int nsamples, int transform, const double* q, int nq, double* mean_out, double* q_out);
 
