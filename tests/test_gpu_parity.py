@@ -1866,6 +1866,18 @@ def test_c_driven_sweeps_walk_the_python_driven_chain(golden, name, monkeypatch)
     assert set(rc) == set(rd)
     for k in rc:
         assert np.array_equal(rc[k], rd[k]), k
+    # the same run queued in blocks of two sweeps (verbose: a block per progress line), no burn-in, every sweep kept:
+    # the collection schedule of the C side survives the calls in between
+    e = make()
+    re = e.run_gibbs(g["Y"], nburn=3, nthin=2, nsamples=4, verbose=True, print_freq=2)
+    for k in rc:
+        assert np.array_equal(rc[k], re[k]), k
+    f, h = make(), make()
+    monkeypatch.setattr(h, "_sweeps_on_device", lambda: False)
+    rf = f.run_gibbs(g["Y"], nburn=0, nthin=1, nsamples=5, verbose=False)
+    rh = h.run_gibbs(g["Y"], nburn=0, nthin=1, nsamples=5, verbose=False)
+    for k in rf:
+        assert np.array_equal(rf[k], rh[k]), k
 
 
 @pytest.mark.gpu
