@@ -95,7 +95,7 @@ struct btf_ctx {
   double* nb_R = nullptr; double* nb_C = nullptr; size_t nb_relems = 0;
   double* nb_tmp = nullptr; size_t nb_tmp_elems = 0;
   double* nb_out = nullptr; size_t nb_out_elems = 0;
-  int nb_Rr = 0; bool counts = false;
+  int nb_Rr = 0; bool counts = false; bool nb_bwt_written = false;
   unsigned int* nb_H = nullptr; double* nb_Hd = nullptr; double* nb_Hs = nullptr;   // per-row count histograms (u32, f64) and their sum over rows
   double* nb_L = nullptr;            // [N + 1]: per-row sum cnt*log(1-p), then the total
   int* fill_tab = nullptr; int fill_n = 0; int fill_key = -1;   // band assembly program of the twisted kernel
@@ -2324,7 +2324,7 @@ int btf_set_data_counts(btf_ctx* c, const double* counts, int nreps) {
   HIPCHK(c, hipSetDevice(c->dev));
   const int MT = c->M * c->T;
   const size_t cells = (size_t)c->N * MT;
-  c->R = 1; c->binomial = true; c->counts = true; c->nb_Rr = nreps;
+  c->R = 1; c->binomial = true; c->counts = true; c->nb_Rr = nreps; c->nb_bwt_written = false;
   c->pg_has_small = c->pg_has_big = c->pg_has_frac = true;      // pseudo-trial counts change with the rate: every pass
   if (c->C8_wT) { (void)hipFree(c->C8_wT); c->C8_wT = nullptr; }
   if (c->C8_v) { (void)hipFree(c->C8_v); c->C8_v = nullptr; }
@@ -2402,6 +2402,16 @@ int btf_set_data_counts(btf_ctx* c, const double* counts, int nreps) {
   c->have_data = true;
   c->ssw = 0.0; c->nobs = 0.0;
   return BTF_OK;
+}
+
+// The trial counts in the transposed layout: sharded contexts draw their Polya-Gamma weights from them every sweep;
+// an unsharded one draws from the other layout and only ever looks at their zero pattern (btf_set_omega's mask), which
+// the first rebuild has written - later rebuilds skip the 8 B per cell.
+static double* nb_bwt_target(btf_ctx* c) {
+  const bool whole = c->nl == c->N && c->ml == c->M;
+  if (whole && c->nb_bwt_written) return nullptr;
+  c->nb_bwt_written = true;
+  return c->B_wT;
 }
 
 int btf_nb_loglik(btf_ctx* c, const double* R, const double* cand, const int32_t* shared, double* ll) {
@@ -2490,7 +2500,7 @@ int btf_nb_set_rate(btf_ctx* c, const double* R, const int32_t* shared) {
     Prof p(c, BTF_K_STATS);
     p.launch(nb_trials_kernel, dim3((MT + 63) / 64, (c->N + 63) / 64), dim3(256), 0, (const double*)c->nb_S,
              (const double*)c->nb_cnt, (const double*)c->nb_R, sr[0], sr[1], sr[2], c->N, MT, c->T, c->ldv, c->ldw, c->A_v,
-             c->B_v, c->A_wT, c->B_wT, c->row0, c->nl, c->col0 * c->T, c->ml * c->T);
+             c->B_v, c->A_wT, nb_bwt_target(c), c->row0, c->nl, c->col0 * c->T, c->ml * c->T);
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));      // R is a borrowed host buffer
@@ -2592,7 +2602,7 @@ int btf_nb_mh(btf_ctx* c, uint64_t seed, int nsteps, double rpropstdev, double r
     Prof p(c, BTF_K_STATS);
     p.launch(nb_trials_kernel, dim3((MT + 63) / 64, (c->N + 63) / 64), dim3(256), 0, (const double*)c->nb_S,
              (const double*)c->nb_cnt, (const double*)c->nb_R, sr[0], sr[1], sr[2], c->N, MT, c->T, c->ldv, c->ldw, c->A_v,
-             c->B_v, c->A_wT, c->B_wT, c->row0, c->nl, c->col0 * c->T, c->ml * c->T);
+             c->B_v, c->A_wT, nb_bwt_target(c), c->row0, c->nl, c->col0 * c->T, c->ml * c->T);
   }
   HIPCHK(c, hipGetLastError());
   if (R_in) HIPCHK(c, hipStreamSynchronize(c->stream));      // borrowed host buffer

@@ -2505,7 +2505,7 @@ static __global__ __launch_bounds__(256) void nb_trials_kernel(const double* __r
     const int c = rgrp + 4 * q, jj = jt0 + c;
     if (jj < MT && i >= row0 && i < row0 + nl) {
       AwT[(size_t)jj * ldw + (i - row0)] = ta[col][c];
-      BwT[(size_t)jj * ldw + (i - row0)] = tb[col][c];
+      if (BwT) BwT[(size_t)jj * ldw + (i - row0)] = tb[col][c];     // (nullptr: nobody reads the trial counts in this layout)
     }
   }
 }
