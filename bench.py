@@ -191,8 +191,8 @@ def main():
         Y = None
 
     if args.variant != "complete":
-        if world > 1:
-            sys.exit("--variant other than complete is single-GPU only")
+        if world > 1 or as_rank:
+            sys.exit("--variant other than complete is single-GPU only (the sharded runs and --as-rank generate the complete-data slabs)")
         rs = np.random.RandomState(7)
         if args.variant == "heldout":
             Y[:3, :3] = np.nan
