@@ -313,7 +313,7 @@ def main():
         lib.btf_debug_acc_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         dump = {}
         for name, half in (("w", lambda: model._resample_W(data)), ("v", lambda: model._resample_V(data))):
-            buf = np.zeros((8192, 4), dtype=np.int64)
+            buf = np.zeros((8192, 8), dtype=np.int64)
             for _ in range(3):
                 (model._resample_V(data) if name == "w" else model._resample_W(data))
                 fence()

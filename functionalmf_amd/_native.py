@@ -23,7 +23,7 @@ BTF_OK, BTF_EINVAL, BTF_EHIP, BTF_ENOTPD, BTF_ESTATE = 0, 1, 2, 3, 4
 COMPAT = {"reference": 0, "exact": 1}
 KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw", "nb_loglik",
                 "prior_band", "gram_eig", "hyper", "ess"]
-OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT, OPT_CURVE_COUNTS, OPT_SPLIT_ACCUM, OPT_FUSED_SWEEP = 0, 1, 2, 3, 4, 5, 6
+OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT, OPT_CURVE_COUNTS, OPT_SPLIT_ACCUM, OPT_FUSED_SWEEP, OPT_FUSED_STEP = 0, 1, 2, 3, 4, 5, 6, 7
 SAMPLERS = {"banded": 0, "spectral": 1, "chain": 2, "generic": 3, "banded_nopanel": 4}
 
 # every symbol include/btf.h declares: (name, restype, argtypes)
@@ -138,7 +138,7 @@ class NotPositiveDefiniteError(BTFError, np.linalg.LinAlgError):
 
 
 INST_SOURCE = os.path.join(CSRC, "btf_instances.hip")
-INST_PARTS = 8                      # = BTF_INST_PARTS of csrc/btf_instances.h
+INST_PARTS = 9                      # = BTF_INST_PARTS of csrc/btf_instances.h
 OBJ_DIR = os.path.join(ROOT, "build", "obj")          # git- and gpurun-ignored
 
 

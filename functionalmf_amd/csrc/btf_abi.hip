@@ -8,6 +8,7 @@
 #include "btf_banded_chunk.h"
 #include "btf_spectral.h"
 #include "btf_gass.h"
+#include "btf_fused.h"
 #include "btf_instances.h"      // the large kernel families: extern templates, compiled in btf_instances.hip
 #include <hip/hip_ext.h>
 
@@ -141,6 +142,12 @@ struct btf_ctx {
   bool sc_pending = false; unsigned long long sc_seed = 0; int sc_which = 0; double sc_prior[4] = {0, 0, 0, 0};
   bool lam_pending = false; unsigned long long lam_seed = 0; int lam_exact = 0;            // btf_queue_lam2
   unsigned long long sweep_w = 0, sweep_v = 0;
+  // the two-launch W+V step (BTF_OPT_FUSED_STEP, btf_fused.h): tickets / flags (zeroed once; 32 words = one 128-byte line
+  // per flag), the write-through copies the tails read, the epoch of the hand-offs (one per fused launch, never reused)
+  int fused_step = 0;                // BTF_OPT_FUSED_STEP: 0 (default) four launches, 1 the V launch carries its sampler, 2 the W launch its solve too
+  unsigned* fz_words = nullptr; int fz_tiles_w = 0, fz_tiles_v = 0;
+  double* fz_pub = nullptr;
+  unsigned fz_epoch = 0, fz_gram_total = 0, fz_w_total = 0;
   bool profiling = false;
   std::vector<EvPair> ev_pool;
   size_t ev_used = 0;
@@ -335,7 +342,8 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
                   const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr},
                   EigSideCols sidec = EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
                   TauSide tau = TauSide{}, GramSide gram = GramSide{nullptr, 0, nullptr, 0},
-                  ChunkMap cm = ChunkMap{0, 0, INT_MAX, 0, 0, 0}, SweepSide sw = SweepSide{}) {
+                  ChunkMap cm = ChunkMap{0, 0, INT_MAX, 0, 0, 0}, SweepSide sw = SweepSide{},
+                  const FuseW* fw = nullptr, const FuseV* fv = nullptr) {
   // nch: the chunks THIS launch covers (all of them unless cm says otherwise)
   if (cm.row_end == 0) cm.row_end = Rdim;
 #ifdef BTF_ACC_STAMPS
@@ -344,25 +352,37 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
   Prof p(c, kid);
   const int cpw = TAU_SIDE_CPW;
   cm.nside = (sw.sc.hyp ? 1 : 0) + (sw.lam.hyp ? 1 : 0) + (side.out ? 1 + eig_side_groups(sidec.ncols, acc_waves(K, mode)) : 0) +
-             (tau.Tau2 ? (tau.M + cpw - 1) / cpw : 0) + (gram.gpart ? gram.nblocks : 0);   // the side tasks' workgroups, in front
+             (tau.Tau2 ? (tau.M + cpw - 1) / cpw : 0) + (gram.gpart ? gram.nblocks : 0) + (fw ? fw->owners : 0);   // the side tasks' workgroups (and the fused W launch's owners), in front
   dim3 grid((ld / ACC_TILE) * nch + cm.nside);
+  if (fw || fv) {              // the two-launch step: complete data, 16 waves, the tail in the same launch (btf_fused.h)
+    const bool unr3 = rpb >= unr3_min_rpb();
+    if constexpr (K == 8) {
+      if (unr3 && fw) { p.launch(accum_kernel<K, 0, 16, double, double, 3, 2, FUSE_W>, grid, dim3(16 * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, *fw); return; }
+      if (unr3 && fv) { p.launch(accum_kernel<K, 0, 16, double, double, 3, 2, FUSE_V>, grid, dim3(16 * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, *fv); return; }
+    }
+    if constexpr (K <= 8) {
+      if (fw) p.launch(accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_W>, grid, dim3(16 * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, *fw);
+      else p.launch(accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_V>, grid, dim3(16 * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, *fv);
+    }
+    return;
+  }
   const signed char* A8 = (mode >= 1 && !C8 && X == c->A_wT) ? c->A8_wT : ((mode >= 1 && !C8 && X == c->A_v) ? c->A8_v : nullptr);
   if (A8) {                    // Binomial pseudo-data as bytes (f64 weights)
-    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), double, signed char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
-    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), double, signed char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), double, signed char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), double, signed char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, A8, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
     return;
   }
   if (mode >= 1 && C8) {       // byte weights (Gaussian replicate counts)
-    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
-    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
-  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
-  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+    if (mode == 2) p.launch(accum_kernel<K, 2, acc_waves(K, 2), unsigned char>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
+    else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
+  } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
+  else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
   else if (K >= 10 && ACC_WAVES != acc_waves(10, 0) && !side.out && rpb < unr3_min_rpb()) {
     // nembeds 10: a launch without eigen side tasks (the W half-sweep's) takes the 16-wave instance
-    if constexpr (K >= 10) p.launch(accum_kernel<K, 0, ACC_WAVES>, grid, dim3(ACC_WAVES * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+    if constexpr (K >= 10) p.launch(accum_kernel<K, 0, ACC_WAVES>, grid, dim3(ACC_WAVES * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
   }
-  else if (rpb >= unr3_min_rpb()) p.launch(accum_kernel<K, 0, acc_waves(K, 0), double, double, 3>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
-  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw);
+  else if (rpb >= unr3_min_rpb()) p.launch(accum_kernel<K, 0, acc_waves(K, 0), double, double, 3>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
+  else p.launch(accum_kernel<K, 0>, grid, dim3(acc_waves(K, 0) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
 }
 // Which Polya-Gamma launches a draw needs (pg_class_of): the flat exact kernel for the integer counts it takes
 // under the mode, the series kernel and / or the f64 Devroye kernel with a fractional part for the rest - each only
@@ -696,6 +716,7 @@ int check_status(btf_ctx* c) {
     c->fail_index = st[1];
     int zero[2] = {0, -1};
     HIPCHK(c, hipMemcpy(c->status, zero, sizeof(zero), hipMemcpyHostToDevice));
+    if (st[0] == 2) return fail(c, BTF_EHIP, "a hand-off inside a fused launch timed out (btf_fused.h): its producer workgroup never published");
     return fail(c, BTF_ENOTPD, "conditional precision not positive definite at index " + std::to_string(st[1]));
   }
   return BTF_OK;
@@ -860,6 +881,7 @@ int btf_create(btf_ctx** out, int nrows, int ncols, int ndepth, int nembeds, int
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) { g_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete c; return BTF_EHIP; }
   { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->ncu = n; }
+  { const char* e = std::getenv("BTF_FUSED_STEP"); if (e) c->fused_step = std::max(0, std::min(2, std::atoi(e))); }      // (A/B aid; BTF_OPT_FUSED_STEP is the interface)
   if (stream) { c->stream = (hipStream_t)stream; }
   else {
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -898,6 +920,8 @@ void btf_destroy(btf_ctx* c) {
   for (void* p : {(void*)c->nb_data, (void*)c->nb_S, (void*)c->nb_cnt, (void*)c->nb_R, (void*)c->nb_C, (void*)c->nb_tmp, (void*)c->nb_out, (void*)c->nb_H, (void*)c->nb_Hd, (void*)c->nb_Hs, (void*)c->nb_G, (void*)c->nb_L, (void*)c->nb_optr, (void*)c->nb_oval, (void*)c->fill_tab, (void*)c->C8_wT, (void*)c->C8_v, (void*)c->smp_W, (void*)c->smp_V, (void*)c->smp_T, (void*)c->smp_s})
     if (p) (void)hipFree(p);
   if (c->hyp) (void)hipFree(c->hyp);
+  if (c->fz_words) (void)hipFree(c->fz_words);
+  if (c->fz_pub) (void)hipFree(c->fz_pub);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->ev_draw) (void)hipEventDestroy(c->ev_draw);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1318,9 +1342,35 @@ bool split_applies(const btf_ctx* c) {
   return c->split_accum && !c->binomial && !c->counts && !(c->nl == c->N && c->ml == c->M) && c->nl > 0 && c->ml > 0;
 }
 enum { ACC_ALL = 2, ACC_LOCAL = 0 };
+
+// ---- the two-launch W+V step (btf_fused.h) ----------------------------------------------------------------------
+// words: one 128-byte line per flag / counter, then the tiles' tickets of the W launch, then those of the V launch
+enum { FZ_EIG = 0, FZ_SC = 32, FZ_LAM = 64, FZ_GRAM = 96, FZ_GSUM = 128, FZ_TICKETS = 160 };
+constexpr int FZ_PUB_EIG = 0, FZ_PUB_HYP = 128, FZ_PUB_GSUM = 136, FZ_PUB_DOUBLES = 200;
+int ensure_fused(btf_ctx* c) {
+  const int tw = c->ldw / ACC_TILE, tv = c->ldv / ACC_TILE;
+  if (c->fz_words && c->fz_tiles_w == tw && c->fz_tiles_v == tv) return BTF_OK;
+  int rc;
+  const size_t nwords = (size_t)((FZ_TICKETS + tw + tv + 31) / 32) * 32;
+  if ((rc = dev_alloc(c, &c->fz_words, nwords))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->fz_words, 0, nwords * sizeof(unsigned), c->stream));      // once: the last arrivers reset their tickets
+  if (!c->fz_pub) { if ((rc = dev_alloc(c, &c->fz_pub, (size_t)FZ_PUB_DOUBLES))) return rc; }
+  c->fz_tiles_w = tw; c->fz_tiles_v = tv;
+  c->fz_gram_total = 0; c->fz_w_total = 0;
+  return BTF_OK;
+}
+// the W launch can carry w_solve's work as its tail: complete-data stream on the 16-wave instances (two rows in flight
+// for every nembeds, three - long row ranges - for nembeds 8), no curve-count corrections, no split accumulation
+bool fuse_w_applies(const btf_ctx* c, bool wt, bool cv, int mode, int rpb) {
+  if (c->fused_step < 2 || wt || cv || mode != 0 || c->nl <= 0 || c->K > 8) return false;
+  if (split_applies(c)) return false;
+  if (rpb >= unr3_min_rpb() && c->K != 8) return false;
+  return true;
+}
+struct WFuseReq { const double* dz; uint64_t seed; bool done; };
 // part: ACC_ALL - whatever is still missing (every chunk, or the rest behind an ACC_LOCAL launch); ACC_LOCAL - only the
 // chunks of this rank's own columns of V, no side tasks (queued right behind the V draw, before the all-gather of V)
-int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL) {
+int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL, WFuseReq* wf = nullptr) {
   const int K = c->K, KK = c->KK, MT = c->M * c->T;
   const bool wt = lik_weighted(c), cv = c->weighted && !wt;
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_w && c->srcmap_w ? 2 : 1);
@@ -1329,7 +1379,8 @@ int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL) {
   const int rpb = pick_rpb(MT, tiles, c->rpb_w, wt, acc_slots(c, K, mode, true), w_side_reserve(c, wt));
   const int nch = (MT + rpb - 1) / rpb;
   int rc;
-  if ((rc = ensure_part(c, (size_t)nch * NV * c->ldw))) return rc;
+  // (the fused tail fetches the chunk sums in whole batches of up to 32 slots: room for the last batch - btf_fused.h)
+  if ((rc = ensure_part(c, (size_t)round_up(nch, 32) * NV * c->ldw))) return rc;
   const SplitGeom sg = split_applies(c) ? split_geom(c->col0 * c->T, (c->col0 + c->ml) * c->T, MT, rpb, tiles) : SplitGeom{};
   if (sg.ok) { if ((rc = ensure_part(c, (size_t)(sg.nch_r + sg.nch_l) * NV * c->ldw))) return rc; }
   if (part == ACC_LOCAL) {
@@ -1376,8 +1427,63 @@ int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL) {
                          c->sc_prior[0], c->sc_prior[1], c->sc_prior[2], c->sc_prior[3], c->sc_which, c->sc_seed, c->hyp};
       c->sc_pending = false;
     }
+    FuseW fw{};
+    // (the owner workgroups stream nothing: only when owners, side and streaming workgroups fit the chip in one round.
+    //  Rows per owner: as few as the chip has room for - the hand-off of a tile's chunk sums is bandwidth-bound per
+    //  reading workgroup - but whole virtual w_solve workgroups, and the fetched sums within the instance's LDS)
+    int own_rows = 0;
+    if (wf && !rest_only && fuse_w_applies(c, wt, cv, mode, rpb)) {
+      const long long others = (long long)tiles * nch + (tau.Tau2 ? (tau.M + TAU_SIDE_CPW - 1) / TAU_SIDE_CPW : 0) + (gram.gpart ? gram.nblocks : 0) + (sw.sc.hyp ? 1 : 0);
+      static const int min_rows = [] { const char* e = std::getenv("BTF_OWNER_ROWS"); return e ? std::atoi(e) : 32; }();     // (A/B aid)
+      for (int r = std::max(ws_rows_for(c->nl), min_rows); r <= ACC_TILE; r *= 2) {
+        if (others + (long long)tiles * (ACC_TILE / r) <= (long long)c->ncu && w_owner_lds_doubles(K, r, nch) <= w_owner_lds_budget(K)) { own_rows = r; break; }
+      }
+    }
+    const bool fuse = own_rows > 0;
+    if (fuse) {
+      // w_solve's work as the tail of this launch (btf_fused.h): its arguments, the tiles' tickets, and - when scalar
+      // draws or the Gram of V are made by side workgroups of this same launch - their flags
+      if ((rc = ensure_fused(c))) return rc;
+      ++c->fz_epoch;
+      WSolveArgs& a = fw.a;
+      a.part = c->part; a.nch = nch_total; a.ld = c->ldw; a.weighted = 0;
+      a.gpart = use_gv ? c->gpart_v : c->gpart; a.ngp = use_gv ? c->ngp_v : c->ngp_gram;
+      if (whole && c->fuse_gram) {
+        if (!c->gpart_w) { if ((rc = dev_alloc(c, &c->gpart_w, (size_t)std::max(64, (c->N + WS_ROWS - 1) / WS_ROWS) * KK))) return rc; }
+        a.gout = c->gpart_w;
+      }
+      a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
+      a.sR = a.s * c->R;
+      a.inv_sigma2 = 1.0 / c->sigma2;
+      a.hyp = c->dev_scalars ? c->hyp : nullptr; a.Rrep = c->R; a.hyp_noise = c->binomial ? 0 : 1;
+      a.W = c->W; a.row0 = c->row0; a.nl = c->nl;
+      a.z = wf->dz; a.seed = wf->seed; a.stream = 2 * c->sweep_w + 0x10000ULL;
+      a.status = c->status;
+      fw.cnt = c->fz_words + FZ_TICKETS;
+      fw.rw = ws_rows_for(c->nl);
+      if (sw.sc.hyp) {
+        sw.sc.pub = c->fz_pub + FZ_PUB_HYP; sw.sc.flag = c->fz_words + FZ_SC; sw.sc.epoch = c->fz_epoch;
+        fw.hp = HypPub{c->fz_pub + FZ_PUB_HYP, c->fz_words + FZ_SC, c->fz_epoch, sw.sc.which & 3};
+      }
+      if (gram.gpart) {                        // V'V by Gram side workgroups of this launch (sharded runs): the owners wait for them
+        gram.cnt = c->fz_words + FZ_GRAM;
+        c->fz_gram_total += (unsigned)gram.nblocks;
+        fw.gram_cnt = gram.cnt; fw.gram_expected = c->fz_gram_total;
+      }
+      c->fz_w_total += (unsigned)nch_total;
+      fw.expected = c->fz_w_total;
+      fw.rows = own_rows;
+      fw.owners = tiles * (ACC_TILE / own_rows);
+    }
     K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, rpb, nch_launch,
-                                 EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}, tau, gram, cm, sw));
+                                 EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr}, tau, gram, cm, sw,
+                                 fuse ? &fw : nullptr));
+    if (fuse) {
+      wf->done = true;
+      const int wrows = ws_rows_for(c->nl);
+      c->ngp_w = fw.a.gout ? (c->nl + wrows - 1) / wrows : 0;
+      c->ngp_v = 0;
+    }
     c->tau_pending = false;
   } else if (c->tau_pending && c->dev_scalars && c->have_chain) {
     // a rank without rows (ceil chunks: N = 10 over 8 ranks leaves ranks 5-7 empty) has no accumulation launch to
@@ -1414,11 +1520,6 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
   const int want_mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_w && c->srcmap_w ? 2 : 1);
   int rc;
   c->v_local_done = false;                                 // W is about to change
-  if (!(c->w_part_valid && c->w_part_mode == want_mode && c->w_part_curve == cv)) { if ((rc = w_accum_phase(c, compat))) return rc; }
-  if (c->sc_pending) return fail(c, BTF_ESTATE, "btf_queue_scalars must be followed by the W accumulation that carries it");
-  const int nch = c->w_part_nch;
-  const bool use_gv = c->w_part_gv;
-  c->w_part_valid = false;                                 // consumed: W changes below
   const double* dz = nullptr;
   if (z) {
     const size_t nz = (size_t)w_z_offset(c->N, K);
@@ -1426,7 +1527,14 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     HIPCHK(c, hipMemcpyAsync(c->zbuf, z, nz * sizeof(double), hipMemcpyHostToDevice, c->stream));
     dz = c->zbuf;
   }
-  if (c->nl > 0) {
+  // (no current partials: the accumulation is launched here - with the solve as its tail where that applies, btf_fused.h)
+  WFuseReq wf{dz, seed, false};
+  if (!(c->w_part_valid && c->w_part_mode == want_mode && c->w_part_curve == cv)) { if ((rc = w_accum_phase(c, compat, ACC_ALL, &wf))) return rc; }
+  if (c->sc_pending) return fail(c, BTF_ESTATE, "btf_queue_scalars must be followed by the W accumulation that carries it");
+  const int nch = c->w_part_nch;
+  const bool use_gv = c->w_part_gv;
+  c->w_part_valid = false;                                 // consumed: W changes below
+  if (c->nl > 0 && !wf.done) {
     const bool whole = c->nl == c->N && c->ml == c->M;
     WSolveArgs a{};
     a.part = c->part; a.nch = nch; a.ld = c->ldw; a.weighted = wt ? 1 : 0;
@@ -1647,13 +1755,19 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     EigSideCols sidec{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr};
     const bool cols_aside = choice == 3 && cv;
     if (cols_aside) sidec = EigSideCols{c->cv_dcols, c->cv_ndef, CurveLists{c->cv_cptr, c->cv_crow, c->cv_cdef}, c->W, 1.0 / c->R, c->eig_cols};
-    {
-      const ChunkMap cm = v_rest_only ? ChunkMap{0, 0, vsg.lo, vsg.hi - vsg.lo, c->N, 0} : ChunkMap{0, 0, INT_MAX, 0, c->N, 0};
-      SweepSide sw{};
-      if (c->lam_pending && c->dev_scalars && c->lsum && c->have_chain) {     // a queued lam2 | rest draw no scalar launch took
-        sw.lam = LamSide{c->lsum, c->M, (double)c->nD * c->M * c->K + 1.0, c->lam_exact, c->lam_seed, c->hyp};
-        c->lam_pending = false;
-      }
+    // the spectral sampler as the tail of the accumulation launch (btf_fused.h): complete-data stream on a 16-wave
+    // instance, tf_order 2 with the pivot records in LDS, whole columns per 128-output tile and their layouts within the
+    // instance's LDS, no curve columns, no split accumulation
+    const bool fuse_v = c->fused_step >= 1 && choice == 3 && !wt && !cv && mode == 0 && c->TF == 2 && K <= 8 && !v_rest_only && !split_applies(c) &&
+                        vf_fits(T, K, c->TF, c->nD, 16, rpb >= unr3_min_rpb()) && vs_lds_bytes(T, K, c->TF, c->nD, false) <= 160 * 1024 &&
+                        !(rpb >= unr3_min_rpb() && K != 8);
+    const ChunkMap cm = v_rest_only ? ChunkMap{0, 0, vsg.lo, vsg.hi - vsg.lo, c->N, 0} : ChunkMap{0, 0, INT_MAX, 0, c->N, 0};
+    SweepSide sw{};
+    if (c->lam_pending && c->dev_scalars && c->lsum && c->have_chain) {     // a queued lam2 | rest draw no scalar launch took
+      sw.lam = LamSide{c->lsum, c->M, (double)c->nD * c->M * c->K + 1.0, c->lam_exact, c->lam_seed, c->hyp};
+      c->lam_pending = false;
+    }
+    if (!fuse_v) {
       K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb,
                                    v_rest_only ? vsg.nch_r : nch_all, side, sidec, TauSide{}, GramSide{nullptr, 0, nullptr, 0}, cm, sw));
     }
@@ -1706,6 +1820,27 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
                    (const double*)(c->dev_scalars ? c->hyp : nullptr));
         }
         sa.pband = c->pband;
+      }
+      if (fuse_v) {
+        if ((rc = ensure_fused(c))) return rc;
+        ++c->fz_epoch;
+        FuseV fv{};
+        fv.a = sa;
+        fv.cnt = nch_all > 1 ? c->fz_words + FZ_TICKETS + c->fz_tiles_w : nullptr;
+        { static const int be = [] { const char* e = std::getenv("BTF_BAND_EARLY"); return e ? std::atoi(e) : 0; }(); fv.band_early = be; }      // (A/B aid)
+        fv.eig_pub = c->fz_pub + FZ_PUB_EIG; fv.eig_flag = c->fz_words + FZ_EIG; fv.epoch = c->fz_epoch;
+        side.pub = c->fz_pub + FZ_PUB_EIG; side.flag = c->fz_words + FZ_EIG; side.epoch = c->fz_epoch;
+        if (sw.lam.hyp) {
+          sw.lam.pub = c->fz_pub + FZ_PUB_HYP; sw.lam.flag = c->fz_words + FZ_LAM; sw.lam.epoch = c->fz_epoch;
+          fv.hp = HypPub{c->fz_pub + FZ_PUB_HYP, c->fz_words + FZ_LAM, c->fz_epoch, 4};
+        }
+        K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb,
+                                     nch_all, side, sidec, TauSide{}, GramSide{nullptr, 0, nullptr, 0}, cm, sw, nullptr, &fv));
+        c->sweep_v++;
+        c->nb_L_valid = false;
+        c->w_part_valid = false;
+        HIPCHK(c, hipGetLastError());
+        return after_v_draw(c, compat);
       }
       const size_t sl = vs_lds_bytes(T, K, c->TF, c->nD, rg);
       switch ((c->TF + 1) * 2 + (rg ? 1 : 0)) {
@@ -3220,11 +3355,11 @@ extern "C" int btf_debug_acc_stamps(btf_ctx* c, long long* out) {
   HIPCHK(c, hipSetDevice(c->dev));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (!c->acc_stamps) {
-    int rc = dev_alloc(c, &c->acc_stamps, (size_t)8192 * 4);
+    int rc = dev_alloc(c, &c->acc_stamps, (size_t)8192 * 8);
     if (rc) return rc;
   }
-  HIPCHK(c, hipMemcpy(out, c->acc_stamps, sizeof(long long) * 8192 * 4, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemset(c->acc_stamps, 0, sizeof(long long) * 8192 * 4));
+  HIPCHK(c, hipMemcpy(out, c->acc_stamps, sizeof(long long) * 8192 * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemset(c->acc_stamps, 0, sizeof(long long) * 8192 * 8));
   return BTF_OK;
 }
 #endif
@@ -3267,6 +3402,10 @@ int btf_set_option(btf_ctx* c, int option, int value) {
     case BTF_OPT_FUSE_GRAM:
       c->fuse_gram = value != 0;
       c->ngp_v = c->ngp_w = 0;
+      return BTF_OK;
+    case BTF_OPT_FUSED_STEP:
+      if (value < 0 || value > 2) return fail(c, BTF_EINVAL, "BTF_OPT_FUSED_STEP: 0, 1 or 2");
+      c->fused_step = value;
       return BTF_OK;
     case BTF_OPT_FUSED_SWEEP:
       c->fused_sweep = value != 0;

@@ -29,6 +29,27 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+
+// ---------------------------------------------------------------- sc1 (write-through / L1-bypassing) accesses
+// 8-byte relaxed agent-scope atomics: global_store_dwordx2 ... sc1 / global_load_dwordx2 ... sc1.  The payload of every
+// in-launch hand-off between workgroups goes through these on BOTH sides (btf_fused.h states the protocol).
+// (explicitly GLOBAL address space: a generic pointer lowers to flat_ instructions, which the measured hand-offs do not cover)
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+typedef __attribute__((address_space(1))) unsigned gu32_t;
+__device__ __forceinline__ void store_sc1(double* p, double v) {
+  __hip_atomic_store((gu64_t*)reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_sc1(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const gu64_t*)reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT));
+}
+// every storing wave, after its sc1 stores and before the barrier in front of the flag store / ticket add
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void publish_epoch(unsigned* flag, unsigned epoch) {     // ONE lane, behind the drain (+ barrier)
+  __hip_atomic_store((gu32_t*)flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 // Counter-based generator (Salmon et al. 2011): draws are a pure function of
 // (seed, stream, index), so results do not depend on launch geometry or on how

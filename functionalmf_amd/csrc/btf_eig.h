@@ -54,9 +54,11 @@ __device__ __forceinline__ void eig_for(int K, F f) {
 // calling wave (all 64 lanes must call).
 // KC > 0: K known at compile time (the callers inside kernels templated on it) - the K-long inner products unroll and
 // their LDS reads go out together; a lone wave otherwise pays one LDS round trip per term (K = 10, warm path: ~20 us).
+// pub != nullptr: the eigenvalues and vectors (K + K K doubles) are also stored write-through (sc1) there, for consumers
+// inside the same launch (btf_fused.h); the caller drains the stores and raises the flag
 template <int KC = 0>
 __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, int Krt, double* __restrict__ out,
-                                     double* __restrict__ scratch, bool warm_ok = true) {
+                                     double* __restrict__ scratch, bool warm_ok = true, double* pub = nullptr) {
   const int K = KC > 0 ? KC : Krt;
   __builtin_amdgcn_s_setprio(3);       // beside a streaming kernel: win the issue arbitration, the stream waits on memory anyway
   const int lane = threadIdx.x & 63;
@@ -274,7 +276,12 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
     });
     const double sgn = U[bigr * K + lane] < 0.0 ? -1.0 : 1.0;
     out[rank] = lam;
-    for (int r = 0; r < K; ++r) out[K + r * K + rank] = sgn * U[r * K + lane];
+    if (pub) store_sc1(pub + rank, lam);
+    for (int r = 0; r < K; ++r) {
+      const double v = sgn * U[r * K + lane];
+      out[K + r * K + rank] = v;
+      if (pub) store_sc1(pub + K + r * K + rank, v);
+    }
   }
   if (lane == 0) {
     out[K + K * K] = (double)sweeps;           // Jacobi sweeps (0: the refinement path converged)
@@ -285,7 +292,8 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
 
 // side task of a streaming launch (accum_kernel): out == nullptr: none
 // (Usrc != nullptr: no partials exist - the side workgroup forms the Gram of Usrc's nrows rows itself)
-struct EigSide { const double* gpart; int ngp; int K; double* out; const double* Usrc; int nrows; };
+// (pub / flag / epoch: the fused V launch's tails read the eigen-system inside the launch - btf_fused.h)
+struct EigSide { const double* gpart; int ngp; int K; double* out; const double* Usrc; int nrows; double* pub; unsigned* flag; unsigned epoch; };
 
 static __global__ __launch_bounds__(WAVE) void gram_eig_kernel(const double* __restrict__ gpart, int ngp, int K,
                                                         double* __restrict__ out, int warm) {

@@ -1,0 +1,771 @@
+// The W+V step as TWO launches instead of four (BTF_OPT_FUSED_STEP): the latency kernel that follows each streaming
+// accumulation - w_solve_kernel behind the W accumulation, v_spectral_kernel behind the V accumulation - runs as the
+// TAIL of the accumulation launch itself.
+//
+//   W launch  accum_kernel<K, 0, 16, ..., FUSE_W>: the workgroups of a 128-row tile write their chunk sums write-through
+//             (sc1) and draw a ticket from the tile's counter; the workgroup whose ticket comes last sums the chunks,
+//             factors and draws its 128 rows (factor.py:349-362) and leaves its share of W'W - what w_solve_kernel did one
+//             launch boundary and one cold start later.  Every wave of the tail plays one virtual w_solve workgroup (same
+//             chunk order, same butterflies, same matrix-core products): the draws are bit-identical to the four-launch path.
+//   V launch  accum_kernel<K, 0, 16, ..., FUSE_V>: a 128-output tile of the (column, depth) axis is 128 / T whole columns.
+//             With one chunk (C3: the workgroup streams all rows of W) the column sums never leave the workgroup: they
+//             go from the cross-wave reduction straight into the spectral sampler's LDS layout; with several chunks the
+//             last arriver of the tile sums them as above.  The eigen-system of W'W is still solved by the side
+//             workgroup of the same launch; it is published write-through with a flag the tails poll (once, by one
+//             lane, after their stream has ended).  Then the 2K elimination chains of every column of the tile run as in
+//             v_spectral_kernel<S, false, K> - a four-wave "virtual workgroup" per column, the chain waves of the columns
+//             on different SIMDs - with the same arithmetic in the same order: bit-identical draws again.
+//
+// Hand-off protocol (MI355X_MICROARCH.md, workgroup dispatch / inter-workgroup visibility, first row of the table of
+// measured sc1 hand-offs): every handed-off byte is stored sc1 (8-byte relaxed agent-scope atomic stores), every storing
+// wave drains its stores (s_waitcnt vmcnt(0)) in front of a workgroup barrier, ONE lane then adds to the counter /
+// stores the flag, and every load of those bytes is an sc1 load (8-byte relaxed agent-scope atomic loads) issued behind
+// the returned ticket / the matched poll and a workgroup barrier.  No fences.  The counters are zeroed when they are
+// allocated and reset by the last arriver (the next launch starts behind this one on the stream); the flags carry an
+// epoch that the host increments per launch and never reuses.
+#pragma once
+#include "btf_kernels.h"
+#include "btf_spectral.h"
+
+namespace btf {
+
+// One lane polls one word until it holds `epoch` (relaxed sc1 loads, s_sleep between them); bounded: a producer that
+// never shows up (it is block 0 / 1 of the same launch and depends on nothing this workgroup does) ends the wait after
+// ~0.2 s with `false`, and the caller reports BTF_EHIP through the status words instead of hanging the GPU.
+__device__ __forceinline__ bool poll_flag(const unsigned* flag, unsigned epoch) {
+  for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+    if (__hip_atomic_load((const gu32_t*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  return false;
+}
+
+// scalars drawn by a side workgroup of THIS launch (the four-launch sweep's nu2 / sigma2 in the W launch, lam2 in the V
+// launch) reach the tails through a published copy and a flag; scalars of earlier launches are read from `hyp` itself
+struct HypPub { const double* pub; const unsigned* flag; unsigned epoch; int which; };   // which: bit 0 nu2, bit 1 sigma2, bit 2 lam2
+
+// =================================================================================================================
+// W launch: the tiles' owner workgroups
+// =================================================================================================================
+struct FuseW {
+  WSolveArgs a;            // what launch_wsolve would have been handed (a.part: this launch's partials)
+  unsigned* cnt;           // [tiles] arrivals of the tiles' streaming workgroups: running totals, never reset
+  unsigned expected;       // ... the value a tile's counter holds when its nch workgroups of THIS launch have all arrived
+  int owners;              // owner workgroups in front of the grid: tiles x (128 / rows)
+  int rows;                // rows per owner: 128, 64, ... (>= rw)
+  int rw;                  // rows per virtual w_solve workgroup: ws_rows_for(nl)
+  HypPub hp;               // flag == nullptr: no scalar side workgroup in this launch
+  const unsigned* gram_cnt; unsigned gram_expected;   // the Gram partials are made by side workgroups of this launch (GramSide.cnt), else nullptr
+};
+template <> __device__ __forceinline__ unsigned* fuse_tickets<FUSE_W>(const FuseW& fz) { return fz.cnt; }
+template <> __device__ __forceinline__ int fuse_chunks<FUSE_W>(const FuseW& fz) { return fz.a.nch; }
+template <> __device__ __forceinline__ int fuse_owners<FUSE_W>(const FuseW& fz) { return fz.owners; }
+
+// several flags at once: lane l < 3 of the calling wave polls word l until it holds its value (nullptr: nothing to wait
+// for); returns (to every lane) whether all of them showed up before the bound
+__device__ __forceinline__ bool poll_flags(const unsigned* f0, unsigned e0, const unsigned* f1, unsigned e1, const unsigned* f2, unsigned e2) {
+  const int lane = threadIdx.x & 63;
+  const unsigned* f = lane == 0 ? f0 : (lane == 1 ? f1 : (lane == 2 ? f2 : nullptr));
+  const unsigned e = lane == 0 ? e0 : (lane == 1 ? e1 : e2);
+  bool done = f == nullptr;
+  for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+    if (!done) done = __hip_atomic_load((const gu32_t*)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e;
+    if (__all(done)) return true;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return false;
+}
+
+// LDS of an owner of R rows (doubles): [G 64][normals K x R][stage K x R][Gram scratch 256][words 8][chunk sums nch x K x R]
+__host__ __device__ constexpr int w_owner_lds_doubles(int K, int R, int nch) { return 64 + 2 * K * R + 256 + 8 + nch * K * R; }
+__host__ __device__ constexpr int w_tail_lds_doubles(int K) { return w_owner_lds_doubles(K, 8, 1); }
+// what the FUSE_W instances have (the reduction's scratch): 16 waves x ACC_RG x 128 doubles, ACC_RG = min(6, K) but >= 4
+__host__ __device__ constexpr int w_owner_lds_budget(int K) { return 16 * (K < 4 ? 4 : (K > 6 ? 6 : K)) * ACC_TILE; }
+
+// An owner of R = fw.rows consecutive rows of a 128-row tile (128 / R owners per tile: the hand-off of the chunk sums is
+// bandwidth-bound per reading workgroup - ~65 GB/s - so a tile's sums are read by several).  Everything the solve needs
+// besides the chunk sums is made HERE, beside the stream and with nothing to publish - the rows' normals (device rng), the
+// shared Gram summed as a 256-thread w_solve workgroup sums it, the scalars - then the owner waits for the tile's
+// streaming workgroups (one counter), fetches their chunk sums (sc1 loads, all in flight), adds them per (row, value) in
+// chunk order (w_solve_kernel's canonical order, chunk_sum_seq), factors and draws the rows (factor.py:349-362) and leaves
+// the W'W shares of its virtual w_solve workgroups.  Bit for bit what w_solve_kernel does.
+template <int K, int WAVES>
+__device__ __forceinline__ void w_fused_owner(const FuseW& fw, int ob, double* lds, long long* stamps) {
+  constexpr int KK = tri(K);
+  constexpr int NT = WAVES * WAVE;
+  constexpr int NTG = WS_ROWS * ws_split_of(K, false);  // threads of a w_solve workgroup (the Gram reduction's geometry)
+  constexpr int GL = (NTG / KK) > 32 ? 32 : ((NTG / KK) < 1 ? 1 : (NTG / KK));
+  const WSolveArgs& a = fw.a;
+  const int RW = fw.rw;                                 // rows per virtual w_solve workgroup: 8, 16, 32 or 64
+  const int R = fw.rows, OPT = ACC_TILE / R;            // rows of this owner, owners per tile
+  const int tile = ob / OPT, r0 = tile * ACC_TILE + (ob - tile * OPT) * R;      // first (local) row
+  double as = a.s, asR = a.sR, ainv_sigma2 = a.inv_sigma2;      // (device-resident scalars replace them below)
+  double* G = lds;                                      // [64] the shared Gram, unscaled
+  double* zsh = lds + 64;                               // [K][R] the rows' normals
+  double* stg = zsh + K * R;                            // [K][R] the fresh rows, for the W'W shares
+  double* gscr = stg + K * R;                           // [256]
+  unsigned* word = reinterpret_cast<unsigned*>(gscr + 256);
+  double* csum = gscr + 256 + 8;                        // [nch][K][R] the chunk sums as fetched
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (r0 >= a.nl) return;                               // (a ragged last tile: no such rows; uniform)
+  // ---- prepare, while the tile's rows are being streamed elsewhere ----
+  // (a) the Gram partials of the fixed factor - made by side workgroups of this launch in sharded runs: then all of
+  //     them first - thread (l, q) adds the partials l, l + lanes, ... in order
+  bool okp = true;
+  if (fw.gram_cnt) {
+    if (threadIdx.x == 0) word[0] = poll_flag(fw.gram_cnt, fw.gram_expected) ? 1u : 0u;
+    __syncthreads();
+    okp = word[0] != 0u;
+  }
+  {
+    const int gl = threadIdx.x / KK, gq = threadIdx.x - gl * KK;
+    if ((int)threadIdx.x < NTG && gl < GL) {
+      double s = 0.0;
+      for (int b0 = gl; b0 < a.ngp; b0 += 8 * GL) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int bb = b0 + u * GL;
+          x[u] = bb < a.ngp ? (fw.gram_cnt ? load_sc1(a.gpart + (size_t)bb * KK + gq) : a.gpart[(size_t)bb * KK + gq]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += x[u];
+      }
+      gscr[gl * KK + gq] = s;
+    }
+  }
+  // (b) the normals of the rows: (component, row) pairs over the threads
+  for (int t = threadIdx.x; t < K * R; t += NT) {
+    const int k = t / R, r = t - k * R;
+    double zv = 0.0;
+    if (r0 + r < a.nl) {
+      const int i = a.row0 + r0 + r;
+      const long long zoff = w_z_offset(i, K);
+      const int d = i + 1 < K ? i + 1 : K;
+      if (k < d) zv = a.z ? a.z[zoff + k] : philox_normal(a.seed, a.stream, (unsigned long long)(zoff + k));
+    }
+    zsh[t] = zv;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < KK) {
+    double t = 0.0;
+    for (int bb = 0; bb < GL; ++bb) t += gscr[bb * KK + threadIdx.x];
+    G[threadIdx.x] = t;                                  // (scaled by R / nu2 where it is used: w_solve_kernel's product)
+  }
+  // (c) scalars: earlier launches' draws, or - full sweeps - the scalar side workgroup's of this launch (its flag)
+  if (a.hyp) {
+    double hnu2 = a.hyp[HYP_NU2], hsg2 = a.hyp[HYP_SIGMA2];
+    if (fw.hp.flag) {
+      if (threadIdx.x == 0) word[0] = poll_flag(fw.hp.flag, fw.hp.epoch) ? 1u : 0u;
+      __syncthreads();
+      okp = okp && word[0] != 0u;
+      if (fw.hp.which & 1) hnu2 = load_sc1(fw.hp.pub + HYP_NU2);
+      if (fw.hp.which & 2) hsg2 = load_sc1(fw.hp.pub + HYP_SIGMA2);
+    }
+    if (a.hyp_noise) { as = 1.0 / hnu2; asR = as * a.Rrep; }
+    ainv_sigma2 = 1.0 / hsg2;
+  }
+  TAIL_STAMP(stamps, 4);
+  // ---- wait for the tile's streaming workgroups: one lane polls the tile's counter ----
+  __syncthreads();                                       // (word[0] is read by everybody above)
+  if (threadIdx.x == 0) word[0] = (okp && poll_flag(fw.cnt + tile, fw.expected)) ? 1u : 0u;
+  __syncthreads();
+  if (word[0] == 0u) {                                   // somebody never showed up: report, write nothing
+    if (threadIdx.x == 0 && atomicCAS(&a.status[0], 0, 2) == 0) a.status[1] = -1;
+    return;
+  }
+  TAIL_STAMP(stamps, 5);
+  // ---- the chunk sums of the rows: every (chunk, value, row) a load of its own (sc1), all in flight; then the thread
+  //      of a (value, row) pair adds its nch values in chunk order ----
+  {
+    const int KR = K * R, tot = a.nch * KR;
+    const size_t cst = (size_t)K * a.ld;
+    for (int e0 = threadIdx.x; e0 < tot; e0 += 8 * NT) {
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * NT;
+        if (e < tot) {
+          const int c = e / KR, rem = e - c * KR, v = rem / R, r = rem - v * R;
+          x[u] = load_sc1(a.part + (size_t)c * cst + (size_t)v * a.ld + (size_t)(r0 + r));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (e0 + u * NT < tot) csum[e0 + u * NT] = x[u];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < KR) {
+      double sum = 0.0;
+      for (int c = 0; c < a.nch; ++c) sum += csum[c * KR + threadIdx.x];
+      stg[threadIdx.x] = sum;                            // (stg [v][r] holds the sums until the fresh rows replace them)
+    }
+    __syncthreads();
+  }
+  TAIL_STAMP(stamps, 6);
+  // ---- the solve: thread r < R takes row r0 + r ----
+  const int il = r0 + (int)threadIdx.x;
+  const bool solver = (int)threadIdx.x < R;
+  const bool live = solver && il < a.nl;
+  const int i = a.row0 + (live ? il : r0);
+  const int d = i + 1 < K ? i + 1 : K;
+  double wrow[K];
+  if (solver) {
+  double m[K], Q[KK];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double s = 0.0;
+    s += stg[k * R + threadIdx.x];
+    m[k] = __dmul_rn(s, as);
+  }
+#pragma unroll
+  for (int q = 0; q < KK; ++q) Q[q] = __dmul_rn(G[q], asR);      // (w_solve_kernel rounds the scaled Gram before the shift is added)
+#pragma unroll
+  for (int k = 0; k < K; ++k) Q[lidx(k, k)] += ainv_sigma2;
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    if (r >= d) {
+      m[r] = 0.0;
+#pragma unroll
+      for (int c = 0; c <= r; ++c) Q[lidx(r, c)] = (r == c) ? 1.0 : 0.0;
+    }
+  }
+  bool ok = true;
+  double invl[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    double p = Q[lidx(c, c)];
+#pragma unroll
+    for (int q = 0; q < c; ++q) p = fma(-Q[lidx(c, q)], Q[lidx(c, q)], p);
+    if (!(p > 0.0)) ok = false;
+    const double inv = rsq_nr(p);
+    const double l = __dmul_rn(p, inv);
+    invl[c] = inv;
+    Q[lidx(c, c)] = l;
+#pragma unroll
+    for (int r = c + 1; r < K; ++r) {
+      double v = Q[lidx(r, c)];
+#pragma unroll
+      for (int q = 0; q < c; ++q) v = fma(-Q[lidx(r, q)], Q[lidx(c, q)], v);
+      Q[lidx(r, c)] = __dmul_rn(v, inv);
+    }
+  }
+  if (live && !ok && atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = i;
+  double y[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    double v = m[r];
+#pragma unroll
+    for (int c = 0; c < r; ++c) v = fma(-Q[lidx(r, c)], y[c], v);
+    y[r] = __dmul_rn(v, invl[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < K; ++r)
+    if (r < d) y[r] = __dadd_rn(y[r], zsh[r * R + threadIdx.x]);
+#pragma unroll
+  for (int r = K - 1; r >= 0; --r) {
+    double v = y[r];
+#pragma unroll
+    for (int c = r + 1; c < K; ++c) v = fma(-Q[lidx(c, r)], y[c], v);
+    y[r] = __dmul_rn(v, invl[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    const bool fresh = live && ok && r < d;
+    if (fresh) a.W[(size_t)i * K + r] = y[r];
+    wrow[r] = fresh ? y[r] : 0.0;
+  }
+  if (live && (d < K || !ok)) {
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+      if (!(ok && r < d)) wrow[r] = a.W[(size_t)i * K + r];
+  }
+  }
+  if (!a.gout) return;                                   // (uniform)
+  __syncthreads();                                       // (every solver has read its sums: stg is free)
+  if (solver) {
+#pragma unroll
+    for (int r = 0; r < K; ++r) stg[r * R + threadIdx.x] = wrow[r];
+  }
+  __syncthreads();
+  {
+    // W'W shares on the matrix cores, one per virtual w_solve workgroup of RW rows, as w_solve_kernel forms them: rows
+    // 4 s + kk of the workgroup in step s (its steps beyond RW / 4 multiply zeros there and are skipped here: adding +0
+    // products to an accumulator that started at +0 changes no bit).  Wave w takes the workgroups w, w + WAVES, ...
+    typedef double v4f64_w __attribute__((ext_vector_type(4)));
+    const int kk = lane >> 4, ii = lane & 15;
+    const int nlt = a.nl - r0;                           // rows of this owner that exist
+    for (int vbl = wave; vbl < R / RW; vbl += WAVES) {
+      if (vbl * RW < nlt) {                              // (a workgroup launch_wsolve would have launched; wave-uniform)
+        const double* src = stg + (ii < K ? ii : 0) * R + vbl * RW + kk;
+        v4f64_w acc = {0.0, 0.0, 0.0, 0.0};
+        for (int sidx = 0; sidx < RW / 4; ++sidx) {
+          const double x = ii < K ? src[4 * sidx] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+        }
+        const int vb = r0 / RW + vbl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * r + kk;
+          if (row < K && ii <= row) a.gout[(size_t)vb * KK + lidx(row, ii)] = acc[r];
+        }
+      }
+    }
+  }
+  TAIL_STAMP(stamps, 7);
+}
+
+// =================================================================================================================
+// V tail
+// =================================================================================================================
+struct FuseV {
+  VSpecArgs a;             // what launch_vspectral would have been handed (a.part: this launch's partials; a.eig unused)
+  unsigned* cnt;           // [tiles] arrival tickets (several chunks), or nullptr: one chunk, the sums stay in LDS
+  const double* eig_pub;   // [K + K K] eigen-system of W'W as published by the side workgroup of this launch
+  const unsigned* eig_flag; unsigned epoch;
+  HypPub hp;               // lam2 drawn by a side workgroup of this launch (flag == nullptr: none)
+  int band_early;          // 1: the prior band is formed before the stream (v_fused_band_early)
+};
+template <> __device__ __forceinline__ unsigned* fuse_tickets<FUSE_V>(const FuseV& fz) { return fz.cnt; }
+template <> __device__ __forceinline__ int fuse_chunks<FUSE_V>(const FuseV& fz) { return fz.a.nch; }
+template <> __device__ __forceinline__ int fuse_owners<FUSE_V>(const FuseV&) { return 0; }
+constexpr int VF_GROUP_WAVES = 4;
+constexpr int VF_MAILBOX = 128;                          // doubles at the top of the instance's LDS: eigen-system, lam2, poll result
+// what a thread of a column's virtual workgroup fetches between its stream and the cross-wave reduction - the loads fly
+// while the slower waves finish their rows and the sums are reduced: the stencil of its band entry, its Tau2 values
+template <> struct FusePre<FUSE_V> { typedef struct VPre type; };
+static_assert(VF_MAILBOX == VF_MAILBOX_DOUBLES, "mailbox");
+struct VPre { int se0, se1; int srow[VS_MAXE]; double scf[VS_MAXE]; double tau[2]; };                        // waves of a column's virtual workgroup (= VS_THREADS / 64)
+// the prior band of the tile's columns, formed BEFORE the stream (v_fused_band_early): per column [1/(lam2 Tau2) nD][P][Pm]
+// below the mailbox at the top of the instance's LDS
+__host__ __device__ inline int vf_band_doubles(int T, int TF, int nD) { return ((nD + 1) & ~1) + 2 * (((T + TF + 2) * (TF + 2) + 1) & ~1); }
+__host__ __device__ inline int vf_top_base(int T, int TF, int nD, bool unr3) {
+  return vf_red_doubles(unr3) - VF_MAILBOX - (ACC_TILE / T) * vf_band_doubles(T, TF, nD);
+}
+// columns per 128-output tile, 0 = the fused V tail does not apply to this depth axis
+__host__ __device__ constexpr int vf_cols_per_tile(int T) { return (T == 32 || T == 64 || T == 128) ? ACC_TILE / T : 0; }
+__host__ __device__ inline int vf_col_stride(int T, int K, int TF, int nD) { return (vs_layout(T, K, TF, nD, false).total + 1) & ~1; }
+__host__ __device__ inline bool vf_fits(int T, int K, int TF, int nD, int waves, bool unr3) {
+  const int ng = vf_cols_per_tile(T);
+  if (!(ng > 0 && ng * VF_GROUP_WAVES <= waves && nD <= 2 * VF_GROUP_WAVES * WAVE && K + K * K + 8 <= VF_MAILBOX)) return false;
+  const int top = vf_top_base(T, TF, nD, unr3);
+  return ng * vf_col_stride(T, K, TF, nD) <= top && 16 * 6 * ACC_TILE <= top;       // (the sampler's layouts and the reduction's scratch below the early bands)
+}
+
+// BEFORE the stream (every thread of the workgroup calls it; two barriers): the prior band of the tile's columns,
+// P[t][d] = sum_r Delta[r,t] Delta[r,t+d] / (lam2 Tau2[j,r]) (rows ascending, as factor.py:404-405 forms the product) and
+// its mirror image, into the top of the LDS - it depends on the hyper-parameters only, and the memory system is idle
+// now; behind the stream the same loads queue behind everybody's.  Not in full sweeps whose lam2 is drawn by a side
+// workgroup of this very launch (fv.hp.flag): returns false, and the tail forms the band itself.
+template <int K, int S>
+__device__ __forceinline__ bool v_fused_band_early(const FuseV& fv, int tile, double* lds, bool unr3) {
+  if (fv.hp.flag || !fv.band_early) return false;         // (uniform)
+  const VSpecArgs& a = fv.a;
+  const int T = a.T;
+  constexpr int D1 = S + 1, MAXE = VS_MAXE, NT = VF_GROUP_WAVES * WAVE;
+  const int NG = ACC_TILE / T;
+  const int lane = threadIdx.x & 63;
+  const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = pw % NG, wave = pw / NG, tid = wave * WAVE + lane;
+  const int j = tile * NG + cg, jg = a.col0 + j;
+  const bool act = wave < VF_GROUP_WAVES && j < a.ml;
+  const int PB = ((T + S + 1) * D1 + 1) & ~1, nDp = (a.nD + 1) & ~1;
+  double* top = lds + vf_top_base(T, a.TF, a.nD, unr3) + (size_t)cg * (nDp + 2 * PB);
+  double* itau = top;
+  double* P = top + nDp;
+  double* Pm = P + PB;
+  const double lam2 = a.hyp ? a.hyp[HYP_LAM2] : a.lam2;
+  int se0 = 0, se1 = 0;
+  int srow[MAXE];
+  double scf[MAXE];
+  if (act) {
+    if (tid < T * D1) {
+      se0 = a.st_ptr[tid]; se1 = a.st_ptr[tid + 1];
+#pragma unroll
+      for (int u = 0; u < MAXE; u += 4) {
+        const int4 r4 = *reinterpret_cast<const int4*>(a.st_drow + (size_t)tid * MAXE + u);
+        srow[u] = r4.x; srow[u + 1] = r4.y; srow[u + 2] = r4.z; srow[u + 3] = r4.w;
+      }
+#pragma unroll
+      for (int u = 0; u < MAXE; u += 2) {
+        const double2 c2 = *reinterpret_cast<const double2*>(a.st_dcoef + (size_t)tid * MAXE + u);
+        scf[u] = c2.x; scf[u + 1] = c2.y;
+      }
+    }
+    for (int idx = tid; idx < a.nD; idx += NT) itau[idx] = 1.0 / (lam2 * a.Tau2[(size_t)jg * a.nD + idx]);
+    for (int idx = tid; idx < (T + S + 1) * D1; idx += NT) Pm[idx] = 0.0;
+  }
+  __syncthreads();
+  if (act) {
+    const int scnt = se1 - se0;
+    for (int idx = tid; idx < (T + S + 1) * D1; idx += NT) {
+      double s = 0.0;
+      if (idx == tid && idx < T * D1) {
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) if (u < scnt) s = fma(scf[u], itau[srow[u]], s);
+      } else if (idx < T * D1) {
+        for (int e = a.st_ptr[idx]; e < a.st_ptr[idx + 1]; ++e) s = fma(a.st_coef[e], itau[a.st_row[e]], s);
+      }
+      P[idx] = s;
+      const int t = idx / D1, d = idx - t * D1;
+      if (t + d < T) Pm[(T - 1 - t - d) * D1 + d] = s;
+    }
+  }
+  return true;                                           // (published by the reduction's barriers)
+}
+
+// A few row groups before the stream ends (every thread calls it): the tail's own global loads - the stencil of the
+// thread's band entry, its Tau2 values - so that they fly under the last rows instead of sitting in front of the
+// reduction's first barrier (unless the band was formed before the stream: nothing to fetch).
+template <int K, int S, class PRE>
+__device__ __forceinline__ void v_fused_prefetch_loads(const FuseV& fv, int tile, PRE& pre, bool band_early) {
+  const VSpecArgs& a = fv.a;
+  const int T = a.T;
+  constexpr int D1 = S + 1, MAXE = VS_MAXE, NT = VF_GROUP_WAVES * WAVE;
+  const int NG = ACC_TILE / T;
+  const int lane = threadIdx.x & 63;
+  const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = pw % NG, wave = pw / NG, tid = wave * WAVE + lane;
+  const int j = tile * NG + cg, jg = a.col0 + j;
+  const bool act = wave < VF_GROUP_WAVES && j < a.ml;
+  pre.se0 = pre.se1 = 0;
+  pre.tau[0] = pre.tau[1] = 1.0;
+  if (act && !band_early) {
+    if (tid < T * D1) {
+      pre.se0 = a.st_ptr[tid]; pre.se1 = a.st_ptr[tid + 1];
+#pragma unroll
+      for (int u = 0; u < MAXE; u += 4) {
+        const int4 r4 = *reinterpret_cast<const int4*>(a.st_drow + (size_t)tid * MAXE + u);
+        pre.srow[u] = r4.x; pre.srow[u + 1] = r4.y; pre.srow[u + 2] = r4.z; pre.srow[u + 3] = r4.w;
+      }
+#pragma unroll
+      for (int u = 0; u < MAXE; u += 2) {
+        const double2 c2 = *reinterpret_cast<const double2*>(a.st_dcoef + (size_t)tid * MAXE + u);
+        pre.scf[u] = c2.x; pre.scf[u + 1] = c2.y;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (tid + u * NT < a.nD) pre.tau[u] = a.Tau2[(size_t)jg * a.nD + tid + u * NT];
+  }
+}
+
+// Between the stream and the reduction: wave 0 waits for this launch's side workgroups (eigen-system of W'W; lam2 in
+// full sweeps); their published values go to the mailbox at the top of the LDS (the reduction and the sampler's layouts
+// stay below it).
+template <int K, int S>
+__device__ __forceinline__ void v_fused_prefetch(const FuseV& fv, int tile, double* mailbox, VPre& pre, bool band_early) {
+  const int lane = threadIdx.x & 63;
+  const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (pw == 0) {
+    const bool okw = poll_flags(fv.eig_flag, fv.epoch, fv.hp.flag, fv.hp.epoch, nullptr, 0u);
+    if (okw) {
+      for (int idx = lane; idx < K + K * K; idx += WAVE) mailbox[idx] = load_sc1(fv.eig_pub + idx);
+      if (fv.hp.flag && lane == 0) mailbox[VF_MAILBOX - 2] = load_sc1(fv.hp.pub + HYP_LAM2);
+    }
+    if (lane == 0) *reinterpret_cast<unsigned*>(mailbox + VF_MAILBOX - 1) = okw ? 1u : 0u;
+  }
+}
+
+// `sums`: this thread's values of the cross-wave reduction (value g0 + tv of column tc for its rounds), used when the
+// launch has ONE chunk; otherwise the last arriver of the tile adds the chunks from the partials.
+// Control flow: every thread of the workgroup runs every barrier; `act` marks the threads of a live column group.
+template <int K, int S, int WAVES, int NSUM>
+__device__ __forceinline__ void v_fused_tail(const FuseV& fv, int tile, double* lds, const double (&sums)[NSUM], int nv_round, int tv, int tc,
+                             long long* stamps, const VPre& pre, const double* mailbox, bool band_early, bool unr3) {
+  TAIL_STAMP(stamps, 4);
+  VSpecArgs a = fv.a;
+  const int T = a.T, n = T * K, KK = tri(K);
+  constexpr int D1 = S + 1, RS = S + 2, WN = S * (S + 1) + S;
+  constexpr int MAXE = VS_MAXE;
+  constexpr int NT = VF_GROUP_WAVES * WAVE;              // threads of a column's virtual workgroup (= VS_THREADS)
+  static_assert(NT == VS_THREADS, "the virtual workgroup is v_spectral_kernel's");
+  const int NG = ACC_TILE / T;                           // columns in the tile
+  const VsLayout L = vs_layout(T, K, a.TF, a.nD, false);
+  const int stride = (L.total + 1) & ~1;
+  const int Tp = L.Tp;
+  int nl, nr, ns;
+  spectral_split(T, S, nl, nr, ns);
+  const int lane = threadIdx.x & 63;
+  const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // physical wave
+  const int cg = pw % NG, wave = pw / NG;                // column group, wave of its virtual workgroup
+  const int tid = wave * WAVE + lane;                    // thread of the virtual workgroup
+  const int j = tile * NG + cg, jg = a.col0 + j;         // local / global column
+  const bool act = wave < VF_GROUP_WAVES && j < a.ml;
+  double* base = lds + (size_t)cg * stride;
+  double* Ush = base + L.U;
+  double* gsh = base + L.g;
+  double* itau = base + L.itau;
+  double* P = base + L.P;
+  double* Pm = base + L.Pm;
+  if (band_early) {                                        // (formed before the stream: v_fused_band_early)
+    const int PB = ((T + S + 1) * (S + 1) + 1) & ~1, nDp = (a.nD + 1) & ~1;
+    double* top = lds + vf_top_base(T, a.TF, a.nD, unr3) + (size_t)cg * (nDp + 2 * PB);
+    itau = top; P = top + nDp; Pm = P + PB;
+  }
+  double* mraw = base + L.mraw;
+  double* mt = base + L.mt;
+  double* mtm = base + L.mtm;
+  double* zz = base + L.zz;
+  double* rec = base + L.rec;
+  double* win = base + L.win;
+  double* flag = base + L.flag;
+
+  // ---- the column sums into the sampler's layout (one chunk: straight from the reduction's registers) ----
+  if (!fv.cnt) {
+    const int scg = tc / T, st = tc - scg * T;
+#pragma unroll
+    for (int r = 0; r < NSUM; ++r) {
+      const int k = r * nv_round + tv;
+      if (tv < nv_round && k < K) lds[(size_t)scg * stride + L.mraw + st * K + k] = 0.0 + sums[r];
+    }
+  }
+  // ---- (the stencil, Tau2 and the published eigen-system / lam2 came in before the reduction: v_fused_prefetch) ----
+  const int pidx = tid;
+  const int scnt = pre.se1 - pre.se0;
+  if (*reinterpret_cast<const unsigned*>(mailbox + VF_MAILBOX - 1) == 0u) {      // a producer of this launch never showed up (uniform)
+    if (threadIdx.x == 0 && atomicCAS(&a.status[0], 0, 2) == 0) a.status[1] = -1;
+    return;
+  }
+  if (a.hyp) {
+    if (a.hyp_noise) { a.s = 1.0 / a.hyp[HYP_NU2]; a.sR = a.s * a.Rrep; }
+    a.lam2 = (fv.hp.flag && (fv.hp.which & 4)) ? mailbox[VF_MAILBOX - 2] : a.hyp[HYP_LAM2];
+  }
+  if (act) {
+    for (int idx = tid; idx < K + K * K; idx += NT) {
+      const double v = mailbox[idx];
+      if (idx < K) gsh[idx] = v; else Ush[idx - K] = v;
+    }
+  }
+  if (act) {
+    if (!band_early) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * NT < a.nD) itau[tid + u * NT] = 1.0 / (a.lam2 * pre.tau[u]);
+    }
+    if (fv.cnt) {
+      const size_t st = (size_t)K * a.ld;
+      for (int e0 = tid; e0 < n; e0 += 2 * NT) {             // element e = k*T + t: coalesced along t
+        const int e1 = e0 + NT;
+        const bool h1 = e1 < n;
+        const int k0 = e0 / T, t0 = e0 - k0 * T;
+        const int e1c = h1 ? e1 : e0;
+        const int k1 = e1c / T, t1 = e1c - k1 * T;
+        const double* p0 = a.part + (size_t)k0 * a.ld + (size_t)j * T + t0;
+        const double* p1 = a.part + (size_t)k1 * a.ld + (size_t)j * T + t1;
+        double s0 = 0.0, s1 = 0.0;
+        int c = 0;
+        for (; c + 4 <= a.nch; c += 4) {                       // fixed order, four chunks in flight per element
+          const double x0 = load_sc1(p0 + (size_t)c * st), x1 = load_sc1(p0 + (size_t)(c + 1) * st), x2 = load_sc1(p0 + (size_t)(c + 2) * st), x3 = load_sc1(p0 + (size_t)(c + 3) * st);
+          const double y0 = load_sc1(p1 + (size_t)c * st), y1 = load_sc1(p1 + (size_t)(c + 1) * st), y2 = load_sc1(p1 + (size_t)(c + 2) * st), y3 = load_sc1(p1 + (size_t)(c + 3) * st);
+          s0 += x0; s0 += x1; s0 += x2; s0 += x3;
+          s1 += y0; s1 += y1; s1 += y2; s1 += y3;
+        }
+        for (; c < a.nch; ++c) { s0 += load_sc1(p0 + (size_t)c * st); s1 += load_sc1(p1 + (size_t)c * st); }
+        mraw[t0 * K + k0] = s0;
+        if (h1) mraw[t1 * K + k1] = s1;
+      }
+    }
+    if (!band_early) for (int idx = tid; idx < (T + S + 1) * D1; idx += NT) Pm[idx] = 0.0;
+  }
+  __syncthreads();
+  TAIL_STAMP(stamps, 5);
+  // ---- prior band and its mirror image (rows ascending, as factor.py:404-405 forms the product); rotated right-hand
+  //      sides and their mirror image ----
+  if (act) {
+    if (!band_early)
+    for (int idx = tid; idx < (T + S + 1) * D1; idx += NT) {
+      double s = 0.0;
+      if (idx == pidx) {
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) if (u < scnt) s = fma(pre.scf[u], itau[pre.srow[u]], s);
+      } else if (idx < T * D1) {
+        for (int e = a.st_ptr[idx]; e < a.st_ptr[idx + 1]; ++e) s = fma(a.st_coef[e], itau[a.st_row[e]], s);
+      }
+      P[idx] = s;
+      const int t = idx / D1, d = idx - t * D1;
+      if (t + d < T) Pm[(T - 1 - t - d) * D1 + d] = s;
+    }
+    for (int idx = tid; idx < K * Tp; idx += NT) {
+      const int k = idx / Tp, t = idx - k * Tp;
+      double s = 0.0;
+      if (t < T) {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) s = fma(Ush[kk * K + k], mraw[t * K + kk], s);
+        s *= a.s;
+      }
+      mt[idx] = s;
+      mtm[k * Tp + (t < T ? T - 1 - t : t)] = s;
+    }
+  }
+  __syncthreads();
+  // ---- the 2K chains (wave 0 of the group) while its other waves draw the normals ----
+  if (act) {
+    if (wave == 0) {
+      const bool chain = tid < (nr > 0 ? 2 * K : K);
+      const int side = tid >= K ? 1 : 0;
+      const int k = chain ? tid - side * K : 0;
+      const double* Pv = side ? Pm : P;
+      const double* rv = (side ? mtm : mt) + k * Tp;
+      double* crec = rec + (size_t)(k * T + (side ? nl : 0)) * RS;
+      const int n_elim = side ? nr : nl;
+      const int n_common = nr > 0 ? (nl < nr ? nl : nr) : nl;
+      double shift = 0.0, eps = a.eps0;
+      int tried = 0;
+      bool ok;
+      while (true) {
+        bool good = true;
+        const double gk = fma(gsh[k], a.sR, shift);
+        SpecWin<S> w;
+        if (chain) {
+          good = spectral_forward<S>(Pv, rv, crec, n_elim, n_common, gk, w);
+          if (ns > 0) {
+            double* wp = win + (size_t)(side * K + k) * WN;
+#pragma unroll
+            for (int b = 0; b < S; ++b) {
+#pragma unroll
+              for (int d = 0; d <= S; ++d) wp[b * (S + 1) + d] = w.c[b][d];
+              wp[S * (S + 1) + b] = w.r[b];
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (ns > 0 && tid < K) {
+          const double* wl = win + (size_t)k * WN;
+          const double* wr = win + (size_t)(K + k) * WN;
+          double Sg[S][S], us[S];
+#pragma unroll
+          for (int b = 0; b < S; ++b) {
+#pragma unroll
+            for (int aa = b; aa < S; ++aa)
+              Sg[aa][b] = wl[b * (S + 1) + aa - b] + wr[(S - 1 - aa) * (S + 1) + aa - b] - (P[(nl + b) * D1 + aa - b] + (aa == b ? gk : 0.0));
+            us[b] = wl[S * (S + 1) + b] + wr[S * (S + 1) + S - 1 - b] - mt[k * Tp + nl + b];
+          }
+          double* srec = rec + (size_t)(k * T + nl + nr) * RS;
+#pragma unroll
+          for (int c = 0; c < S; ++c) {
+            const double d0 = Sg[c][c];
+            good &= d0 > 0.0;
+            const double inv = rcp_cubic(d0);
+#pragma unroll
+            for (int d = 1; d <= S; ++d) {
+              double l = 0.0;
+              if (c + d < S) {
+                l = Sg[c + d][c] * inv;
+                us[c + d] = fma(-l, us[c], us[c + d]);
+#pragma unroll
+                for (int b2 = 1; b2 <= d; ++b2) Sg[c + d][c + b2] = fma(-l, Sg[c + b2][c], Sg[c + d][c + b2]);
+              }
+              srec[c * RS + d - 1] = l;
+            }
+            srec[c * RS + S] = inv;
+            srec[c * RS + S + 1] = us[c];
+          }
+        }
+        ok = __builtin_amdgcn_readfirstlane(__ballot(!good) == 0ULL ? 1 : 0) != 0;
+        if (ok || tried >= a.attempts) break;
+        shift += eps;   // fast_mvn.py:64-68: cumulative eps, eps *= 10
+        eps *= 10.0;
+        ++tried;
+      }
+      if (tid == 0) { flag[0] = ok ? 1.0 : 0.0; flag[1] = (double)tried; }
+    } else {
+      for (int idx = tid - WAVE; idx < n; idx += NT - WAVE)
+        zz[idx] = a.z ? a.z[(size_t)jg * n + idx] : philox_normal(a.seed, a.stream, (unsigned long long)jg * n + idx);
+    }
+  }
+  __syncthreads();
+  TAIL_STAMP(stamps, 6);
+  const bool ok = act && flag[0] != 0.0;                   // this column's factorisation went through
+  if (act && tid == 0) a.tries[j] = (int)flag[1];
+  if (act && !ok) {
+    if (tid == 0 && atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = jg;
+  }
+  // ---- w = D^-1 u + D^-1/2 z  (pivot order) ----
+  if (ok) {
+    for (int idx = tid; idx < n; idx += NT) {
+      const double iv = rec[(size_t)idx * RS + S], w = rec[(size_t)idx * RS + S + 1];
+      rec[(size_t)idx * RS + S + 1] = fma(w, iv, zz[idx] * sqrt(iv));
+    }
+  }
+  __syncthreads();
+  if (ok && wave == 0) {
+    double x[S + 1];
+#pragma unroll
+    for (int d = 0; d <= S; ++d) x[d] = 0.0;
+    if (ns > 0 && tid < K) {                              // separator: S x S unit upper solve
+      double* srec = rec + (size_t)(tid * T + nl + nr) * RS;
+#pragma unroll
+      for (int c = S - 1; c >= 0; --c) {
+        double acc = srec[c * RS + S + 1];
+#pragma unroll
+        for (int d = 1; d <= S; ++d) if (c + d < S) acc = fma(-srec[c * RS + d - 1], srec[(c + d) * RS + S + 1], acc);
+        srec[c * RS + S + 1] = acc;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (tid < (nr > 0 ? 2 * K : K)) {
+      const int side = tid >= K ? 1 : 0, k = tid - side * K;
+      if (ns > 0) {
+        const double* srec = rec + (size_t)(k * T + nl + nr) * RS;
+#pragma unroll
+        for (int d = 1; d <= S; ++d) x[d] = srec[(side ? S - d : d - 1) * RS + S + 1];
+      }
+      spectral_backward<S>(rec + (size_t)(k * T + (side ? nl : 0)) * RS, side ? nr : nl, x);
+    }
+  }
+  __syncthreads();
+  // ---- rotate back, write V[j] (depth-major), residual part, Gram share ----
+  double* xout = mraw;
+  double sse_acc = 0.0;
+  const double inv_s2 = -2.0 / a.s;
+  const double* xs = rec + S + 1;
+  if (ok) {
+    for (int idx = tid; idx < n; idx += NT) {
+      const int t = idx / K, k = idx - t * K;
+      const int pos = t < nl ? t : (t < nl + ns ? nl + nr + (t - nl) : nl + (T - 1 - t));
+      double s = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) s = fma(Ush[k * K + kk], xs[(size_t)(kk * T + pos) * RS], s);
+      xout[idx] = s;
+      a.V[(size_t)jg * n + idx] = s;
+      if (a.sse_out) {
+        const double xt = xs[(size_t)(k * T + pos) * RS];
+        sse_acc = fma(xt, fma(a.Rrep * gsh[k], xt, inv_s2 * mt[k * Tp + t]), sse_acc);
+      }
+    }
+  }
+  if (a.sse_out) {                                         // (workgroup-uniform)
+    const double v = wave_sum(sse_acc);
+    if (ok && lane == 0) flag[2 + wave] = v;
+    __syncthreads();
+    if (ok && tid == 0) a.sse_out[j] = (flag[2] + flag[3]) + (flag[4] + flag[5]);
+  }
+  if (a.gout) {                                            // (workgroup-uniform)
+    __syncthreads();
+    int ng = NT / KK;
+    if (ng > 16) ng = 16;
+    if (ng < 1) ng = 1;
+    const int g = tid / KK, q = tid - g * KK;
+    int p = 0;
+    while ((p + 1) * (p + 2) / 2 <= q) ++p;
+    const int pq = q - p * (p + 1) / 2;
+    double* scratch = base + L.gs;
+    if (ok && g < ng) {
+      double s = 0.0;
+      for (int t = g; t < T; t += ng) s = fma(xout[t * K + p], xout[t * K + pq], s);
+      scratch[g * KK + q] = s;
+    }
+    __syncthreads();
+    if (ok && tid < KK) {
+      double s = 0.0;
+      for (int b = 0; b < ng; ++b) s += scratch[b * KK + tid];
+      a.gout[(size_t)j * KK + tid] = s;
+    }
+  }
+  TAIL_STAMP(stamps, 7);
+}
+
+}  // namespace btf

@@ -8,11 +8,14 @@
 #pragma once
 #include "btf_kernels.h"
 #include "btf_banded_twist.h"
+#include "btf_spectral.h"
+#include "btf_fused.h"
 
 namespace btf {
 
-#define BTF_ACC_ARGS(XT, CT) \
-  (const XT*, const CT*, const double*, const int*, double*, int, int, int, EigSide, EigSideCols, TauSide, GramSide, ChunkMap, SweepSide)
+#define BTF_ACC_ARGS_F(XT, CT, FZ) \
+  (const XT*, const CT*, const double*, const int*, double*, int, int, int, EigSide, EigSideCols, TauSide, GramSide, ChunkMap, SweepSide, FZ)
+#define BTF_ACC_ARGS(XT, CT) BTF_ACC_ARGS_F(XT, CT, FuseNone)
 #define BTF_ACCUM_SET(P, K)                                                                              \
   P void accum_kernel<K, 0> BTF_ACC_ARGS(double, double);                                                \
   P void accum_kernel<K, 0, acc_waves(K, 0), double, double, 3> BTF_ACC_ARGS(double, double);            \
@@ -28,6 +31,22 @@ namespace btf {
 // form of long row ranges: two spilled VGPRs at 16 waves - it stays with 8)
 #define BTF_ACCUM_K10W_SET(P)                                                                            \
   P void accum_kernel<10, 0, ACC_WAVES> BTF_ACC_ARGS(double, double);
+
+// the fused forms of the W+V step (btf_fused.h, BTF_OPT_FUSED_STEP): complete data, 16 waves, nembeds <= 8 (where the owner's
+// batch of chunk loads / the eigen side task fit the 16-wave register budget); two and - nembeds 8 - three rows in flight
+#define BTF_FUSED_W_SET(P, K)                                                                            \
+  P void accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_W> BTF_ACC_ARGS_F(double, double, FuseW);
+#define BTF_FUSED_V_SET(P, K)                                                                            \
+  P void accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_V> BTF_ACC_ARGS_F(double, double, FuseV);
+#define BTF_FUSED_UNR3_SET(P, K)                                                                         \
+  P void accum_kernel<K, 0, 16, double, double, 3, 2, FUSE_W> BTF_ACC_ARGS_F(double, double, FuseW);     \
+  P void accum_kernel<K, 0, 16, double, double, 3, 2, FUSE_V> BTF_ACC_ARGS_F(double, double, FuseV);
+#define BTF_FUSED_SET(P)                                                                                 \
+  BTF_FUSED_W_SET(P, 1) BTF_FUSED_W_SET(P, 2) BTF_FUSED_W_SET(P, 3) BTF_FUSED_W_SET(P, 4)                \
+  BTF_FUSED_W_SET(P, 5) BTF_FUSED_W_SET(P, 6) BTF_FUSED_W_SET(P, 7) BTF_FUSED_W_SET(P, 8)                \
+  BTF_FUSED_V_SET(P, 1) BTF_FUSED_V_SET(P, 2) BTF_FUSED_V_SET(P, 3) BTF_FUSED_V_SET(P, 4)                \
+  BTF_FUSED_V_SET(P, 5) BTF_FUSED_V_SET(P, 6) BTF_FUSED_V_SET(P, 7) BTF_FUSED_V_SET(P, 8)                \
+  BTF_FUSED_UNR3_SET(P, 8)
 
 #define BTF_WSOLVE_SET(P, K)                                                                             \
   P void w_solve_kernel<K, false, 8>(WSolveArgs);  P void w_solve_kernel<K, true, 8>(WSolveArgs);        \
@@ -70,7 +89,8 @@ namespace btf {
 //   0: accumulation K = 10, 4      1: accumulation K = 9, 5      2: accumulation K = 8, 6
 //   3: accumulation K = 7, 3, 2, 1 4: W solve                    5: Polya-Gamma
 //   6: Negative-Binomial log-likelihood                         7: twisted banded sampler
-constexpr int BTF_INST_PARTS = 8;
+//   8: the fused W / V launches
+constexpr int BTF_INST_PARTS = 9;
 
 #ifndef BTF_INST_PART
 #define BTF_X extern template __global__
@@ -80,6 +100,7 @@ BTF_FOR_K(BTF_WSOLVE_SET, BTF_X)
 BTF_FOR_K(BTF_PG_SET, BTF_X)
 BTF_FOR_K(BTF_NB_SET, BTF_X)
 BTF_TWIST_SET(BTF_X)
+BTF_FUSED_SET(BTF_X)
 #undef BTF_X
 #else
 #define BTF_D template __global__
@@ -99,6 +120,8 @@ BTF_FOR_K(BTF_PG_SET, BTF_D)
 BTF_FOR_K(BTF_NB_SET, BTF_D)
 #elif BTF_INST_PART == 7
 BTF_TWIST_SET(BTF_D)
+#elif BTF_INST_PART == 8
+BTF_FUSED_SET(BTF_D)
 #else
 #error "BTF_INST_PART out of range"
 #endif

@@ -172,8 +172,9 @@ __device__ __forceinline__ void gram_mfma_groups(const double* __restrict__ U, i
 // the whole workgroup: NW waves split the row groups [0, ceil(Rdim / 4)) of this workgroup's share (block b of nb) into
 // contiguous runs, then the NW tiles are added in a fixed order; out[lidx(p, q)], q <= p < K (packed lower triangle).
 // scr: NW * 256 doubles of LDS.  No barrier after the last write.
+// (sc1: the partial is stored write-through - a tail of the same launch reads it, btf_fused.h)
 template <int K, int NW>
-__device__ __forceinline__ void gram_mfma_block(const double* __restrict__ U, int Rdim, int b, int nb, double* scr, double* out) {
+__device__ __forceinline__ void gram_mfma_block(const double* __restrict__ U, int Rdim, int b, int nb, double* scr, double* out, bool sc1 = false) {
   static_assert(NW >= 4, "256 threads write the tile out");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int G = (Rdim + 3) >> 2;
@@ -189,7 +190,7 @@ __device__ __forceinline__ void gram_mfma_block(const double* __restrict__ U, in
     if (p < K && q <= p) {
       double t = 0.0;
       for (int w = 0; w < NW; ++w) t += scr[w * 256 + threadIdx.x];
-      out[lidx(p, q)] = t;
+      if (sc1) store_sc1(&out[lidx(p, q)], t); else out[lidx(p, q)] = t;
     }
   }
 }
@@ -232,7 +233,8 @@ constexpr int TAU_SIDE_CPW = 2;
 
 // the Gram of the fixed factor (what gram_kernel computes) as side workgroups of the accumulation launch that the
 // solve kernel FOLLOWS: nblocks partial Grams of U's rows, one per side workgroup, consumed across the kernel boundary
-struct GramSide { const double* U; int Rdim; double* gpart; int nblocks; };
+// (cnt != nullptr: the partials are consumed inside this launch - stored write-through, every block adds one to *cnt)
+struct GramSide { const double* U; int Rdim; double* gpart; int nblocks; unsigned* cnt; };
 
 // Which rows of the reduction axis a launch covers, and where its partial sums go: logical chunk l of the launch takes
 // rows r0 .. min(r0 + rows_per_block, row_end) - 1 with r0 = row_base + l rows_per_block, moved up by `skip_rows` from
@@ -243,7 +245,7 @@ struct GramSide { const double* U; int Rdim; double* gpart; int nblocks; };
 struct ChunkMap {
   int slot_base, row_base, skip_at, skip_rows, row_end; int nside;     // nside: side workgroups in front (set by launch_accum)
 #ifdef BTF_ACC_STAMPS
-  long long* stamps;       // diagnostic builds: [8192][4] wall-clock stamps of the streaming workgroups
+  long long* stamps;       // diagnostic builds: [8192][8] wall-clock stamps of the streaming workgroups (4..7: the fused tails)
 #endif
 };
 
@@ -252,14 +254,16 @@ struct ChunkMap {
 // end of the previous sweep (sse_cols: sum_t R v'W'Wv - 2 v.m with the W and V that still stand) plus the constants of
 // the data, sum W^2 from W itself; w_solve - the next kernel - reads the two draws.  Same Philox streams as
 // scalars_kernel.  hyp == nullptr: no such workgroup.
+// (pub / flag / epoch: the fused W launch's tails read the draws inside the launch - btf_fused.h)
 struct ScalarSide {
   const double* sse_cols; int M; double sconst, nobs;
   const double* W; int NK; double nfree;
   double nu2_a, nu2_b, sig_a, sig_b; int which; unsigned long long seed; double* hyp;
+  double* pub; unsigned* flag; unsigned epoch;
 };
 // lam2 | rest (and lam2_a) as a side workgroup of the V accumulation launch: it needs the column sums the Tau2 chain left
 // in the W accumulation launch; the V sampler - the next kernel - reads the draw.  hyp == nullptr: none.
-struct LamSide { const double* lsum; int M; double shape; int exact; unsigned long long seed; double* hyp; };
+struct LamSide { const double* lsum; int M; double shape; int exact; unsigned long long seed; double* hyp; double* pub; unsigned* flag; unsigned epoch; };
 struct SweepSide { ScalarSide sc; LamSide lam; };
 
 // MODE 0: X only (complete data)
@@ -302,6 +306,50 @@ __host__ __device__ constexpr int acc_opl(int K, int MODE) { return MODE >= 1 &&
 template <int NW> __device__ void sweep_scalar_side(const ScalarSide& sc, double* red);
 template <int NW> __device__ void sweep_lam_side(const LamSide& lm, double* red);
 
+// FUSE: the latency kernel that follows the accumulation runs as the tail of this launch (btf_fused.h): FUSE_W - the
+// workgroup that finishes a 128-row tile last sums the chunks and draws the rows (w_solve_kernel's work); FUSE_V - the
+// columns of a 128-output tile are sampled where their sums are (v_spectral_kernel's work).  The extra kernel argument
+// is empty for FUSE_NONE.
+enum { FUSE_NONE = 0, FUSE_W = 1, FUSE_V = 2 };
+struct FuseNone {};
+struct FuseW;
+struct FuseV;
+template <int FUSE> struct FuseSel { typedef FuseNone type; };
+template <> struct FuseSel<FUSE_W> { typedef FuseW type; };
+template <> struct FuseSel<FUSE_V> { typedef FuseV type; };
+template <int K, int WAVES> __device__ __forceinline__ void w_fused_owner(const FuseW& fw, int tile, double* lds, long long* stamps);
+template <int FUSE> __device__ __forceinline__ int fuse_owners(const typename FuseSel<FUSE>::type& fz);
+struct VPre;
+template <int K, int S, int WAVES, int NSUM>
+__device__ __forceinline__ void v_fused_tail(const FuseV& fv, int tile, double* lds, const double (&sums)[NSUM], int nv_round, int tv, int tc, long long* stamps,
+                                             const VPre& pre, const double* mailbox, bool band_early, bool unr3);
+template <int K, int S> __device__ __forceinline__ void v_fused_prefetch(const FuseV& fv, int tile, double* mailbox, VPre& pre, bool band_early);
+template <int K, int S, class PRE> __device__ __forceinline__ void v_fused_prefetch_loads(const FuseV& fv, int tile, PRE& pre, bool band_early);
+constexpr int VF_PRE = 4;                  // row groups of the stream behind the fused V tail's prefetch
+template <int K, int S> __device__ __forceinline__ bool v_fused_band_early(const FuseV& fv, int tile, double* lds, bool unr3);
+template <int FUSE> struct FusePre { struct type {}; };
+constexpr int VF_MAILBOX_DOUBLES = 128;
+template <int FUSE> __device__ __forceinline__ unsigned* fuse_tickets(const typename FuseSel<FUSE>::type& fz);
+template <int FUSE> __device__ __forceinline__ int fuse_chunks(const typename FuseSel<FUSE>::type& fz);
+// a tile's arrival ticket: call after drain_stores() + __syncthreads(); tells every thread whether this workgroup came
+// last.  `word`: an LDS word free across the two barriers inside.  The counter is reset for the next launch.
+__device__ __forceinline__ bool last_arriver_of(unsigned* cnt, unsigned expected, unsigned* word) {
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add((gu32_t*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = t + 1u == expected;
+    if (last) __hip_atomic_store((gu32_t*)cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *word = last ? 1u : 0u;
+  }
+  __syncthreads();
+  const bool last = *word != 0u;
+  __syncthreads();
+  return last;
+}
+// LDS doubles of the FUSE_V instances: 144 KiB; 120 KiB beside the staged factor rows (ULDS) of the three-rows-in-flight form
+__host__ __device__ constexpr int vf_red_doubles(bool unr3) { return unr3 ? 15360 : 18432; }
+__host__ __device__ constexpr int w_tail_lds_doubles(int K);
+__host__ __device__ constexpr int w_owner_lds_budget(int K);
+
 // CT: storage type of the weights C: double (Binomial: the Polya-Gamma draws) or unsigned char (Gaussian data with
 // missing replicates: C is the replicate count 0..R, 1 byte instead of 8 per cell: 9 instead of 16 B/cell)
 // XT: storage type of the linear statistic X: double, or signed char for Binomial pseudo-data kappa = Y - N/2 with
@@ -309,18 +357,26 @@ template <int NW> __device__ void sweep_lam_side(const LamSide& lm, double* red)
 // UNRV: rows in flight per wave; 0 = the build's default (2).  Long row ranges per workgroup (C5-sized slabs) stream
 // 1-2 % faster with 3 (359 / 346 us against 361 / 353 us per launch at C5), short ones (C3: 32 rows per wave) slower.
 #ifdef BTF_ACC_STAMPS     // diagnostic builds (scripts/acc_stamps.sh): wall-clock stamps (100 MHz) of every streaming workgroup
-#define ACC_STAMP(i) do { if (threadIdx.x == 0 && b < 4096 && cm.stamps) cm.stamps[b * 4 + (i)] = wall_clock64(); } while (0)
-#define ACC_SIDE_STAMP(i) do { if (threadIdx.x == 0 && cm.stamps) cm.stamps[(4096 + blockIdx.x) * 4 + (i)] = wall_clock64(); } while (0)
+#define ACC_STAMP(i) do { if (threadIdx.x == 0 && b < 4096 && cm.stamps) cm.stamps[b * 8 + (i)] = wall_clock64(); } while (0)
+#define ACC_SIDE_STAMP(i) do { if (threadIdx.x == 0 && cm.stamps) cm.stamps[(4096 + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#define ACC_TAIL_STAMPS (cm.stamps && b < 4096 ? cm.stamps + b * 8 : nullptr)
+#define ACC_OWNER_STAMPS (cm.stamps ? cm.stamps + (size_t)(4096 + blockIdx.x) * 8 : nullptr)
 #else
 #define ACC_STAMP(i) do { } while (0)
 #define ACC_SIDE_STAMP(i) do { } while (0)
+#define ACC_TAIL_STAMPS nullptr
+#define ACC_OWNER_STAMPS nullptr
 #endif
+// (fused tails: thread 0 of the workgroup stamps slot i of its record - diagnostic builds only, else st is nullptr)
+#define TAIL_STAMP(st, i) do { if ((st) && threadIdx.x == 0) (st)[i] = wall_clock64(); } while (0)
 template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double, typename XT = double, int UNRV = 0,
-          int OPL = acc_opl(K, MODE)>
+          int OPL = acc_opl(K, MODE), int FUSE = FUSE_NONE>
 __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void accum_kernel(
     const XT* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
-    int rows_per_block, EigSide side, EigSideCols sidec, TauSide tau, GramSide gram, ChunkMap cm, SweepSide sw) {
+    int rows_per_block, EigSide side, EigSideCols sidec, TauSide tau, GramSide gram, ChunkMap cm, SweepSide sw,
+    typename FuseSel<FUSE>::type fz) {
+  static_assert(FUSE == FUSE_NONE || (MODE == 0 && OPL == 2 && WAVES == 16), "the fused tails follow the complete-data stream");
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
@@ -332,7 +388,12 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   constexpr int ACC_RG0 = ACC_RGT < 4 ? ACC_RGT : 4;
   constexpr int ACC_RGW = ACC_RGT < ACC_RGL ? (ACC_RGT < NV ? ACC_RGT : NV) : (ACC_RGL < NV ? ACC_RGL : NV);
   constexpr int ACC_RG = ACC_RGW > ACC_RG0 ? ACC_RGW : ACC_RG0;
-  __shared__ double red[ACC_WAVES][ACC_RG][ACC_TILE];
+  // (FUSE_V: the same array also holds the sampler's layout of the tile's columns - btf_fused.h - and is sized for it)
+  constexpr int RED_SLOT = ACC_RG * ACC_TILE;
+  constexpr int RED_SLOTS = FUSE == FUSE_V ? (vf_red_doubles(UNRV == 3) + RED_SLOT - 1) / RED_SLOT : ACC_WAVES;
+  static_assert(RED_SLOTS >= ACC_WAVES, "reduction scratch");
+  __shared__ double red[RED_SLOTS][ACC_RG][ACC_TILE];
+  static_assert(FUSE != FUSE_W || (w_tail_lds_doubles(K) <= WAVES * ACC_RG * ACC_TILE && w_owner_lds_budget(K) == WAVES * ACC_RG * ACC_TILE), "W owner scratch");
   // ULDS: the factor rows U[r][:] of the workgroup's row range come in through LDS (one coalesced copy per block of
   // ACC_UROWS rows, then a broadcast ds_read per row and wave) instead of scalar loads - for the long row ranges of
   // C5-sized slabs at K >= 8 (the three-rows-in-flight instance): 353 / 346 -> 342 / 337 us per launch at C5.  Short
@@ -347,6 +408,19 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   int b = blockIdx.x;
   // (one scalar test keeps the streaming workgroups clear of the side tasks' arguments)
   if (b < cm.nside) {
+  if constexpr (FUSE == FUSE_W) {
+    // the tiles' OWNER workgroups (btf_fused.h): they stream nothing - each prepares what the solve of its 128 rows needs
+    // besides the chunk sums (normals, the shared Gram, the scalars), waits for the tile's streaming workgroups and
+    // draws the rows
+    const int nown = fuse_owners<FUSE>(fz);
+    if (b < nown) {
+      ACC_SIDE_STAMP(0);
+      w_fused_owner<K, WAVES>(fz, b, &red[0][0][0], ACC_OWNER_STAMPS);
+      ACC_SIDE_STAMP(3);
+      return;
+    }
+    b -= nown;
+  }
   if (sw.sc.hyp) {
     if (b == 0) { sweep_scalar_side<WAVES>(sw.sc, &red[0][0][0]); return; }
     b -= 1;
@@ -376,6 +450,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       // (the unrolled eigen-solver needs registers: two matrix elements per lane from K = 9 on, which the 128-VGPR
       //  budget of a 16-wave workgroup does not have beside the stream's - there K stays a run-time value)
       constexpr int EIG_KC = (K <= 8 || WAVES <= 8) ? K : 0;
+      ACC_SIDE_STAMP(0);
       const int t = (b - 1) * TPW + wave;
       const bool task = b > 0 && wave < TPW && t < sidec.ncols;
       const int col = task ? sidec.cols[t] : 0;
@@ -387,7 +462,15 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
         reduce_gram(side.gpart, side.ngp, KK, 1.0, rsc, gsum);
       }
       if (b == 0) {
-        if (wave == 0) gram_eig_wave<EIG_KC>(gsum, 1, K, side.out, sc);
+        ACC_SIDE_STAMP(1);
+        if (wave == 0) {
+          gram_eig_wave<EIG_KC>(gsum, 1, K, side.out, sc, true, side.pub);
+          if (side.flag) {                     // the tails of this launch wait for it (btf_fused.h): one storing wave
+            drain_stores();
+            if (lane == 0) publish_epoch(side.flag, side.epoch);
+          }
+          ACC_SIDE_STAMP(3);
+        }
       } else if (task) {
         if (lane < KK) gown[wave * 64 + lane] = fma(-sidec.inv_R, gown[wave * 64 + lane], gsum[lane]);
         wave_lds_sync();
@@ -415,7 +498,12 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       // this block's share of the rows on the matrix cores (gram_mfma_block), fixed-order reduction over the waves
       ACC_SIDE_STAMP(0);
       static_assert(ACC_WAVES * 256 <= ACC_WAVES * ACC_RG * ACC_TILE, "Gram side scratch");
-      gram_mfma_block<K, WAVES>(gram.U, gram.Rdim, b, gram.nblocks, &red[0][0][0], gram.gpart + (size_t)b * KK);
+      gram_mfma_block<K, WAVES>(gram.U, gram.Rdim, b, gram.nblocks, &red[0][0][0], gram.gpart + (size_t)b * KK, gram.cnt != nullptr);
+      if (gram.cnt) {
+        drain_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add((gu32_t*)gram.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       ACC_SIDE_STAMP(3);
       return;
     }
@@ -439,6 +527,10 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   if (r0 >= cm.skip_at) r0 += cm.skip_rows;
   const int r1 = min(r0 + rows_per_block, cm.row_end);
 
+  // (fused V launch: the prior band of the tile's columns while the memory system is still idle - btf_fused.h)
+  bool band_early = false;
+  if constexpr (FUSE == FUSE_V) band_early = v_fused_band_early<K, 3>(fz, tile, &red[0][0][0], UNRV == 3);
+  typename FusePre<FUSE>::type vpre;
   double acc[NV][OPL];
 #pragma unroll
   for (int v = 0; v < NV; ++v)
@@ -584,6 +676,17 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       rb += STEP;
     }
   } else {
+    if constexpr (FUSE == FUSE_V) {
+      // fused V launch: the tail's own global loads (stencil, Tau2) go out VF_PRE row groups before the stream ends - under
+      // load they take ~2 us, and behind the stream they would sit in front of the reduction's first barrier
+      const int pre_end = full_end - VF_PRE * STEP;
+      for (; rb < pre_end; rb += STEP) {
+        Rows A;
+        load_rows(rb, A, std::true_type{});
+        compute(rb, A);
+      }
+      v_fused_prefetch_loads<K, 3>(fz, tile, vpre, band_early);
+    }
     for (; rb < full_end; rb += STEP) {
       Rows A;
       load_rows(rb, A, std::true_type{});
@@ -599,9 +702,19 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   }
 
   ACC_STAMP(2);
+  // (fused V launch: the tail's global loads and its wait for the side workgroups go out here, under the wave skew and
+  //  the reduction - btf_fused.h)
+  if constexpr (FUSE == FUSE_V) {
+    if constexpr (ULDS) v_fused_prefetch_loads<K, 3>(fz, tile, vpre, band_early);      // (the staged-factor form of long row ranges: here)
+    v_fused_prefetch<K, 3>(fz, tile, &red[0][0][0] + RED_SLOTS * RED_SLOT - VF_MAILBOX_DOUBLES, vpre, band_early);
+  }
   // cross-wave reduction through LDS, ACC_RG values per round, fixed order
   const int tv = threadIdx.x >> 7;   // value slot 0..3
   const int tc = threadIdx.x & 127;  // column inside the tile
+  constexpr int NFS = FUSE == FUSE_NONE ? 1 : (NV + ACC_RG - 1) / ACC_RG;
+  double fsum[NFS];                  // (fused tails: this thread's sums, one per round)
+#pragma unroll
+  for (int r = 0; r < NFS; ++r) fsum[r] = 0.0;
 #pragma unroll
   for (int g = 0; g < NV; g += ACC_RG) {
 #pragma unroll
@@ -617,11 +730,36 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       double s = 0.0;
 #pragma unroll
       for (int w = 0; w < NWR; ++w) s += red[w][tv][tc];
-      part[((size_t)chunk * NV + (g + tv)) * ld + (size_t)tile * ACC_TILE + tc] = s;
+      if constexpr (FUSE == FUSE_NONE) {
+        part[((size_t)chunk * NV + (g + tv)) * ld + (size_t)tile * ACC_TILE + tc] = s;
+      } else {
+        // the tail of another workgroup of this launch reads them: write-through (one chunk, FUSE_V: they stay here)
+        if (FUSE == FUSE_W || fuse_tickets<FUSE>(fz)) store_sc1(&part[((size_t)chunk * NV + (g + tv)) * ld + (size_t)tile * ACC_TILE + tc], s);
+        if constexpr (FUSE == FUSE_V) fsum[g / ACC_RG] = s;
+      }
     }
     __syncthreads();
   }
   ACC_STAMP(3);
+  if constexpr (FUSE == FUSE_W) {
+    // every wave's chunk sums are on their way (write-through): drained, then ONE add to the tile's counter - its owner
+    // workgroup is waiting for the tile's last one
+    drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add((gu32_t*)(fuse_tickets<FUSE>(fz) + tile), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if constexpr (FUSE == FUSE_V) {
+    double* lds = &red[0][0][0];
+    unsigned* tickets = fuse_tickets<FUSE>(fz);
+    if (tickets) {
+      // every wave's chunk sums are on their way: drained, then ONE ticket for the workgroup; whoever draws the tile's
+      // last ticket goes on alone
+      drain_stores();
+      __syncthreads();
+      if (!last_arriver_of(tickets + tile, (unsigned)fuse_chunks<FUSE>(fz), reinterpret_cast<unsigned*>(lds))) return;
+    }
+    v_fused_tail<K, 3, WAVES, NFS>(fz, tile, lds, fsum, ACC_RG, tv, tc, ACC_TAIL_STAMPS, vpre, lds + RED_SLOTS * RED_SLOT - VF_MAILBOX_DOUBLES, band_early, UNRV == 3);
+  }
 }
 
 // ============================================================================
@@ -801,6 +939,31 @@ __host__ __device__ constexpr size_t ws_gram_stage(int K, bool weighted) {
 // row take ONE chunk each.  The solve itself is a per-lane latency chain whatever the number of live lanes.
 __host__ __device__ constexpr int ws_rows_for(int nl) { return nl > 2048 ? 64 : (nl > 1024 ? 32 : (nl > 512 ? 16 : 8)); }
 
+// sum of one (row, value) pair over the chunks of the accumulation partials, in chunk order (the canonical order of the
+// complete-data W step: w_solve_kernel and the fused tail both call this).  p: the pair's slot in chunk 0, cst: chunk
+// stride.  WS_CHB loads in flight.  SC1: the partials were written by other workgroups of the SAME launch (sc1 loads).
+constexpr int WS_CHB = 32;
+template <bool SC1 = false>
+__device__ __forceinline__ double chunk_sum_seq(const double* __restrict__ p, size_t cst, int nch) {
+  double s = 0.0;
+  int c = 0;
+  for (; c + WS_CHB <= nch; c += WS_CHB) {
+    double x[WS_CHB];
+#pragma unroll
+    for (int u = 0; u < WS_CHB; ++u) x[u] = SC1 ? load_sc1(p + (size_t)(c + u) * cst) : p[(size_t)(c + u) * cst];
+#pragma unroll
+    for (int u = 0; u < WS_CHB; ++u) s += x[u];
+  }
+  if (c < nch) {                                          // the last, partial batch: the same loads under a guard
+    double x[WS_CHB];
+#pragma unroll
+    for (int u = 0; u < WS_CHB; ++u) x[u] = c + u < nch ? (SC1 ? load_sc1(p + (size_t)(c + u) * cst) : p[(size_t)(c + u) * cst]) : 0.0;
+#pragma unroll
+    for (int u = 0; u < WS_CHB; ++u) if (c + u < nch) s += x[u];
+  }
+  return s;
+}
+
 template <int K, bool WEIGHTED, int RW = WS_ROWS>
 __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_kernel(WSolveArgs a) {
   constexpr int KK = tri(K);
@@ -863,6 +1026,33 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
   const int rr = lane % RW, sub = lane / RW;
   const int il = blockIdx.x * RW + rr;
   constexpr int CS = WS_SPLIT * SUB;                     // chunk stride of one (wave, subgroup) pair
+  if constexpr (!WEIGHTED) {
+    // Complete data (and curve counts): the chunk sums of a (row, value) pair are added by ONE thread in chunk order
+    // 0, 1, 2, ... - an order that depends on nothing but the number of chunks, so that the tail of the fused W launch
+    // (btf_fused.h: w_tail_rows) lands on the same bits whatever its own geometry.  Thread t < RW K takes the pair
+    // (value t / RW, row t % RW), WS_CHB chunks' loads in flight; the normals are drawn meanwhile by the other threads.
+    constexpr int NT = WS_ROWS * WS_SPLIT;
+    const size_t cst = (size_t)NV * a.ld;
+    for (int t = threadIdx.x; t < RW * K; t += NT) {
+      const int v = t / RW, r = t - v * RW;
+      const int ilr = blockIdx.x * RW + r;
+      red[0][v][r] = ilr < a.nl ? chunk_sum_seq(a.part + (size_t)v * a.ld + ilr, cst, a.nch) : 0.0;
+    }
+    // (threads from the far end take the normals: at RW = 8, K = 5 the first 40 threads sum chunks, the last 40 draw)
+    for (int t = NT - 1 - (int)threadIdx.x; t < RW * K; t += NT) {
+      const int k = t / RW, r = t - k * RW;
+      const int ilr = blockIdx.x * RW + r;
+      double zv = 0.0;
+      if (ilr < a.nl) {
+        const int i = a.row0 + ilr;
+        const long long zoff = w_z_offset(i, K);
+        const int d = i + 1 < K ? i + 1 : K;
+        if (k < d) zv = a.z ? a.z[zoff + k] : philox_normal(a.seed, a.stream, (unsigned long long)(zoff + k));
+      }
+      zsh[k][r] = zv;
+    }
+    if (g_early) reduce_gram_finish(gx, a.ngp, KK, a.sR, &red[1][0][0], G);     // ends with a barrier (red[1]: scratch; red[0] holds the sums)
+  } else {
   // stage 1: pair (grp, sub) sums chunks grp*SUB+sub, +CS, ... (fixed order => deterministic).  The first
   // batch of loads is issued BEFORE the Philox normals of the row are computed (component k by wave
   // k % WS_SPLIT), so the transcendental work hides under the memory latency.
@@ -928,6 +1118,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
 #pragma unroll
     for (int v = 0; v < NVMAX; ++v) red[grp][v][lane] = part[v];
   }
+  }
   __syncthreads();
   // Weighted rows of K = 6 and 8 leave WS_SPLIT (K + KK) = 216 / 176 values per row in LDS: wave 0 summing them all on
   // its own kept two hundred loaded doubles alive next to the solve's registers (148 VGPRs spilled at K = 6).  There
@@ -945,7 +1136,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     }
     __syncthreads();
   }
-  constexpr int NSH = TWO_LEVEL ? 1 : WS_SPLIT;          // shares wave 0 still has to add
+  constexpr int NSH = (TWO_LEVEL || !WEIGHTED) ? 1 : WS_SPLIT;          // shares wave 0 still has to add (complete data: the pair's sum is whole)
   if (grp != 0) return;                      // wave 0 finishes: one lane per row
   const bool live = lane < RW && il < a.nl;
   const int i = a.row0 + (live ? il : 0);
@@ -956,7 +1147,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < NSH; ++w) s += red[w][k][rr];
-    m[k] = s * a.s;
+    m[k] = __dmul_rn(s, a.s);
   }
 #pragma unroll
   for (int q = 0; q < KK; ++q) {
@@ -964,7 +1155,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
       double s = 0.0;
 #pragma unroll
       for (int w = 0; w < NSH; ++w) s += red[w][K + q][rr];
-      Q[q] = s * a.s;
+      Q[q] = __dmul_rn(s, a.s);
     } else {
       Q[q] = G[q];
     }
@@ -986,7 +1177,9 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
       for (int c = 0; c <= r; ++c) Q[lidx(r, c)] = (r == c) ? 1.0 : 0.0;
     }
   }
-  // in-register Cholesky (lower, packed); 1/L_cc kept so that the solves multiply instead of divide
+  // in-register Cholesky (lower, packed); 1/L_cc kept so that the solves multiply instead of divide.  (Every product
+  // that an addition follows is a __dmul_rn / __dadd_rn: the fused tail of btf_fused.h repeats this arithmetic in another
+  // code shape, and -ffp-contract=fast must not be allowed to fuse differently there)
   bool ok = true;
   double invl[K];
 #pragma unroll
@@ -998,7 +1191,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     // 1/sqrt(p) by v_rsq_f64 + two Newton steps (full precision), l = p / sqrt(p): ~12 instructions on the lane's
     // dependent chain instead of the ~55 of an IEEE square root and division
     const double inv = rsq_nr(p);
-    const double l = p * inv;
+    const double l = __dmul_rn(p, inv);
     invl[c] = inv;
     Q[lidx(c, c)] = l;
 #pragma unroll
@@ -1006,7 +1199,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
       double v = Q[lidx(r, c)];
 #pragma unroll
       for (int q = 0; q < c; ++q) v = fma(-Q[lidx(r, q)], Q[lidx(c, q)], v);
-      Q[lidx(r, c)] = v * inv;
+      Q[lidx(r, c)] = __dmul_rn(v, inv);
     }
   }
   if (live && !ok && atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = i;
@@ -1017,17 +1210,17 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     double v = m[r];
 #pragma unroll
     for (int c = 0; c < r; ++c) v = fma(-Q[lidx(r, c)], y[c], v);
-    y[r] = v * invl[r];
+    y[r] = __dmul_rn(v, invl[r]);
   }
 #pragma unroll
   for (int r = 0; r < K; ++r)
-    if (r < d) y[r] += zsh[r][rr];
+    if (r < d) y[r] = __dadd_rn(y[r], zsh[r][rr]);
 #pragma unroll
   for (int r = K - 1; r >= 0; --r) {
     double v = y[r];
 #pragma unroll
     for (int c = r + 1; c < K; ++c) v = fma(-Q[lidx(c, r)], y[c], v);
-    y[r] = v * invl[r];
+    y[r] = __dmul_rn(v, invl[r]);
   }
   // the row as it now stands (entries >= d keep their stored value), written back and
   // folded into this workgroup's share of W'W for the next V half-sweep
@@ -2267,12 +2460,21 @@ __device__ void sweep_scalar_side(const ScalarSide& sc, double* red) {
   if ((sc.which & 1) && threadIdx.x == 0) {
     CellRng g(sc.seed, (unsigned long long)HYP_NU2);
     sc.hyp[HYP_SSE] = sse;
-    sc.hyp[HYP_NU2] = (sc.nu2_b + 0.5 * sse) / gamma_mt(sc.nu2_a + 0.5 * sc.nobs, g);
+    const double nu2 = (sc.nu2_b + 0.5 * sse) / gamma_mt(sc.nu2_a + 0.5 * sc.nobs, g);
+    sc.hyp[HYP_NU2] = nu2;
+    if (sc.flag) store_sc1(sc.pub + HYP_NU2, nu2);
   }
   if ((sc.which & 2) && threadIdx.x == 64) {
     CellRng g(sc.seed, (unsigned long long)HYP_SIGMA2);
     sc.hyp[HYP_WSQ] = wsq;
-    sc.hyp[HYP_SIGMA2] = (sc.sig_b + 0.5 * wsq) / gamma_mt(sc.sig_a + 0.5 * sc.nfree, g);
+    const double sg2 = (sc.sig_b + 0.5 * wsq) / gamma_mt(sc.sig_a + 0.5 * sc.nfree, g);
+    sc.hyp[HYP_SIGMA2] = sg2;
+    if (sc.flag) store_sc1(sc.pub + HYP_SIGMA2, sg2);
+  }
+  if (sc.flag) {                         // two storing waves: drained, barrier, one flag store
+    drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) publish_epoch(sc.flag, sc.epoch);
   }
 }
 template <int NW>
@@ -2290,6 +2492,11 @@ __device__ void sweep_lam_side(const LamSide& lm, double* red) {
     const double lam2 = fmax(1e-5, rate / gamma_mt(0.5 * lm.shape, g));
     lm.hyp[HYP_LAM2] = lam2;
     lm.hyp[HYP_LAM2A] = (1.0 / lam2 + 1.0) / g.expo();
+    if (lm.flag) {                       // one storing lane: drained, then the flag
+      store_sc1(lm.pub + HYP_LAM2, lam2);
+      drain_stores();
+      publish_epoch(lm.flag, lm.epoch);
+    }
   }
 }
 

@@ -1,0 +1,115 @@
+"""The two-launch W+V step (BTF_OPT_FUSED_STEP, csrc/btf_fused.h) against the four-launch path.
+
+The batched K x K solve of `_resample_W` (factor.py:349-362) runs as the tail of the W accumulation launch, the spectral
+sampler of `_resample_V` (factor.py:377-409 with fast_mvn.py:35-47) as the tail of the V accumulation launch.  Both tails
+repeat the arithmetic of w_solve_kernel / v_spectral_kernel in the same order, so the chains must agree BIT FOR BIT with
+the four-launch path - for host normals (the reference-reproducible mode) and for device normals, under both `compat`s,
+at shapes with one and with several chunks per tile, whole and ragged tiles.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _synth(N, M, T, R, K, seed=3):
+    rs = np.random.RandomState(seed)
+    Wt = rs.normal(size=(N, K))
+    Vt = 0.1 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    return np.einsum("nk,mtk->nmt", Wt, Vt)[..., None] + rs.normal(0, 0.5, size=(N, M, T, R))
+
+
+def _make(dims, fused, rng, compat, sampler="spectral", rpb=None, seed=11):
+    from functionalmf_amd import _native
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    N, M, T, R, K = dims
+    np.random.seed(seed)
+    m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, nu2_init=1.0,
+                                        rng=rng, device_seed=5, compat=compat, sampler=sampler)
+    m._ctx.call("btf_set_option", _native.OPT_FUSED_STEP, int(fused))      # 0: four launches, 1: V launch fused, 2: W launch too
+    if rpb:
+        m._ctx.call("btf_set_tuning", rpb[0], rpb[1])
+    return m
+
+
+def _launches(m):
+    kt = m._ctx.kernel_times()
+    return {k: v[1] for k, v in kt.items() if v[1]}
+
+
+# (N, M, T, R, K): one chunk per V tile and 2 columns per tile (T = 64); four columns per tile (T = 32); one (T = 128);
+# a ragged last tile (M T not a multiple of 128); several W tiles; nembeds 8
+SHAPES = [(96, 6, 64, 2, 5), (70, 9, 32, 2, 3), (40, 3, 128, 1, 4), (300, 5, 64, 2, 8), (130, 7, 64, 3, 1)]
+
+
+@pytest.mark.parametrize("dims", SHAPES)
+@pytest.mark.parametrize("rng", ["host", "device"])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_two_launch_step_is_bit_identical_to_four_launches(dims, rng, mode):
+    Y = _synth(*dims)
+    a, b = _make(dims, mode, rng, "reference"), _make(dims, 0, rng, "reference")
+    for m in (a, b):
+        np.random.seed(21)
+        m._bind_data(Y)
+        m._ctx.kernel_times()
+        for _ in range(4):
+            m._resample_W(Y)
+            m._resample_V(Y)
+        m.sync()
+    la, lb = _launches(a), _launches(b)
+    assert la == ({"w_accum": 4, "v_accum": 4} if mode == 2 else {"w_accum": 4, "w_solve": 4, "v_accum": 4}), la      # two / three launches per step
+    assert lb == {"w_accum": 4, "w_solve": 4, "v_accum": 4, "v_banded": 4}, lb
+    assert np.array_equal(a.W, b.W)
+    assert np.array_equal(a.V, b.V)
+    assert np.isfinite(a.W).all() and np.isfinite(a.V).all() and np.abs(a.V).max() > 0
+
+
+@pytest.mark.parametrize("compat", ["reference", "exact"])
+def test_two_launch_step_several_chunks_per_tile(compat):
+    """Rows-per-workgroup overrides force several chunks per tile in BOTH launches: the last arriver of a tile sums the
+    chunks of the other workgroups (write-through partials, tickets)."""
+    dims = (640, 6, 64, 2, 5)
+    Y = _synth(*dims)
+    a, b = _make(dims, 2, "device", compat, rpb=(64, 128)), _make(dims, 0, "device", compat, rpb=(64, 128))
+    for m in (a, b):
+        for _ in range(6):
+            m._resample_W(Y)
+            m._resample_V(Y)
+        m.sync()
+    assert np.array_equal(a.W, b.W) and np.array_equal(a.V, b.V)
+
+
+def test_two_launch_full_sweeps_walk_the_same_chain():
+    """Full device sweeps (nu2, sigma2, Tau2 chain, lam2, W, V): the scalar draws that ride in the accumulation launches as
+    side workgroups reach the tails of the same launch through their published copies."""
+    dims = (96, 8, 64, 2, 5)
+    Y = _synth(*dims)
+    a, b = _make(dims, 2, "device", "reference"), _make(dims, 0, "device", "reference")
+    for m in (a, b):
+        m.resample(Y)
+        m.resample_sweeps(Y, 6)
+        m.sync()
+    assert np.array_equal(a.W, b.W) and np.array_equal(a.V, b.V) and np.array_equal(np.asarray(a.Tau2), np.asarray(b.Tau2))
+    assert (a.nu2, a.sigma2, a.lam2) == (b.nu2, b.sigma2, b.lam2)
+    c = _make(dims, 1, "device", "reference")
+    for _ in range(7):
+        c.resample(Y)                                                   # Python-driven: the same decisions
+    assert np.array_equal(a.W, c.W) and np.array_equal(a.V, c.V)
+
+
+def test_two_launch_step_at_c3_size_matches_and_repeats():
+    """BASELINE config 3 (512,256,64,4) nembeds 5: 128 + 1 workgroups per launch, every tail polling the eigen side
+    workgroup's flag; 30 steps, fused against unfused, and the fused run twice (the tickets / epochs carry no state
+    from one run into the next)."""
+    dims = (512, 256, 64, 4, 5)
+    Y = _synth(*dims, seed=1)
+    runs = []
+    for fused in (2, 0, 1, 2):
+        m = _make(dims, fused, "device", "reference")
+        for _ in range(30):
+            m._resample_W(Y)
+            m._resample_V(Y)
+        m.sync()
+        runs.append((m.W.copy(), m.V.copy()))
+    for W, V in runs[1:]:
+        assert np.array_equal(runs[0][0], W) and np.array_equal(runs[0][1], V)
