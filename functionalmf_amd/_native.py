@@ -24,6 +24,7 @@ COMPAT = {"reference": 0, "exact": 1}
 KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw", "nb_loglik",
                 "prior_band", "gram_eig", "hyper", "ess"]
 OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT, OPT_CURVE_COUNTS, OPT_SPLIT_ACCUM, OPT_FUSED_SWEEP, OPT_FUSED_STEP = 0, 1, 2, 3, 4, 5, 6, 7
+ESS_HOST_LIKELIHOOD = -1          # BTF_ESS_HOST_LIKELIHOOD of include/btf.h
 SAMPLERS = {"banded": 0, "spectral": 1, "chain": 2, "generic": 3, "banded_nopanel": 4}
 
 # every symbol include/btf.h declares: (name, restype, argtypes)

@@ -939,6 +939,7 @@ int btf_set_shard(btf_ctx* c, int row0, int nrows_local, int col0, int ncols_loc
   if (row0 < 0 || nrows_local < 0 || row0 + nrows_local > c->N || col0 < 0 || ncols_local < 0 || col0 + ncols_local > c->M)
     return fail(c, BTF_EINVAL, "shard out of range");
   c->row0 = row0; c->nl = nrows_local; c->col0 = col0; c->ml = ncols_local;
+  c->nb_bwt_written = false;      // (the skip of nb_bwt_target is only valid for the shard geometry B_wT was written under)
   return BTF_OK;
 }
 void* btf_stream(btf_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -1901,7 +1902,12 @@ int ess_alloc(btf_ctx* c) {
   return BTF_OK;
 }
 int ess_check(btf_ctx* c, int what, int link) {
-  if (what < 0 || what > 1 || link < 0 || link >= ESS_FAM_COUNT) return fail(c, BTF_EINVAL, "bad elliptical-slice arguments");
+  if (what < 0 || what > 1 || link < BTF_ESS_HOST_LIKELIHOOD || link >= ESS_FAM_COUNT) return fail(c, BTF_EINVAL, "bad elliptical-slice arguments");
+  if (link == BTF_ESS_HOST_LIKELIHOOD) {                   // the caller's own likelihood: nothing of the data is needed here
+    if (!c->have_W || !c->have_V || !c->have_hyper) return fail(c, BTF_ESTATE, "elliptical slice sampling needs W, V and hyper-parameters");
+    if (c->nl != c->N || c->ml != c->M) return fail(c, BTF_ESTATE, "elliptical slice sampling needs an unsharded context");
+    return BTF_OK;
+  }
   if (!c->have_data || c->binomial || !c->have_W || !c->have_V || !c->have_hyper)
     return fail(c, BTF_ESTATE, "elliptical slice sampling needs count data (btf_set_data_gaussian statistics), W, V and hyper-parameters");
   if (c->nl != c->N || c->ml != c->M) return fail(c, BTF_ESTATE, "elliptical slice sampling needs an unsharded context");
@@ -1974,7 +1980,7 @@ int ess_begin(btf_ctx* c, int what, const double* z, uint64_t seed, double eps0,
 int btf_ess_begin(btf_ctx* c, int what, const double* z, uint64_t seed, double eps0, int attempts) {
   if (!c) return BTF_EINVAL;
   int rc;
-  if ((rc = ess_check(c, what, 0))) return rc;
+  if ((rc = ess_check(c, what, BTF_ESS_HOST_LIKELIHOOD))) return rc;      // (the prior draw needs no data; btf_ess_eval checks what its family needs)
   HIPCHK(c, hipSetDevice(c->dev));
   if ((rc = ess_begin(c, what, z, seed, eps0, attempts < 0 ? 0 : attempts))) return rc;
   // one joint chain: not done
@@ -1999,6 +2005,11 @@ int btf_ess_eval(btf_ctx* c, int what, double theta, int current, int link, doub
     c->w_local_done = c->v_local_done = false; c->sse_cols_valid = false;
     if (what == 0) { c->ngp_w = 0; c->w_part_valid = false; } else { c->ngp_v = 0; c->w_part_valid = false; }
     c->nb_L_valid = false;
+  }
+  if (link == BTF_ESS_HOST_LIKELIHOOD) {                   // the proposal stands in W / V: the caller evaluates its own function
+    *ll = 0.0;
+    HIPCHK(c, hipGetLastError());
+    return check_status(c);
   }
   K_SWITCH(c->K, launch_ess_ll<KT>(c, what, 0, link, d.nbx));
   HIPCHK(c, hipGetLastError());
@@ -2765,6 +2776,7 @@ int btf_collect_begin(btf_ctx* c, int nsamples) {
   if ((rc = dev_alloc(c, &c->smp_T, (size_t)nsamples * c->M * c->nD))) return rc;
   if ((rc = dev_alloc(c, &c->smp_s, (size_t)nsamples * HYP_COUNT))) return rc;
   c->smp_n = nsamples;
+  c->col_every = 0; c->col_slot = 0; c->col_count = 0;     // (a schedule left armed by an interrupted run ends here)
   return BTF_OK;
 }
 

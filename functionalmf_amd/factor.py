@@ -66,8 +66,17 @@ def _digest(a):
         import xxhash
         return xxhash.xxh3_64_intdigest(a.data)
     except ImportError:
+        import warnings
         import zlib
+        global _CRC_WARNED
+        if not _CRC_WARNED:
+            _CRC_WARNED = True
+            warnings.warn("xxhash is not installed: the periodic check for in-place edits of the observation array hashes with "
+                          "zlib.crc32 (~1 GB/s instead of ~10 GB/s); its period stretches accordingly (see set_data)", RuntimeWarning)
         return zlib.crc32(a.data)
+
+
+_CRC_WARNED = False
 
 
 def stale_row_sources(nrows, nembeds, any_nan):
@@ -347,10 +356,13 @@ class BayesianTensorFiltering(_BayesianModel):
             import time
             every = getattr(self, "data_check_seconds", 5.0)
             now = time.monotonic()
-            if every is None or now - self._data_checked < every:
+            # (bounded duty cycle: the hash is O(data) on the host thread - 0.9 s for the 8.6 GB of config C5 - so the next
+            #  check is at least 50 hash times away, whatever `data_check_seconds` says: never more than 2 % of the wall clock)
+            if every is None or now - self._data_checked < max(every, 50.0 * getattr(self, "_digest_seconds", 0.0)):
                 return
             dig = tuple(_digest(a) for a in arrays)
             self._data_checked = time.monotonic()
+            self._digest_seconds = self._data_checked - now
             if dig == self._data_digest:
                 return
             import warnings
@@ -359,8 +371,10 @@ class BayesianTensorFiltering(_BayesianModel):
                           RuntimeWarning, stacklevel=3)
         self._upload(data)
         import time
+        t0 = time.monotonic()
         self._data_digest = tuple(_digest(a) for a in arrays)
         self._data_checked = self._data_uploaded = time.monotonic()
+        self._digest_seconds = self._data_checked - t0
         if self._exchange.active:      # observation count over all ranks (a constant of the data set)
             (tot,) = self._exchange.sum_scalars(float(self._local_nobs(data)))
             self._ctx.call("btf_set_global_nobs", float(tot))
@@ -379,9 +393,11 @@ class BayesianTensorFiltering(_BayesianModel):
         """Force a re-upload.  The reference re-reads the observation array on every half-sweep
         (factor.py:329-330, :374-375); here it is uploaded once and recognised again by identity, shape and
         a 64-point fingerprint, which catches wholesale in-place edits (imputation, rescaling) at once; a few
-        changed cells are caught by a hash of the whole array taken every `data_check_seconds` (default 5 s; None: never),
-        with a RuntimeWarning.  After mutating the array in place, call set_data() to have the change apply from the next
-        half-sweep on."""
+        changed cells are caught by a hash of the whole array taken every `data_check_seconds` (default 5 s; None: never;
+        never more often than every 50 hash times - the hash is O(data) on the host thread), with a RuntimeWarning.  That
+        check runs on the WALL clock: the sweep at which a silent in-place edit takes effect is not reproducible.  After
+        mutating the array in place, call set_data(): the change then applies, deterministically, from the next half-sweep
+        on."""
         self._data_key = None
         self._bind_data(data)
 
@@ -528,15 +544,22 @@ class BayesianTensorFiltering(_BayesianModel):
         dsq = self._penalised_differences()
         shape = (self.nembeds + 1) / 2
         T2, Ta, Tb, Tc = self.Tau2, self.Tau2_a, self.Tau2_b, self.Tau2_c
-        # first level: everything but the draw itself is the same for all columns -> vectorised;
-        # the gamma calls stay per column, in the reference's order (Tau2, c, b, a for column j, then j+1)
+        # The reference draws, column after column, gamma(shape, scale) for Tau2 and gamma(1, scale) for the three further
+        # levels (nD variates each).  A legacy gamma(shape, scale) IS scale * standard_gamma(shape), and what a standard
+        # gamma takes from the generator depends on its shape only - so ONE standard_gamma call over the shapes in the
+        # reference's order ((K+1)/2, 1, 1, 1 per column) yields the same variates bit for bit and leaves the generator
+        # where the reference's 4 M calls leave it (pinned by the G1 / G6 chain fixtures); the four scale levels - each a
+        # function of the level before - are then applied to all columns at once.
+        M, nD = self.ncols, dsq.shape[1]
+        shapes = np.ones((M, 4, nD))
+        shapes[:, 0, :] = shape
+        sg = np.random.standard_gamma(shapes)
         scale1 = 1 / (dsq / (2 * self.lam2) + 1 / Tc.clip(lo, hi)).clip(lo, hi)
-        gamma = np.random.gamma
-        for j in range(self.ncols):
-            t = T2[j] = 1 / gamma(shape, scale1[j])
-            c = Tc[j] = 1 / gamma(1, 1 / (1 / t + 1 / Tb[j]).clip(lo, hi))
-            b = Tb[j] = 1 / gamma(1, 1 / (1 / c + 1 / Ta[j]).clip(lo, hi))
-            Ta[j] = 1 / gamma(1, 1 / (1 / b + 1).clip(lo, hi))
+        t = 1 / (scale1 * sg[:, 0])
+        c = 1 / ((1 / (1 / t + 1 / Tb).clip(lo, hi)) * sg[:, 1])
+        b = 1 / ((1 / (1 / c + 1 / Ta).clip(lo, hi)) * sg[:, 2])
+        a = 1 / ((1 / (1 / b + 1).clip(lo, hi)) * sg[:, 3])
+        T2[:], Tc[:], Tb[:], Ta[:] = t, c, b, a
 
     def _resample_lam2(self):
         """Global scale.  compat="reference": the rate keeps only the LAST column's term
@@ -587,26 +610,27 @@ class BayesianTensorFiltering(_BayesianModel):
         if callback is not None or not self._collects_on_device() or nsamples < 1:
             return super().run_gibbs(data, nburn=nburn, nthin=nthin, nsamples=nsamples, verbose=verbose,
                                      print_freq=print_freq, callback=callback, **kwargs)
-        self._ctx.call("btf_collect_begin", int(nsamples))
+        self._ctx.call("btf_collect_begin", int(nsamples))        # (also clears a schedule an interrupted run left armed)
         self._collected = 0
         if self._sweeps_on_device():
             # whole sweeps queued by the C side (btf_gibbs_sweeps): the same chain as the loop below, without a
-            # Python round trip per step
             # Python round trip per step; the kept states (the first after nburn + 1 sweeps, then every nthin-th) are copied
             # into their slots by the same C call (btf_collect_schedule) - one call per block of sweeps, not per sample
             done, total = 0, nburn + (nsamples - 1) * nthin + 1
             scheduled = False
-            while done < total:
-                if not scheduled and done >= nburn:
-                    self._ctx.call("btf_collect_schedule", int(nthin), 0, 1)
-                    scheduled = True
-                limit = total if scheduled else nburn
-                n = min(limit - done, max(1, print_freq - done % print_freq)) if verbose else limit - done
-                if verbose and done % print_freq == 0:
-                    print('\tStep {}'.format(done))
-                self.resample_sweeps(data, n)
-                done += n
-            self._ctx.call("btf_collect_schedule", 0, 0, 0)
+            try:
+                while done < total:
+                    if not scheduled and done >= nburn:
+                        self._ctx.call("btf_collect_schedule", int(nthin), 0, 1)
+                        scheduled = True
+                    limit = total if scheduled else nburn
+                    n = min(limit - done, max(1, print_freq - done % print_freq)) if verbose else limit - done
+                    if verbose and done % print_freq == 0:
+                        print('\tStep {}'.format(done))
+                    self.resample_sweeps(data, n)
+                    done += n
+            finally:           # (an exception / KeyboardInterrupt inside the loop must not leave later sweeps copying states)
+                self._ctx.call("btf_collect_schedule", 0, 0, 0)
         else:
             for step in range(nburn + nthin * nsamples):
                 if verbose and step % print_freq == 0:
@@ -714,7 +738,10 @@ class BayesianTensorFiltering(_BayesianModel):
         """The chain's state between two sweeps as a dict of numpy arrays and numbers (np.savez-able): factors,
         horseshoe+ levels, scalars, the device draw counter (rng="device": every Philox stream is keyed by
         device_seed and that counter) and the legacy numpy generator's state (rng="host").  A model built with the
-        same arguments, `restore`d from it and given the same data continues the chain bit for bit.  (Conjugate
+        same arguments, `restore`d from it and given the same data continues the chain bit for bit.  Taking a checkpoint
+        is NOT invisible to the chain that goes on: like `restore`, it drops the spectral sampler's eigen warm start and
+        the residual parts of the four-launch sweep (so that both continuations take the same path) - the next draws
+        agree with an un-checkpointed run to rounding, not bit for bit.  (Conjugate
         models: Gaussian, Binomial, Negative-Binomial.  The slice-sampling models keep further generator state in
         `chain_rngs` / the context's round counters, which a checkpoint does not carry.)"""
         self.sync()
@@ -954,11 +981,17 @@ class BinomialBayesianTensorFiltering(GaussianBayesianTensorFiltering):
     def _extra_state(self):           # (omega itself is redrawn from W, V at the start of every sweep)
         st = super()._extra_state()
         st["pg_calls"] = int(self._pg_calls)
+        st["pg_mode"] = int(self.PG_MODES[self.pg_exact])     # which sampler drew the chain so far (BTF_OPT_PG_EXACT)
         return st
 
     def _set_extra_state(self, st):
         super()._set_extra_state(st)
         self._pg_calls = int(st["pg_calls"])
+        # (round 3 changed what pg_exact=False / None select: a checkpoint continued under another Polya-Gamma sampler
+        #  would silently walk a different chain)
+        if "pg_mode" in st and int(st["pg_mode"]) != int(self.PG_MODES[self.pg_exact]):
+            raise ValueError("checkpoint was taken with Polya-Gamma mode %d (BTF_OPT_PG_EXACT), this model runs mode %d"
+                             % (int(st["pg_mode"]), int(self.PG_MODES[self.pg_exact])))
 
     PG_MODES = {None: 0, "auto": 0, True: 1, "exact": 1, False: 2, "series": 2}
 
@@ -1191,7 +1224,8 @@ class NonconjugateBayesianTensorFiltering(BayesianTensorFiltering):
 
     The reference takes a Python callback `loglikelihood(W, V, data)` and evaluates it on the whole tensor for
     every proposal.  Here the likelihood is evaluated by a device kernel, so `loglikelihood` names one of
-    the built-in families instead (a callable raises NotImplementedError: no host evaluation path exists):
+    the built-in families instead; a callable is accepted too and evaluated on the HOST for every proposal (the reference's
+    interface, for any likelihood: prior draws and proposals on the device, each proposal read back - a slow path):
         "poisson" / "poisson_log"   counts y ~ Poisson(exp(w.v))
         "poisson_identity"          counts y ~ Poisson(w.v), zero likelihood where w.v <= 0
                                     (the likelihood of examples/poisson_tensor_filtering.py:26-37)
@@ -1211,18 +1245,22 @@ class NonconjugateBayesianTensorFiltering(BayesianTensorFiltering):
     LINKS = {"poisson": 0, "poisson_log": 0, "poisson_identity": 1, "bernoulli_logit": 2, "gaussian": 3, "negbin_logit": 4}
 
     def __init__(self, nrows, ncols, ndepth, loglikelihood, ess="joint", ess_max_rounds=40, likelihood_param=None, **kwargs):
-        if callable(loglikelihood) or loglikelihood not in self.LINKS:
-            raise NotImplementedError("loglikelihood must name a device likelihood %s: the slice loop evaluates it on "
-                                      "the GPU, there is no host path for a Python callback" % sorted(self.LINKS))
+        self._callback = callable(loglikelihood)
+        if not self._callback and loglikelihood not in self.LINKS:
+            raise ValueError("loglikelihood must be a function (W, V, data) -> log-likelihood, as in the reference, or name a "
+                             "device likelihood %s" % sorted(self.LINKS))
         if ess not in ("joint", "rows"):
             raise ValueError("ess must be 'joint' or 'rows'")
         super().__init__(nrows, ncols, ndepth, **kwargs)
         if self._plan.world > 1:
             raise NotImplementedError("NonconjugateBayesianTensorFiltering: unsharded runs only")
-        if ess == "rows" and self.rng != "device":
-            raise ValueError("ess='rows' draws its uniforms on the device: use rng='device'")
+        if ess == "rows" and (self.rng != "device" or self._callback):
+            raise ValueError("ess='rows' runs its slices on the device: use rng='device' and a device likelihood")
         self.loglikelihood = loglikelihood
-        self._link = self.LINKS[loglikelihood]
+        # a Python callback (the reference's interface, factor.py:567-570): the HOST-EVALUATED path - prior draws and
+        # proposals on the device (same declared orders as the device likelihoods), every proposal read back and handed to
+        # the function; correct for any likelihood, and as slow as the function and two PCIe copies per evaluation make it
+        self._link = _native.ESS_HOST_LIKELIHOOD if self._callback else self.LINKS[loglikelihood]
         if self._link in (3, 4):
             if likelihood_param is None or not likelihood_param > 0:
                 raise ValueError("loglikelihood=%r needs likelihood_param > 0 (the variance / the rate)" % loglikelihood)
@@ -1233,6 +1271,11 @@ class NonconjugateBayesianTensorFiltering(BayesianTensorFiltering):
         self.ess, self.ess_max_rounds = ess, int(ess_max_rounds)
         self.ess_evaluations = 0          # likelihood evaluations of the last host-driven slice (diagnostic)
         self._ll_const = 0.0
+
+    def _bind_data(self, data):
+        if self._callback:           # the function's `data` is its own business (any object): nothing goes to the device
+            return
+        super()._bind_data(data)
 
     def _upload(self, Y):
         if Y.ndim not in (3, 4):
@@ -1260,6 +1303,8 @@ class NonconjugateBayesianTensorFiltering(BayesianTensorFiltering):
     def log_likelihood(self, data):
         """Log-likelihood of the current state (what the reference's callback returns), normalising terms included."""
         import ctypes
+        if self._callback:
+            return float(self.loglikelihood(self.W, self.V, data))
         self._bind_data(data)
         self._push_state()
         if not getattr(self, "_ess_ready", False):
@@ -1275,7 +1320,40 @@ class NonconjugateBayesianTensorFiltering(BayesianTensorFiltering):
         self._push_state()
         o = self.linalg_opts
         eps, att = float(o["force_psd_eps"]), int(o["force_psd_attempts"]) if o["force_psd"] else 0
-        if self.rng == "device":
+        if self._callback:
+            # elliptical_slice.py:59-124 around the caller's function: prior draw and proposals x0 cos(phi) + nu sin(phi) on
+            # the device (rng="host": from the reference's normals, fast_mvn.py:41; rng="device": Philox), the uniforms from
+            # the global legacy generator in the reference's order, every proposal read back for the function
+            z = self._w_normals() if what == 0 else self._v_normals()
+            self._keep_z = z
+            self._ctx.call("btf_ess_begin", what, _native.dptr(_native.as_f64(z)) if z is not None else None, self._next_seed(), eps, att)
+            ll = ctypes.c_double()
+
+            def value():
+                if what == 0:
+                    self._W_dev_new = True
+                else:
+                    self._V_dev_new = True
+                return float(self.loglikelihood(self.W, self.V, data))
+            cur = float(self.loglikelihood(self.W, self.V, data))
+            hh = np.log(np.random.rand()) + cur
+            phi = np.random.rand() * 2 * np.pi
+            phi_min, phi_max = phi - 2 * np.pi, phi
+            nev = 0
+            while True:
+                self._ctx.call("btf_ess_eval", what, float(phi), 0, self._link, ctypes.byref(ll))
+                nev += 1
+                if value() >= hh:
+                    break
+                if phi > 0:
+                    phi_max = phi
+                elif phi < 0:
+                    phi_min = phi
+                else:
+                    break
+                phi = np.random.rand() * (phi_max - phi_min) + phi_min
+            self.ess_evaluations = nev
+        elif self.rng == "device":
             self._ctx.call("btf_ess_run", what, self._link, 0 if self.ess == "joint" else 1, None, self._next_seed(),
                            self.ess_max_rounds, eps, att)
         else:
@@ -1347,6 +1425,10 @@ class ConstrainedNonconjugateBayesianTensorFiltering(NonconjugateBayesianTensorF
         if ep_approx is not None:
             raise NotImplementedError("ep_approx (EP-centred proposals, factor.py:677-688) is not supported")
         kwargs.setdefault("ess", "joint")
+        if callable(loglikelihood):
+            raise NotImplementedError("ConstrainedNonconjugateBayesianTensorFiltering evaluates up to 100 candidate angles per curve "
+                                      "and sweep on the device: `loglikelihood` must name a device likelihood (a Python callback is "
+                                      "taken by NonconjugateBayesianTensorFiltering)")
         super().__init__(nrows, ncols, ndepth, loglikelihood, **kwargs)
         Constraints = _native.as_f64(np.atleast_2d(Constraints))
         if Constraints.shape[1] != ndepth + 1:

@@ -413,12 +413,17 @@ int btf_mvn_dense(int device, int batch, int n, const double* A, int form, const
  * btf_ess_eval(theta, current=0) sets the state to x0 cos(theta) + nu sin(theta) and returns its log-likelihood
  * (current=1: of the state as it stands); when the caller stops, the state holds the last proposal, exactly what
  * elliptical_slice_ returns.  Synchronises.
+ * link = BTF_ESS_HOST_LIKELIHOOD (-1): the likelihood is the CALLER's (the reference's Python callback
+ * `loglikelihood(W, V, data)`, factor.py:567-612): btf_ess_begin draws nu as above (it needs no data on the device),
+ * btf_ess_eval only forms the proposal in W (resp. V) - the caller reads it back (btf_get_W / btf_get_V), evaluates its
+ * function and decides; *ll = 0.
  *
  * Device-driven form: btf_ess_run = begin + at most max_rounds proposal / likelihood / decision rounds queued on the
  * stream, uniforms from Philox, nothing read back.  mode 0: one slice over all of W (resp. V), as the reference;
  * mode 1: one slice per row of W (resp. per column of V) - the rows are conditionally independent given V - all
  * brackets shrinking in lockstep, one proposal per row per round.  btf_ess_info (synchronises): chains that used up
  * max_rounds (they keep the current state) and the log-likelihood the first chain ended on.                      */
+#define BTF_ESS_HOST_LIKELIHOOD (-1)
 int btf_set_likelihood_param(btf_ctx* ctx, int link, double parameter);   /* links 3 (1 / variance) and 4 (rate); > 0 */
 int btf_ess_begin(btf_ctx* ctx, int what, const double* z, uint64_t seed, double eps0, int attempts);
 int btf_ess_eval(btf_ctx* ctx, int what, double theta, int current, int link, double* ll);

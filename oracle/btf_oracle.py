@@ -1120,7 +1120,10 @@ def family_loglik(W, V, Y, family, param=None):
 
 
 def nc_loglik(W, V, Y, link, param=None):
-    """dispatcher: the Poisson links of poisson_loglik, or a family of family_loglik"""
+    """dispatcher: a callable (the reference's own interface, factor.py:567-570: loglikelihood(W, V, data)), the Poisson
+    links of poisson_loglik, or a family of family_loglik"""
+    if callable(link):
+        return link(W, V, Y)
     return poisson_loglik(W, V, Y, link) if link in ("log", "identity") else family_loglik(W, V, Y, link, param)
 
 

@@ -1319,6 +1319,44 @@ def test_nonconjugate_joint_slice_walks_the_reference_path(golden, link):
     assert relerr(model.V, g[tag + "V_after"]) < 1e-6
 
 
+@pytest.mark.gpu
+def test_nonconjugate_python_callback_walks_the_reference_path(golden):
+    """`loglikelihood` as a Python function, the reference's own interface (factor.py:567-612; the callers pass functions:
+    examples/poisson_tensor_filtering.py:60-70): prior draws and proposals on the GPU, every proposal read back and handed
+    to the function.  rng="host": the chain lands where the reference landed with the same (arbitrary: Student-t around a
+    tanh link) function - fixture g9 case (e), three W / V slices in a row, evaluation counts included."""
+    from functionalmf_amd.factor import NonconjugateBayesianTensorFiltering
+    from test_oracle_golden import _cb_case, student_t_tanh_loglik
+    g, st, (N, M, T, R, K, tf) = _cb_case(golden)
+    Y = g["cb_Y"]
+    calls = [0]
+
+    def counted(W, V, data):
+        calls[0] += 1
+        assert data is Y and W.shape == (N, K) and V.shape == (M, T, K)
+        return student_t_tanh_loglik(W, V, data)
+    model = NonconjugateBayesianTensorFiltering(N, M, T, counted, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
+                                                W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"])
+    assert abs(model.log_likelihood(Y) - student_t_tanh_loglik(st["W"], st["V"], Y)) < 1e-9
+    for sweep in range(3):
+        calls[0] = 0
+        np.random.seed(1300 + 2 * sweep)
+        model._resample_W(Y)
+        assert model.ess_evaluations == int(g["cb_nev"][2 * sweep]) == calls[0] - 1
+        assert relerr(model.W, g["cb_W_chain"][sweep]) < 1e-10
+        np.random.seed(1301 + 2 * sweep)
+        model._resample_V(Y)
+        assert model.ess_evaluations == int(g["cb_nev"][2 * sweep + 1])
+        assert relerr(model.V, g["cb_V_chain"][sweep]) < 1e-6
+    # run_gibbs with a callback and device normals: runs, stays finite, keeps the result layout
+    model2 = NonconjugateBayesianTensorFiltering(N, M, T, student_t_tanh_loglik, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"],
+                                                 lam2_init=st["lam2"], W_init=st["W"], V_init=st["V"], rng="device", device_seed=3)
+    np.random.seed(5)
+    out = model2.run_gibbs(Y, nburn=2, nthin=1, nsamples=3, verbose=False)
+    assert out["W"].shape == (3, N, K) and out["V"].shape == (3, M, T, K) and np.isfinite(out["V"]).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("family", ["bernoulli_logit", "gaussian", "negbin_logit"])
 def test_nonconjugate_other_likelihoods_walk_the_reference_path(golden, family):
     """The device likelihoods beyond Poisson (include/btf.h, links 2..4): rng="host", the chain must land where the

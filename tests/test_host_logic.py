@@ -212,3 +212,22 @@ def test_host_side_under_address_and_ub_sanitizers():
     out = subprocess.run(["bash", os.path.join(ROOT, "scripts", "asan_host.sh")], capture_output=True, text=True, timeout=850)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "btf_host_selftest: 0" in out.stdout and "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
+
+
+def test_one_standard_gamma_call_equals_the_references_per_column_gamma_calls():
+    """What the vectorised parity-mode Tau2 step relies on (functionalmf_amd/factor.py:_resample_Tau2; the reference draws,
+    per column, gamma((K+1)/2, scale) and three gamma(1, scale) vectors: factor.py:134-141): a legacy gamma(shape, scale) is
+    scale * standard_gamma(shape) and consumes the generator by its shape alone, so ONE standard_gamma call over the shapes
+    in that order gives the same variates bit for bit and leaves the legacy stream at the same position."""
+    M, nD, shape = 7, 23, 3.0
+    rs = np.random.RandomState(3)
+    sc = np.array([rs.rand(4, nD) + 0.1 for _ in range(M)])
+    np.random.seed(11)
+    ref = np.array([[np.random.gamma(shape if lev == 0 else 1, sc[j][lev]) for lev in range(4)] for j in range(M)])
+    after_ref = np.random.normal(size=3)
+    np.random.seed(11)
+    shapes = np.ones((M, 4, nD))
+    shapes[:, 0] = shape
+    sg = np.random.standard_gamma(shapes)
+    after = np.random.normal(size=3)
+    assert np.array_equal(ref, sc * sg) and np.array_equal(after, after_ref)

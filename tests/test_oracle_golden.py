@@ -371,6 +371,37 @@ def test_nonconjugate_joint_slice_steps_vs_reference(golden, link):
     assert relerr(st["V"], g[tag + "V_after"]) < 1e-9 and info["evaluations"] == int(g[tag + "V_nev"])
 
 
+def student_t_tanh_loglik(W, V, data):
+    """The arbitrary callback of fixture g9 case (e) (tests/golden/make_golden_ess.py): Student-t(4) residuals of scale 0.3
+    around 3 tanh(w.v) - none of the build's device likelihoods."""
+    mu = 3.0 * np.tanh(np.einsum("nk,mtk->nmt", W, V))[..., None]
+    r = (data - mu) / 0.3
+    return float(np.sum(np.where(np.isnan(data), 0.0, -2.5 * np.log1p(r * r / 4.0))))
+
+
+def _cb_case(golden):
+    g = golden("g9_ess.npz")
+    st = {k: (float(g["cb_s0_" + k]) if k in ("lam2", "sigma2") else g["cb_s0_" + k].copy()) for k in ("W", "V", "Tau2", "lam2", "sigma2")}
+    return g, st, [int(x) for x in g["cb_dims"]]
+
+
+def test_nonconjugate_steps_with_an_arbitrary_callback_vs_reference(golden):
+    """The reference's NonconjugateBayesianTensorFiltering run with an arbitrary Python log-likelihood (factor.py:567-612):
+    three W / V slices in a row - the oracle, handed the same function, lands on the same states after the same numbers of
+    evaluations."""
+    g, st, (N, M, T, R, K, tf) = _cb_case(golden)
+    Y = g["cb_Y"]
+    Delta = orc.trend_penalty(T, tf)
+    info = {}
+    for sweep in range(3):
+        np.random.seed(1300 + 2 * sweep)
+        orc.nonconjugate_w_step(st, Y, link=student_t_tanh_loglik, info=info)
+        assert relerr(st["W"], g["cb_W_chain"][sweep]) < 1e-12 and info["evaluations"] == int(g["cb_nev"][2 * sweep])
+        np.random.seed(1301 + 2 * sweep)
+        orc.nonconjugate_v_step(st, Y, Delta, link=student_t_tanh_loglik, perm="twist", info=info)
+        assert relerr(st["V"], g["cb_V_chain"][sweep]) < 1e-9 and info["evaluations"] == int(g["cb_nev"][2 * sweep + 1])
+
+
 @pytest.mark.parametrize("family", ["bernoulli_logit", "gaussian", "negbin_logit"])
 def test_nonconjugate_steps_with_other_likelihoods_vs_reference(golden, family):
     """The reference's NonconjugateBayesianTensorFiltering run with scipy.stats callbacks for a Bernoulli-logit, a
