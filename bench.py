@@ -43,7 +43,17 @@ CONFIGS = {
     "flu": dict(N=50, M=1, T=370, R=1, K=10),        # flutrends/benchmark.py:31-34: 50 states x 1 x 370 weeks, nembeds 10
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-METRIC = "Gibbs sweeps/sec (full W+V update) at (512,256,64) K=5; % HBM roofline"
+METRIC = "Gibbs sweeps/sec (full W+V update) at (512,256,64) K=5; % HBM roofline"      # BASELINE.json's metric: config c3
+
+
+def metric_for(config, world):
+    """BASELINE.json's metric string for its own configuration (C3); any other workload - the C5 tensor of the N > 1 runs
+    included - names its shape instead of passing for it."""
+    if config == "c3":
+        return METRIC
+    c = CONFIGS[config]
+    return "Gibbs sweeps/sec (full W+V update) at (%d,%d,%d) K=%d%s; %% HBM roofline" % (
+        c["N"], c["M"], c["T"], c["K"], ", row/column-sharded over %d GPUs" % world if world > 1 else "")
 
 
 SYNTH_CB = 128     # columns per noise block of the synthetic tensor
@@ -101,6 +111,8 @@ def parse_args(argv=None):
                     "(the default already draws integer counts up to 32 exactly)")
     ap.add_argument("--pg-series", action="store_true", help="binomial / negbinom: the approximate sum-of-gammas series for every count")
     ap.add_argument("--burn", type=int, default=10, help="full Gibbs sweeps before timing (leave the initial state)")
+    ap.add_argument("--lean", action="store_true", help="profiling runs: nothing but W+V steps after the burn-in - no full-sweep leg, no banded-"
+                    "sampler leg, no CPU baseline - so that a rocprofv3 --stats average is over the dispatches the HIP events time")
     ap.add_argument("--as-rank", default=None, metavar="R/P", help="ONE GPU plays rank R of a P-GPU run of --config (default c5): its "
                     "kernels on that rank's real slabs, every collective of the sharded step in a one-rank RCCL group at the full "
                     "message size; adds a `projected` block (never `value`: that stays this GPU's own rate)")
@@ -333,18 +345,20 @@ def main():
     model._ctx.call("btf_set_profiling", 0)
 
     # full Gibbs sweep (nu2, sigma2, Tau2, lam2, W, V), everything drawn on the device
-    nfull = max(10, min(args.steps, 100))
-    for _ in range(3):
-        model.resample(data)
-    fence()
-    t0 = time.perf_counter()
-    if hasattr(model, "resample_sweeps"):
-        model.resample_sweeps(data, nfull)      # one GPU, rng="device": the sweeps are queued by the C side (btf_gibbs_sweeps);
-    else:                                       # otherwise this is the same loop of resample() calls
-        for _ in range(nfull):
+    full_per_s = None
+    if not args.lean:
+        nfull = max(10, min(args.steps, 100))
+        for _ in range(3):
             model.resample(data)
-    fence()
-    full_per_s = nfull / (time.perf_counter() - t0)
+        fence()
+        t0 = time.perf_counter()
+        if hasattr(model, "resample_sweeps"):
+            model.resample_sweeps(data, nfull)      # one GPU, rng="device": the sweeps are queued by the C side (btf_gibbs_sweeps);
+        else:                                       # otherwise this is the same loop of resample() calls
+            for _ in range(nfull):
+                model.resample(data)
+        fence()
+        full_per_s = nfull / (time.perf_counter() - t0)
 
     sweeps_per_s = args.steps / dt
     units = world if weak else 1
@@ -368,7 +382,7 @@ def main():
     # the same W+V step with the reference-reproducible V sampler (`sampler="banded"`: P'L^-T of a declared ordering,
     # the mode that can walk a seeded reference chain) beside the spectral one the headline uses
     banded_per_s = None
-    if model.v_sampler() == "spectral" and world == 1 and not as_rank and args.sampler == "auto":
+    if model.v_sampler() == "spectral" and world == 1 and not as_rank and args.sampler == "auto" and not args.lean:
         model._ctx.call("btf_set_option", _native.OPT_SAMPLER, _native.SAMPLERS["banded"])
         nb = max(20, min(args.steps, 200))
         for _ in range(10):
@@ -387,7 +401,7 @@ def main():
     kernels_us = {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in kt.items() if v[1] > 0}
     sampler = model.v_sampler()
     out = {
-        "metric": METRIC,
+        "metric": metric_for(args.config, world),
         "value": round(value, 2),
         "unit": "sweeps/s",
         "n_gpus": world,
@@ -406,21 +420,46 @@ def main():
                    "global_sweeps_per_s": round(sweeps_per_s, 2), "units_per_sweep": units,
                    "median_ms_per_step": round(float(np.median(per_step_ms)), 4), "median_over_steps": int(nmed),
                    "burn_in_sweeps": args.burn,
-                   "full_resample_sweeps_per_s": round(full_per_s, 2),
+                   "full_resample_sweeps_per_s": None if full_per_s is None else round(full_per_s, 2),
                    "v_sampler": sampler, "banded_sweeps_per_s": None if banded_per_s is None else round(banded_per_s, 2),
                    "likelihood_form": form,
                    "parallelism": "rows(W)/cols(V) x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "accum_kernel (w_accum + v_accum launches)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": pmc_traffic(args.config, args.variant, "_rank%dof%d" % as_rank if as_rank else "") if world == 1 else None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(acc_us, 2),
+                     "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(acc_us, 2),
                      "timing": "hipExtLaunchKernelGGL start/stop events of each accumulation dispatch, %d steps (median of five block averages)" % nprof,
                      "whole_step_bytes": b_wv,
                      "whole_step_frac": round(b_wv / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "copy_ceiling_GBs": copy_ceiling(torch), "read_ceiling_GBs": read_ceiling(local_rank)},
         "kernels_us": kernels_us,
     }
+    # ---- the roofline object against the committed profiles of THIS workload (profiles/README.md) --------------------------
+    #  traffic: HBM bytes per accumulation launch from the PMC passes (never another workload's figure);
+    #  rocprof_avg_us: rocprofv3 --kernel-trace --stats AverageNs of the accumulation kernels in a `--lean` run of this command
+    #  (nothing but W+V steps): when it disagrees with the live HIP events, `achieved` / `frac` report the LOWER of the two.
+    rl = out["roofline"]
+    sfx = "_rank%dof%d" % as_rank if as_rank else ""
+    if world == 1:
+        tr = pmc_traffic(args.config, args.variant, sfx)
+        if tr:
+            rl["traffic"], rl["traffic_source"] = tr
+        rp = rocprof_accum_avg(args.config, args.variant, sfx)
+        if rp:
+            rl["rocprof_avg_us"], rl["rocprof_source"] = round(rp[0], 2), rp[1]
+            rl["events_frac"] = rl["frac"]
+            ach_rp = alg_bytes / (rp[0] * 1e-6) / 1e9
+            if ach_rp < achieved:
+                rl["achieved"], rl["frac"] = round(ach_rp, 1), round(ach_rp / HBM_PEAK_GBS, 4)
+                rl["frac_basis"] = "rocprofv3 AverageNs (lower than the live events' %.4f)" % rl["events_frac"]
+            else:
+                rl["frac_basis"] = "live HIP events (rocprofv3 AverageNs of the committed run gives %.4f)" % (ach_rp / HBM_PEAK_GBS)
+        if args.config == "c3":
+            # C3's 67 MB statistic sits inside the 256 MiB Infinity Cache between sweeps, so its byte counters are not HBM
+            # traffic proper: the launch that is - the whole C5 tensor on one GPU, 2.1 GB per launch - from its committed run
+            big = hbm_resident_reference()
+            if big:
+                rl["hbm_resident"] = big
     if args.variant in ("binomial", "negbinom"):
         out["config"]["pg_sampler"] = getattr(model, "pg_sampler", "series")
     if world > 1 or exercise:
@@ -448,8 +487,10 @@ def main():
         # whole fixed tensor on one GPU; weak - one rank's slab.  From the committed profile of that run, with its file.
         ref = same_config_one_gpu(args.config, "complete")      # (weak: args.config names one rank's slab)
         if ref is not None:
+            ref["note"] = "builder-run committed figure of the SAME workload on one MI355X; the driver's --gpus 1 run is the C3 headline, another workload"
             out["config"]["one_gpu_same_workload"] = ref
-    if world == 1 and not as_rank and not args.no_cpu and args.variant not in ("binomial", "negbinom"):
+            out["config"]["speedup_vs_one_gpu_same_workload"] = round(sweeps_per_s / ref["value"], 3) if not weak else None
+    if world == 1 and not as_rank and not args.no_cpu and not args.lean and args.variant not in ("binomial", "negbinom"):
         out["cpu_baseline"] = cpu_baseline(Y, model, cfg)
 
     if rank == 0:
@@ -482,7 +523,7 @@ def dry_run(args, world, rank, dist, backend):
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    out = {"metric": METRIC, "value": round(args.steps / dt, 2), "unit": "sweeps/s", "n_gpus": world, "steps": args.steps,
+    out = {"metric": metric_for(args.config, world), "value": round(args.steps / dt, 2), "unit": "sweeps/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
            "scaling": "weak" if (args.weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f64", "data": "dry-run (no GPU work)",
            "config": {"workload": "DRY RUN %s x%d" % (args.config, world), "rccl_ranks": dist.get_world_size() if world > 1 else 1,
@@ -557,7 +598,47 @@ def pmc_traffic(config, variant, suffix=""):
     try:
         d = json.load(open(files[-1]))
         vals = [v["hbm_bytes_per_launch_corrected"] for k, v in d.items() if "accum_kernel" in k]
-        return round(max(vals), 1) if vals else None
+        return (round(max(vals), 1), os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2 x FETCH + WRITE)") if vals else None
+    except Exception:
+        return None
+
+
+def rocprof_accum_avg(config, variant, suffix=""):
+    """(average us, file) of the accumulation kernels in the newest committed `rocprofv3 --kernel-trace --stats` summary of a
+    --lean run of this workload (profiles/r*_<config>_<variant><suffix>_lean_kernel_stats.csv: calls-weighted AverageNs
+    of every accum_kernel instance); None if no such file is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_%s%s_lean_kernel_stats.csv" % (config, variant, suffix))))
+    if not files:
+        return None
+    try:
+        tot = calls = 0.0
+        for r in csv.DictReader(open(files[-1])):
+            if "accum_kernel" in r["Name"]:
+                tot += float(r["TotalDurationNs"]); calls += float(r["Calls"])
+        return (1e-3 * tot / calls, os.path.relpath(files[-1], ROOT)) if calls else None
+    except Exception:
+        return None
+
+
+def hbm_resident_reference():
+    """The accumulation launch of the whole C5 tensor on one GPU (2.147 GB per launch, 8 x the Infinity Cache) from its
+    committed run - builder-run, not this run: bench line + PMC traffic + rocprofv3 average where committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c5_complete_bench.json")))
+    if not files:
+        return None
+    try:
+        d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+        r = d["roofline"]
+        out = {"workload": d["config"]["workload"], "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+               "avg_launch_us": r["avg_launch_us"], "achieved": r["achieved"], "frac": r["frac"], "traffic": r.get("traffic"),
+               "source": os.path.relpath(files[-1], ROOT) + " (builder-run on one MI355X, not this run)"}
+        rp = rocprof_accum_avg("c5", "complete")
+        if rp:
+            out["rocprof_avg_us"], out["rocprof_source"] = round(rp[0], 2), rp[1]
+        return out
     except Exception:
         return None
 

@@ -11,6 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--config $CFG --variant $VAR --no-cpu ${EXTRA:-}"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$NAME -o $NAME --output-format csv -- python3 $R/bench.py $ARGS --steps $STEPS --warmup 10 > $R/gpurun_out/prof_$NAME.log 2>&1 || exit 1
 echo "stats pass done"
+# the same with --lean: nothing but W+V steps behind the burn-in, so that AverageNs of the accumulation kernels is over the
+# dispatches bench.py's HIP events time (bench.py reads it back as roofline.rocprof_avg_us)
+timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${NAME}_lean -o ${NAME}_lean --output-format csv -- python3 $R/bench.py $ARGS --lean --steps $STEPS --warmup 10 > $R/gpurun_out/prof_${NAME}_lean.log 2>&1 || exit 1
+echo "lean stats pass done"
 timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch_$NAME -o $NAME --output-format csv -- python3 $R/bench.py $ARGS --steps 20 --warmup 2 --burn 2 > $R/gpurun_out/pmc_fetch_$NAME.log 2>&1 || exit 1
 echo "fetch pass done"
 timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write_$NAME -o $NAME --output-format csv -- python3 $R/bench.py $ARGS --steps 20 --warmup 2 --burn 2 > $R/gpurun_out/pmc_write_$NAME.log 2>&1 || exit 1

@@ -10,6 +10,9 @@ out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 shutil.copy(os.path.join(root, "gpurun_out", "prof_%s" % name, "%s_kernel_stats.csv" % name),
             os.path.join(out, "%s_kernel_stats.csv" % name))
+lean = os.path.join(root, "gpurun_out", "prof_%s_lean" % name, "%s_lean_kernel_stats.csv" % name)
+if os.path.exists(lean):          # the W+V-steps-only population (bench.py --lean): what roofline.rocprof_avg_us reads
+    shutil.copy(lean, os.path.join(out, "%s_lean_kernel_stats.csv" % name))
 clean = os.path.join(root, "gpurun_out", "bench_%s.log" % name)      # the un-profiled run of the same command, when the job made one
 log = open(clean if os.path.exists(clean) else os.path.join(root, "gpurun_out", "prof_%s.log" % name)).read().splitlines()
 line = [ln for ln in log if ln.startswith("{") and '"metric"' in ln]

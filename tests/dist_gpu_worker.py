@@ -13,6 +13,9 @@ import numpy as np
 import torch.distributed as dist
 
 OVERLAP = os.environ.get("BTF_DIST_OVERLAP", "0") == "1"      # base section: all-gathers on the communication stream
+# BTF_DIST_GPU_PER_RANK=1 (test_rccl_ranks_on_their_own_gpus: a box with >= 2 GPUs): rank r runs on cuda:LOCAL_RANK and the
+# collectives are real RCCL traffic between devices; otherwise every rank shares cuda:0
+DEV = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("BTF_DIST_GPU_PER_RANK", "0") == "1" else 0
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -43,7 +46,7 @@ def split_section(rank, world):
     for Y, form in ((Yc, "complete"), (Ym, "weighted")):
         model = GaussianBayesianTensorFiltering(
             N, M, T, nembeds=K, tf_order=2, sigma2_init=st0["sigma2"], lam2_init=st0["lam2"], nu2_init=st0["nu2"],
-            W_init=st0["W"], V_init=st0["V"], Tau2_init=st0["Tau2"], compat="exact", shard=(rank, world), device=0, sampler="banded",
+            W_init=st0["W"], V_init=st0["V"], Tau2_init=st0["Tau2"], compat="exact", shard=(rank, world), device=DEV, sampler="banded",
             overlap_exchange=True)
         model._ctx.call("btf_set_tuning", 64, 64)          # 64-row chunks: every shard is a whole number of them
         ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st0.items()}
@@ -81,7 +84,7 @@ def split_section(rank, world):
         np.random.seed(7)
         m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=st0["sigma2"], lam2_init=st0["lam2"],
                                             nu2_init=st0["nu2"], W_init=st0["W"], V_init=st0["V"], compat="exact", shard=(rank, world),
-                                            device=0, rng="device", device_seed=9, overlap_exchange=overlap)
+                                            device=DEV, rng="device", device_seed=9, overlap_exchange=overlap)
         m._ctx.call("btf_set_tuning", 64, 64)
         for _ in range(4):
             m.resample(Yc)
@@ -97,8 +100,8 @@ def main():
     exercise = os.environ.get("BTF_EXERCISE_EXCHANGE", "0")
     if backend == "nccl":
         import torch
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        torch.cuda.set_device(DEV)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", DEV))
     else:
         dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -116,7 +119,7 @@ def main():
         st = state_from(g, "s0_")
         model = GaussianBayesianTensorFiltering(
             N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
-            W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], compat="exact", shard=(rank, world), device=0, overlap_exchange=OVERLAP)
+            W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], compat="exact", shard=(rank, world), device=DEV, overlap_exchange=OVERLAP)
         assert model._exchange.active and model._plan.world == world
         Delta = orc.trend_penalty(T, tf)
         ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
@@ -151,7 +154,7 @@ def main():
             os.environ["BTF_EXERCISE_EXCHANGE"] = exercise if shard is not None else "0"     # the plain chain: no collectives
             m = GaussianBayesianTensorFiltering(
                 N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
-                W_init=st["W"], V_init=st["V"], compat="exact", shard=shard, device=0, rng="device", device_seed=9, overlap_exchange=OVERLAP,
+                W_init=st["W"], V_init=st["V"], compat="exact", shard=shard, device=DEV, rng="device", device_seed=9, overlap_exchange=OVERLAP,
                 # (held-out cells: a rank whose slabs happen to be complete would pick the spectral sampler where the
                 #  unsharded run - one weighted tensor - uses the banded one: same distribution, another square root)
                 sampler="auto" if name.startswith("g2") else "banded")
@@ -173,7 +176,7 @@ def main():
         np.random.seed(7)
         os.environ["BTF_EXERCISE_EXCHANGE"] = exercise if shard is not None else "0"
         m = BinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"],
-                                            W_init=st["W"], V_init=st["V"], compat="exact", shard=shard, device=0, rng="device",
+                                            W_init=st["W"], V_init=st["V"], compat="exact", shard=shard, device=DEV, rng="device",
                                             device_seed=9, overlap_exchange=OVERLAP)
         for _ in range(2):
             m.resample((g["Ysucc"], g["Ntrials"]))
@@ -199,7 +202,7 @@ def main():
             np.random.seed(7)
             os.environ["BTF_EXERCISE_EXCHANGE"] = exercise if shard is not None else "0"
             m = NegativeBinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=0.7, lam2_init=0.2, W_init=W0.copy(),
-                                                        V_init=V0.copy(), rdims=rdims, nmetropolis=5, compat="exact", shard=shard, device=0,
+                                                        V_init=V0.copy(), rdims=rdims, nmetropolis=5, compat="exact", shard=shard, device=DEV,
                                                         rng="device", device_seed=9, overlap_exchange=OVERLAP)
             for _ in range(2):
                 m.resample(cnts)
@@ -211,7 +214,7 @@ def main():
         assert np.abs(a[2] - b[2]).max() / np.abs(b[2]).max() < 1e-9, ("R", rdims)
         assert np.abs(a[3] - b[3]).max() / np.abs(b[3]).max() < 1e-9, ("omega", rdims)
         assert np.abs(a[0] - b[0]).max() / np.abs(b[0]).max() < 1e-7 and np.abs(a[1] - b[1]).max() / np.abs(b[1]).max() < 1e-5, rdims
-    print("SHARD_GPU_OK rank", rank, flush=True)
+    print("SHARD_GPU_OK rank", rank, "backend", dist.get_backend(), "world", dist.get_world_size(), "device", DEV, flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -756,6 +756,30 @@ def test_rccl_exchange_with_one_rank_reproduces_the_plain_chain():
         assert out.stdout.count("SHARD_GPU_OK") == 1, out.stdout[-2000:]
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_rccl_ranks_on_their_own_gpus(world):
+    """A real N-rank RCCL run, one GPU per rank (skipped on a one-GPU box): tests/dist_gpu_worker.py with the "nccl" backend
+    and BTF_DIST_GPU_PER_RANK=1 - host-RNG half-sweeps against the oracle, then whole rng="device" chains (Gaussian complete,
+    Gaussian with held-out cells, Binomial, Negative-Binomial) that must reproduce the unsharded chains, and the split
+    accumulation with the overlapped exchange; every rank reports the backend and the world size it ran in."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs (this box has %d)" % (world, torch.cuda.device_count()))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, BTF_DIST_BACKEND="nccl", BTF_DIST_GPU_PER_RANK="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", BTF_DIST_SECTION="base,split")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+           "--master-addr", "127.0.0.1", "--master-port", "29587", os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("SHARD_GPU_OK") == world, out.stdout[-2000:]
+    assert out.stdout.count("backend nccl world %d" % world) == world, out.stdout[-2000:]
+
+
 def test_device_scalar_draws_have_the_right_conditionals(golden):
     """rng='device': nu2, sigma2 (btf_draw_scalars) and lam2, lam2_a (btf_draw_lam2) are drawn on
     the GPU.  Repeat each draw from a fixed state and compare with the analytic conditionals
