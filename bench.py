@@ -100,6 +100,7 @@ def parse_args(argv=None):
     ap.add_argument("--weak", action="store_true", help="N>1: weak scaling over rows (one C3-sized slab per rank) instead of the fixed C5 tensor")
     ap.add_argument("--strong", action="store_true", help="(default for N>1; kept for compatibility)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-c4", action="store_true", help="skip the short BASELINE-config-4 (Binomial) leg of the default run")
     ap.add_argument("--rpb", type=int, nargs=2, default=[0, 0], help="rows per workgroup (W, V) tuning override")
     ap.add_argument("--variant", default="complete", choices=["complete", "heldout", "curves5", "missing5", "binomial", "negbinom"],
                     help="complete: headline; heldout: Y[:3,:3]=NaN; curves5: 5%% of the (i,j) curves NaN; "
@@ -492,12 +493,75 @@ def main():
             out["config"]["speedup_vs_one_gpu_same_workload"] = round(sweeps_per_s / ref["value"], 3) if not weak else None
     if world == 1 and not as_rank and not args.no_cpu and not args.lean and args.variant not in ("binomial", "negbinom"):
         out["cpu_baseline"] = cpu_baseline(Y, model, cfg)
+    if world == 1 and not as_rank and not args.no_cpu and not args.lean and args.variant == "binomial":
+        out["cpu_baseline"] = cpu_baseline_binomial(Y, model, cfg)
+    if args.variant == "binomial" and world == 1 and "pg_draw" in kernels_us:
+        # the step's dominant kernel is the exact Polya-Gamma draw - bound by VALU issue, not by bytes: its instruction count
+        # from the committed PMC pass of this workload over the live kernel time, against one wave64 VALU instruction per
+        # 4 cycles and SIMD (1024 SIMDs, 2.4 GHz peak clock)
+        vi = valu_insts("c3" if args.config == "c3" else args.config, "binomial", "pgx_tile_kernel")
+        if vi:
+            peak = 1024 * 2.4e9 / 4 / 1e9
+            ach = vi[0] / (kernels_us["pg_draw"] * 1e-6) / 1e9
+            out["roofline_dominant"] = {"kernel": "pgx_tile_kernel (exact Polya-Gamma draw)", "bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1),
+                                        "unit": "G wave-instructions/s", "frac": round(ach / peak, 4), "avg_launch_us": kernels_us["pg_draw"],
+                                        "valu_insts_per_launch": vi[0], "source": vi[1]}
 
+    # BASELINE config 4 beside the headline (the default single-GPU run only): the Binomial model at the same (512,256,64),
+    # 4 trials per cell, the device Polya-Gamma draw inside the step - a short leg of its own, so that the driver's run sees
+    # a C4 number too (`python bench.py --variant binomial` is the full line of that workload)
+    if world == 1 and not as_rank and not args.lean and args.config == "c3" and args.variant == "complete" and not args.no_c4:
+        try:
+            del model
+            out["config"]["c4_binomial"] = c4_leg(N, M, T, K, Vt, local_rank, stream, fence, torch)
+        except Exception as e:         # pragma: no cover  (never let the extra leg cost the headline line)
+            out["config"]["c4_binomial"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1 or exercise:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def c4_leg(N, M, T, K, Vt, device, stream, fence, torch, steps=200):
+    """BASELINE config 4: Binomial BTF (512,256,64), 4 trials per cell, nembeds 5; a step = device Polya-Gamma draw of all
+    cells (exact sampler, factor.py:459) + W half-sweep + V half-sweep (factor.py:425-460), rng="device"."""
+    from functionalmf_amd.factor import BinomialBayesianTensorFiltering
+    rs = np.random.RandomState(7)
+    Mu = np.einsum("nk,mtk->nmt", synth_rows(1, range(N), M, T, 1, K, Vt, noise=0.0)[1], Vt)
+    data = (rs.binomial(4, 1 / (1 + np.exp(-Mu))).astype(float), np.full((N, M, T), 4.0))
+    np.random.seed(1)
+    m = BinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, rng="device", compat="reference",
+                                        device=device, stream=stream, device_seed=1)
+    for _ in range(5):
+        m.resample(data)
+
+    def step():
+        m._resample_nu2(data)
+        m._resample_W(data)
+        m._resample_V(data)
+    for _ in range(10):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    m.sync()
+    m._ctx.call("btf_set_profiling", 1)
+    m._ctx.kernel_times()
+    for _ in range(50):
+        step()
+    fence()
+    kt = m._ctx.kernel_times()
+    m._ctx.call("btf_set_profiling", 0)
+    cells = N * M * T
+    return {"workload": "binomial_btf c3 (%d,%d,%d) 4 trials per cell nembeds=%d: Polya-Gamma draw + W + V per step, rng=device" % (N, M, T, K),
+            "steps_per_s": round(steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
+            "pg_sampler": getattr(m, "pg_sampler", None),
+            "kernels_us": {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in kt.items() if v[1] > 0},
+            "whole_step_frac_48B_per_cell": round(48.0 * cells / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def dry_run(args, world, rank, dist, backend):
@@ -601,6 +665,23 @@ def pmc_traffic(config, variant, suffix=""):
         return (round(max(vals), 1), os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2 x FETCH + WRITE)") if vals else None
     except Exception:
         return None
+
+
+def valu_insts(config, variant, kernel):
+    """(SQ_INSTS_VALU per launch, file) of `kernel` from the committed PMC pass of this workload
+    (profiles/r*_pmc_valu_<config>_<variant>.json), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_valu_%s_%s.json" % (config, variant))))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        for k, v in d.items():
+            if kernel in k and isinstance(v, dict) and "SQ_INSTS_VALU" in v:
+                return float(v["SQ_INSTS_VALU"]), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        pass
+    return None
 
 
 def rocprof_accum_avg(config, variant, suffix=""):
@@ -721,6 +802,46 @@ def cpu_baseline(Y, model, cfg):
         out["strong_cpu_value"] = None
         out["strong_cpu_sample"] = "failed: %r" % (e,)
     return out
+
+
+def cpu_baseline_binomial(data, model, cfg):
+    """Config C4 on the host cores: the oracle's Binomial step - Polya-Gamma weights omega ~ PG(N, w.v) for every cell
+    (factor.py:447-460), then the weighted W and V half-sweeps on kappa = (Y - N/2)/omega (factor.py:437-445 with :313-409).
+    pypolyagamma is absent: the draws are the oracle's definition-based series sampler
+    (pg_draw_series_cells, 200 gamma terms + the tail's mean - what PyPolyaGamma's own truncated sampler does), timed on a
+    SAMPLE of the cells and scaled to all of them; the two half-sweeps are timed on the whole tensor, once."""
+    from oracle import btf_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    Ys, Ntr = data
+    W, V = model.W.copy(), model.V.copy()
+    st = dict(W=W, V=V, Tau2=np.array(model.Tau2, dtype=float).copy(), lam2=float(model.lam2), sigma2=float(model.sigma2))
+    psi = np.einsum("nk,mtk->nmt", W, V)
+    cells = psi.size
+    ns = min(cells, 1 << 19)
+    rng = np.random.RandomState(5)
+    idx = rng.choice(cells, ns, replace=False)
+    t0 = time.perf_counter()
+    om_s = orc.pg_draw_series_cells(float(np.nanmax(Ntr)), psi.reshape(-1)[idx], rng)
+    t_pg = (time.perf_counter() - t0) * cells / ns
+    omega = np.full(cells, float(np.mean(om_s)))
+    omega[idx] = om_s
+    with np.errstate(divide="ignore"):
+        st["nu2"] = np.where(np.isnan(Ys), np.inf, 1.0 / omega.reshape(psi.shape))
+    Delta = orc.trend_penalty(cfg["T"], 2)
+    np.random.seed(123)
+    t0 = time.perf_counter()
+    orc.binomial_w_step(st, Ys, Ntr)
+    orc.binomial_v_step(st, Ys, Ntr, Delta)
+    t_wv = time.perf_counter() - t0
+    return {"value": round(1.0 / (t_pg + t_wv), 4), "unit": "sweeps/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model(),
+            "sample": "Polya-Gamma draws of %d of the %d cells by oracle.pg_draw_series_cells (%.2f s, scaled to %.1f s for all cells; one "
+                      "thread) + one weighted W and one weighted V half-sweep of the whole (%d,%d,%d) K=%d tensor by oracle.binomial_w_step / "
+                      "binomial_v_step (%.1f s; numpy/LAPACK, BLAS threads=%d)" % (ns, cells, t_pg * ns / cells, t_pg, cfg["N"], cfg["M"], cfg["T"],
+                                                                                   cfg["K"], t_wv, cores)}
 
 
 if __name__ == "__main__":

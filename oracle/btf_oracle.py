@@ -576,6 +576,22 @@ def pg_draw_series(b, c, size, rng, nterms=256):
     return (x + tail) / (2 * np.pi ** 2)
 
 
+def pg_draw_series_cells(b, c, rng, nterms=200):
+    """The same definition-based sampler for MANY cells at once (b: common shape, c: one tilt per cell), the truncated
+    tail replaced by its mean - the CPU stand-in for `pgdrawv` (factor.py:459) that bench.py's Binomial cpu_baseline
+    times on a sample of the cells (pypolyagamma itself is absent: DESIGN.md section 2)."""
+    c = np.abs(np.asarray(c, float)).reshape(-1)
+    k = np.arange(1, nterms + 1)
+    c2 = (c * c / (4 * np.pi ** 2))[:, None]
+    den = (k - 0.5) ** 2 + c2
+    x = (rng.gamma(b, 1.0, size=(c.size, nterms)) / den).sum(axis=1)
+    # tail mean sum_{k > nterms} b / ((k - 1/2)^2 + c2) ~ b * integral: (1/sqrt(c2)) (pi/2 - atan(nterms / sqrt(c2))), 1/nterms at c2 = 0
+    r = np.sqrt(c2[:, 0])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tail = np.where(r > 1e-12, (np.pi / 2 - np.arctan(nterms / r)) / r, 1.0 / nterms) * b
+    return (x + tail) / (2 * np.pi ** 2)
+
+
 # --------------------------------------------------------------------------
 # Negative-Binomial rate update      (factor.py:462-563; SURVEY 8(f) rank 2)
 #   counts y ~ NB(R, p), p = ilogit(w.v): given R the augmented model is the

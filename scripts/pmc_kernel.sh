@@ -11,6 +11,6 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
-    if "pg_" in k or "accum" in k or "twist" in k or "w_solve" in k:
+    if "pg" in k or "accum" in k or "twist" in k or "w_solve" in k:
         print(k, {c: round(sum(v) / len(v)) for c, v in d.items()}, "launches", len(next(iter(d.values()))))
 PY
