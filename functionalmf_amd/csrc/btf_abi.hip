@@ -527,17 +527,17 @@ hipError_t dispatch_vbanded_chunk(btf_ctx* c, const VBandArgs& a, int bw, int CH
   *handled = false;
   return hipSuccess;
 }
-template <int NPL, bool ROW16, int KC = 0, int TFC = 0>
+template <int NPL, bool ROW16, int KC = 0, int TFC = 0, int TC = 0>
 hipError_t launch_vbanded_twist(btf_ctx* c, const VBandArgs& a, size_t lds_bytes) {
   static std::atomic<unsigned long long> attr_set{0};      // one bit per device: the attribute is per device
   if (!dev_flag_is_set(attr_set, c->dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)v_banded_twist_kernel<NPL, ROW16, KC, TFC>,
+    hipError_t e = hipFuncSetAttribute((const void*)v_banded_twist_kernel<NPL, ROW16, KC, TFC, TC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     dev_flag_set(attr_set, c->dev);
   }
   Prof p(c, BTF_K_V_BANDED);
-  p.launch(v_banded_twist_kernel<NPL, ROW16, KC, TFC>, dim3(a.ml), dim3(VT_THREADS), lds_bytes, a, c->K);
+  p.launch(v_banded_twist_kernel<NPL, ROW16, KC, TFC, TC>, dim3(a.ml), dim3(VT_THREADS), lds_bytes, a, c->K);
   return hipSuccess;
 }
 // Band assembly program of v_banded_twist_kernel: one entry per structurally non-zero band word of the left
@@ -594,6 +594,10 @@ hipError_t dispatch_vbanded_twist(btf_ctx* c, const VBandArgs& a, int bw, size_t
   const int npairs = (bw - 1) * (bw - 2) / 2;
   const int npl = std::max(1, (npairs + WAVE - 1) / WAVE);
   *handled = true;
+  if (c->TF == 2 && c->T == 64 && (c->K == 5 || c->K == 8)) {      // ... and the depth axis of BASELINE configs 3 / 4 / 5
+    if (c->K == 5) return launch_vbanded_twist<tw_npl(5, 2), tw_row16(5, 2), 5, 2, 64>(c, a, lds_bytes);
+    return launch_vbanded_twist<tw_npl(8, 2), tw_row16(8, 2), 8, 2, 64>(c, a, lds_bytes);
+  }
   if (c->TF == 2 && bw == 3 * c->K) {        // the instances with (nembeds, tf_order = 2) compiled in
 #define TW_FIXED(KV) case KV: return launch_vbanded_twist<tw_npl(KV, 2), tw_row16(KV, 2), KV, 2>(c, a, lds_bytes)
     switch (c->K) { TW_FIXED(1); TW_FIXED(2); TW_FIXED(3); TW_FIXED(4); TW_FIXED(5); TW_FIXED(6); TW_FIXED(7); TW_FIXED(8); TW_FIXED(9); TW_FIXED(10); default: break; }

@@ -104,9 +104,12 @@ __host__ __device__ constexpr bool tw_row16(int K, int TF) { return (TF + 1) * K
 
 // KC > 0: nembeds and the trend-filter order as compile-time constants (the instances of BTF_TWIST_SET for the reference's
 // default tf_order = 2): the setup's address arithmetic folds - 234 -> 109 spilled SGPRs, 37.0 -> 35.2 us at C3
-template <int NPL, bool ROW16, int KC = 0, int TFC = 0>
+// TC > 0: the depth axis as a compile-time constant too (round 4: the instance of BASELINE configs 3 / 4, ndepth 64) - every
+// offset of tw_layout folds into the instructions
+template <int NPL, bool ROW16, int KC = 0, int TFC = 0, int TC = 0>
 __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a, int K) {
   if constexpr (KC > 0) { K = KC; a.TF = TFC; }
+  if constexpr (TC > 0) a.T = TC;
   vband_load_hyp(a);
   extern __shared__ double lds[];
   const int tid = threadIdx.x;

@@ -78,9 +78,12 @@ namespace btf {
   P void v_banded_twist_kernel<6, false>(VBandArgs, int); P void v_banded_twist_kernel<7, false>(VBandArgs, int); \
   P void v_banded_twist_kernel<8, false>(VBandArgs, int);                                                \
   BTF_TWIST_FIXED(P, 1, 2) BTF_TWIST_FIXED(P, 2, 2) BTF_TWIST_FIXED(P, 3, 2) BTF_TWIST_FIXED(P, 4, 2) BTF_TWIST_FIXED(P, 5, 2) \
-  BTF_TWIST_FIXED(P, 6, 2) BTF_TWIST_FIXED(P, 7, 2) BTF_TWIST_FIXED(P, 8, 2) BTF_TWIST_FIXED(P, 9, 2) BTF_TWIST_FIXED(P, 10, 2)
+  BTF_TWIST_FIXED(P, 6, 2) BTF_TWIST_FIXED(P, 7, 2) BTF_TWIST_FIXED(P, 8, 2) BTF_TWIST_FIXED(P, 9, 2) BTF_TWIST_FIXED(P, 10, 2) \
+  BTF_TWIST_FIXED_T(P, 5, 2, 64) BTF_TWIST_FIXED_T(P, 8, 2, 64)
 // (nembeds, tf_order) as compile-time constants: the reference's default tf_order = 2, every supported nembeds
 #define BTF_TWIST_FIXED(P, K, TF) P void v_banded_twist_kernel<tw_npl(K, TF), tw_row16(K, TF), K, TF>(VBandArgs, int);
+// ... and ndepth 64 (BASELINE configs 3 / 4 / 5): nembeds 5 and 8
+#define BTF_TWIST_FIXED_T(P, K, TF, T) P void v_banded_twist_kernel<tw_npl(K, TF), tw_row16(K, TF), K, TF, T>(VBandArgs, int);
 
 #define BTF_FOR_K(SET, P) \
   SET(P, 1) SET(P, 2) SET(P, 3) SET(P, 4) SET(P, 5) SET(P, 6) SET(P, 7) SET(P, 8) SET(P, 9) SET(P, 10)
