@@ -43,6 +43,7 @@ SIGNATURES = {
     "btf_set_data_gaussian": (C.c_int, [_ctx, _c_dp, _c_dp, C.c_int]),
     "btf_set_data_binomial": (C.c_int, [_ctx, _c_dp, _c_dp, _c_dp, _c_dp]),
     "btf_set_stale_sources": (C.c_int, [_ctx, _c_ip, _c_ip]),
+    "btf_set_shard_halo": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "btf_set_W": (C.c_int, [_ctx, _c_dp]),
     "btf_get_W": (C.c_int, [_ctx, _c_dp]),
     "btf_set_V": (C.c_int, [_ctx, _c_dp]),

@@ -40,6 +40,8 @@ struct btf_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int row0 = 0, nl = 0, col0 = 0, ml = 0;
+  int hrow = -1, hcol = -1;  // btf_set_shard_halo: global index of the ONE stale-weight source row / column outside the blocks (-1: none);
+                             // its statistics sit at local index nl / ml of the slabs (never updated, never summed - only its weights are read)
   int ldw = 0, ldv = 0;      // padded leading dimensions of A_wT / A_v
   int R = 1;
   bool have_data = false, binomial = false, weighted = false;
@@ -776,6 +778,9 @@ int pick_rpb(int Rdim, int tiles, int user, bool weighted, int slots = 0, int re
   }
   return (int)rpb;
 }
+// slab extents: the rank's block plus the halo source (btf_set_shard_halo)
+inline int slab_rows(const btf_ctx* c) { return c->nl + (c->hrow >= 0 ? 1 : 0); }
+inline int slab_cols(const btf_ctx* c) { return c->ml + (c->hcol >= 0 ? 1 : 0); }
 // (w_launch: the W half-sweep's launches carry no eigen side task and run the 16-wave instance at nembeds 10 too)
 inline int acc_slots(const btf_ctx* c, int K, int mode, bool w_launch = false) {
   const int waves = (w_launch && mode == 0 && K >= 10) ? ACC_WAVES : acc_waves(K, mode);
@@ -798,7 +803,7 @@ inline int v_side_reserve(const btf_ctx* c, bool wt) {
 // case hands in one array as both the row and the column slab): uploaded once, freed by the second call.
 struct Uploaded { const double* h = nullptr; const double* h2 = nullptr; double* d = nullptr; double* d2 = nullptr; };
 int make_stats(btf_ctx* c, const double* hY, const double* hY2, int rows, int cols, int R, bool transposed,
-               double** A, double** C, double** B, int ld, size_t out_rows, bool want_sums, Uploaded* keep, bool last) {
+               double** A, double** C, double** B, int ld, size_t out_rows, bool want_sums, Uploaded* keep, bool last, int sum_rows = -1) {
   const size_t cells = (size_t)rows * cols;
   double* dY = nullptr; double* dY2 = nullptr;
   int rc;
@@ -825,7 +830,7 @@ int make_stats(btf_ctx* c, const double* hY, const double* hY2, int rows, int co
       c->bsum_elems = (size_t)blocks * 3;
     }
   }
-  StatsArgs a{dY, dY2, rows, cols, R, ld, transposed ? 1 : 0, *A, *C, want_sums ? c->bsum : nullptr, dflag};
+  StatsArgs a{dY, dY2, rows, cols, R, ld, transposed ? 1 : 0, *A, *C, want_sums ? c->bsum : nullptr, dflag, sum_rows < 0 ? rows : sum_rows};
   {
     Prof p(c, BTF_K_STATS);
     p.launch(stats_kernel, dim3(blocks), dim3(256), 0, a);
@@ -943,7 +948,20 @@ int btf_set_shard(btf_ctx* c, int row0, int nrows_local, int col0, int ncols_loc
   if (row0 < 0 || nrows_local < 0 || row0 + nrows_local > c->N || col0 < 0 || ncols_local < 0 || col0 + ncols_local > c->M)
     return fail(c, BTF_EINVAL, "shard out of range");
   c->row0 = row0; c->nl = nrows_local; c->col0 = col0; c->ml = ncols_local;
+  c->hrow = c->hcol = -1;
   c->nb_bwt_written = false;      // (the skip of nb_bwt_target is only valid for the shard geometry B_wT was written under)
+  return BTF_OK;
+}
+int btf_set_shard_halo(btf_ctx* c, int halo_row, int halo_col) {
+  if (!c) return BTF_EINVAL;
+  if (halo_row < -1 || halo_row >= c->N || halo_col < -1 || halo_col >= c->M) return fail(c, BTF_EINVAL, "halo source out of range");
+  if ((halo_row >= c->row0 && halo_row < c->row0 + c->nl) || (halo_col >= c->col0 && halo_col < c->col0 + c->ml))
+    return fail(c, BTF_EINVAL, "halo source inside the shard's own block");
+  if (halo_row != c->hrow || halo_col != c->hcol) {        // the slabs change shape: whatever was uploaded is gone
+    c->have_data = false;
+    c->nb_bwt_written = false;
+  }
+  c->hrow = halo_row; c->hcol = halo_col;
   return BTF_OK;
 }
 void* btf_stream(btf_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -1046,17 +1064,17 @@ int btf_set_data_gaussian(btf_ctx* c, const double* y_rows, const double* y_cols
   HIPCHK(c, hipSetDevice(c->dev));
   c->R = nreps; c->binomial = false; c->counts = false;
   const int MT = c->M * c->T;
-  c->ldw = round_up(std::max(c->nl, 1), ACC_TILE);
-  c->ldv = round_up(std::max(c->ml * c->T, 1), ACC_TILE);
+  c->ldw = round_up(std::max(slab_rows(c), 1), ACC_TILE);
+  c->ldv = round_up(std::max(slab_cols(c) * c->T, 1), ACC_TILE);
   int zero = 0;
   HIPCHK(c, hipMemcpy(c->status + 2, &zero, sizeof(int), hipMemcpyHostToDevice));
   int rc;
   // row slab -> transposed layout A_wT[MT][ldw] (W half-sweep); carries the global sums
   Uploaded up;
   const bool same = y_rows == y_cols && c->nl == c->N && c->ml == c->M;     // unsharded: one upload serves both layouts
-  if ((rc = make_stats(c, y_rows, nullptr, c->nl, MT, nreps, true, &c->A_wT, &c->C_wT, nullptr, c->ldw, MT, true, same ? &up : nullptr, false))) return rc;
+  if ((rc = make_stats(c, y_rows, nullptr, slab_rows(c), MT, nreps, true, &c->A_wT, &c->C_wT, nullptr, c->ldw, MT, true, same ? &up : nullptr, false, c->nl))) return rc;
   // column slab -> A_v[N][ldv] (V half-sweep, SSE)
-  if ((rc = make_stats(c, y_cols, nullptr, c->N, c->ml * c->T, nreps, false, &c->A_v, &c->C_v, nullptr, c->ldv, c->N, false, same ? &up : nullptr, true))) {
+  if ((rc = make_stats(c, y_cols, nullptr, c->N, slab_cols(c) * c->T, nreps, false, &c->A_v, &c->C_v, nullptr, c->ldv, c->N, false, same ? &up : nullptr, true))) {
     if (up.d) (void)hipFree(up.d);
     return rc;
   }
@@ -1069,15 +1087,15 @@ int btf_set_data_binomial(btf_ctx* c, const double* succ_rows, const double* tri
   HIPCHK(c, hipSetDevice(c->dev));
   c->R = 1; c->binomial = true; c->counts = false;
   const int MT = c->M * c->T;
-  c->ldw = round_up(std::max(c->nl, 1), ACC_TILE);
-  c->ldv = round_up(std::max(c->ml * c->T, 1), ACC_TILE);
+  c->ldw = round_up(std::max(slab_rows(c), 1), ACC_TILE);
+  c->ldv = round_up(std::max(slab_cols(c) * c->T, 1), ACC_TILE);
   int zero = 0;
   HIPCHK(c, hipMemcpy(c->status + 2, &zero, sizeof(int), hipMemcpyHostToDevice));
   int rc;
   Uploaded up;
   const bool same = succ_rows == succ_cols && trials_rows == trials_cols && c->nl == c->N && c->ml == c->M;
-  if ((rc = make_stats(c, succ_rows, trials_rows, c->nl, MT, 1, true, &c->A_wT, &c->C_wT, &c->B_wT, c->ldw, MT, true, same ? &up : nullptr, false))) return rc;
-  if ((rc = make_stats(c, succ_cols, trials_cols, c->N, c->ml * c->T, 1, false, &c->A_v, &c->C_v, &c->B_v, c->ldv, c->N, false, same ? &up : nullptr, true))) {
+  if ((rc = make_stats(c, succ_rows, trials_rows, slab_rows(c), MT, 1, true, &c->A_wT, &c->C_wT, &c->B_wT, c->ldw, MT, true, same ? &up : nullptr, false, c->nl))) return rc;
+  if ((rc = make_stats(c, succ_cols, trials_cols, c->N, slab_cols(c) * c->T, 1, false, &c->A_v, &c->C_v, &c->B_v, c->ldv, c->N, false, same ? &up : nullptr, true))) {
     if (up.d) (void)hipFree(up.d);
     if (up.d2) (void)hipFree(up.d2);
     return rc;
@@ -1093,8 +1111,8 @@ int btf_set_data_binomial(btf_ctx* c, const double* succ_rows, const double* tri
         else big = true;
       }
     };
-    scan(trials_cols, (size_t)c->N * c->ml * c->T);
-    scan(trials_rows, (size_t)c->nl * MT);
+    scan(trials_cols, (size_t)c->N * slab_cols(c) * c->T);
+    scan(trials_rows, (size_t)slab_rows(c) * MT);
     c->pg_has_small = small; c->pg_has_big = big; c->pg_has_frac = frac;
   }
   // until the first PG draw / set_omega the weights are zero
@@ -1129,16 +1147,18 @@ int btf_set_stale_sources(btf_ctx* c, const int32_t* src_row, const int32_t* src
   if (!c->weighted) src_row = src_col = nullptr;   // constant weights: staleness cannot change anything
   if (src_row)
     for (int il = 0; il < c->nl; ++il) {
-      const int s = src_row[c->row0 + il] - c->row0;
-      if (s < 0 || s >= c->nl) return fail(c, BTF_EINVAL, "stale weight source row outside this shard (use compat=exact when sharding)");
+      int s = src_row[c->row0 + il] - c->row0;
+      if (src_row[c->row0 + il] == c->hrow) s = c->nl;                    // the halo slot (btf_set_shard_halo)
+      else if (s < 0 || s >= c->nl) return fail(c, BTF_EINVAL, "stale weight source row outside this shard: declare it with btf_set_shard_halo before the upload (or use compat=exact)");
       if (s != il && c->curve && !std::memcmp(&c->cv_cij[(size_t)il * c->M], &c->cv_cij[(size_t)s * c->M], (size_t)c->M)) continue;   // same counts: nothing stale
       mw[il] = s;
       c->stale_w |= (s != il);
     }
   if (src_col)
     for (int jl = 0; jl < c->ml; ++jl) {
-      const int s = src_col[c->col0 + jl] - c->col0;
-      if (s < 0 || s >= c->ml) return fail(c, BTF_EINVAL, "stale weight source column outside this shard (use compat=exact when sharding)");
+      int s = src_col[c->col0 + jl] - c->col0;
+      if (src_col[c->col0 + jl] == c->hcol) s = c->ml;
+      else if (s < 0 || s >= c->ml) return fail(c, BTF_EINVAL, "stale weight source column outside this shard: declare it with btf_set_shard_halo before the upload (or use compat=exact)");
       if (s != jl && c->curve) {
         bool same = true;
         for (int i = 0; i < c->N && same; ++i) same = c->cv_cij[(size_t)i * c->M + jl] == c->cv_cij[(size_t)i * c->M + s];
@@ -1302,8 +1322,8 @@ int btf_set_omega(btf_ctx* c, const double* omega_rows, const double* omega_cols
   const int MT = c->M * c->T;
   HIPCHK(c, hipMemsetAsync(c->C_wT, 0, (size_t)MT * c->ldw * sizeof(double), c->stream));
   HIPCHK(c, hipMemsetAsync(c->C_v, 0, (size_t)c->N * c->ldv * sizeof(double), c->stream));
-  if ((rc = upload_relayout(c, omega_rows, c->nl, MT, c->C_wT, c->ldw, true))) return rc;
-  if ((rc = upload_relayout(c, omega_cols, c->N, c->ml * c->T, c->C_v, c->ldv, false))) return rc;
+  if ((rc = upload_relayout(c, omega_rows, slab_rows(c), MT, c->C_wT, c->ldw, true))) return rc;
+  if ((rc = upload_relayout(c, omega_cols, c->N, slab_cols(c) * c->T, c->C_v, c->ldv, false))) return rc;
   // cells without an observation (trials stored as 0) carry no weight
   hipLaunchKernelGGL(mask_kernel, dim3(1024), dim3(256), 0, c->stream, c->C_wT, c->B_wT, (size_t)MT * c->ldw);
   hipLaunchKernelGGL(mask_kernel, dim3(1024), dim3(256), 0, c->stream, c->C_v, c->B_v, (size_t)c->N * c->ldv);
@@ -2478,8 +2498,8 @@ int btf_set_data_counts(btf_ctx* c, const double* counts, int nreps) {
   c->pg_has_small = c->pg_has_big = c->pg_has_frac = true;      // pseudo-trial counts change with the rate: every pass
   if (c->C8_wT) { (void)hipFree(c->C8_wT); c->C8_wT = nullptr; }
   if (c->C8_v) { (void)hipFree(c->C8_v); c->C8_v = nullptr; }
-  c->ldw = round_up(std::max(c->nl, 1), ACC_TILE);
-  c->ldv = round_up(std::max(c->ml * c->T, 1), ACC_TILE);
+  c->ldw = round_up(std::max(slab_rows(c), 1), ACC_TILE);
+  c->ldv = round_up(std::max(slab_cols(c) * c->T, 1), ACC_TILE);
   int rc;
   if ((rc = dev_alloc(c, &c->nb_data, cells * nreps))) return rc;
   if ((rc = dev_alloc(c, &c->nb_S, cells))) return rc;
@@ -2650,7 +2670,7 @@ int btf_nb_set_rate(btf_ctx* c, const double* R, const int32_t* shared) {
     Prof p(c, BTF_K_STATS);
     p.launch(nb_trials_kernel, dim3((MT + 63) / 64, (c->N + 63) / 64), dim3(256), 0, (const double*)c->nb_S,
              (const double*)c->nb_cnt, (const double*)c->nb_R, sr[0], sr[1], sr[2], c->N, MT, c->T, c->ldv, c->ldw, c->A_v,
-             c->B_v, c->A_wT, nb_bwt_target(c), c->row0, c->nl, c->col0 * c->T, c->ml * c->T);
+             c->B_v, c->A_wT, nb_bwt_target(c), c->row0, c->nl, c->col0 * c->T, c->ml * c->T, c->hrow, c->hcol >= 0 ? c->hcol * c->T : -1);
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));      // R is a borrowed host buffer
@@ -2752,7 +2772,7 @@ int btf_nb_mh(btf_ctx* c, uint64_t seed, int nsteps, double rpropstdev, double r
     Prof p(c, BTF_K_STATS);
     p.launch(nb_trials_kernel, dim3((MT + 63) / 64, (c->N + 63) / 64), dim3(256), 0, (const double*)c->nb_S,
              (const double*)c->nb_cnt, (const double*)c->nb_R, sr[0], sr[1], sr[2], c->N, MT, c->T, c->ldv, c->ldw, c->A_v,
-             c->B_v, c->A_wT, nb_bwt_target(c), c->row0, c->nl, c->col0 * c->T, c->ml * c->T);
+             c->B_v, c->A_wT, nb_bwt_target(c), c->row0, c->nl, c->col0 * c->T, c->ml * c->T, c->hrow, c->hcol >= 0 ? c->hcol * c->T : -1);
   }
   HIPCHK(c, hipGetLastError());
   if (R_in) HIPCHK(c, hipStreamSynchronize(c->stream));      // borrowed host buffer
@@ -3077,6 +3097,16 @@ int btf_pg_draw(btf_ctx* c, uint64_t seed) {
   if (c->ml > 0) {  // V layout [i][jt_local]
     K_SWITCH(c->K, launch_pg<KT>(c, c->B_v, c->C_v, c->V + (size_t)c->col0 * c->T * c->K, c->W, c->ml * c->T, c->ldv,
                                  c->N, (unsigned long long)c->col0 * c->T, MT, 1ULL, seed));
+  }
+  // the halo sources (btf_set_shard_halo): the weights of ONE more row / column, from the streams of its global cells -
+  // the values its owner draws
+  if (c->hrow >= 0) {
+    K_SWITCH(c->K, launch_pg<KT>(c, c->B_wT + c->nl, c->C_wT + c->nl, c->W + (size_t)c->hrow * c->K, c->V, 1, c->ldw, (int)MT,
+                                 (unsigned long long)c->hrow * MT, 1ULL, MT, seed));
+  }
+  if (c->hcol >= 0) {
+    K_SWITCH(c->K, launch_pg<KT>(c, c->B_v + (size_t)c->ml * c->T, c->C_v + (size_t)c->ml * c->T, c->V + (size_t)c->hcol * c->T * c->K,
+                                 c->W, c->T, c->ldv, c->N, (unsigned long long)c->hcol * c->T, MT, 1ULL, seed));
   }
   HIPCHK(c, hipGetLastError());
   return BTF_OK;

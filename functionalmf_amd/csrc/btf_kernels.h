@@ -1650,6 +1650,7 @@ struct StatsArgs {
   double* A; double* C;               // C may be nullptr (not kept)
   double* bsum;                       // [gridDim][3] : ssw, nobs, sum S1^2/cnt   (may be nullptr)
   int* incomplete;                    // set to 1 if any cell has cnt != R (Gaussian) / is missing (binomial)
+  int sum_rows;                       // rows >= sum_rows (a halo source row, btf_set_shard_halo) stay out of the block sums
 };
 
 static __global__ __launch_bounds__(256) void stats_kernel(StatsArgs a) {
@@ -1675,15 +1676,16 @@ static __global__ __launch_bounds__(256) void stats_kernel(StatsArgs a) {
         const double y = a.Y[cell * a.R + r];
         if (y == y) { s1 += y; ++cnt; }
       }
-      if (cnt > 0) {
+      const bool summed = (int)row < a.sum_rows;
+      if (cnt > 0 && summed) {
         const double mean = s1 / cnt;
         for (int r = 0; r < a.R; ++r) {
           const double y = a.Y[cell * a.R + r];
           if (y == y) ssw = fma(y - mean, y - mean, ssw);
         }
       }
-      nobs += cnt;
-      if (cnt > 0) sa2 = fma(s1, s1 / cnt, sa2);
+      if (summed) nobs += cnt;
+      if (cnt > 0 && summed) sa2 = fma(s1, s1 / cnt, sa2);
       inc |= (cnt != a.R);
       A = s1;
       C = (double)cnt;
@@ -1693,7 +1695,7 @@ static __global__ __launch_bounds__(256) void stats_kernel(StatsArgs a) {
       A = miss ? 0.0 : y - 0.5 * nt;
       C = miss ? 0.0 : nt;
       inc |= miss;
-      nobs += miss ? 0.0 : 1.0;
+      nobs += miss || (int)row >= a.sum_rows ? 0.0 : 1.0;
     }
     const size_t o = a.transposed ? col * a.ld + row : row * a.ld + col;
     a.A[o] = A;
@@ -2682,7 +2684,8 @@ static __global__ __launch_bounds__(256) void nb_trials_kernel(const double* __r
                                                        long long sr2, int N, int MT, int T, int ldv, int ldw,
                                                        double* __restrict__ Av, double* __restrict__ Bv,
                                                        double* __restrict__ AwT, double* __restrict__ BwT,
-                                                       int row0, int nl, int jt_lo, int jt_n) {
+                                                       int row0, int nl, int jt_lo, int jt_n, int hrow, int hjt) {
+  // (hrow / hjt: the halo source row / first (j,t) of the halo source column, -1: none - local index nl / jt_n .. jt_n+T-1)
   __shared__ double ta[64][65], tb[64][65];
   const int col = threadIdx.x & 63;
   const int rgrp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2702,6 +2705,9 @@ static __global__ __launch_bounds__(256) void nb_trials_kernel(const double* __r
       if (jt >= jt_lo && jt < jt_lo + jt_n) {
         Av[(size_t)i * ldv + (jt - jt_lo)] = a;
         Bv[(size_t)i * ldv + (jt - jt_lo)] = b;
+      } else if (hjt >= 0 && jt >= hjt && jt < hjt + T) {
+        Av[(size_t)i * ldv + (jt_n + jt - hjt)] = a;
+        Bv[(size_t)i * ldv + (jt_n + jt - hjt)] = b;
       }
     }
     ta[r][col] = a; tb[r][col] = b;
@@ -2713,6 +2719,9 @@ static __global__ __launch_bounds__(256) void nb_trials_kernel(const double* __r
     if (jj < MT && i >= row0 && i < row0 + nl) {
       AwT[(size_t)jj * ldw + (i - row0)] = ta[col][c];
       if (BwT) BwT[(size_t)jj * ldw + (i - row0)] = tb[col][c];     // (nullptr: nobody reads the trial counts in this layout)
+    } else if (jj < MT && i == hrow) {
+      AwT[(size_t)jj * ldw + nl] = ta[col][c];
+      if (BwT) BwT[(size_t)jj * ldw + nl] = tb[col][c];
     }
   }
 }

@@ -404,15 +404,25 @@ class BayesianTensorFiltering(_BayesianModel):
     def _upload(self, data):
         raise NotImplementedError
 
-    def _set_stale_sources(self, any_nan, missing):
-        """Quirks Q1/Q2 are reproduced only under compat="reference"; "exact" uses every output's own weights (and a
-        sharded run could not reach a source row / column outside its slabs)."""
-        if self.compat != "reference":
+    def _stale_sources(self, any_nan, missing):
+        """Quirks Q1/Q2 are reproduced only under compat="reference"; "exact" uses every output's own weights.  BEFORE the
+        upload: works out the source rows / columns and, in a sharded run, declares the one source row and the one source
+        column that may lie outside this rank's blocks (btf_set_shard_halo: the slabs then carry them as one more row /
+        column - ShardPlan.slabs)."""
+        self._src = None
+        if self.compat == "reference":
+            self._src = (stale_row_sources(self.nrows, self.nembeds, any_nan), stale_col_sources(missing))
+        if self._plan.world > 1:
+            hr, hc = self._plan.halo_of(*self._src) if self._src is not None else (-1, -1)
+            self._plan.halo_row, self._plan.halo_col = hr, hc
+            self._ctx.call("btf_set_shard_halo", hr, hc)
+
+    def _set_stale_sources(self):
+        """AFTER the upload: hands the sources of _stale_sources to the context."""
+        if self._src is None:
             self._ctx.call("btf_set_stale_sources", None, None)
             return
-        self._ctx.call("btf_set_stale_sources",
-                       stale_row_sources(self.nrows, self.nembeds, any_nan).ctypes.data_as(_native._c_ip),
-                       stale_col_sources(missing).ctypes.data_as(_native._c_ip))
+        self._ctx.call("btf_set_stale_sources", self._src[0].ctypes.data_as(_native._c_ip), self._src[1].ctypes.data_as(_native._c_ip))
 
     # ---- construction draws ------------------------------------------------------
     def _init_sigma2(self):
@@ -834,10 +844,11 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
         Y4 = Y[..., None] if Y.ndim == 3 else Y
         if Y4.shape[:3] != (self.nrows, self.ncols, self.ndepth):
             raise ValueError("data shape %r does not match the model" % (Y.shape,))
+        miss = np.isnan(Y4)
+        self._stale_sources(bool(miss.any()), miss.all(axis=3))
         rows, cols = self._plan.slabs(Y4)
         self._ctx.call("btf_set_data_gaussian", _native.dptr(rows), _native.dptr(cols), int(Y4.shape[3]))
-        miss = np.isnan(Y4)
-        self._set_stale_sources(bool(miss.any()), miss.all(axis=3))
+        self._set_stale_sources()
 
     def resample(self, data):
         self._in_sweep = True
@@ -1036,11 +1047,12 @@ class BinomialBayesianTensorFiltering(GaussianBayesianTensorFiltering):
         Y, N = data
         if Y.shape != (self.nrows, self.ncols, self.ndepth) or N.shape != Y.shape:
             raise ValueError("binomial data must be a (Y, N) pair of (nrows, ncols, ndepth) arrays")
+        miss = np.isnan(Y) | np.isnan(N)
+        self._stale_sources(bool(miss.any()), miss)
         yr, yc = self._plan.slabs(Y[..., None])
         nr, nc = self._plan.slabs(N[..., None])
         self._ctx.call("btf_set_data_binomial", _native.dptr(yr), _native.dptr(nr), _native.dptr(yc), _native.dptr(nc))
-        miss = np.isnan(Y) | np.isnan(N)
-        self._set_stale_sources(bool(miss.any()), miss)
+        self._set_stale_sources()
         self._omega_host_new = True
 
     def _set_noise(self):
@@ -1134,9 +1146,10 @@ class NegativeBinomialBayesianTensorFiltering(BinomialBayesianTensorFiltering):
         d4 = _native.as_f64(self._counts4(data))
         if d4.ndim != 4 or d4.shape[:3] != (self.nrows, self.ncols, self.ndepth):
             raise ValueError("data shape %r does not match the model" % (data.shape,))
-        self._ctx.call("btf_set_data_counts", _native.dptr(d4), int(d4.shape[3]))
         miss = np.all(np.isnan(d4), axis=-1)
-        self._set_stale_sources(bool(miss.any()), miss)
+        self._stale_sources(bool(miss.any()), miss)
+        self._ctx.call("btf_set_data_counts", _native.dptr(d4), int(d4.shape[3]))
+        self._set_stale_sources()
         self._nb_sum = np.nansum(d4, axis=-1)
         self._nb_cnt = (~np.isnan(d4)).sum(axis=-1).astype(float)
         self._rate_key = None

@@ -33,18 +33,42 @@ class ShardPlan:
         self.nrows, self.ncols, self.rank, self.world = nrows, ncols, rank, world
         self.row0, self.nl, self.row_chunk = _block(nrows, rank, world)
         self.col0, self.ml, self.col_chunk = _block(ncols, rank, world)
+        # compat="reference": the one stale-weight source row / column outside the blocks (-1: none), carried as one more
+        # row / column of every slab (btf_set_shard_halo)
+        self.halo_row = self.halo_col = -1
+
+    def halo_of(self, src_row, src_col):
+        """The source row and the source column (global indices, -1: none) that the weights of this rank's rows / columns
+        come from but that lie outside its blocks.  The row sources of the reference are nembeds-1 or the row itself
+        (factor.py:320,349), its column sources never decrease and are a column's own index or its left neighbour's source
+        (factor.py:394-401): at most one of each per contiguous block."""
+        out = []
+        for src, lo, n in ((src_row, self.row0, self.nl), (src_col, self.col0, self.ml)):
+            s = np.asarray(src[lo:lo + n])
+            far = np.unique(s[(s < lo) | (s >= lo + n)])
+            if far.size > 1:
+                raise ValueError("more than one stale-weight source outside a shard (%r): not the reference's source pattern" % (far,))
+            out.append(int(far[0]) if far.size else -1)
+        return tuple(out)
 
     def mine(self):
         return self.row0, self.nl, self.col0, self.ml
 
     def slabs(self, Y4):
         """Row slab Y[row0:row0+nl] and column slab Y[:, col0:col0+ml] as contiguous
-        float64 arrays (the same object twice when unsharded)."""
+        float64 arrays (the same object twice when unsharded); with a halo source row / column, that row / column
+        appended."""
         if self.world == 1:
             a = np.ascontiguousarray(Y4, dtype=np.float64)
             return a, a
-        rows = np.ascontiguousarray(Y4[self.row0:self.row0 + self.nl], dtype=np.float64)
-        cols = np.ascontiguousarray(Y4[:, self.col0:self.col0 + self.ml], dtype=np.float64)
+        ri = np.arange(self.row0, self.row0 + self.nl)
+        ci = np.arange(self.col0, self.col0 + self.ml)
+        if self.halo_row >= 0:
+            ri = np.append(ri, self.halo_row)              # the halo source LAST (btf_set_shard_halo)
+        if self.halo_col >= 0:
+            ci = np.append(ci, self.halo_col)
+        rows = np.ascontiguousarray(Y4[ri], dtype=np.float64)
+        cols = np.ascontiguousarray(Y4[:, ci], dtype=np.float64)
         return rows, cols
 
     def assemble(self, blocks, axis_len):

@@ -139,6 +139,18 @@ int btf_fail_index(const btf_ctx* ctx);
  * Default: everything.  W and V are replicated: after each half-sweep the host
  * all-gathers the updated block (device pointers via btf_dev_W / btf_dev_V). */
 int btf_set_shard(btf_ctx* ctx, int row0, int nrows_local, int col0, int ncols_local);
+/* compat=REFERENCE in a sharded run (compat caveat).  The cached likelihood weights of quirks Q1/Q2 come from
+ * a SOURCE row / column (factor.py:320,349: row nembeds-1 for every later row when the data hold no NaN;
+ * factor.py:394-401: the last column at which the NaN pattern changed), which may lie outside the rank's blocks.  With
+ * contiguous blocks at most ONE such row and ONE such column exist per rank (the row sources are nembeds-1 or the row
+ * itself; the column sources never decrease and are a column's own index or its left neighbour's source).  Declare them
+ * here (global indices, -1: none), after btf_set_shard and before the upload: every row slab handed to
+ * btf_set_data_* / btf_set_omega then has nrows_local + 1 rows, the source row LAST, every column slab
+ * ncols_local + 1 columns, the source column last (btf_set_data_counts keeps taking the whole tensor).  The halo is
+ * never updated and never enters a sum (nobs, SSE); only its weights are read - by the stale-weight accumulation
+ * (btf_set_stale_sources maps a source equal to the halo onto its slot) - and btf_pg_draw draws them from the streams
+ * of the source's global cells, i.e. the values the owning rank draws.  A changed halo invalidates the uploaded data. */
+int btf_set_shard_halo(btf_ctx* ctx, int halo_row, int halo_col);
 void* btf_stream(btf_ctx* ctx); /* the hipStream_t every step function of this ctx enqueues on (the one passed
                                   to btf_create, or the private one): collectives on the ctx's buffers and event
                                   timing must be ordered against it */
@@ -168,7 +180,8 @@ int btf_set_data_binomial(btf_ctx* ctx, const double* succ_rows, const double* t
 /* Quirks Q1/Q2: which row / column the cached likelihood weights
  * come from in compat=REFERENCE.  src_row[N], src_col[M] (global indices);
  * NULL = identity.  Only consulted by the weighted kernels.  Call after
- * btf_set_data_*; a source outside this ctx's shard is BTF_EINVAL.             */
+ * btf_set_data_*; a source outside this ctx's shard that is not its declared halo
+ * (btf_set_shard_halo) is BTF_EINVAL.                                           */
 int btf_set_stale_sources(btf_ctx* ctx, const int32_t* src_row, const int32_t* src_col);
 
 /* ---- Negative-Binomial counts (unsharded contexts) -----------------

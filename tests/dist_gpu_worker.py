@@ -95,6 +95,107 @@ def split_section(rank, world):
     assert all(abs(x - y) / abs(y) < 1e-8 for x, y in zip(a[2:], b[2:])), (a[2:], b[2:])
 
 
+def reference_section(rank, world):
+    """compat="reference" SHARDED (compat caveat; btf_set_shard_halo): the stale cached weights of quirks Q1/Q2
+    (reference factor.py:320,349 and :394-401) come from a source row / column that may lie outside the rank's blocks - one
+    more row / column of its slabs.  The sharded chains must reproduce the unsharded compat="reference" chains:
+    Gaussian data whose missing curves repeat over groups of columns that straddle the shard borders (static counts in the
+    halo column), Binomial data without a NaN (every row >= nembeds reads row nembeds-1's Polya-Gamma weights, every column
+    those of column 0: both halos redrawn each sweep from the source's own cell streams), Binomial with missing cells,
+    Negative-Binomial counts."""
+    from functionalmf_amd.factor import BinomialBayesianTensorFiltering, NegativeBinomialBayesianTensorFiltering
+    rs = np.random.RandomState(5)
+    N, M, T, R, K, tf = 26, 10, 12, 2, 3, 1
+    Wt = rs.normal(size=(N, K))
+    Vt = 0.2 * np.cumsum(rs.normal(size=(M, T, K)), axis=1)
+    Y = np.einsum("nk,mtk->nmt", Wt, Vt)[..., None] + rs.normal(0, 0.5, size=(N, M, T, R))
+    group = np.array([0, 0, 0, 1, 1, 1, 1, 2, 2, 2])                  # columns sharing one pattern of missing curves
+    pat = rs.rand(3, N, T) < 0.15
+    Y[np.broadcast_to(pat[group].transpose(1, 0, 2)[..., None], Y.shape)] = np.nan
+    W0, V0 = Wt + 0.1 * rs.normal(size=Wt.shape), Vt + 0.05 * rs.normal(size=Vt.shape)
+    W0[np.triu_indices(N, 1, K)] = 0
+    chains = []
+    for shard in ((rank, world), None):
+        np.random.seed(7)
+        m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=0.6, lam2_init=0.2, nu2_init=0.4, W_init=W0.copy(),
+                                            V_init=V0.copy(), compat="reference", shard=shard, device=DEV, rng="device", device_seed=9,
+                                            sampler="banded")
+        for _ in range(3):
+            m.resample(Y)
+        if shard is not None and world == 2:
+            assert (m._plan.halo_row, m._plan.halo_col) == ((-1, -1) if rank == 0 else (-1, 3)), (m._plan.halo_row, m._plan.halo_col)
+        chains.append((m.W.copy(), m.V.copy(), float(m.nu2), float(m.sigma2), float(m.lam2)))
+        del m
+    a, b = chains
+    assert np.abs(a[0] - b[0]).max() / np.abs(b[0]).max() < 1e-7 and np.abs(a[1] - b[1]).max() / np.abs(b[1]).max() < 1e-5, "gaussian"
+    assert all(abs(x - y) / abs(y) < 1e-7 for x, y in zip(a[2:], b[2:])), (a[2:], b[2:])
+    # the quirk is really in play: own weights (compat="exact") give another chain
+    np.random.seed(7)
+    m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=0.6, lam2_init=0.2, nu2_init=0.4, W_init=W0.copy(),
+                                        V_init=V0.copy(), compat="exact", shard=(rank, world), device=DEV, rng="device", device_seed=9,
+                                        sampler="banded")
+    for _ in range(3):
+        m.resample(Y)
+    assert np.abs(m.V - b[1]).max() / np.abs(b[1]).max() > 1e-3
+    del m
+    # ---- Binomial: without and with missing cells
+    Nt = rs.randint(1, 40, size=(N, M, T)).astype(float)
+    Ys = rs.binomial(Nt.astype(int), 1.0 / (1.0 + np.exp(-np.einsum("nk,mtk->nmt", Wt, Vt)))).astype(float)
+    Ym, Nm = Ys.copy(), Nt.copy()
+    holes = np.broadcast_to(pat[group].transpose(1, 0, 2), Ys.shape)
+    Ym[holes] = np.nan
+    Nm[holes] = np.nan
+    for name, data in (("binomial", (Ys, Nt)), ("binomial+missing", (Ym, Nm))):
+        chains = []
+        for shard in ((rank, world), None):
+            np.random.seed(7)
+            m = BinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=0.6, lam2_init=0.2, W_init=W0.copy(),
+                                                V_init=V0.copy(), compat="reference", shard=shard, device=DEV, rng="device", device_seed=9)
+            for _ in range(3):
+                m.resample(data)
+            if shard is not None and rank > 0 and name == "binomial":
+                assert (m._plan.halo_row, m._plan.halo_col) == (K - 1, 0)
+            chains.append((m.W.copy(), m.V.copy(), np.array(m.nu2).copy()))
+            del m
+        a, b = chains
+        fin = np.isfinite(b[2])
+        assert np.array_equal(fin, np.isfinite(a[2])) and np.abs(a[2][fin] - b[2][fin]).max() / np.abs(b[2][fin]).max() < 1e-9, name
+        assert np.abs(a[0] - b[0]).max() / np.abs(b[0]).max() < 1e-7 and np.abs(a[1] - b[1]).max() / np.abs(b[1]).max() < 1e-5, name
+    # host-fed weights (btf_set_omega with the halo row / column in the slabs): one W+V update from a given nu2 with host
+    # normals, against the oracle's restatement of the reference's half-sweeps (quirks included)
+    nu2 = 1.0 / np.random.RandomState(3).gamma(2.0, 0.2, size=(N, M, T))
+    m = BinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=0.6, lam2_init=0.2, W_init=W0.copy(),
+                                        V_init=V0.copy(), compat="reference", shard=(rank, world), device=DEV)
+    m.nu2 = nu2.copy()
+    Delta = orc.trend_penalty(T, tf)
+    ost = dict(W=W0.copy(), V=V0.copy(), Tau2=np.array(m.Tau2).copy(), lam2=0.2, sigma2=0.6, nu2=nu2.copy())
+    np.random.seed(31)
+    m._resample_W((Ys, Nt))
+    m._resample_V((Ys, Nt))
+    np.random.seed(31)
+    orc.binomial_w_step(ost, Ys, Nt)
+    orc.binomial_v_step(ost, Ys, Nt, Delta, compat="reference", perm=orc.perm_from_order(m.v_order(), K, T))
+    ew, ev = np.abs(m.W - ost["W"]).max() / np.abs(ost["W"]).max(), np.abs(m.V - ost["V"]).max() / np.abs(ost["V"]).max()
+    assert ew < 1e-9 and ev < 1e-6, ("host omega", ew, ev)
+    del m
+    # ---- Negative-Binomial counts
+    cnts = rs.poisson(3.0, size=(N, M, T, 2)).astype(float)
+    cnts[np.broadcast_to(holes[..., None], cnts.shape)] = np.nan
+    chains = []
+    for shard in ((rank, world), None):
+        np.random.seed(7)
+        m = NegativeBinomialBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=tf, sigma2_init=0.7, lam2_init=0.2, W_init=0.3 * W0,
+                                                    V_init=0.3 * V0, rdims=(1, 2), nmetropolis=5, compat="reference", shard=shard, device=DEV,
+                                                    rng="device", device_seed=9)
+        for _ in range(2):
+            m.resample(cnts)
+        chains.append((m.W.copy(), m.V.copy(), np.array(m.R).copy()))
+        del m
+    a, b = chains
+    assert np.abs(a[2] - b[2]).max() / np.abs(b[2]).max() < 1e-9, "R"
+    assert np.abs(a[0] - b[0]).max() / np.abs(b[0]).max() < 1e-7 and np.abs(a[1] - b[1]).max() / np.abs(b[1]).max() < 1e-5, "negbinom"
+
+
 def main():
     backend = os.environ.get("BTF_DIST_BACKEND", "gloo")
     exercise = os.environ.get("BTF_EXERCISE_EXCHANGE", "0")
@@ -108,6 +209,8 @@ def main():
     sections = os.environ.get("BTF_DIST_SECTION", "base,split").split(",")
     if "split" in sections and world > 1:
         split_section(rank, world)
+    if "reference" in sections and world > 1:
+        reference_section(rank, world)
     if "base" not in sections:
         print("SHARD_GPU_OK rank", rank, flush=True)
         dist.barrier()

@@ -734,6 +734,26 @@ def test_three_ranks_overlapped_exchange_split_accumulation():
 
 
 @pytest.mark.timeout(400)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_reference_compat_reads_its_stale_weights_from_the_halo(world):
+    """compat="reference" sharded: ranks on cuda:0 (gloo control plane) whose stale-weight source row / column lies in
+    another rank's block carry it as one more row / column of their slabs (btf_set_shard_halo) and must reproduce the
+    unsharded compat="reference" chains - Gaussian with missing curves, Binomial (Polya-Gamma weights of the halo redrawn
+    every sweep), Binomial with missing cells, host-fed weights, Negative-Binomial (tests/dist_gpu_worker.py:
+    reference_section)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, BTF_DIST_SECTION="reference")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+           "--master-addr", "127.0.0.1", "--master-port", "29589", os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=380)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("SHARD_GPU_OK") == world, out.stdout[-2000:]
+
+
+@pytest.mark.timeout(400)
 def test_rccl_exchange_with_one_rank_reproduces_the_plain_chain():
     """The DEVICE collective path of sharded runs (functionalmf_amd/parallel.py: all_gather_into_tensor on the
     context's own W / V buffers and the 8-byte all-reduce of the residual sum of squares, issued under
@@ -771,7 +791,7 @@ def test_rccl_ranks_on_their_own_gpus(world):
     if torch.cuda.device_count() < world:
         pytest.skip("needs %d GPUs (this box has %d)" % (world, torch.cuda.device_count()))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, BTF_DIST_BACKEND="nccl", BTF_DIST_GPU_PER_RANK="1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0", BTF_DIST_SECTION="base,split")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", BTF_DIST_SECTION="base,split,reference")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
            "--master-addr", "127.0.0.1", "--master-port", "29587", os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)

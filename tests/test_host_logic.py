@@ -170,6 +170,41 @@ def test_bench_launches_its_own_ranks_and_prints_one_line():
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
 
 
+def test_shard_plan_finds_the_one_halo_source_and_appends_it_to_the_slabs():
+    """compat="reference" sharded (btf_set_shard_halo): per contiguous block at most one stale-weight source row and one
+    source column lie outside it; ShardPlan.halo_of finds them from the reference's source patterns (factor.py:320,349 and
+    :394-401, restated by stale_row_sources / stale_col_sources) and ShardPlan.slabs carries them LAST."""
+    from functionalmf_amd.factor import stale_col_sources, stale_row_sources
+    from functionalmf_amd.parallel import ShardPlan
+    N, M, T, K = 12, 10, 4, 3
+    group = np.array([0, 0, 0, 1, 1, 1, 1, 2, 2, 2])
+    pat = np.random.RandomState(0).rand(3, N, T) < 0.3
+    miss = pat[group].transpose(1, 0, 2)                                  # (N, M, T)
+    src_col = stale_col_sources(miss)
+    assert list(src_col) == [0, 0, 0, 3, 3, 3, 3, 7, 7, 7]
+    Y4 = np.arange(N * M * T, dtype=float).reshape(N, M, T, 1)
+    for world, want in ((2, [(-1, -1), (-1, 3)]), (3, [(-1, -1), (-1, 3), (-1, 7)])):
+        for r in range(world):
+            p = ShardPlan(N, M, r, world)
+            assert p.halo_of(stale_row_sources(N, K, True), src_col) == want[r]
+            p.halo_row, p.halo_col = want[r]
+            rows, cols = p.slabs(Y4)
+            assert rows.shape[0] == p.nl and cols.shape[1] == p.ml + (want[r][1] >= 0)
+            if want[r][1] >= 0:
+                assert np.array_equal(cols[:, -1], Y4[:, want[r][1]]) and np.array_equal(cols[:, :-1], Y4[:, p.col0:p.col0 + p.ml])
+    # no NaN anywhere: every row >= nembeds reads row nembeds-1, every column reads column 0
+    src_row, src_col = stale_row_sources(N, K, False), stale_col_sources(np.zeros((N, M, T), bool))
+    for r in range(1, 3):
+        p = ShardPlan(N, M, r, 3)
+        assert p.halo_of(src_row, src_col) == (K - 1, 0)
+        p.halo_row, p.halo_col = K - 1, 0
+        rows, cols = p.slabs(Y4)
+        assert rows.shape[0] == p.nl + 1 and np.array_equal(rows[-1], Y4[K - 1]) and np.array_equal(cols[:, -1], Y4[:, 0])
+    assert ShardPlan(N, M, 0, 3).halo_of(src_row, src_col) == (-1, -1)         # rank 0 owns both sources
+    with pytest.raises(ValueError):
+        ShardPlan(N, M, 1, 2).halo_of(src_row, np.array([0, 1, 2, 3, 4, 0, 1, 7, 8, 9], dtype=np.int32))
+
+
 def test_shard_plan_rejects_more_shards_than_the_padding_allows():
     from functionalmf_amd.parallel import ShardPlan
     with pytest.raises(ValueError):
