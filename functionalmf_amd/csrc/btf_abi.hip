@@ -1482,6 +1482,9 @@ int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL, WFuseReq* wf = nul
       a.inv_sigma2 = 1.0 / c->sigma2;
       a.hyp = c->dev_scalars ? c->hyp : nullptr; a.Rrep = c->R; a.hyp_noise = c->binomial ? 0 : 1;
       a.W = c->W; a.row0 = c->row0; a.nl = c->nl;
+#ifdef BTF_WS_STAMPS
+      a.dbg = c->dbg;
+#endif
       a.z = wf->dz; a.seed = wf->seed; a.stream = 2 * c->sweep_w + 0x10000ULL;
       a.status = c->status;
       fw.cnt = c->fz_words + FZ_TICKETS;
@@ -1575,6 +1578,9 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     a.inv_sigma2 = 1.0 / c->sigma2;
     a.hyp = c->dev_scalars ? c->hyp : nullptr; a.Rrep = c->R; a.hyp_noise = c->binomial ? 0 : 1;
     a.W = c->W; a.row0 = c->row0; a.nl = c->nl;
+#ifdef BTF_WS_STAMPS
+    a.dbg = c->dbg;
+#endif
     a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_w + 0x10000ULL;
     a.status = c->status;
     if (cv) { a.cv = CurveLists{c->cv_rptr, c->cv_rcol, c->cv_rdef}; a.cv_blocks = c->gpart_v; }

@@ -911,7 +911,15 @@ struct WSolveArgs {
   int hyp_noise;       // 1: the noise scale s comes from hyp[HYP_NU2] (scalar-nu2 models only)
   CurveLists cv;       // curve-structured counts: deficient columns of every row (global row index), or ptr == nullptr
   const double* cv_blocks;   // [M][KK] per-column Grams V_j'V_j
+#ifdef BTF_WS_STAMPS
+  long long* dbg;      // diagnostic builds: [gridDim.x][6] shader-clock stamps of wave 0 (scripts/ws_stamps.py)
+#endif
 };
+#ifdef BTF_WS_STAMPS
+#define WS_STAMP(n) do { if (threadIdx.x == 0 && a.dbg) a.dbg[(size_t)blockIdx.x * 6 + (n)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WS_STAMP(n) do {} while (0)
+#endif
 
 // device-resident scalar hyper-parameters (rng="device": drawn by scalars_kernel / lam2_kernel,
 // read by the half-sweep kernels, so that a full sweep needs no host round trip)
@@ -971,6 +979,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
   constexpr int WS_SPLIT = ws_split_of(K, WEIGHTED);
   constexpr int NVMAX = WEIGHTED ? K + KK : K;
   constexpr int NV = NVMAX;
+  WS_STAMP(0);
   // chunks whose loads are in flight together (weighted rows of K >= 6 carry 27+ values per chunk: two chunks' worth of
   // them beside the running sums did not fit the 256 VGPRs of the 8-wave workgroup - 156 spilled at K = 6)
   constexpr int UNR = WEIGHTED ? (K + KK > 24 ? 1 : 2) : 4;
@@ -1063,28 +1072,39 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     const size_t cst = (size_t)NV * a.ld;               // chunk stride
     const bool live1 = il < a.nl;
     int c = grp * SUB + sub;
+    // (slot u of the first batch exists if chunk c + u CS does: at C3 the 64 (wave, subgroup) pairs of a row own ONE chunk
+    //  each, and a batch that asked for all UNR of them never left before the normals - 1.6 us of Philox in front of the
+    //  only round of loads)
     double x0[UNR][NV];
-    const bool first = live1 && c + (UNR - 1) * CS < a.nch;
+    const bool first = live1 && c < a.nch;
+    int nfirst = 0;
     if (first) {
       const double* p = a.part + (size_t)c * cst + il;
 #pragma unroll
-      for (int u = 0; u < UNR; ++u)
+      for (int u = 0; u < UNR; ++u) {
+        const bool has = c + u * CS < a.nch;
+        nfirst += has ? 1 : 0;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) x0[u][v] = p[(size_t)u * CS * cst + (size_t)v * a.ld];
+        for (int v = 0; v < NV; ++v) x0[u][v] = has ? p[(size_t)u * CS * cst + (size_t)v * a.ld] : 0.0;
+      }
     }
     if (live1) {
       const int i = a.row0 + il;
       const long long zoff = w_z_offset(i, K);
       const int d = i + 1 < K ? i + 1 : K;
-      for (int k = grp * SUB + sub; k < K; k += CS)
+      // (component k by the pair CS - 1 - k, i.e. by the LAST wave: wave 0 - which finishes the rows alone - goes from its
+      //  loads straight to the butterfly)
+      for (int k = CS - 1 - (grp * SUB + sub); k < K; k += CS)
         zsh[k][rr] = k < d ? (a.z ? a.z[zoff + k] : philox_normal(a.seed, a.stream, (unsigned long long)(zoff + k))) : 0.0;
     }
     if (first) {
 #pragma unroll
       for (int u = 0; u < UNR; ++u)
+        if (u < nfirst) {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) part[v] += x0[u][v];
-      c += UNR * CS;
+          for (int v = 0; v < NV; ++v) part[v] += x0[u][v];
+        }
+      c += nfirst * CS;
     }
     if (live1) {
       for (; c + (UNR - 1) * CS < a.nch; c += UNR * CS) {   // UNR chunks' loads in flight, added in order
@@ -1119,12 +1139,16 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     for (int v = 0; v < NVMAX; ++v) red[grp][v][lane] = part[v];
   }
   }
+  WS_STAMP(1);
   __syncthreads();
+  WS_STAMP(2);
   // Weighted rows of K = 6 and 8 leave WS_SPLIT (K + KK) = 216 / 176 values per row in LDS: wave 0 summing them all on
   // its own kept two hundred loaded doubles alive next to the solve's registers (148 VGPRs spilled at K = 6).  There
   // the waves first add the WS_SPLIT shares of every WS_SPLIT-th value each (same order: bit-identical sums), in place.
+  // (round 4: from 128 values on, i.e. nembeds 5 too - wave 0's 160 dependent LDS reads on 8 live lanes were 0.5 us of the
+  //  9.0 us launch at C3 with 5 % of the replicates missing)
 #ifndef BTF_WS_TWO_LEVEL_MIN
-#define BTF_WS_TWO_LEVEL_MIN 160
+#define BTF_WS_TWO_LEVEL_MIN 128
 #endif
   constexpr bool TWO_LEVEL = WEIGHTED && WS_SPLIT * (K + KK) > BTF_WS_TWO_LEVEL_MIN;
   if constexpr (TWO_LEVEL) {
@@ -1138,6 +1162,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
   }
   constexpr int NSH = (TWO_LEVEL || !WEIGHTED) ? 1 : WS_SPLIT;          // shares wave 0 still has to add (complete data: the pair's sum is whole)
   if (grp != 0) return;                      // wave 0 finishes: one lane per row
+  WS_STAMP(3);
   const bool live = lane < RW && il < a.nl;
   const int i = a.row0 + (live ? il : 0);
   const int d = i + 1 < K ? i + 1 : K;
@@ -1203,6 +1228,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     }
   }
   if (live && !ok && atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = i;
+  WS_STAMP(4);
   // y = L^-1 m ; x = L^-T (y + z)
   double y[K];
 #pragma unroll
@@ -1248,8 +1274,9 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     const int kk = lane >> 4, ii = lane & 15;
     const double* src = stg + (ii < K ? ii : 0) * WS_ROWS + kk;
     v4f64_w acc = {0.0, 0.0, 0.0, 0.0};
+    // (only the first RW staged rows are live - the others hold exact zeros: (RW + 3) / 4 steps give the same bits as 16)
 #pragma unroll
-    for (int sidx = 0; sidx < WS_ROWS / 4; ++sidx) {
+    for (int sidx = 0; sidx < (RW + 3) / 4; ++sidx) {
       const double x = ii < K ? src[4 * sidx] : 0.0;
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
     }
@@ -1260,6 +1287,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
       if (row < K && ii <= row) a.gout[(size_t)blockIdx.x * KK + lidx(row, ii)] = acc[r];
     }
   }
+  WS_STAMP(5);
 }
 
 // ============================================================================

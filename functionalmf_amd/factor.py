@@ -357,8 +357,9 @@ class BayesianTensorFiltering(_BayesianModel):
             every = getattr(self, "data_check_seconds", 5.0)
             now = time.monotonic()
             # (bounded duty cycle: the hash is O(data) on the host thread - 0.9 s for the 8.6 GB of config C5 - so the next
-            #  check is at least 50 hash times away, whatever `data_check_seconds` says: never more than 2 % of the wall clock)
-            if every is None or now - self._data_checked < max(every, 50.0 * getattr(self, "_digest_seconds", 0.0)):
+            #  check is at least 50 hash times away, whatever a positive `data_check_seconds` says: never more than 2 % of
+            #  the wall clock.  An explicit 0 asks for the reference's behaviour - look at the data on every half-sweep)
+            if every is None or now - self._data_checked < (max(every, 50.0 * getattr(self, "_digest_seconds", 0.0)) if every > 0 else 0.0):
                 return
             dig = tuple(_digest(a) for a in arrays)
             self._data_checked = time.monotonic()
@@ -393,8 +394,9 @@ class BayesianTensorFiltering(_BayesianModel):
         """Force a re-upload.  The reference re-reads the observation array on every half-sweep
         (factor.py:329-330, :374-375); here it is uploaded once and recognised again by identity, shape and
         a 64-point fingerprint, which catches wholesale in-place edits (imputation, rescaling) at once; a few
-        changed cells are caught by a hash of the whole array taken every `data_check_seconds` (default 5 s; None: never;
-        never more often than every 50 hash times - the hash is O(data) on the host thread), with a RuntimeWarning.  That
+        changed cells are caught by a hash of the whole array taken every `data_check_seconds` (default 5 s; None: never; 0: on
+        every half-sweep; otherwise never more often than every 50 hash times - the hash is O(data) on the host thread), with a
+        RuntimeWarning.  That
         check runs on the WALL clock: the sweep at which a silent in-place edit takes effect is not reproducible.  After
         mutating the array in place, call set_data(): the change then applies, deterministically, from the next half-sweep
         on."""
