@@ -424,6 +424,11 @@ def main():
                    "full_resample_sweeps_per_s": None if full_per_s is None else round(full_per_s, 2),
                    "v_sampler": sampler, "banded_sweeps_per_s": None if banded_per_s is None else round(banded_per_s, 2),
                    "likelihood_form": form,
+                   # what pins the mode this line times: the device-RNG chain is checked statistically, the
+                   # reference-reproducible chain (rng="host", legacy numpy stream) bit-level against the reference's fixtures
+                   "parity_of_this_mode": "rng=device (Philox normals, %s square root): statistical - whitening, KS / Anderson-Darling, "
+                                          "moment and conditional-mean tests at this size (tests/test_gpu_fullsize.py); the same kernels under "
+                                          "rng=host reproduce the reference's fixtures to 1e-10 (W) / 1e-6 (V) (tests/golden, G1-G9)" % sampler,
                    "parallelism": "rows(W)/cols(V) x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "accum_kernel (w_accum + v_accum launches)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -661,7 +666,12 @@ def pmc_traffic(config, variant, suffix=""):
         return None
     try:
         d = json.load(open(files[-1]))
-        vals = [v["hbm_bytes_per_launch_corrected"] for k, v in d.items() if "accum_kernel" in k]
+        # (the instances of THIS variant's likelihood form: the default run's short C4 leg leaves Binomial accumulation
+        #  launches in a complete-data profile)
+        import re
+        unweighted = variant in ("complete", "heldout", "curves5")
+        vals = [v["hbm_bytes_per_launch_corrected"] for k, v in d.items()
+                if (m := re.search(r"accum_kernel<\d+, (\d+),", k)) and ((m.group(1) == "0") == unweighted)]
         return (round(max(vals), 1), os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2 x FETCH + WRITE)") if vals else None
     except Exception:
         return None
