@@ -154,7 +154,11 @@ def build(force=False, verbose=False, jobs=None):
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
     tag = os.path.splitext(os.path.basename(LIB_PATH))[0]
+    # -amdgpu-kernarg-preload-count: gfx950's command processor hands the first 16 dwords of the kernel arguments over in
+    # SGPRs - the accumulation waves issue their first loads without a scalar round trip for the pointers (10.98 -> 10.63 us
+    # and 10.66 -> 10.33 us per launch at C3; the code object keeps the s_load prologue for firmware without the feature)
     base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function",
+            "-mllvm", "-amdgpu-kernarg-preload-count=16",
             "-I", os.path.join(ROOT, "include")] + os.environ.get("BTF_BUILD_DEFS", "").split()   # A/B builds: -DBTF_... tuning macros
     units = [(SOURCES[0], os.path.join(OBJ_DIR, tag + "_abi.o"), [])]
     units += [(INST_SOURCE, os.path.join(OBJ_DIR, "%s_inst%d.o" % (tag, p)), ["-DBTF_INST_PART=%d" % p])
