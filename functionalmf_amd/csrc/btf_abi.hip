@@ -87,6 +87,9 @@ struct btf_ctx {
   long long* acc_stamps = nullptr;
 #endif
   double* pband = nullptr;
+  // what the precomputed prior band (fused V launch, btf_fused.h) was formed from: every change of Tau2 / lam2 / the shard
+  // moves prior_version on; the band is rebuilt (prior_band_kernel) when pband_version lags behind
+  unsigned long long prior_version = 1, pband_version = 0;
   double* Ta = nullptr; double* Tb = nullptr; double* Tc = nullptr; double* lsum = nullptr;   // horseshoe+ chain (device mode)
   int* dr_ptr = nullptr; int* dr_col = nullptr; double* dr_val = nullptr;                   // Delta, CSR by row
   bool have_chain = false;
@@ -949,6 +952,7 @@ int btf_set_shard(btf_ctx* c, int row0, int nrows_local, int col0, int ncols_loc
     return fail(c, BTF_EINVAL, "shard out of range");
   c->row0 = row0; c->nl = nrows_local; c->col0 = col0; c->ml = ncols_local;
   c->hrow = c->hcol = -1;
+  ++c->prior_version;
   c->nb_bwt_written = false;      // (the skip of nb_bwt_target is only valid for the shard geometry B_wT was written under)
   return BTF_OK;
 }
@@ -1233,6 +1237,7 @@ int btf_set_hyper(btf_ctx* c, const double* Tau2, double lam2, double sigma2) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_hyper = true;
   }
+  if (Tau2 || lam2 != c->lam2) ++c->prior_version;        // (the host-RNG path re-sends the same scalars before every half-sweep)
   c->lam2 = lam2; c->sigma2 = sigma2;
   return BTF_OK;
 }
@@ -1271,6 +1276,7 @@ int btf_get_tau(btf_ctx* c, double* Tau2, double* Ta, double* Tb, double* Tc) {
 
 static TauSide tau_side_of(btf_ctx* c, uint64_t seed, double lam2, double stability) {
   TauSide t{};
+  ++c->prior_version;                                    // (whoever launches this side task redraws Tau2)
   t.V = c->V; t.T = c->T; t.nD = c->nD; t.M = c->M;
   t.dr_ptr = c->dr_ptr; t.dr_col = c->dr_col; t.dr_val = c->dr_val;
   t.lam2 = lam2; t.lo = stability; t.hi = 1.0 / stability;
@@ -1654,7 +1660,7 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
       Prof p(c, BTF_K_PRIOR);
       p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
                (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
-               (const double*)(c->dev_scalars ? c->hyp : nullptr));
+               (const double*)(c->dev_scalars ? c->hyp : nullptr), 0);
     }
     a.pband = c->pband;
   }
@@ -1797,6 +1803,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     if (c->lam_pending && c->dev_scalars && c->lsum && c->have_chain) {     // a queued lam2 | rest draw no scalar launch took
       sw.lam = LamSide{c->lsum, c->M, (double)c->nD * c->M * c->K + 1.0, c->lam_exact, c->lam_seed, c->hyp};
       c->lam_pending = false;
+      ++c->prior_version;
     }
     if (!fuse_v) {
       K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb,
@@ -1848,7 +1855,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
           Prof p(c, BTF_K_PRIOR);
           p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
                    (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
-                   (const double*)(c->dev_scalars ? c->hyp : nullptr));
+                   (const double*)(c->dev_scalars ? c->hyp : nullptr), 0);
         }
         sa.pband = c->pband;
       }
@@ -1857,6 +1864,20 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
         ++c->fz_epoch;
         FuseV fv{};
         fv.a = sa;
+        if (!sw.lam.hyp) {
+          // the prior band of every column, precomputed (rebuilt only when Tau2 / lam2 changed since): the tails load their
+          // entries at kernel start.  Not when lam2 is drawn by a side workgroup of this very launch - those tails form it
+          const int TD1 = T * (c->TF + 2);
+          if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; c->pband_version = 0; }
+          if (c->pband_version != c->prior_version) {
+            Prof p(c, BTF_K_PRIOR);
+            p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
+                     (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
+                     (const double*)(c->dev_scalars ? c->hyp : nullptr), 1);
+            c->pband_version = c->prior_version;
+          }
+          fv.a.pband = c->pband;
+        }
         fv.cnt = nch_all > 1 ? c->fz_words + FZ_TICKETS + c->fz_tiles_w : nullptr;
         { static const int be = [] { const char* e = std::getenv("BTF_BAND_EARLY"); return e ? std::atoi(e) : 0; }(); fv.band_early = be; }      // (A/B aid)
         fv.eig_pub = c->fz_pub + FZ_PUB_EIG; fv.eig_flag = c->fz_words + FZ_EIG; fv.epoch = c->fz_epoch;
@@ -2892,6 +2913,7 @@ int btf_device_scalars(btf_ctx* c, int enable) {
     if ((rc = ensure_hyp(c))) return rc;
   }
   c->dev_scalars = enable != 0;
+  ++c->prior_version;
   return BTF_OK;
 }
 
@@ -2902,6 +2924,7 @@ int btf_set_scalars(btf_ctx* c, double nu2, double sigma2, double lam2, double l
   if ((rc = ensure_hyp(c))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));      // the staging word may still be in flight
   c->nu2 = nu2; c->sigma2 = sigma2; c->lam2 = lam2;
+  ++c->prior_version;
   c->pin_hyp[HYP_NU2] = nu2; c->pin_hyp[HYP_SIGMA2] = sigma2; c->pin_hyp[HYP_LAM2] = lam2; c->pin_hyp[HYP_LAM2A] = lam2_a;
   HIPCHK(c, hipMemcpyAsync(c->hyp, c->pin_hyp, 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   return BTF_OK;
@@ -2915,6 +2938,7 @@ int btf_get_scalars(btf_ctx* c, double* out) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < 6; ++i) out[i] = c->pin_hyp[i];
   c->nu2 = out[HYP_NU2]; c->sigma2 = out[HYP_SIGMA2]; c->lam2 = out[HYP_LAM2];
+  ++c->prior_version;
   return BTF_OK;
 }
 
@@ -2984,7 +3008,7 @@ int btf_draw_scalars(btf_ctx* c, uint64_t seed, int which, double nu2_a, double 
              c->nobs_global >= 0.0 ? c->nobs_global : c->nobs, (const double*)c->W,
              c->N, c->K, nfree, nu2_a, nu2_b, sigma2_a, sigma2_b, which & 3, (unsigned long long)seed, c->hyp, phase,
              (const double*)c->lsum, c->M, (double)c->nD * c->M * c->K + 1.0, c->lam_exact, c->lam_seed);
-    if (with_lam) c->lam_pending = false;
+    if (with_lam) { c->lam_pending = false; ++c->prior_version; }
   }
   HIPCHK(c, hipGetLastError());
   return BTF_OK;
@@ -3027,6 +3051,7 @@ int btf_draw_lam2(btf_ctx* c, uint64_t seed, int compat) {
   HIPCHK(c, hipSetDevice(c->dev));
   const double shape = (double)c->nD * c->M * c->K + 1.0;
   c->lam_pending = false;
+  ++c->prior_version;
   {
     Prof p(c, BTF_K_HYPER);
     p.launch(lam2_kernel, dim3(1), dim3(256), 0, (const double*)c->lsum, c->M, shape, compat == BTF_COMPAT_EXACT ? 1 : 0,

@@ -335,7 +335,19 @@ constexpr int VF_MAILBOX = 128;                          // doubles at the top o
 // while the slower waves finish their rows and the sums are reduced: the stencil of its band entry, its Tau2 values
 template <> struct FusePre<FUSE_V> { typedef struct VPre type; };
 static_assert(VF_MAILBOX == VF_MAILBOX_DOUBLES, "mailbox");
-struct VPre { int se0, se1; int srow[VS_MAXE]; double scf[VS_MAXE]; double tau[2]; };                        // waves of a column's virtual workgroup (= VS_THREADS / 64)
+// BTF_VF_BANDPRE (default): the prior band of the tile's columns comes PRECOMPUTED (prior_band_kernel, whenever Tau2 / lam2
+// changed: btf_abi.hip, pband_version) - one double per thread loaded at kernel start and parked in a register pair through
+// the stream.  The form it replaces fetched the thread's stencil (16 rows + 16 coefficients) and Tau2 values a few row
+// groups before the stream ended: 50 live VGPRs under the 128-VGPR cap of the 16-wave instance, and the stream of the
+// fused launch ran 10.4 us instead of 8.5 (stamps).
+#ifndef BTF_VF_BANDPRE
+#define BTF_VF_BANDPRE 1
+#endif
+#if BTF_VF_BANDPRE
+struct VPre { double pv[2]; };      // entries tid and tid + 256 of the column's band (T (S+1) <= 512: T <= 128 at tf_order 2)
+#else
+struct VPre { int se0, se1; int srow[VS_MAXE]; double scf[VS_MAXE]; double tau[2]; };
+#endif                        // waves of a column's virtual workgroup (= VS_THREADS / 64)
 // the prior band of the tile's columns, formed BEFORE the stream (v_fused_band_early): per column [1/(lam2 Tau2) nD][P][Pm]
 // below the mailbox at the top of the instance's LDS
 __host__ __device__ inline int vf_band_doubles(int T, int TF, int nD) { return ((nD + 1) & ~1) + 2 * (((T + TF + 2) * (TF + 2) + 1) & ~1); }
@@ -357,8 +369,57 @@ __host__ __device__ inline bool vf_fits(int T, int K, int TF, int nD, int waves,
 // its mirror image, into the top of the LDS - it depends on the hyper-parameters only, and the memory system is idle
 // now; behind the stream the same loads queue behind everybody's.  Not in full sweeps whose lam2 is drawn by a side
 // workgroup of this very launch (fv.hp.flag): returns false, and the tail forms the band itself.
+#if BTF_VF_BANDPRE
+// at kernel start: this thread's entry of the precomputed band (a.pband: [ml][T][S+1]), issued ahead of the stream's first
+// loads (loads return in order: it is back when they are)
+template <int K, int S>
+__device__ __forceinline__ bool v_fused_band_preload(const FuseV& fv, int tile, VPre& pre) {
+  pre.pv[0] = pre.pv[1] = 0.0;
+  const VSpecArgs& a = fv.a;
+  if (!a.pband) return false;                             // (uniform: the tail forms the band itself)
+  const int T = a.T, NG = ACC_TILE / T;
+  const int lane = threadIdx.x & 63;
+  const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = pw % NG, wave = pw / NG, tid = wave * WAVE + lane;
+  const int j = tile * NG + cg;
+  constexpr int NT = VF_GROUP_WAVES * WAVE;
+  if (wave < VF_GROUP_WAVES && j < a.ml) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (tid + u * NT < T * (S + 1)) pre.pv[u] = a.pband[(size_t)j * T * (S + 1) + tid + u * NT];
+  }
+  return true;
+}
+// behind the stream, in front of the reduction (whose barriers publish it): the band and its mirror image into the top of
+// the LDS.  Thread (t, d) writes P[t][d] and its mirror entry Pm[T-1-t-d][d]; the entries of Pm no mirror image lands on
+// are those with t + d >= T, written as zeros by their own (t, d) thread - no zero fill, no barrier of its own.
+template <int K, int S>
+__device__ __forceinline__ void v_fused_band_store(const FuseV& fv, int tile, double* lds, const VPre& pre, bool unr3) {
+  const VSpecArgs& a = fv.a;
+  const int T = a.T, NG = ACC_TILE / T;
+  constexpr int D1 = S + 1, NT = VF_GROUP_WAVES * WAVE;
+  const int lane = threadIdx.x & 63;
+  const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = pw % NG, wave = pw / NG, tid = wave * WAVE + lane;
+  const int j = tile * NG + cg;
+  if (!(wave < VF_GROUP_WAVES && j < a.ml)) return;
+  const int PB = ((T + S + 1) * D1 + 1) & ~1, nDp = (a.nD + 1) & ~1;
+  double* top = lds + vf_top_base(T, a.TF, a.nD, unr3) + (size_t)cg * (nDp + 2 * PB);
+  double* P = top + nDp;
+  double* Pm = P + PB;
+  for (int idx = tid, u = 0; idx < (T + S + 1) * D1; idx += NT, ++u) {
+    const double v = (idx < T * D1 && u < 2) ? (u == 0 ? pre.pv[0] : pre.pv[1]) : 0.0;      // (T D1 <= 2 NT: vf_fits)
+    const int t = idx / D1, d = idx - t * D1;
+    P[idx] = v;
+    if (t + d < T) Pm[(T - 1 - t - d) * D1 + d] = v; else Pm[idx] = 0.0;
+  }
+}
+#endif
 template <int K, int S>
 __device__ __forceinline__ bool v_fused_band_early(const FuseV& fv, int tile, double* lds, bool unr3) {
+#if BTF_VF_BANDPRE
+  return false;                                           // (replaced by v_fused_band_preload / v_fused_band_store)
+#endif
   if (fv.hp.flag || !fv.band_early) return false;         // (uniform)
   const VSpecArgs& a = fv.a;
   const int T = a.T;
@@ -428,6 +489,9 @@ __device__ __forceinline__ void v_fused_prefetch_loads(const FuseV& fv, int tile
   const int cg = pw % NG, wave = pw / NG, tid = wave * WAVE + lane;
   const int j = tile * NG + cg, jg = a.col0 + j;
   const bool act = wave < VF_GROUP_WAVES && j < a.ml;
+#if BTF_VF_BANDPRE
+  (void)act; (void)jg; (void)tid;
+#else
   pre.se0 = pre.se1 = 0;
   pre.tau[0] = pre.tau[1] = 1.0;
   if (act && !band_early) {
@@ -448,6 +512,7 @@ __device__ __forceinline__ void v_fused_prefetch_loads(const FuseV& fv, int tile
     for (int u = 0; u < 2; ++u)
       if (tid + u * NT < a.nD) pre.tau[u] = a.Tau2[(size_t)jg * a.nD + tid + u * NT];
   }
+#endif
 }
 
 // Between the stream and the reduction: wave 0 waits for this launch's side workgroups (eigen-system of W'W; lam2 in
@@ -521,8 +586,10 @@ __device__ __forceinline__ void v_fused_tail(const FuseV& fv, int tile, double* 
     }
   }
   // ---- (the stencil, Tau2 and the published eigen-system / lam2 came in before the reduction: v_fused_prefetch) ----
+#if !BTF_VF_BANDPRE
   const int pidx = tid;
   const int scnt = pre.se1 - pre.se0;
+#endif
   if (*reinterpret_cast<const unsigned*>(mailbox + VF_MAILBOX - 1) == 0u) {      // a producer of this launch never showed up (uniform)
     if (threadIdx.x == 0 && atomicCAS(&a.status[0], 0, 2) == 0) a.status[1] = -1;
     return;
@@ -539,9 +606,14 @@ __device__ __forceinline__ void v_fused_tail(const FuseV& fv, int tile, double* 
   }
   if (act) {
     if (!band_early) {
+#if BTF_VF_BANDPRE
+      // (no precomputed band - lam2 is drawn by a side workgroup of this very launch: Tau2 fetched here, the stencil below)
+      for (int idx = tid; idx < a.nD; idx += NT) itau[idx] = 1.0 / (a.lam2 * a.Tau2[(size_t)jg * a.nD + idx]);
+#else
 #pragma unroll
       for (int u = 0; u < 2; ++u)
         if (tid + u * NT < a.nD) itau[tid + u * NT] = 1.0 / (a.lam2 * pre.tau[u]);
+#endif
     }
     if (fv.cnt) {
       const size_t st = (size_t)K * a.ld;
@@ -576,10 +648,14 @@ __device__ __forceinline__ void v_fused_tail(const FuseV& fv, int tile, double* 
     if (!band_early)
     for (int idx = tid; idx < (T + S + 1) * D1; idx += NT) {
       double s = 0.0;
+#if BTF_VF_BANDPRE
+      if (idx < T * D1) {
+#else
       if (idx == pidx) {
 #pragma unroll
         for (int u = 0; u < MAXE; ++u) if (u < scnt) s = fma(pre.scf[u], itau[pre.srow[u]], s);
       } else if (idx < T * D1) {
+#endif
         for (int e = a.st_ptr[idx]; e < a.st_ptr[idx + 1]; ++e) s = fma(a.st_coef[e], itau[a.st_row[e]], s);
       }
       P[idx] = s;

@@ -327,6 +327,13 @@ template <int K, int S> __device__ __forceinline__ void v_fused_prefetch(const F
 template <int K, int S, class PRE> __device__ __forceinline__ void v_fused_prefetch_loads(const FuseV& fv, int tile, PRE& pre, bool band_early);
 constexpr int VF_PRE = 4;                  // row groups of the stream behind the fused V tail's prefetch
 template <int K, int S> __device__ __forceinline__ bool v_fused_band_early(const FuseV& fv, int tile, double* lds, bool unr3);
+#ifndef BTF_VF_BANDPRE
+#define BTF_VF_BANDPRE 1
+#endif
+#if BTF_VF_BANDPRE
+template <int K, int S> __device__ __forceinline__ bool v_fused_band_preload(const FuseV& fv, int tile, VPre& pre);
+template <int K, int S> __device__ __forceinline__ void v_fused_band_store(const FuseV& fv, int tile, double* lds, const VPre& pre, bool unr3);
+#endif
 template <int FUSE> struct FusePre { struct type {}; };
 constexpr int VF_MAILBOX_DOUBLES = 128;
 template <int FUSE> __device__ __forceinline__ unsigned* fuse_tickets(const typename FuseSel<FUSE>::type& fz);
@@ -531,6 +538,9 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   bool band_early = false;
   if constexpr (FUSE == FUSE_V) band_early = v_fused_band_early<K, 3>(fz, tile, &red[0][0][0], UNRV == 3);
   typename FusePre<FUSE>::type vpre;
+#if BTF_VF_BANDPRE
+  if constexpr (FUSE == FUSE_V) band_early = v_fused_band_preload<K, 3>(fz, tile, vpre);
+#endif
   double acc[NV][OPL];
 #pragma unroll
   for (int v = 0; v < NV; ++v)
@@ -706,6 +716,9 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   //  the reduction - btf_fused.h)
   if constexpr (FUSE == FUSE_V) {
     if constexpr (ULDS) v_fused_prefetch_loads<K, 3>(fz, tile, vpre, band_early);      // (the staged-factor form of long row ranges: here)
+#if BTF_VF_BANDPRE
+    if (band_early) v_fused_band_store<K, 3>(fz, tile, &red[0][0][0], vpre, UNRV == 3);
+#endif
     v_fused_prefetch<K, 3>(fz, tile, &red[0][0][0] + RED_SLOTS * RED_SLOT - VF_MAILBOX_DOUBLES, vpre, band_early);
   }
   // cross-wave reduction through LDS, ACC_RG values per round, fixed order
@@ -1343,14 +1356,23 @@ __device__ __forceinline__ void vband_load_hyp(VBandArgs& a) {
 static __global__ void prior_band_kernel(const double* __restrict__ Tau2, double lam2, int nD,
                                   const int* __restrict__ st_ptr, const int* __restrict__ st_row,
                                   const double* __restrict__ st_coef, int TD1, int col0, int ml,
-                                  double* __restrict__ pband, const double* __restrict__ hyp) {
+                                  double* __restrict__ pband, const double* __restrict__ hyp, int spectral_form) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= ml * TD1) return;
   if (hyp) lam2 = hyp[HYP_LAM2];
   const int j = idx / TD1, e0 = idx - j * TD1;
   const double* tau = Tau2 + (size_t)(col0 + j) * nD;
   double s = 0.0;
-  for (int e = st_ptr[e0]; e < st_ptr[e0 + 1]; ++e) s += st_coef[e] / (lam2 * tau[st_row[e]]);
+  if (spectral_form) {
+    // the arithmetic of v_spectral_kernel's own band (reciprocal of the rounded product, then one fma per penalty row): the
+    // fused V tails (btf_fused.h) load this band and must land on the bits of the four-launch path
+    for (int e = st_ptr[e0]; e < st_ptr[e0 + 1]; ++e) {
+      const double it = 1.0 / __dmul_rn(lam2, tau[st_row[e]]);
+      s = fma(st_coef[e], it, s);
+    }
+  } else {
+    for (int e = st_ptr[e0]; e < st_ptr[e0 + 1]; ++e) s += st_coef[e] / (lam2 * tau[st_row[e]]);
+  }
   pband[idx] = s;
 }
 

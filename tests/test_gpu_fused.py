@@ -57,7 +57,10 @@ def test_two_launch_step_is_bit_identical_to_four_launches(dims, rng, mode):
             m._resample_V(Y)
         m.sync()
     la, lb = _launches(a), _launches(b)
-    assert la == ({"w_accum": 4, "v_accum": 4} if mode == 2 else {"w_accum": 4, "w_solve": 4, "v_accum": 4}), la      # two / three launches per step
+    # two / three launches per step, and ONE prior_band launch in all: the fused V tails load the precomputed prior band of
+    # their columns, rebuilt only when Tau2 / lam2 change
+    assert la.pop("prior_band") == 1, la
+    assert la == ({"w_accum": 4, "v_accum": 4} if mode == 2 else {"w_accum": 4, "w_solve": 4, "v_accum": 4}), la
     assert lb == {"w_accum": 4, "w_solve": 4, "v_accum": 4, "v_banded": 4}, lb
     assert np.array_equal(a.W, b.W)
     assert np.array_equal(a.V, b.V)
