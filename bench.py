@@ -375,10 +375,16 @@ def main():
     _b = _C.c_double()
     model._ctx.call("btf_get_accum_bytes_per_cell", _C.byref(_b))
     bpc = _b.value                     # 8: statistic alone; 9: + byte counts, or byte pseudo-data + f64 weights; 16: f64 + f64
-    acc_ms = kt["w_accum"][0] + kt["v_accum"][0]
-    acc_n = kt["w_accum"][1] + kt["v_accum"][1]
+    # (BTF_OPT_FUSED_STEP, the default on complete data at whole-column tiles: the V accumulation launch carries the spectral
+    #  sampler as its tail - no launch of its own - and its duration is stream + sampler; the roofline of the streaming kernel
+    #  is then taken from the W accumulation launch alone, the same kernel without a tail)
+    v_fused = model.v_sampler() == "spectral" and kt.get("v_banded", (0.0, 0))[1] == 0 and kt["v_accum"][1] > 0
+    w_fused = kt.get("w_solve", (0.0, 0))[1] == 0 and kt["w_accum"][1] > 0
+    plain = [k for k, f in (("w_accum", w_fused), ("v_accum", v_fused)) if not f] or ["w_accum", "v_accum"]
+    acc_ms = sum(kt[k][0] for k in plain)
+    acc_n = sum(kt[k][1] for k in plain)
     acc_us = 1e3 * acc_ms / max(acc_n, 1)
-    alg_bytes = bpc * 0.5 * (cells_local + cells_local_v)
+    alg_bytes = bpc * sum({"w_accum": cells_local, "v_accum": cells_local_v}[k] for k in plain) / len(plain)
     achieved = alg_bytes / (acc_us * 1e-6) / 1e9 if acc_us > 0 else 0.0
     # the same W+V step with the reference-reproducible V sampler (`sampler="banded"`: P'L^-T of a declared ordering,
     # the mode that can walk a seeded reference chain) beside the spectral one the headline uses
@@ -424,13 +430,17 @@ def main():
                    "full_resample_sweeps_per_s": None if full_per_s is None else round(full_per_s, 2),
                    "v_sampler": sampler, "banded_sweeps_per_s": None if banded_per_s is None else round(banded_per_s, 2),
                    "likelihood_form": form,
+                   "launches_per_step": 4 - int(v_fused) - int(w_fused),
                    # what pins the mode this line times: the device-RNG chain is checked statistically, the
                    # reference-reproducible chain (rng="host", legacy numpy stream) bit-level against the reference's fixtures
                    "parity_of_this_mode": "rng=device (Philox normals, %s square root): statistical - whitening, KS / Anderson-Darling, "
                                           "moment and conditional-mean tests at this size (tests/test_gpu_fullsize.py); the same kernels under "
                                           "rng=host reproduce the reference's fixtures to 1e-10 (W) / 1e-6 (V) (tests/golden, G1-G9)" % sampler,
                    "parallelism": "rows(W)/cols(V) x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "accum_kernel (w_accum + v_accum launches)",
+        "roofline": {"bound": "hbm", "kernel": "accum_kernel (%s)" % (" + ".join(plain) + " launches" if len(plain) == 2 else
+                                                                       plain[0] + " launch; the other accumulation launch carries its "
+                                                                       "sampler / solve as a fused tail: kernels_us." +
+                                                                       ("v_accum" if v_fused else "w_accum") + " = stream + tail"),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(acc_us, 2),
@@ -668,10 +678,9 @@ def pmc_traffic(config, variant, suffix=""):
         d = json.load(open(files[-1]))
         # (the instances of THIS variant's likelihood form: the default run's short C4 leg leaves Binomial accumulation
         #  launches in a complete-data profile)
-        import re
         unweighted = variant in ("complete", "heldout", "curves5")
         vals = [v["hbm_bytes_per_launch_corrected"] for k, v in d.items()
-                if (m := re.search(r"accum_kernel<\d+, (\d+),", k)) and ((m.group(1) == "0") == unweighted)]
+                if (mode := _plain_accum(k)) is not None and ((mode == "0") == unweighted)]
         return (round(max(vals), 1), os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2 x FETCH + WRITE)") if vals else None
     except Exception:
         return None
@@ -694,6 +703,18 @@ def valu_insts(config, variant, kernel):
     return None
 
 
+def _plain_accum(name):
+    """Is this kernel name a plain accumulation launch - accum_kernel<K, MODE, WAVES, TX, TC, UNR, OPL, FUSE> with FUSE == 0
+    (FUSE 1 / 2: the launch carries the W solves / the spectral sampler as its tail, csrc/btf_fused.h - its duration is
+    not the stream's)?  Returns the likelihood MODE as a string, or None."""
+    import re
+    m = re.search(r"accum_kernel<\d+, (\d+), \d+, [^,]+, [^,]+, \d+, \d+, (\d+)>", name)
+    if m:
+        return m.group(1) if m.group(2) == "0" else None
+    m = re.search(r"accum_kernel<\d+, (\d+), \d+, [^,]+, [^,]+, \d+, \d+>", name)      # (profiles of rounds 2-3: no FUSE argument)
+    return m.group(1) if m else None
+
+
 def rocprof_accum_avg(config, variant, suffix=""):
     """(average us, file) of the accumulation kernels in the newest committed `rocprofv3 --kernel-trace --stats` summary of a
     --lean run of this workload (profiles/r*_<config>_<variant><suffix>_lean_kernel_stats.csv: calls-weighted AverageNs
@@ -706,7 +727,7 @@ def rocprof_accum_avg(config, variant, suffix=""):
     try:
         tot = calls = 0.0
         for r in csv.DictReader(open(files[-1])):
-            if "accum_kernel" in r["Name"]:
+            if _plain_accum(r["Name"]) is not None:      # (not the launches that carry a fused tail)
                 tot += float(r["TotalDurationNs"]); calls += float(r["Calls"])
         return (1e-3 * tot / calls, os.path.relpath(files[-1], ROOT)) if calls else None
     except Exception:

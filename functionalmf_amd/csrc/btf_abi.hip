@@ -149,7 +149,7 @@ struct btf_ctx {
   unsigned long long sweep_w = 0, sweep_v = 0;
   // the two-launch W+V step (BTF_OPT_FUSED_STEP, btf_fused.h): tickets / flags (zeroed once; 32 words = one 128-byte line
   // per flag), the write-through copies the tails read, the epoch of the hand-offs (one per fused launch, never reused)
-  int fused_step = 0;                // BTF_OPT_FUSED_STEP: 0 (default) four launches, 1 the V launch carries its sampler, 2 the W launch its solve too
+  int fused_step = 1;                // BTF_OPT_FUSED_STEP: 0 four launches, 1 (default) the V launch carries its sampler, 2 the W launch its solve too
   unsigned* fz_words = nullptr; int fz_tiles_w = 0, fz_tiles_v = 0;
   double* fz_pub = nullptr;
   unsigned fz_epoch = 0, fz_gram_total = 0, fz_w_total = 0;

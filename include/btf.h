@@ -84,16 +84,16 @@ enum {
                                 (a residual reduction and a scalar-draw launch between W accumulation and W solve).  Same
                                 conditionals, same Philox streams; the sums are formed in another order (rounding).  0: six.   */
   BTF_OPT_FUSED_STEP = 7,    /* Latency kernels as parts of the streaming launches (csrc/btf_fused.h), complete Gaussian data.
-                                0 (default): a W+V step is four launches.
-                                1: the spectral sampler of _resample_V (factor.py:377-409, fast_mvn.py:35-47) is the TAIL of the V
-                                accumulation launch - a tile of 128 (column, depth) outputs is whole columns (ndepth 32, 64 or 128;
-                                tf_order 2; nembeds <= 8), their sums go from the reduction straight into the sampler's layout.
+                                0: a W+V step is four launches.
+                                1 (default): the spectral sampler of _resample_V (factor.py:377-409, fast_mvn.py:35-47) is the TAIL
+                                of the V accumulation launch - a tile of 128 (column, depth) outputs is whole columns (ndepth 32, 64
+                                or 128; tf_order 2; nembeds <= 8; other shapes run the four-launch form), their sums go from the
+                                reduction straight into the sampler's layout; the prior band of the columns is precomputed
+                                (prior_band_kernel, only when Tau2 / lam2 changed) and loaded at kernel start.
                                 2: also the batched K x K solve of _resample_W (factor.py:349-362), by "owner" workgroups of the W
                                 accumulation launch that wait for their tile's streaming workgroups: two launches.
                                 All three walk the same chain bit for bit (tests/test_gpu_fused.py).  Measured on MI355X at
-                                (512,256,64) nembeds 5: 41.9 / 42.2 / 45.5 us per step - a kernel boundary between queued launches
-                                costs ~0.8 us there, an in-launch hand-off between workgroups 2-4 us: the
-                                fused forms are kept as measured A/B options, not as the default. */
+                                (512,256,64) nembeds 5: 41.2 / 38.7 / 42.2 us per step. */
   BTF_OPT_SPLIT_ACCUM = 5,   /* sharded Gaussian contexts: 1 - the streaming accumulation of a half-sweep runs in two launches: the
                                 chunks that reduce over this rank's OWN block of the fixed factor (its columns of V for the W
                                 half-sweep, its rows of W for the V half-sweep) are queued right behind the kernel that drew
