@@ -212,7 +212,7 @@ def test_shard_plan_rejects_more_shards_than_the_padding_allows():
 
 
 def test_no_vgpr_spills_in_the_hot_kernels():
-    """Code-object notes of the built library (scripts/kernel_notes.py: the NT_AMDGPU_METADATA note of every embedded
+    """(and bounded SGPR spills in the instances of BASELINE configs 3 / 4)  Code-object notes of the built library (scripts/kernel_notes.py: the NT_AMDGPU_METADATA note of every embedded
     gfx950 ELF): the streaming accumulation, the W solve and the flat Polya-Gamma kernels must not spill VGPRs for any
     supported nembeds (1..10) - K = 9 / 10 weighted accumulation, w_solve<6, weighted> and the K = 10 eigen side task
     did before round 3."""
@@ -231,6 +231,18 @@ def test_no_vgpr_spills_in_the_hot_kernels():
     assert not bad, bad
     ks = {int(m) for r in hot for m in __import__("re").findall(r"accum_kernelILi(\d+)E", r["mangled"])}
     assert ks == set(range(1, 11)), ks
+    # SGPR spills of the instances BASELINE configs 3 / 4 launch (VERDICT r03 asked for an honest count): ceilings a little
+    # above what the shipped build has (kernel_notes: accumulation 19 - all in the side-task code, the streaming waves
+    # execute none -, spectral sampler 6, W solves and the flat Polya-Gamma kernel 0, twisted sampler 121 - its target of
+    # < 32 is NOT met), so that a change that brings spills back is seen here
+    c3 = {"accum_kernelILi5ELi0ELi16EddLi0ELi2ELi0E": 24, "accum_kernelILi5ELi0ELi16EddLi0ELi2ELi2E": 24,
+          "accum_kernelILi5ELi1ELi12EhdLi0ELi2ELi0E": 24, "accum_kernelILi5ELi2ELi12EdaLi0ELi2ELi0E": 24,
+          "w_solve_kernelILi5ELb0ELi8E": 0, "w_solve_kernelILi5ELb1ELi8E": 0, "v_spectral_kernelILi3ELb0ELi5E": 16,
+          "pgx_tile_kernelILi5ELi4ELi4E": 0, "v_banded_twist_kernelILi2ELb1ELi5ELi2ELi64E": 128}
+    for tag, cap in c3.items():
+        inst = [r for r in rows if tag in r["mangled"]]
+        assert len(inst) == 1, (tag, len(inst))
+        assert inst[0]["sgpr_spill"] <= cap and inst[0]["vgpr_spill"] == 0, (tag, inst[0]["sgpr_spill"], inst[0]["vgpr_spill"])
 
 
 def test_host_selftest_of_tables_layouts_and_chunk_maps():
