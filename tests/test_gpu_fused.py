@@ -116,3 +116,36 @@ def test_two_launch_step_at_c3_size_matches_and_repeats():
         runs.append((m.W.copy(), m.V.copy()))
     for W, V in runs[1:]:
         assert np.array_equal(runs[0][0], W) and np.array_equal(runs[0][1], V)
+
+
+@pytest.mark.parametrize("rng", ["host", "device"])
+def test_precomputed_prior_band_follows_the_hyper_parameters(rng):
+    """The fused V tails load a prior band that is rebuilt only when Tau2 / lam2 change (prior_version in btf_abi.hip): new
+    values pushed from the host between steps - the Tau2 array, lam2 alone, both - must reach the next V draw, i.e. the chain
+    stays bit-identical to the four-launch path, which forms the band from Tau2 and lam2 inside the sampler every time."""
+    dims = (96, 6, 64, 2, 5)
+    Y = _synth(*dims)
+    a, b = _make(dims, 1, rng, "reference"), _make(dims, 0, rng, "reference")
+    rs = np.random.RandomState(4)
+    nD = np.asarray(a.Tau2).shape[1]
+    edits = [None, ("Tau2", rs.gamma(2.0, 0.5, size=(dims[1], nD))), ("lam2", 0.37), None,
+             ("both", rs.gamma(2.0, 0.5, size=(dims[1], nD)), 0.05), None]
+    for m in (a, b):
+        np.random.seed(5)
+        m._bind_data(Y)
+        m._ctx.kernel_times()
+        for e in edits:
+            if e is not None:
+                if e[0] in ("Tau2", "both"):
+                    m.Tau2 = e[1].copy()
+                if e[0] == "lam2":
+                    m.lam2 = e[1]
+                if e[0] == "both":
+                    m.lam2 = e[2]
+            m._resample_W(Y)
+            m._resample_V(Y)
+        m.sync()
+    assert np.array_equal(a.W, b.W) and np.array_equal(a.V, b.V)
+    la = _launches(a)
+    assert la["prior_band"] == 4, la            # first use + three edits; the steps without an edit reuse the band
+    assert "v_banded" not in la and la["v_accum"] == len(edits), la
