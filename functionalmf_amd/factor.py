@@ -50,12 +50,13 @@ def _scalar(x):
 
 
 def _fingerprint(a):
-    """Cheap content check of an observation array (see set_data): sum and NaN count of 64 strided entries."""
+    """Cheap content check of an observation array (see set_data): the bytes of 64 strided entries (NaN patterns
+    included).  ~1 us - it runs in front of every half-sweep's launches (np.nansum + isnan took 8 us of the ~15 us a
+    half-sweep spends on the host)."""
     flat = a.reshape(-1) if isinstance(a, np.ndarray) and a.flags.c_contiguous else None
     if flat is None or flat.size == 0:
         return None
-    s = flat[::max(1, flat.size // 61)][:64]
-    return float(np.nansum(s)), int(np.isnan(s).sum())
+    return flat[::max(1, flat.size // 61)][:64].tobytes()
 
 
 def _digest(a):
