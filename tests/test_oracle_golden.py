@@ -177,6 +177,22 @@ def test_pg_series_sampler_moments():
         assert abs(x.var() - v) / v < 0.08
 
 
+def test_pg_series_sampler_for_many_cells_has_the_moments_of_each_cell():
+    """pg_draw_series_cells (the CPU stand-in for pgdrawv that bench.py's Binomial cpu_baseline times): one tilt per cell,
+    the truncated tail replaced by its mean in closed form - mean and variance per group of equal tilts against the
+    Polya-Gamma moments (Polson, Scott & Windle 2013, sec. 2.3)."""
+    rng = np.random.RandomState(3)
+    tilts = np.array([0.0, 0.3, 1.5, 4.0, 9.0])
+    n = 20000
+    for b in (1.0, 4.0):
+        x = orc.pg_draw_series_cells(b, np.repeat(tilts, n), rng).reshape(len(tilts), n)
+        for row, c in zip(x, tilts):
+            m, v = orc.pg_mean(b, c), orc.pg_var(b, c)
+            assert abs(row.mean() - m) < 5 * np.sqrt(v / n), (b, c, row.mean(), m)
+            assert abs(row.var() - v) / v < 0.08, (b, c)
+    assert np.all(orc.pg_draw_series_cells(4.0, np.array([-2.0, 2.0]), np.random.RandomState(1)) > 0)     # (even in the tilt)
+
+
 def test_strong_cpu_path_equals_reference_faithful_path(golden):
     """The vectorised / banded-LAPACK CPU baseline computes the same draws (depth-major order)."""
     g = golden("g2_c2_complete.npz")
