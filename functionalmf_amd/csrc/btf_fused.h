@@ -1,20 +1,25 @@
-// The W+V step as TWO launches instead of four (BTF_OPT_FUSED_STEP): the latency kernel that follows each streaming
-// accumulation - w_solve_kernel behind the W accumulation, v_spectral_kernel behind the V accumulation - runs as the
-// TAIL of the accumulation launch itself.
+// Latency kernels as TAILS of the streaming launches (BTF_OPT_FUSED_STEP): the kernel that follows each streaming
+// accumulation - w_solve_kernel behind the W accumulation, v_spectral_kernel behind the V accumulation - runs inside the
+// accumulation launch itself.  1 (the default): the V launch only; 2: both (two launches per W+V step).
 //
-//   W launch  accum_kernel<K, 0, 16, ..., FUSE_W>: the workgroups of a 128-row tile write their chunk sums write-through
-//             (sc1) and draw a ticket from the tile's counter; the workgroup whose ticket comes last sums the chunks,
-//             factors and draws its 128 rows (factor.py:349-362) and leaves its share of W'W - what w_solve_kernel did one
-//             launch boundary and one cold start later.  Every wave of the tail plays one virtual w_solve workgroup (same
-//             chunk order, same butterflies, same matrix-core products): the draws are bit-identical to the four-launch path.
 //   V launch  accum_kernel<K, 0, 16, ..., FUSE_V>: a 128-output tile of the (column, depth) axis is 128 / T whole columns.
 //             With one chunk (C3: the workgroup streams all rows of W) the column sums never leave the workgroup: they
 //             go from the cross-wave reduction straight into the spectral sampler's LDS layout; with several chunks the
-//             last arriver of the tile sums them as above.  The eigen-system of W'W is still solved by the side
-//             workgroup of the same launch; it is published write-through with a flag the tails poll (once, by one
-//             lane, after their stream has ended).  Then the 2K elimination chains of every column of the tile run as in
-//             v_spectral_kernel<S, false, K> - a four-wave "virtual workgroup" per column, the chain waves of the columns
-//             on different SIMDs - with the same arithmetic in the same order: bit-identical draws again.
+//             last arriver of the tile (ticket) sums the others' write-through partials.  The prior band of the columns
+//             comes precomputed (prior_band_kernel, rebuilt when Tau2 / lam2 changed): one double per thread loaded at
+//             kernel start, parked in registers through the stream (v_fused_band_preload / _store).  The eigen-system of
+//             W'W is still solved by the side workgroup of the same launch; it is published write-through with a flag
+//             the tails poll (once, by one lane, after their stream has ended).  Then the 2K elimination chains of every
+//             column of the tile run as in v_spectral_kernel<S, false, K> - a four-wave "virtual workgroup" per column,
+//             the chain waves of the columns on different SIMDs - with the same arithmetic in the same order:
+//             bit-identical draws.  Measured at C3: 20.8 us against 10.6 + 0.8 + 12.1 us for the two launches.
+//   W launch  accum_kernel<K, 0, 16, ..., FUSE_W>: the streaming workgroups of a 128-row tile write their chunk sums
+//             write-through (sc1) and add to the tile's counter; dedicated OWNER workgroups (32 rows each; they stream
+//             nothing and have prepared normals, Gram and scalars meanwhile) poll the counter, fetch the chunk sums, add
+//             them per (row, value) pair in chunk order - w_solve_kernel's canonical order - factor and draw their rows
+//             (factor.py:349-362) and leave the W'W shares of their virtual w_solve workgroups: bit-identical draws.
+//             Measured at C3: 18.9 us against 10.7 + 0.8 + 4.7 us - the write-through partials of 32 workgroups have to
+//             drain before the counter may move (3.6 us) and be fetched (2.8 us): an option, not the default.
 //
 // Hand-off protocol (MI355X_MICROARCH.md, workgroup dispatch / inter-workgroup visibility, first row of the table of
 // measured sc1 hand-offs): every handed-off byte is stored sc1 (8-byte relaxed agent-scope atomic stores), every storing
