@@ -351,6 +351,13 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
                   const FuseW* fw = nullptr, const FuseV* fv = nullptr) {
   // nch: the chunks THIS launch covers (all of them unless cm says otherwise)
   if (cm.row_end == 0) cm.row_end = Rdim;
+  {
+    // Non-temporal loads for slabs the Infinity Cache cannot keep: a half-sweep pair streams both layouts, so a layout is
+    // still there one step later only if two of them (plus the weights) fit.  Threshold on the f64 statistic of ONE launch;
+    // BTF_NT_MIN_MB overrides (0: always, a huge value: never).
+    static const double min_mb = [] { const char* e = std::getenv("BTF_NT_MIN_MB"); return e ? std::atof(e) : 100.0; }();
+    cm.nt = (double)Rdim * (double)ld * 8.0 >= min_mb * 1048576.0 ? 1 : 0;
+  }
 #ifdef BTF_ACC_STAMPS
   cm.stamps = c->acc_stamps;
 #endif

@@ -50,6 +50,16 @@ __device__ __forceinline__ void publish_epoch(unsigned* flag, unsigned epoch) { 
   __hip_atomic_store((gu32_t*)flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------- streaming (non-temporal) loads
+// global_load_dwordx4 ... nt: read-once data that does not fit the 256 MB Infinity Cache should not be allocated there
+// (C5: the 2.1 GB statistic streams at 6.87 TB/s with the hint, 6.59 without); data that does fit must NOT carry it
+// (C3: 67 MB per launch, both layouts resident: 10.7 us per launch, 13.4 with the hint - every read goes to HBM).
+typedef double v2d_stream __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 stream_load2(const double* p) {
+  const v2d_stream v = __builtin_nontemporal_load(reinterpret_cast<const v2d_stream*>(p));
+  return make_double2(v.x, v.y);
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 // Counter-based generator (Salmon et al. 2011): draws are a pure function of
 // (seed, stream, index), so results do not depend on launch geometry or on how

@@ -244,6 +244,7 @@ struct GramSide { const double* U; int Rdim; double* gpart; int nblocks; unsigne
 // slots.  {0, 0, INT_MAX, 0, Rdim}: every row, slot = chunk.
 struct ChunkMap {
   int slot_base, row_base, skip_at, skip_rows, row_end; int nside;     // nside: side workgroups in front (set by launch_accum)
+  int nt;                  // 1: the statistic is streamed with non-temporal loads (slabs beyond the Infinity Cache: launch_accum)
 #ifdef BTF_ACC_STAMPS
   long long* stamps;       // diagnostic builds: [8192][8] wall-clock stamps of the streaming workgroups (4..7: the fused tails)
 #endif
@@ -546,6 +547,11 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   for (int v = 0; v < NV; ++v)
 #pragma unroll
     for (int o = 0; o < OPL; ++o) acc[v][o] = 0.0;
+#ifdef BTF_NO_NT
+  constexpr bool nt = false;                              // (A/B builds: the loop without the second form of the load)
+#else
+  const bool nt = __builtin_amdgcn_readfirstlane(cm.nt) != 0;      // (uniform: the loop is compiled for both forms of the load)
+#endif
   int s0 = 0, s1 = 0;
   if constexpr (MODE == 2) {
     s0 = srcmap[col];
@@ -557,8 +563,9 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   // FULL: every row of the group exists - no guards, one basic block (the guarded form is the tail's)
   // (OPL == 1: only the .x halves of the pairs are used)
   struct Rows { double2 x[ACC_UNR]; double2 c[MODE >= 1 ? ACC_UNR : 1]; double2 cs[MODE == 2 ? ACC_UNR : 1]; double uk[ACC_UNR][K]; };
-  auto load_rows = [&](int rb, Rows& R, auto full) {
+  auto load_rows = [&](int rb, Rows& R, auto full, auto ntc) {
     constexpr bool FULL = decltype(full)::value;
+    constexpr bool NT = decltype(ntc)::value;       // (the statistic by non-temporal loads: see ChunkMap.nt)
 #pragma unroll
     for (int u = 0; u < ACC_UNR; ++u) {
       const int r = rb + u * NWR;  // wave-uniform
@@ -582,14 +589,16 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
             const char2 xx = *reinterpret_cast<const char2*>(X + (size_t)r * ld + col);
             R.x[u] = make_double2(0.5 * (double)xx.x, 0.5 * (double)xx.y);
           } else {
-            R.x[u] = *reinterpret_cast<const double2*>(X + (size_t)r * ld + col);
+            if constexpr (NT) R.x[u] = stream_load2(reinterpret_cast<const double*>(X) + (size_t)r * ld + col);
+            else R.x[u] = *reinterpret_cast<const double2*>(X + (size_t)r * ld + col);
           }
           if constexpr (MODE >= 1) {
             if constexpr (sizeof(CT) == 1) {
               const uchar2 cc = *reinterpret_cast<const uchar2*>(Cx + (size_t)r * ld + col);
               R.c[u] = make_double2((double)cc.x, (double)cc.y);
             } else {
-              R.c[u] = *reinterpret_cast<const double2*>(Cx + (size_t)r * ld + col);
+              if constexpr (NT) R.c[u] = stream_load2(reinterpret_cast<const double*>(Cx) + (size_t)r * ld + col);
+              else R.c[u] = *reinterpret_cast<const double2*>(Cx + (size_t)r * ld + col);
             }
           }
           if constexpr (MODE == 2) R.cs[u] = make_double2((double)Cx[(size_t)r * ld + s0], (double)Cx[(size_t)r * ld + s1]);
@@ -640,6 +649,8 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   constexpr bool PIPELINED = MODE >= 1 && BTF_ACC_PF_WT;      // (complete data: 5 FMAs per load, nothing to hide)
   const int full_end = r1 - (ACC_UNR - 1) * NWR;              // groups starting below it have all their rows
   int rb = r0 + wv;
+  // (the whole stream once per form of the load: no branch inside the loops)
+  auto run_stream = [&](auto ntc) {
   if constexpr (ULDS) {
     // blocks of ACC_UROWS rows: copy the block's factor rows (contiguous: rows x K doubles, 16-byte aligned since the
     // block starts at a multiple of 64 rows), then the waves stream its rows as below; STEP divides ACC_UROWS, so a
@@ -660,12 +671,12 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       const int bfull = min(full_end, bend - (ACC_UNR - 1) * NWR);
       for (; rb < bfull; rb += STEP) {
         Rows A;
-        load_rows(rb, A, std::true_type{});
+        load_rows(rb, A, std::true_type{}, ntc);
         compute(rb, A);
       }
       if (rb < bend) {                                         // the block's (= the range's: blocks before the last are whole) tail
         Rows A;
-        load_rows(rb, A, std::false_type{});
+        load_rows(rb, A, std::false_type{}, ntc);
         compute(rb, A);
         rb += STEP;
       }
@@ -673,15 +684,15 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   } else if constexpr (PIPELINED) {
     Rows A, B;
     bool more = rb < full_end;
-    if (more) load_rows(rb, A, std::true_type{});
+    if (more) load_rows(rb, A, std::true_type{}, ntc);
     while (more) {
       const bool nextB = rb + STEP < full_end;
-      if (nextB) load_rows(rb + STEP, B, std::true_type{});
+      if (nextB) load_rows(rb + STEP, B, std::true_type{}, ntc);
       compute(rb, A);
       rb += STEP;
       if (!nextB) break;
       more = rb + STEP < full_end;
-      if (more) load_rows(rb + STEP, A, std::true_type{});
+      if (more) load_rows(rb + STEP, A, std::true_type{}, ntc);
       compute(rb, B);
       rb += STEP;
     }
@@ -692,25 +703,27 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       const int pre_end = full_end - VF_PRE * STEP;
       for (; rb < pre_end; rb += STEP) {
         Rows A;
-        load_rows(rb, A, std::true_type{});
+        load_rows(rb, A, std::true_type{}, ntc);
         compute(rb, A);
       }
       v_fused_prefetch_loads<K, 3>(fz, tile, vpre, band_early);
     }
     for (; rb < full_end; rb += STEP) {
       Rows A;
-      load_rows(rb, A, std::true_type{});
+      load_rows(rb, A, std::true_type{}, ntc);
       compute(rb, A);
     }
   }
   if constexpr (!ULDS) {
     if (rb < r1) {
       Rows A;
-      load_rows(rb, A, std::false_type{});
+      load_rows(rb, A, std::false_type{}, ntc);
       compute(rb, A);
     }
   }
 
+  };
+  if (nt) run_stream(std::true_type{}); else run_stream(std::false_type{});
   ACC_STAMP(2);
   // (fused V launch: the tail's global loads and its wait for the side workgroups go out here, under the wave skew and
   //  the reduction - btf_fused.h)
