@@ -89,7 +89,7 @@ struct btf_ctx {
   double* pband = nullptr;
   // what the precomputed prior band (fused V launch, btf_fused.h) was formed from: every change of Tau2 / lam2 / the shard
   // moves prior_version on; the band is rebuilt (prior_band_kernel) when pband_version lags behind
-  unsigned long long prior_version = 1, pband_version = 0;
+  unsigned long long prior_version = 1, pband_version = 0, last_v_prior_version = 0;
   double* Ta = nullptr; double* Tb = nullptr; double* Tc = nullptr; double* lsum = nullptr;   // horseshoe+ chain (device mode)
   int* dr_ptr = nullptr; int* dr_col = nullptr; double* dr_val = nullptr;                   // Delta, CSR by row
   bool have_chain = false;
@@ -1659,7 +1659,27 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
   const int tw_npl = std::max(1, ((bw - 1) * (bw - 2) / 2 + WAVE - 1) / WAVE);      // (dispatch_vbanded_twist's own test)
   const bool tw_handles = bw <= 15 ? tw_npl <= 2 : (tw_npl >= 2 && tw_npl <= 8);
   const bool own_prior = choice == 2 && tw_handles && c->st_dense_ok && c->st_drow && (c->TF + 2) * T >= c->nD;
-  if (own_prior) { a.st_drow = c->st_drow; a.st_dcoef = c->st_dcoef; a.pband = nullptr; }
+  if (own_prior) {
+    a.st_drow = c->st_drow; a.st_dcoef = c->st_dcoef; a.pband = nullptr;
+    // ... unless Tau2 / lam2 have stood still since the last V half-sweep (loops of bare W+V steps, host-driven chains with
+    // fixed hyper-parameters): then the band of every column is built ONCE, in the kernel's own arithmetic
+    // (prior_band_kernel's spectral form: same bits), and the sampler workgroups load it instead of their stencil - 49 KB
+    // less per workgroup in the cold batch of loads the kernel starts with.  Full sweeps redraw Tau2 every time: nothing changes.
+    const int TD1 = T * D1;
+    static const bool lazy_band = [] { const char* e = std::getenv("BTF_TWIST_PBAND"); return !e || std::atoi(e) != 0; }();      // (A/B aid)
+    if (!lazy_band) { /* the kernel forms the band itself, every time */ }
+    else if (c->pband && c->pband_version == c->prior_version) a.pband = c->pband;
+    else if (c->last_v_prior_version == c->prior_version) {
+      if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; }
+      Prof p(c, BTF_K_PRIOR);
+      p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
+               (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
+               (const double*)(c->dev_scalars ? c->hyp : nullptr), 1);
+      c->pband_version = c->prior_version;
+      a.pband = c->pband;
+    }
+    c->last_v_prior_version = c->prior_version;
+  }
   if (fast && !own_prior) {
     const int TD1 = T * D1;
     if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; }
@@ -1669,6 +1689,7 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
                (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
                (const double*)(c->dev_scalars ? c->hyp : nullptr), 0);
     }
+    c->pband_version = 0;                 // (this form of the band is not the one the version stands for)
     a.pband = c->pband;
   }
   // V'V partials for the next W half-sweep (one KK block per column; bounded: every w_solve workgroup sums all of them)
@@ -1864,6 +1885,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
                    (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
                    (const double*)(c->dev_scalars ? c->hyp : nullptr), 0);
         }
+        c->pband_version = 0;
         sa.pband = c->pband;
       }
       if (fuse_v) {

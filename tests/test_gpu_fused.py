@@ -149,3 +149,29 @@ def test_precomputed_prior_band_follows_the_hyper_parameters(rng):
     la = _launches(a)
     assert la["prior_band"] == 4, la            # first use + three edits; the steps without an edit reuse the band
     assert "v_banded" not in la and la["v_accum"] == len(edits), la
+
+
+@pytest.mark.parametrize("rng", ["host", "device"])
+def test_twisted_sampler_with_the_precomputed_band_walks_the_same_chain(rng):
+    """Weighted data (missing replicates): from the second V half-sweep on with unchanged Tau2 / lam2 the twisted sampler's
+    workgroups load the prior band of their column (prior_band_kernel in the sampler's own arithmetic) instead of forming it
+    from their stencil.  A model whose Tau2 is re-sent before every step (same values: the band is formed in the kernel every
+    time) must walk the same chain bit for bit."""
+    dims = (96, 6, 64, 2, 5)
+    Y = _synth(*dims)
+    Y[np.random.RandomState(8).rand(*Y.shape) < 0.1] = np.nan
+    a, b = _make(dims, 1, rng, "reference", sampler="banded"), _make(dims, 1, rng, "reference", sampler="banded")
+    for m, resend in ((a, False), (b, True)):
+        np.random.seed(9)
+        m._bind_data(Y)
+        m._ctx.kernel_times()
+        for _ in range(5):
+            if resend:
+                m.Tau2 = np.array(m.Tau2).copy()
+            m._resample_W(Y)
+            m._resample_V(Y)
+        m.sync()
+    assert a.v_sampler() == "banded" and a.likelihood_form() == "weighted"
+    assert np.array_equal(a.W, b.W) and np.array_equal(a.V, b.V)
+    la, lb = _launches(a), _launches(b)
+    assert la.get("prior_band") == 1 and "prior_band" not in lb, (la, lb)
