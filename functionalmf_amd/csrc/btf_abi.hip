@@ -595,9 +595,17 @@ int make_fill_table(btf_ctx* c, bool weighted) {
   if (c->fill_tab && c->fill_key == key) return BTF_OK;
   std::vector<int> tab;
   fill_table_host(c->T, c->K, c->TF, key, tab);
+  // {dst, src, dia, 0} -> the 8-byte entries the kernel reads (tw_fill_unpack): dst | dia16 << 16, src
+  std::vector<int> packed(tab.size() / 2);
+  for (size_t e = 0; e + 3 < tab.size(); e += 4) {
+    const int dst = tab[e], src = tab[e + 1], dia = tab[e + 2];
+    if (dst < 0 || dst >= 0xffff || dia >= 0xffff) return fail(c, BTF_EINVAL, "band assembly program: LDS offset beyond 16 bits");
+    packed[e / 2] = (int)((unsigned)dst | ((unsigned)(dia < 0 ? 0xffff : dia) << 16));
+    packed[e / 2 + 1] = src;
+  }
   int rc;
-  if ((rc = dev_alloc(c, &c->fill_tab, tab.size()))) return rc;
-  HIPCHK(c, hipMemcpy(c->fill_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+  if ((rc = dev_alloc(c, &c->fill_tab, packed.size()))) return rc;
+  HIPCHK(c, hipMemcpy(c->fill_tab, packed.data(), packed.size() * sizeof(int), hipMemcpyHostToDevice));
   c->fill_n = (int)(tab.size() / 4);
   c->fill_key = key;
   return BTF_OK;

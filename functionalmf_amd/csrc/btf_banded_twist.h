@@ -22,6 +22,16 @@
 namespace btf {
 
 constexpr int VT_THREADS = 256;
+// An entry of the band assembly program as the kernel reads it: 8 bytes {dst | dia16 << 16, src} - dst and the diagonal's
+// source are LDS word offsets below 2^16 (0xffff: no diagonal term), src is an LDS word offset or the negative code of a
+// likelihood-block entry in the accumulation partials (tw_layout, weighted == 2).  (16-byte entries until round 4: the
+// 256 workgroups of a C3 launch pulled 12.5 MB of them through the L2s in the cold batch of loads the kernel starts with.)
+__device__ __forceinline__ void tw_fill_unpack(const int2 f, int& dst, int& src, int& dia) {
+  dst = f.x & 0xffff;
+  const int d16 = (int)((unsigned)f.x >> 16);
+  dia = d16 == 0xffff ? -1 : d16;
+  src = f.y;
+}
 #ifndef BTF_TWIST_BACKPAR
 #define BTF_TWIST_BACKPAR 0       // 1: parallel block solves (backpar16_prepare) + four MFMAs per 16 columns on the chain (backpar16_chain_mfma).
                                   // Round 3: the chain itself shrinks to ~2 k cycles, but the 2 x 11 x 17 triangular solves of the prepare
@@ -153,8 +163,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
 #pragma unroll
     for (int u = 0; u < FILL_REG; ++u) {
       const int e = (u < nfe ? u : 0) * VT_THREADS + tid;
-      const int4 f = reinterpret_cast<const int4*>(a.fill)[e];      // {dst, src, diag-src or -1, 0}: one 16-B load
-      fdst[u] = f.x; fsrc[u] = f.y; fdia[u] = f.z;
+      tw_fill_unpack(reinterpret_cast<const int2*>(a.fill)[e], fdst[u], fsrc[u], fdia[u]);      // one 8-B load
     }
   }
   // prior band built here (no prior_band_kernel launch): 1 / (lam2 Tau2) per penalty row into LDS, and the fixed-slot
@@ -388,8 +397,8 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
       for (int u = 0; u < FILL_REG; ++u) if (u < nfe) lds[fdst[u]] = val[u];
       for (int u = FILL_REG; u < nfe; ++u) {               // (larger systems: the rest on demand)
         const int e = u * VT_THREADS + tid;
-        const int4 f = reinterpret_cast<const int4*>(a.fill)[e];
-        const int dst = f.x, src = f.y, dia = f.z;
+        int dst, src, dia;
+        tw_fill_unpack(reinterpret_cast<const int2*>(a.fill)[e], dst, src, dia);
         double v = lds[src];
         if (dia >= 0) v += lds[dia] + shift;
         lds[dst] = v;
@@ -400,8 +409,8 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
       // loads in the unrolled form above cost the common case 3.5 us of registers and code)
       for (int u = 0; u < nfe; ++u) {
         const int e = u * VT_THREADS + tid;
-        const int4 f = reinterpret_cast<const int4*>(a.fill)[e];
-        const int dst = f.x, src = f.y, dia = f.z;
+        int dst, src, dia;
+        tw_fill_unpack(reinterpret_cast<const int2*>(a.fill)[e], dst, src, dia);
         double v;
         if (src >= 0) v = lds[src];
         else {
