@@ -968,6 +968,7 @@ int btf_set_shard(btf_ctx* c, int row0, int nrows_local, int col0, int ncols_loc
   c->row0 = row0; c->nl = nrows_local; c->col0 = col0; c->ml = ncols_local;
   c->hrow = c->hcol = -1;
   ++c->prior_version;
+  if (c->pband) { (void)hipFree(c->pband); c->pband = nullptr; c->pband_version = 0; }      // (sized for the old column block)
   c->nb_bwt_written = false;      // (the skip of nb_bwt_target is only valid for the shard geometry B_wT was written under)
   return BTF_OK;
 }
