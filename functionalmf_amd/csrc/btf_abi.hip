@@ -120,6 +120,7 @@ struct btf_ctx {
   double* hyp = nullptr;        // device-resident scalars [HYP_COUNT] (nu2, sigma2, lam2, lam2_a, ...)
   bool dev_scalars = false;     // kernels read nu2 / sigma2 / lam2 from hyp instead of the host copies
   double* pin_hyp = nullptr;
+  double* gsum_v = nullptr; bool w_part_gsum = false;   // V'V summed by a side workgroup of the W accumulation launch (GramSide.sum_*): w_solve reads KK doubles
   double* gpart_w = nullptr; int ngp_w = 0;   // W'W partials written by w_solve (valid until W changes otherwise)
   double* gpart_v = nullptr; int ngp_v = 0;   // V'V partials written by the fast banded sampler
   bool fuse_gram = true;
@@ -346,7 +347,7 @@ template <int K>
 void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const unsigned char* C8, const double* U,
                   const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr},
                   EigSideCols sidec = EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
-                  TauSide tau = TauSide{}, GramSide gram = GramSide{nullptr, 0, nullptr, 0},
+                  TauSide tau = TauSide{}, GramSide gram = GramSide{},
                   ChunkMap cm = ChunkMap{0, 0, INT_MAX, 0, 0, 0}, SweepSide sw = SweepSide{},
                   const FuseW* fw = nullptr, const FuseV* fv = nullptr) {
   // nch: the chunks THIS launch covers (all of them unless cm says otherwise)
@@ -364,7 +365,7 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
   Prof p(c, kid);
   const int cpw = TAU_SIDE_CPW;
   cm.nside = (sw.sc.hyp ? 1 : 0) + (sw.lam.hyp ? 1 : 0) + (side.out ? 1 + eig_side_groups(sidec.ncols, acc_waves(K, mode)) : 0) +
-             (tau.Tau2 ? (tau.M + cpw - 1) / cpw : 0) + (gram.gpart ? gram.nblocks : 0) + (fw ? fw->owners : 0);   // the side tasks' workgroups (and the fused W launch's owners), in front
+             (tau.Tau2 ? (tau.M + cpw - 1) / cpw : 0) + (gram.gpart ? gram.nblocks : 0) + (gram.sum_src ? 1 : 0) + (fw ? fw->owners : 0);   // the side tasks' workgroups (and the fused W launch's owners), in front
   dim3 grid((ld / ACC_TILE) * nch + cm.nside);
   if (fw || fv) {              // the two-launch step: complete data, 16 waves, the tail in the same launch (btf_fused.h)
     const bool unr3 = rpb >= unr3_min_rpb();
@@ -939,7 +940,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->A8_wT, c->A8_v, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_llp, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val, c->sse_cols, c->vs_rec, c->vc_scratch, c->gs_cptr, c->gs_cidx, c->gs_cval};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->gsum_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->A8_wT, c->A8_v, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_llp, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val, c->sse_cols, c->vs_rec, c->vc_scratch, c->gs_cptr, c->gs_cidx, c->gs_cval};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
@@ -1435,7 +1436,7 @@ int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL, WFuseReq* wf = nul
     if (!sg.ok || mode == 2) return BTF_OK;               // nothing queued ahead: the next call accumulates everything
     K_SWITCH(K, launch_accum<KT>(c, BTF_K_W_ACCUM, mode, c->A_wT, c->C_wT, c->C8_wT, c->V, c->srcmap_w, MT, c->ldw, sg.rpb_l, sg.nch_l,
                                  EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
-                                 TauSide{}, GramSide{nullptr, 0, nullptr, 0}, ChunkMap{sg.nch_r, sg.lo, INT_MAX, 0, sg.hi, 0}));
+                                 TauSide{}, GramSide{}, ChunkMap{sg.nch_r, sg.lo, INT_MAX, 0, sg.hi, 0}));
     HIPCHK(c, hipGetLastError());
     c->w_local_done = true; c->w_local_rpb = rpb; c->w_local_mode = mode;
     return BTF_OK;
@@ -1462,8 +1463,18 @@ int w_accum_phase(btf_ctx* c, int compat, int part = ACC_ALL, WFuseReq* wf = nul
     GramSide gram{nullptr, 0, nullptr, 0};
     if (!wt && !use_gv) {
       c->ngp_gram = std::min(gram_blocks(MT), 32);
-      gram = GramSide{c->V, MT, c->gpart, c->ngp_gram};
+      gram = GramSide{c->V, MT, c->gpart, c->ngp_gram, nullptr, nullptr, 0, nullptr, 0};
     }
+    // the per-column blocks V_j'V_j of the sampler that drew V (ngp_v = ml of them): summed ONCE, by a side workgroup of this
+    // launch, instead of by every workgroup of the W solve behind it (same order, same bits: GramSide.sum_*)
+    bool gsum = false;
+    c->w_part_gsum = false;
+    if (!wt && use_gv && part == ACC_ALL && c->ngp_v > 8 * std::min(32, (WS_ROWS * ws_split_of(K, false)) / KK)) {
+      if (!c->gsum_v) { if ((rc = dev_alloc(c, &c->gsum_v, (size_t)tri(MAX_K)))) return rc; }
+      gram.sum_src = c->gpart_v; gram.sum_n = c->ngp_v; gram.sum_out = c->gsum_v; gram.sum_threads = WS_ROWS * ws_split_of(K, false);
+      gsum = true;
+    }
+    c->w_part_gsum = gsum;
     TauSide tau{};
     if (c->tau_pending && c->dev_scalars && c->have_chain) tau = tau_side_of(c, c->tau_seed, 1.0, c->tau_stability);
     SweepSide sw{};
@@ -1589,6 +1600,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     WSolveArgs a{};
     a.part = c->part; a.nch = nch; a.ld = c->ldw; a.weighted = wt ? 1 : 0;
     a.gpart = use_gv ? c->gpart_v : c->gpart; a.ngp = use_gv ? c->ngp_v : c->ngp_gram;
+    if (use_gv && c->w_part_gsum) { a.gpart = c->gsum_v; a.ngp = 1; }      // (summed by a side workgroup of the accumulation launch)
     const int wrows = ws_rows_for(c->nl);
     const int wblocks = (c->nl + wrows - 1) / wrows;
     if (whole && c->fuse_gram) {
@@ -1758,7 +1770,7 @@ int v_accum_local(btf_ctx* c, int compat) {
   if ((rc = ensure_part(c, (size_t)std::max(nch, sg.nch_r + sg.nch_l) * NV * c->ldv))) return rc;
   K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, sg.rpb_l, sg.nch_l,
                                EigSide{nullptr, 0, 0, nullptr}, EigSideCols{nullptr, 0, CurveLists{nullptr, nullptr, nullptr}, nullptr, 0.0, nullptr},
-                               TauSide{}, GramSide{nullptr, 0, nullptr, 0}, ChunkMap{sg.nch_r, sg.lo, INT_MAX, 0, sg.hi, 0}));
+                               TauSide{}, GramSide{}, ChunkMap{sg.nch_r, sg.lo, INT_MAX, 0, sg.hi, 0}));
   HIPCHK(c, hipGetLastError());
   c->v_local_done = true; c->v_local_rpb = rpb; c->v_local_mode = mode;
   return BTF_OK;
@@ -1844,7 +1856,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
     }
     if (!fuse_v) {
       K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb,
-                                   v_rest_only ? vsg.nch_r : nch_all, side, sidec, TauSide{}, GramSide{nullptr, 0, nullptr, 0}, cm, sw));
+                                   v_rest_only ? vsg.nch_r : nch_all, side, sidec, TauSide{}, GramSide{}, cm, sw));
     }
     hipError_t e = hipSuccess;
     if (choice == 3) {
@@ -1925,12 +1937,30 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
           fv.hp = HypPub{c->fz_pub + FZ_PUB_HYP, c->fz_words + FZ_LAM, c->fz_epoch, 4};
         }
         K_SWITCH(K, launch_accum<KT>(c, BTF_K_V_ACCUM, mode, c->A_v, c->C_v, c->C8_v, c->W, c->srcmap_v, c->N, c->ldv, rpb,
-                                     nch_all, side, sidec, TauSide{}, GramSide{nullptr, 0, nullptr, 0}, cm, sw, nullptr, &fv));
+                                     nch_all, side, sidec, TauSide{}, GramSide{}, cm, sw, nullptr, &fv));
         c->sweep_v++;
         c->nb_L_valid = false;
         c->w_part_valid = false;
         HIPCHK(c, hipGetLastError());
         return after_v_draw(c, compat);
+      }
+      if (!rg) {
+        // the sampler launch of its own (shapes / data the fused tail does not take): the same precomputed band, from the
+        // second V half-sweep on with unchanged Tau2 / lam2 (as v_banded_dispatch does for the twisted sampler)
+        static const bool lazy_band = [] { const char* e2 = std::getenv("BTF_TWIST_PBAND"); return !e2 || std::atoi(e2) != 0; }();
+        const int TD1 = T * (c->TF + 2);
+        if (!lazy_band) { }
+        else if (c->pband && c->pband_version == c->prior_version) sa.pband = c->pband;
+        else if (c->last_v_prior_version == c->prior_version) {
+          if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; }
+          Prof p(c, BTF_K_PRIOR);
+          p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
+                   (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
+                   (const double*)(c->dev_scalars ? c->hyp : nullptr), 1);
+          c->pband_version = c->prior_version;
+          sa.pband = c->pband;
+        }
+        c->last_v_prior_version = c->prior_version;
       }
       const size_t sl = vs_lds_bytes(T, K, c->TF, c->nD, rg);
       switch ((c->TF + 1) * 2 + (rg ? 1 : 0)) {

@@ -234,7 +234,14 @@ constexpr int TAU_SIDE_CPW = 2;
 // the Gram of the fixed factor (what gram_kernel computes) as side workgroups of the accumulation launch that the
 // solve kernel FOLLOWS: nblocks partial Grams of U's rows, one per side workgroup, consumed across the kernel boundary
 // (cnt != nullptr: the partials are consumed inside this launch - stored write-through, every block adds one to *cnt)
-struct GramSide { const double* U; int Rdim; double* gpart; int nblocks; unsigned* cnt; };
+struct GramSide {
+  const double* U; int Rdim; double* gpart; int nblocks; unsigned* cnt;
+  // ONE more side workgroup: the sum of `sum_n` partial Grams [sum_n][KK] the previous V sampler left (one per column) into
+  // sum_out[KK], in the order w_solve_kernel's reduce_gram would form it with `sum_threads` threads - so that every
+  // workgroup of the W solve that follows reads KK doubles instead of all the partials (30 KB each at C3: a third of its cold
+  // batch of loads) and lands on the same bits.  sum_src == nullptr: none.
+  const double* sum_src; int sum_n; double* sum_out; int sum_threads;
+};
 
 // Which rows of the reduction axis a launch covers, and where its partial sums go: logical chunk l of the launch takes
 // rows r0 .. min(r0 + rows_per_block, row_end) - 1 with r0 = row_base + l rows_per_block, moved up by `skip_rows` from
@@ -516,6 +523,34 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       return;
     }
     b -= gram.nblocks;
+  }
+  if (gram.sum_src) {
+    if (b == 0) {
+      // thread (l, q) of the first sum_threads adds the partials l, l + lanes, ... in batches of eight (reduce_gram's order for
+      // a sum_threads-wide workgroup), then KK threads add the lanes' sums in order
+      double* scratch = &red[0][0][0];
+      const int lanes = gram.sum_threads / KK > 32 ? 32 : (gram.sum_threads / KK < 1 ? 1 : gram.sum_threads / KK);
+      const int l = threadIdx.x / KK, q = threadIdx.x - l * KK;
+      if ((int)threadIdx.x < gram.sum_threads && l < lanes) {
+        double sg = 0.0;
+        for (int b0 = l; b0 < gram.sum_n; b0 += 8 * lanes) {
+          double x[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x[u] = b0 + u * lanes < gram.sum_n ? gram.sum_src[(size_t)(b0 + u * lanes) * KK + q] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) sg += x[u];
+        }
+        scratch[l * KK + q] = sg;
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < KK) {
+        double t = 0.0;
+        for (int bb = 0; bb < lanes; ++bb) t += scratch[bb * KK + threadIdx.x];
+        gram.sum_out[threadIdx.x] = t;
+      }
+      return;
+    }
+    b -= 1;
   }
   return;                                                    // (not reached: cm.nside counts exactly the side workgroups)
   }

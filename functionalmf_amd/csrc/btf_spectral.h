@@ -237,7 +237,13 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
   int se0 = 0, se1 = 0;
   int srow[MAXE];
   double scf[MAXE];
-  if (pidx < T * D1) {
+  // (records in LDS and a.pband set: the prior band of the column comes precomputed in this kernel's own arithmetic - the
+  //  host builds it when Tau2 / lam2 have stood still since the last V half-sweep, btf_abi.hip - and neither the stencil nor
+  //  Tau2 is fetched: 49 KB less per workgroup in the cold batch of loads)
+  const bool lazyb = !RG && a.pband != nullptr;
+  double pbv = 0.0;
+  if (lazyb && pidx < T * D1) pbv = a.pband[(size_t)j * T * D1 + pidx];
+  if (pidx < T * D1 && !lazyb) {
     se0 = a.st_ptr[pidx]; se1 = a.st_ptr[pidx + 1];
 #pragma unroll
     for (int u = 0; u < MAXE; u += 4) {
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) { const int idx = i0 + u * VS_THREADS; if (idx < a.nD) itau[idx] = 1.0 / (a.lam2 * tv[u]); }
     }
-  } else {
+  } else if (!lazyb) {
     for (int idx = tid; idx < a.nD; idx += VS_THREADS) itau[idx] = 1.0 / (a.lam2 * a.Tau2[(size_t)jg * a.nD + idx]);
   }
   if (RG && a.nch == 1) {
@@ -334,7 +340,9 @@ __global__ __launch_bounds__(VS_THREADS) void v_spectral_kernel(VSpecArgs a) {
   //      the rotated right-hand sides and their mirror image ------------------------------------------------
   for (int idx = tid; idx < (T + S + 1) * D1; idx += VS_THREADS) {
     double s = 0.0;
-    if (idx == pidx) {
+    if (lazyb) {
+      if (idx < T * D1) s = idx == pidx ? pbv : a.pband[(size_t)j * T * D1 + idx];
+    } else if (idx == pidx) {
 #pragma unroll
       for (int u = 0; u < MAXE; ++u) if (u < scnt) s = fma(scf[u], itau[srow[u]], s);
     } else if (RG && idx < T * D1 && a.pband) {

@@ -61,6 +61,7 @@ def test_two_launch_step_is_bit_identical_to_four_launches(dims, rng, mode):
     # their columns, rebuilt only when Tau2 / lam2 change
     assert la.pop("prior_band") == 1, la
     assert la == ({"w_accum": 4, "v_accum": 4} if mode == 2 else {"w_accum": 4, "w_solve": 4, "v_accum": 4}), la
+    assert lb.pop("prior_band") == 1, lb         # (the sampler launch of its own loads the same band from its second step on)
     assert lb == {"w_accum": 4, "w_solve": 4, "v_accum": 4, "v_banded": 4}, lb
     assert np.array_equal(a.W, b.W)
     assert np.array_equal(a.V, b.V)
