@@ -165,7 +165,8 @@ def main():
 
     import torch
     import torch.distributed as dist
-    exercise = os.environ.get("BTF_EXERCISE_EXCHANGE", "0") == "1" or as_rank is not None
+    # (a rehearsed rank needs no process group: its communicator is the context's own one-rank one, btf_comm_rehearse)
+    exercise = os.environ.get("BTF_EXERCISE_EXCHANGE", "0") == "1"
     backend = None
     if not dry:
         torch.cuda.set_device(local_rank)
@@ -479,7 +480,11 @@ def main():
     if args.variant in ("binomial", "negbinom"):
         out["config"]["pg_sampler"] = getattr(model, "pg_sampler", "series")
     if world > 1 or exercise:
+        # the data-path collectives are the library's own RCCL calls (btf_allgather_W / _V on the context's communicator);
+        # torch.distributed carried the communicator id, the barrier and the max over ranks of the clock
         out["config"].update({"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                              "exchange_transport": model._exchange.transport,
+                              "communicator": model._exchange.comm_info() if model._exchange.transport == "rccl" else None,
                               "collective_us": coll})
     if as_rank:
         # What ONE rank of a P-GPU run does per step, measured on one GPU: its kernels on its real slabs and the RCCL call
@@ -490,7 +495,8 @@ def main():
         step_us = 1e3 * ms_step
         out["config"]["workload"] += "; REHEARSAL of rank %d of %d on one GPU (row slab %d x %d, column slab %d x %d)" % (
             as_rank[0], as_rank[1], plan.nl, M, N, plan.ml)
-        out["projected"] = {"what": "rank %d of %d: W+V step with both all-gathers (one-rank RCCL group, full message sizes)" % as_rank,
+        out["projected"] = {"what": "rank %d of %d: W+V step with both all-gathers (btf_allgather_W / _V on a one-rank RCCL communicator of the context, full message sizes)" % as_rank,
+                            "communicator": model._exchange.comm_info(),
                             "ranks": as_rank[1], "per_rank_step_us": round(step_us, 1),
                             "projected_sweeps_per_s": round(1e6 / step_us, 1),
                             "exchange": "overlapped (own-block chunks ahead of the all-gather)" if args.overlap else "in line",

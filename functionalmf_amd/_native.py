@@ -23,6 +23,7 @@ BTF_OK, BTF_EINVAL, BTF_EHIP, BTF_ENOTPD, BTF_ESTATE = 0, 1, 2, 3, 4
 COMPAT = {"reference": 0, "exact": 1}
 KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw", "nb_loglik",
                 "prior_band", "gram_eig", "hyper", "ess"]
+COMM_ID_BYTES = 128               # BTF_COMM_ID_BYTES of include/btf.h
 OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT, OPT_CURVE_COUNTS, OPT_SPLIT_ACCUM, OPT_FUSED_SWEEP, OPT_FUSED_STEP = 0, 1, 2, 3, 4, 5, 6, 7
 ESS_HOST_LIKELIHOOD = -1          # BTF_ESS_HOST_LIKELIHOOD of include/btf.h
 SAMPLERS = {"banded": 0, "spectral": 1, "chain": 2, "generic": 3, "banded_nopanel": 4}
@@ -122,6 +123,16 @@ SIGNATURES = {
     "btf_set_likelihood_param": (C.c_int, [_ctx, C.c_int, C.c_double]),
     "btf_comm_fork": (C.c_int, [_ctx, C.c_void_p]),
     "btf_comm_join": (C.c_int, [_ctx, C.c_void_p]),
+    "btf_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte), C.c_int]),
+    "btf_comm_block": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_ip, _c_ip]),
+    "btf_comm_init": (C.c_int, [_ctx, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int]),
+    "btf_comm_rehearse": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "btf_comm_destroy": (C.c_int, [_ctx]),
+    "btf_comm_info": (C.c_int, [_ctx, _c_ip]),
+    "btf_allgather_W": (C.c_int, [_ctx]),
+    "btf_allgather_V": (C.c_int, [_ctx]),
+    "btf_allreduce_sse": (C.c_int, [_ctx]),
+    "btf_allreduce_sum": (C.c_int, [_ctx, _c_dp, C.c_int]),
     "btf_set_gathered_W": (C.c_int, [_ctx, _c_dp]),
     "btf_set_gathered_V": (C.c_int, [_ctx, _c_dp]),
 }

@@ -10,6 +10,7 @@
 #include "btf_gass.h"
 #include "btf_fused.h"
 #include "btf_instances.h"      // the large kernel families: extern templates, compiled in btf_instances.hip
+#include "btf_comm.h"           // RCCL, bound at run time
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -138,6 +139,14 @@ struct btf_ctx {
   bool w_local_done = false, v_local_done = false;                    // own-block chunks of the next W / V accumulation are in c->part
   int w_local_rpb = 0, w_local_mode = 0, v_local_rpb = 0, v_local_mode = 0;
   hipEvent_t ev_draw = nullptr, ev_join = nullptr;                    // behind the last draw kernel / the comm stream's tail
+  // the ctx-owned communicator (btf_comm_init; btf_comm.h).  comm_rank / comm_world are the communicator's; gather_rank /
+  // gather_world the block decomposition the all-gathers reassemble - the same, except in a rehearsal (btf_comm_rehearse:
+  // a one-rank communicator moving the messages of rank gather_rank of gather_world through scratch buffers)
+  ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1, gather_rank = 0, gather_world = 1;
+  bool comm_rehearse = false;
+  hipStream_t comm_stream = nullptr;                                  // the overlapped exchange runs its gathers here
+  double* comm_scr = nullptr; size_t comm_scr_elems = 0;              // rehearsal: [send | recv] of the larger message
+  double* comm_words = nullptr;                                       // 16 device doubles: btf_allreduce_sum's staging
   bool tau_pending = false; unsigned long long tau_seed = 0; double tau_stability = 1e-6;   // btf_queue_Tau2
   // the four-launch sweep (BTF_OPT_FUSED_SWEEP): per-column residual parts left by the spectral V sampler, and a queued
   // nu2 / sigma2 draw that the next W accumulation launch carries as a side workgroup (btf_queue_scalars)
@@ -953,6 +962,7 @@ void btf_destroy(btf_ctx* c) {
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->ev_draw) (void)hipEventDestroy(c->ev_draw);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  (void)btf_comm_destroy(c);
 
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -2020,8 +2030,12 @@ int ess_alloc(btf_ctx* c) {
   HIPCHK(c, hipMemsetAsync(c->ess_done, 0, nc * sizeof(int), c->stream));
   return BTF_OK;
 }
-int ess_check(btf_ctx* c, int what, int link) {
+// allow_host: only btf_ess_begin / btf_ess_eval take BTF_ESS_HOST_LIKELIHOOD (no device likelihood runs for it); every
+// entry point that launches a likelihood kernel rejects a negative family instead of handing it to the kernels
+int ess_check(btf_ctx* c, int what, int link, bool allow_host = false) {
   if (what < 0 || what > 1 || link < BTF_ESS_HOST_LIKELIHOOD || link >= ESS_FAM_COUNT) return fail(c, BTF_EINVAL, "bad elliptical-slice arguments");
+  if (link == BTF_ESS_HOST_LIKELIHOOD && !allow_host)
+    return fail(c, BTF_EINVAL, "BTF_ESS_HOST_LIKELIHOOD is taken by btf_ess_begin / btf_ess_eval only (a device likelihood family expected)");
   if (link == BTF_ESS_HOST_LIKELIHOOD) {                   // the caller's own likelihood: nothing of the data is needed here
     if (!c->have_W || !c->have_V || !c->have_hyper) return fail(c, BTF_ESTATE, "elliptical slice sampling needs W, V and hyper-parameters");
     if (c->nl != c->N || c->ml != c->M) return fail(c, BTF_ESTATE, "elliptical slice sampling needs an unsharded context");
@@ -2099,7 +2113,7 @@ int ess_begin(btf_ctx* c, int what, const double* z, uint64_t seed, double eps0,
 int btf_ess_begin(btf_ctx* c, int what, const double* z, uint64_t seed, double eps0, int attempts) {
   if (!c) return BTF_EINVAL;
   int rc;
-  if ((rc = ess_check(c, what, BTF_ESS_HOST_LIKELIHOOD))) return rc;      // (the prior draw needs no data; btf_ess_eval checks what its family needs)
+  if ((rc = ess_check(c, what, BTF_ESS_HOST_LIKELIHOOD, true))) return rc;      // (the prior draw needs no data; btf_ess_eval checks what its family needs)
   HIPCHK(c, hipSetDevice(c->dev));
   if ((rc = ess_begin(c, what, z, seed, eps0, attempts < 0 ? 0 : attempts))) return rc;
   // one joint chain: not done
@@ -2110,7 +2124,7 @@ int btf_ess_begin(btf_ctx* c, int what, const double* z, uint64_t seed, double e
 int btf_ess_eval(btf_ctx* c, int what, double theta, int current, int link, double* ll) {
   if (!c || !ll) return BTF_EINVAL;
   int rc;
-  if ((rc = ess_check(c, what, link))) return rc;
+  if ((rc = ess_check(c, what, link, true))) return rc;
   if (!c->essX0) return fail(c, BTF_ESTATE, "btf_ess_eval follows btf_ess_begin");
   HIPCHK(c, hipSetDevice(c->dev));
   const EssDims d = ess_dims(c, what, 0);
@@ -3005,8 +3019,10 @@ int btf_get_scalars(btf_ctx* c, double* out) {
   HIPCHK(c, hipMemcpyAsync(c->pin_hyp, c->hyp, HYP_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < 6; ++i) out[i] = c->pin_hyp[i];
+  // a read does not change the prior: with device-resident scalars the band is built from hyp[] itself (prior_band_kernel
+  // reads lam2 there), so only a host copy that actually moved invalidates what was precomputed from it
+  if (out[HYP_LAM2] != c->lam2 && !c->dev_scalars) ++c->prior_version;
   c->nu2 = out[HYP_NU2]; c->sigma2 = out[HYP_SIGMA2]; c->lam2 = out[HYP_LAM2];
-  ++c->prior_version;
   return BTF_OK;
 }
 
@@ -3614,6 +3630,184 @@ int btf_comm_join(btf_ctx* c, void* comm_stream) {
   if (!c->ev_join) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIPCHK(c, hipEventRecord(c->ev_join, (hipStream_t)comm_stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  return BTF_OK;
+}
+
+// ---- the ctx-owned communicator ---------------------------------------------------------------------------------
+namespace {
+#define RCCLCHK(ctx, api, call)                                                                     \
+  do {                                                                                              \
+    ncclResult_t r__ = (call);                                                                      \
+    if (r__ != ncclSuccess)                                                                         \
+      return fail(ctx, BTF_EHIP, std::string(#call) + ": " + (api)->GetErrorString(r__));           \
+  } while (0)
+
+int comm_ready(btf_ctx* c, RcclApi** api) {
+  if (!c) return BTF_EINVAL;
+  if (!c->comm) return fail(c, BTF_ESTATE, "no communicator: btf_comm_init first");
+  std::string why;
+  if (!(*api = rccl_api(&why))) return fail(c, BTF_EHIP, why);
+  HIPCHK(c, hipSetDevice(c->dev));
+  return BTF_OK;
+}
+// the rank's blocks must be the equal-chunk decomposition the in-place gather reassembles
+int comm_blocks_match(btf_ctx* c) {
+  const int r = c->gather_rank, w = c->gather_world;
+  if (c->row0 != comm_block_lo(c->N, r, w) || c->nl != comm_block_len(c->N, r, w) ||
+      c->col0 != comm_block_lo(c->M, r, w) || c->ml != comm_block_len(c->M, r, w))
+    return fail(c, BTF_ESTATE, "btf_set_shard blocks are not rank " + std::to_string(r) + " of " + std::to_string(w) +
+                                   "'s equal chunks ceil(n / world) (btf_comm_block)");
+  return BTF_OK;
+}
+// one gather of `chunk` doubles per rank into `buf` (in place), or - rehearsal - of the whole message through scratch
+int comm_gather(btf_ctx* c, RcclApi* api, double* buf, size_t chunk, hipStream_t s) {
+  if (c->comm_rehearse) {
+    const size_t n = chunk * (size_t)c->gather_world;
+    if (2 * n > c->comm_scr_elems) {
+      int rc;
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+      if ((rc = dev_alloc(c, &c->comm_scr, 2 * n))) return rc;
+      c->comm_scr_elems = 2 * n;
+      HIPCHK(c, hipMemsetAsync(c->comm_scr, 0, 2 * n * sizeof(double), s));
+    }
+    RCCLCHK(c, api, api->AllGather(c->comm_scr, c->comm_scr + n, n, ncclDouble, c->comm, s));
+    return BTF_OK;
+  }
+  RCCLCHK(c, api, api->AllGather(buf + (size_t)c->comm_rank * chunk, buf, chunk, ncclDouble, c->comm, s));
+  return BTF_OK;
+}
+// in line on the ctx's stream, or (BTF_OPT_SPLIT_ACCUM) on the communication stream between btf_comm_fork / btf_comm_join
+int comm_gather_ordered(btf_ctx* c, double* buf, size_t chunk) {
+  RcclApi* api;
+  int rc;
+  if ((rc = comm_ready(c, &api))) return rc;
+  if ((rc = comm_blocks_match(c))) return rc;
+  if (!c->split_accum) return comm_gather(c, api, buf, chunk, c->stream);
+  if (!c->comm_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  if ((rc = btf_comm_fork(c, c->comm_stream))) return rc;
+  if ((rc = comm_gather(c, api, buf, chunk, c->comm_stream))) return rc;
+  return btf_comm_join(c, c->comm_stream);
+}
+int comm_adopt(btf_ctx* c, RcclApi* api, int rank, int world, const ncclUniqueId& id) {
+  if (c->comm) { int rc = btf_comm_destroy(c); if (rc) return rc; }
+  HIPCHK(c, hipSetDevice(c->dev));
+  RCCLCHK(c, api, api->CommInitRank(&c->comm, world, id, rank));
+  c->comm_rank = rank; c->comm_world = world;
+  if (!c->comm_words) { int rc = dev_alloc(c, &c->comm_words, (size_t)16); if (rc) return rc; }
+  return BTF_OK;
+}
+}  // namespace
+
+int btf_comm_unique_id(unsigned char* id, int nbytes) {
+  if (!id || nbytes < BTF_COMM_ID_BYTES) return fail(nullptr, BTF_EINVAL, "id buffer of BTF_COMM_ID_BYTES bytes expected");
+  static_assert(sizeof(ncclUniqueId) == BTF_COMM_ID_BYTES, "BTF_COMM_ID_BYTES is NCCL_UNIQUE_ID_BYTES");
+  std::string why;
+  RcclApi* api = rccl_api(&why);
+  if (!api) return fail(nullptr, BTF_EHIP, why);
+  ncclUniqueId u;
+  RCCLCHK(nullptr, api, api->GetUniqueId(&u));
+  std::memcpy(id, &u, sizeof(u));
+  return BTF_OK;
+}
+
+int btf_comm_block(int n, int rank, int world, int32_t* lo, int32_t* len) {
+  if (n < 0 || world < 1 || rank < 0 || rank >= world || !lo || !len) return BTF_EINVAL;
+  *lo = comm_block_lo(n, rank, world); *len = comm_block_len(n, rank, world);
+  return BTF_OK;
+}
+
+int btf_comm_init(btf_ctx* c, int rank, int world, const unsigned char* id, int nbytes) {
+  if (!c) return BTF_EINVAL;
+  if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(c, BTF_EINVAL, "need 0 <= rank < world <= 64 (W / V are padded for 64 ranks)");
+  if (!id || nbytes != BTF_COMM_ID_BYTES) return fail(c, BTF_EINVAL, "id: the BTF_COMM_ID_BYTES bytes rank 0 got from btf_comm_unique_id");
+  std::string why;
+  RcclApi* api = rccl_api(&why);
+  if (!api) return fail(c, BTF_EHIP, why);
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof(u));
+  int rc;
+  if ((rc = comm_adopt(c, api, rank, world, u))) return rc;
+  c->gather_rank = rank; c->gather_world = world; c->comm_rehearse = false;
+  return BTF_OK;
+}
+
+int btf_comm_rehearse(btf_ctx* c, int rank, int world) {
+  if (!c) return BTF_EINVAL;
+  if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(c, BTF_EINVAL, "need 0 <= rank < world <= 64");
+  std::string why;
+  RcclApi* api = rccl_api(&why);
+  if (!api) return fail(c, BTF_EHIP, why);
+  ncclUniqueId u;
+  RCCLCHK(c, api, api->GetUniqueId(&u));
+  int rc;
+  if ((rc = comm_adopt(c, api, 0, 1, u))) return rc;
+  c->gather_rank = rank; c->gather_world = world; c->comm_rehearse = true;
+  return BTF_OK;
+}
+
+int btf_comm_destroy(btf_ctx* c) {
+  if (!c) return BTF_EINVAL;
+  if (c->comm) {
+    std::string why;
+    RcclApi* api = rccl_api(&why);
+    (void)hipSetDevice(c->dev);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    if (api) (void)api->CommDestroy(c->comm);
+    c->comm = nullptr;
+  }
+  if (c->comm_stream) { (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
+  if (c->comm_scr) { (void)hipFree(c->comm_scr); c->comm_scr = nullptr; c->comm_scr_elems = 0; }
+  if (c->comm_words) { (void)hipFree(c->comm_words); c->comm_words = nullptr; }
+  c->comm_rank = c->gather_rank = 0; c->comm_world = c->gather_world = 1; c->comm_rehearse = false;
+  return BTF_OK;
+}
+
+int btf_comm_info(btf_ctx* c, int32_t* out) {
+  if (!c || !out) return BTF_EINVAL;
+  out[0] = c->comm ? 1 : 0; out[1] = c->comm_rank; out[2] = c->comm_world; out[3] = c->gather_rank; out[4] = c->gather_world;
+  out[5] = c->comm_rehearse ? 1 : 0;
+  int v = 0;
+  std::string why;
+  RcclApi* api = c->comm ? rccl_api(&why) : nullptr;
+  if (api) (void)api->GetVersion(&v);
+  out[6] = v;
+  int n = 0;
+  if (api && api->CommCount(c->comm, &n) == ncclSuccess) out[7] = n; else out[7] = 0;
+  return BTF_OK;
+}
+
+int btf_allgather_W(btf_ctx* c) {
+  if (!c) return BTF_EINVAL;
+  if (!c->have_W) return fail(c, BTF_ESTATE, "set W first");
+  return comm_gather_ordered(c, c->W, (size_t)comm_chunk(c->N, c->gather_world) * c->K);
+}
+
+int btf_allgather_V(btf_ctx* c) {
+  if (!c) return BTF_EINVAL;
+  if (!c->have_V) return fail(c, BTF_ESTATE, "set V first");
+  return comm_gather_ordered(c, c->V, (size_t)comm_chunk(c->M, c->gather_world) * c->T * c->K);
+}
+
+int btf_allreduce_sse(btf_ctx* c) {
+  RcclApi* api;
+  int rc;
+  if ((rc = comm_ready(c, &api))) return rc;
+  if (!c->hyp) return fail(c, BTF_ESTATE, "no device-resident scalars yet (btf_device_scalars)");
+  RCCLCHK(c, api, api->AllReduce(c->hyp + HYP_SSE, c->hyp + HYP_SSE, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  return BTF_OK;
+}
+
+int btf_allreduce_sum(btf_ctx* c, double* vals, int n) {
+  RcclApi* api;
+  int rc;
+  if ((rc = comm_ready(c, &api))) return rc;
+  if (!vals || n < 1 || n > 16) return fail(c, BTF_EINVAL, "1 to 16 doubles");
+  HIPCHK(c, hipMemcpyAsync(c->comm_words, vals, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  RCCLCHK(c, api, api->AllReduce(c->comm_words, c->comm_words, (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
+  HIPCHK(c, hipMemcpyAsync(vals, c->comm_words, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return BTF_OK;
 }
 

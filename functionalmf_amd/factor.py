@@ -133,8 +133,8 @@ class BayesianTensorFiltering(_BayesianModel):
         self._device_seed = int(device_seed)
         self._draws = 0
 
-        # Sharded runs exchange W / V through torch.distributed (parallel.Exchange).  Default: the collectives are issued
-        # under the ctx's own stream, in line.  overlap_exchange=True: the all-gather of the freshly drawn block runs on a
+        # Sharded runs exchange W / V through the context's own RCCL communicator (btf_allgather_W / _V; parallel.Exchange
+        # bootstraps it over torch.distributed).  Default: the collectives are issued on the ctx's own stream, in line.  overlap_exchange=True: the all-gather of the freshly drawn block runs on a
         # communication stream ordered behind the draw kernel (btf_comm_fork), while the ctx's stream already accumulates
         # the chunks of the next half-sweep that reduce over this rank's own block (BTF_OPT_SPLIT_ACCUM); the rest of that
         # accumulation waits for the gather (btf_comm_join).  Measured on one MI355X playing rank 0 of 8 at C5

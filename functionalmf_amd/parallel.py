@@ -5,9 +5,10 @@ the columns of V are (factor.py:378), so rank p updates a contiguous block of
 rows in the W half-sweep and a contiguous block of columns in the V half-sweep,
 from two slabs of the sufficient statistics (its rows x everything, everything
 x its columns).  W and V are replicated; the only exchange per half-sweep is
-one all-gather of the freshly drawn block (RCCL over xGMI through
-torch.distributed's "nccl" backend on the device buffers of the context, or any
-other backend on host copies - used by the CPU tests with gloo).
+one all-gather of the freshly drawn block: RCCL over xGMI, issued by the library
+itself on the context's communicator (btf_allgather_W / btf_allgather_V of
+include/btf.h), or any torch.distributed backend on host copies - used by the
+CPU tests with gloo).
 """
 import numpy as np
 
@@ -78,81 +79,98 @@ class ShardPlan:
         return full[:axis_len]
 
 
-class _DevView:
-    """__cuda_array_interface__ holder so torch can wrap a raw device pointer."""
-
-    def __init__(self, ptr, shape):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
-
-
 class Exchange:
-    """The per-half-sweep exchange.  world == 1: no-ops."""
+    """The per-half-sweep exchange.  world == 1: no-ops.
 
-    def __init__(self, plan, ctx=None, group=None, overlap=True, rehearse=False):
+    transport "rccl" (the default whenever the ranks have a GPU each): the collectives are the library's own -
+    btf_allgather_W / btf_allgather_V / btf_allreduce_sse of include/btf.h, RCCL calls on the context's communicator,
+    buffers and stream (csrc/btf_comm.h).  torch.distributed is then only the channel that carries rank 0's 128-byte
+    communicator id to the other ranks (any backend; what MPI_Bcast is to an NCCL program) - a C caller uses its own.
+    transport "host": the exchange staged through host copies over torch.distributed (any backend) - what the CPU tests
+    (gloo) and the tests that put several ranks on ONE GPU use, since RCCL refuses two ranks on one device."""
+
+    def __init__(self, plan, ctx=None, group=None, overlap=True, rehearse=False, transport=None):
         self.plan, self.ctx, self.group = plan, ctx, group
-        self.overlap = overlap          # all-gathers on a communication stream of their own (see _gather_stream)
+        self.overlap = overlap          # all-gathers on the context's communication stream (BTF_OPT_SPLIT_ACCUM)
         # rehearse: ONE process plays rank `plan.rank` of `plan.world` (bench.py --as-rank): its kernels run on that
-        # rank's real slabs, and every collective of the sharded step is issued in a one-rank group on scratch buffers
-        # of the full message size - the blocks of the other ranks in W / V are never refreshed, so the chain is not a
-        # sampler of anything; only the clock is read
+        # rank's real slabs, and every collective of the sharded step is issued on a one-rank communicator over scratch
+        # buffers of the full message size (btf_comm_rehearse) - the blocks of the other ranks in W / V are never
+        # refreshed, so the chain is not a sampler of anything; only the clock is read
         self.rehearse = rehearse
-        self._Wt = self._Vt = None
-        self._tstream = self._cstream = None
+        self._tstream = None
         self.timing, self._events = False, {"all_gather_W": [], "all_gather_V": [], "all_reduce_sse": []}
         # BTF_EXERCISE_EXCHANGE=1: issue the collectives even in a 1-rank group (lets a 1-GPU box
         # run the exact RCCL call sequence of the sharded path)
         import os
         self.active = plan.world > 1 or rehearse or os.environ.get("BTF_EXERCISE_EXCHANGE", "0") == "1"
-        if self.active:
-            import torch.distributed as dist
-            if not dist.is_initialized():
-                raise RuntimeError("shard=(rank, world) needs an initialised torch.distributed process group")
-            if rehearse:
-                if dist.get_world_size(group) != 1:
-                    raise RuntimeError("a rehearsal runs in a one-rank process group")
-            elif dist.get_world_size(group) != plan.world or dist.get_rank(group) != plan.rank:
-                raise RuntimeError("shard does not match the process group")
+        self.transport = None
+        if not self.active:
+            return
+        if rehearse:
+            if ctx is None:
+                raise RuntimeError("a rehearsal needs a device context")
+            self.transport = "rccl"
+            ctx.call("btf_comm_rehearse", plan.rank, plan.world)
+            return
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("shard=(rank, world) needs an initialised torch.distributed process group "
+                               "(the channel the communicator id travels over)")
+        if dist.get_world_size(group) != plan.world or dist.get_rank(group) != plan.rank:
+            raise RuntimeError("shard does not match the process group")
+        want = transport or os.environ.get("BTF_EXCHANGE_TRANSPORT") or \
+            ("rccl" if dist.get_backend(group) == "nccl" else "host")
+        if want not in ("rccl", "host"):
+            raise ValueError("transport must be 'rccl' or 'host'")
+        self.transport = want if ctx is not None else "host"
+        if self.transport == "rccl":
+            self._init_comm()
 
-    # -- device path (RCCL) ----------------------------------------------------------
+    # -- device path (RCCL under the C ABI) ----------------------------------------------
+    def _init_comm(self):
+        """btf_comm_unique_id on rank 0 -> broadcast over the process group -> btf_comm_init on every rank."""
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _native
+        nb = _native.COMM_ID_BYTES
+        ident = (C.c_ubyte * nb)()
+        if self.plan.rank == 0:
+            rc = self.ctx.lib.btf_comm_unique_id(ident, nb)
+            if rc != _native.BTF_OK:
+                raise _native.BTFError(rc, self.ctx.lib.btf_last_error(None).decode())
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=torch.device("cuda", self.ctx.device) if on_gpu else "cpu")
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast(t, src=src, group=self.group)
+        ident = (C.c_ubyte * nb)(*t.cpu().tolist())
+        self.ctx.call("btf_comm_init", self.plan.rank, self.plan.world, ident, nb)
+
+    def comm_info(self):
+        """{has communicator, rank, world, gather rank, gather world, rehearsal, RCCL version, ncclCommCount} of the
+        context's communicator (btf_comm_info)."""
+        import ctypes as C
+        out = (C.c_int32 * 8)()
+        self.ctx.call("btf_comm_info", out)
+        return dict(zip(("active", "rank", "world", "gather_rank", "gather_world", "rehearsal", "rccl_version", "comm_count"), out))
+
     def _stream(self):
-        """The ctx's HIP stream as a torch stream: the collectives are issued under it, so that RCCL orders
-        them after the draw kernel and the next half-sweep after them - whichever stream is torch's current one."""
+        """The ctx's HIP stream as a torch stream (event timing of the collectives only)."""
         import torch
         if self._tstream is None:
             self._tstream = torch.cuda.ExternalStream(self.ctx.stream_handle, device=torch.device("cuda", self.ctx.device))
         return self._tstream
 
-    def _comm(self):
-        """The communication stream of the overlapped exchange: ordered behind the kernel that drew this rank's block
-        (btf_comm_fork) - NOT behind the own-block chunks of the next accumulation the ctx queues after it - and
-        joined back into the ctx's stream when the gather has been issued (btf_comm_join)."""
+    def _timed(self, name, fn):
+        if not self.timing:
+            return fn()
         import torch
-        if self._cstream is None:
-            self._cstream = torch.cuda.Stream(device=torch.device("cuda", self.ctx.device))
-        return self._cstream
-
-    def _gather(self, name, fn):
-        """One all-gather of the freshly drawn block: overlapped (own stream, fork / join against the ctx's) or in line."""
-        if not self.overlap:
-            return self._timed(name, fn)
-        import ctypes as C
-        comm = self._comm()
-        self.ctx.call("btf_comm_fork", C.c_void_p(comm.cuda_stream))
-        self._timed(name, fn, stream=comm)
-        self.ctx.call("btf_comm_join", C.c_void_p(comm.cuda_stream))
-
-    def _timed(self, name, fn, stream=None):
-        import torch
-        with torch.cuda.stream(stream if stream is not None else self._stream()):
-            if self.timing:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                fn()
-                e1.record()
-                self._events[name].append((e0, e1))
-            else:
-                fn()
+        with torch.cuda.stream(self._stream()):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            self._events[name].append((e0, e1))
 
     def collective_us(self):
         """Mean microseconds per collective since timing was switched on (synchronises)."""
@@ -166,33 +184,9 @@ class Exchange:
             self._events[k] = []
         return out
 
-    def _views(self):
-        import torch
-        p, (N, M, T, K, _) = self.plan, self.ctx.dims
-        if self._Wt is None:
-            lib = self.ctx.lib
-            dev = torch.device("cuda", self.ctx.device)
-            # the context over-allocates W / V by 64 rows / columns, so world*chunk fits
-            self._Wt = torch.as_tensor(_DevView(lib.btf_dev_W(self.ctx.h), (p.world * p.row_chunk * K,)), device=dev)
-            self._Vt = torch.as_tensor(_DevView(lib.btf_dev_V(self.ctx.h), (p.world * p.col_chunk * T * K,)), device=dev)
-        return self._Wt, self._Vt
-
-    def _scratch(self, which):
-        """Rehearsal buffers: a one-rank all-gather moves out = in, so both have the size of the whole gathered factor."""
-        import torch
-        if getattr(self, "_scr", None) is None:
-            p, (N, M, T, K, _) = self.plan, self.ctx.dims
-            dev = torch.device("cuda", self.ctx.device)
-            nW, nV = p.world * p.row_chunk * K, p.world * p.col_chunk * T * K
-            self._scr = {"W": torch.zeros(nW, dtype=torch.float64, device=dev), "W_in": torch.zeros(nW, dtype=torch.float64, device=dev),
-                         "V": torch.zeros(nV, dtype=torch.float64, device=dev), "V_in": torch.zeros(nV, dtype=torch.float64, device=dev)}
-        return self._scr[which]
-
     def _staged(self):
-        """True when the process group cannot move device memory (e.g. gloo): the exchange is then
-        staged through the host (used to rehearse several ranks on one GPU; RCCL refuses that)."""
-        import torch.distributed as dist
-        return dist.get_backend(self.group) != "nccl"
+        """True when the exchange goes through host copies (transport "host")."""
+        return self.transport != "rccl"
 
     def _staged_gather(self, getter, setter, shape, block0, blocklen, gather):
         import ctypes as C
@@ -208,13 +202,7 @@ class Exchange:
         if self._staged():
             N, M, T, K, _ = self.ctx.dims
             return self._staged_gather("btf_get_W", "btf_set_gathered_W", (N, K), self.plan.row0, self.plan.nl, self.gather_rows_host)
-        import torch.distributed as dist
-        if self.rehearse:
-            return self._gather("all_gather_W", lambda: dist.all_gather_into_tensor(self._scratch("W"), self._scratch("W_in"), group=self.group))
-        Wt, _ = self._views()
-        K = self.ctx.dims[3]
-        n = self.plan.row_chunk * K
-        self._gather("all_gather_W", lambda: dist.all_gather_into_tensor(Wt, Wt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group))
+        self._timed("all_gather_W", lambda: self.ctx.call("btf_allgather_W"))
 
     def after_V(self):
         if not self.active:
@@ -222,38 +210,34 @@ class Exchange:
         if self._staged():
             N, M, T, K, _ = self.ctx.dims
             return self._staged_gather("btf_get_V", "btf_set_gathered_V", (M, T, K), self.plan.col0, self.plan.ml, self.gather_cols_host)
-        import torch.distributed as dist
-        if self.rehearse:
-            return self._gather("all_gather_V", lambda: dist.all_gather_into_tensor(self._scratch("V"), self._scratch("V_in"), group=self.group))
-        _, Vt = self._views()
-        _, _, T, K, _ = self.ctx.dims
-        n = self.plan.col_chunk * T * K
-        self._gather("all_gather_V", lambda: dist.all_gather_into_tensor(Vt, Vt[self.plan.rank * n:(self.plan.rank + 1) * n], group=self.group))
+        self._timed("all_gather_V", lambda: self.ctx.call("btf_allgather_V"))
 
     def all_reduce_sse(self):
         """Sum the rank-local residual sum of squares (device scalar slot 4, btf_dev_hyp) over the ranks, in place,
         on the ctx's stream: the one exchange of a sharded nu2 draw (include/btf.h, btf_draw_scalars which | 8 / | 16)."""
         if not self.active:
             return
-        import torch.distributed as dist
         if self._staged():
+            import ctypes as C
             out = np.zeros(6)
-            self.ctx.call("btf_get_scalars", out.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double)))
+            self.ctx.call("btf_get_scalars", out.ctypes.data_as(C.POINTER(C.c_double)))
             (tot,) = self.sum_scalars(float(out[4]))
             self.ctx.call("btf_set_scalar_slot", 4, float(tot))
             return
-        import torch
-        if getattr(self, "_sse_t", None) is None:
-            ptr = self.ctx.lib.btf_dev_hyp(self.ctx.h)
-            self._sse_t = torch.as_tensor(_DevView(ptr + 4 * 8, (1,)), device=torch.device("cuda", self.ctx.device))
-        self._timed("all_reduce_sse", lambda: dist.all_reduce(self._sse_t, group=self.group))
+        self._timed("all_reduce_sse", lambda: self.ctx.call("btf_allreduce_sse"))
 
     def sum_scalars(self, *vals):
         if not self.active:
             return vals
+        if not self._staged():
+            import ctypes as C
+            buf = np.array(vals, dtype=np.float64)
+            self.ctx.call("btf_allreduce_sum", buf.ctypes.data_as(C.POINTER(C.c_double)), len(vals))
+            return tuple(buf.tolist())
         import torch
         import torch.distributed as dist
-        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        dev = torch.device("cuda", self.ctx.device) if (dist.get_backend(self.group) == "nccl" and self.ctx is not None) else \
+            ("cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
         t = torch.tensor(vals, dtype=torch.float64, device=dev)
         dist.all_reduce(t, group=self.group)
         return tuple(t.tolist())

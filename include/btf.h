@@ -136,8 +136,9 @@ int btf_fail_index(const btf_ctx* ctx);
 /* ---- sharding (multi-GPU) --------------------------------------
  * This ctx updates rows [row0,row0+nrows_local) in the W half-sweep and columns
  * [col0,col0+ncols_local) in the V half-sweep.  Must precede btf_set_data_*.
- * Default: everything.  W and V are replicated: after each half-sweep the host
- * all-gathers the updated block (device pointers via btf_dev_W / btf_dev_V). */
+ * Default: everything.  W and V are replicated: after each half-sweep the updated block is
+ * all-gathered - btf_allgather_W / btf_allgather_V below (the ctx's own RCCL communicator), or by
+ * the caller on the device pointers btf_dev_W / btf_dev_V. */
 int btf_set_shard(btf_ctx* ctx, int row0, int nrows_local, int col0, int ncols_local);
 /* compat=REFERENCE in a sharded run (compat caveat).  The cached likelihood weights of quirks Q1/Q2 come from
  * a SOURCE row / column (factor.py:320,349: row nembeds-1 for every later row when the data hold no NaN;
@@ -160,6 +161,44 @@ void* btf_stream(btf_ctx* ctx); /* the hipStream_t every step function of this c
  * `comm_stream` so far.  hipStream_t handles; no host synchronisation. */
 int btf_comm_fork(btf_ctx* ctx, void* comm_stream);
 int btf_comm_join(btf_ctx* ctx, void* comm_stream);
+/* ---- the ctx-owned communicator ("ctx owns device buffers, streams, RCCL communicators"; 8(e)) -----------
+ * The exchange of a sharded run - given V the rows of W are independent (factor.py:333), given W the columns of V are
+ * (factor.py:378), so each half-sweep ends in ONE all-gather of the freshly drawn blocks - issued by the library
+ * itself: ncclAllGather / ncclAllReduce of RCCL, in place on the ctx's own W / V / scalar buffers and on the ctx's own
+ * stream (stream-ordered, no host synchronisation).  RCCL is bound at run time (csrc/btf_comm.h): a process that never
+ * calls these never maps it.  One process per GPU, one ctx per process and communicator.
+ *
+ *   rank 0:      btf_comm_unique_id(id, BTF_COMM_ID_BYTES)       (ncclGetUniqueId)
+ *   the caller:  hands the 128 bytes to every rank over any channel it has (MPI, a file, a socket, torch.distributed)
+ *   every rank:  btf_set_shard(blocks of btf_comm_block) ... btf_comm_init(ctx, rank, world, id, BTF_COMM_ID_BYTES)
+ *   every sweep: btf_resample_W -> btf_allgather_W -> btf_resample_V -> btf_allgather_V
+ *
+ * btf_comm_block: the block [lo, lo + len) of an axis of n rows / columns that rank `rank` of `world` owns - equal
+ * chunks ceil(n / world), the tail ranks short or empty (the only decomposition one in-place all-gather reassembles;
+ * W and V are allocated with 64 spare rows / columns for it, hence world <= 64).  The all-gathers return BTF_ESTATE
+ * if btf_set_shard was given anything else.
+ * btf_allgather_W / _V: all-gather of the block this rank drew in the last half-sweep.  With BTF_OPT_SPLIT_ACCUM the
+ * gather runs on a communication stream of the ctx, ordered by btf_comm_fork / btf_comm_join as described there.
+ * btf_allreduce_sse: sums the device scalar HYP_SSE (slot 4 of btf_dev_hyp) over the ranks - the one exchange of a
+ * sharded nu2 draw (btf_draw_scalars which | 8, this call, which | 16).
+ * btf_allreduce_sum: sums n <= 16 host doubles over the ranks, in place (observation counts at set-up, the host-side
+ * nu2 draw's residual sum of squares).  Synchronises.
+ * btf_comm_rehearse: a timing aid - ONE process plays rank `rank` of `world`: a one-rank communicator, and every
+ * all-gather moves the full gathered message (world x chunk doubles) from one scratch buffer to another, so the step
+ * pays RCCL's call and the message's bytes but the blocks of the other ranks are never refreshed: not a sampler.
+ * btf_comm_info: out[8] = {has communicator, its rank, its size, gather rank, gather world, rehearsal, RCCL version
+ * code, ncclCommCount}.                                                                                              */
+#define BTF_COMM_ID_BYTES 128
+int btf_comm_unique_id(unsigned char* id, int nbytes);
+int btf_comm_block(int n, int rank, int world, int32_t* lo, int32_t* len);
+int btf_comm_init(btf_ctx* ctx, int rank, int world, const unsigned char* id, int nbytes);
+int btf_comm_rehearse(btf_ctx* ctx, int rank, int world);
+int btf_comm_destroy(btf_ctx* ctx);
+int btf_comm_info(btf_ctx* ctx, int32_t* out);
+int btf_allgather_W(btf_ctx* ctx);
+int btf_allgather_V(btf_ctx* ctx);
+int btf_allreduce_sse(btf_ctx* ctx);
+int btf_allreduce_sum(btf_ctx* ctx, double* vals, int n);
 /* btf_set_W / btf_set_V for an exchange staged through the host: the caller's own block is unchanged, so chunks already
  * accumulated from it (BTF_OPT_SPLIT_ACCUM) stay valid. */
 int btf_set_gathered_W(btf_ctx* ctx, const double* W);
@@ -217,6 +256,10 @@ int btf_set_W(btf_ctx* ctx, const double* W);            /* (N,K)      */
 int btf_get_W(btf_ctx* ctx, double* W);
 int btf_set_V(btf_ctx* ctx, const double* V);            /* (M,T,K)    */
 int btf_get_V(btf_ctx* ctx, double* V);
+/* Tau2 NULL: keep the device copy (only lam2 / sigma2 move).  A non-NULL Tau2, or a lam2 that differs from the last
+ * one, invalidates the precomputed prior band of the V half-sweep (prior_band_kernel runs again before the next one):
+ * a host loop that re-sends unchanged hyper-parameters every sweep should pass NULL.  Reading the scalars back
+ * (btf_get_scalars) invalidates nothing.                                                                       */
 int btf_set_hyper(btf_ctx* ctx, const double* Tau2 /* (M,nD) */, double lam2, double sigma2);
 /* Horseshoe+ local scales on the device (rng="device" only - the draws
  * come from Philox, not from the legacy numpy stream).  btf_set_tau_chain uploads the three

@@ -3,9 +3,10 @@ through the host because RCCL refuses two ranks on one device) run the SHARDED k
 and column offsets, local slabs, per-rank partial SSE - on cuda:0 and must reproduce the
 unsharded oracle.
 Also the worker of test_rccl_exchange_with_one_rank_reproduces_the_plain_chain (BTF_DIST_BACKEND=nccl,
-BTF_EXERCISE_EXCHANGE=1, one rank): the same checks with the DEVICE collectives - all_gather_into_tensor on the
-context's W / V buffers and the 8-byte all-reduce of the residual sum of squares, issued under the context's own
-stream - in the call sequence of an N-rank RCCL run."""
+BTF_EXERCISE_EXCHANGE=1, one rank): the same checks with the DEVICE collectives - btf_allgather_W / btf_allgather_V on the
+context's W / V buffers and btf_allreduce_sse, the 8-byte all-reduce of the residual sum of squares: RCCL calls of the
+library itself on the context's communicator and stream (the process group only carries the communicator id) - in the
+call sequence of an N-rank RCCL run."""
 import os
 import sys
 
@@ -224,6 +225,11 @@ def main():
             N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
             W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], compat="exact", shard=(rank, world), device=DEV, overlap_exchange=OVERLAP)
         assert model._exchange.active and model._plan.world == world
+        # "nccl" process group: the exchange is the context's own RCCL communicator (C ABI); gloo: staged through the host
+        assert model._exchange.transport == ("rccl" if backend == "nccl" else "host"), model._exchange.transport
+        if backend == "nccl":
+            info = model._exchange.comm_info()
+            assert info["active"] == 1 and info["rank"] == rank and info["world"] == world and info["comm_count"] == world, info
         Delta = orc.trend_penalty(T, tf)
         ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
         for it in range(2):
@@ -317,7 +323,8 @@ def main():
         assert np.abs(a[2] - b[2]).max() / np.abs(b[2]).max() < 1e-9, ("R", rdims)
         assert np.abs(a[3] - b[3]).max() / np.abs(b[3]).max() < 1e-9, ("omega", rdims)
         assert np.abs(a[0] - b[0]).max() / np.abs(b[0]).max() < 1e-7 and np.abs(a[1] - b[1]).max() / np.abs(b[1]).max() < 1e-5, rdims
-    print("SHARD_GPU_OK rank", rank, "backend", dist.get_backend(), "world", dist.get_world_size(), "device", DEV, flush=True)
+    print("SHARD_GPU_OK rank", rank, "backend", dist.get_backend(), "world", dist.get_world_size(), "device", DEV,
+          "exchange", "ctx-owned RCCL communicator" if backend == "nccl" else "host-staged", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

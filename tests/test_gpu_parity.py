@@ -755,11 +755,11 @@ def test_sharded_reference_compat_reads_its_stale_weights_from_the_halo(world):
 
 @pytest.mark.timeout(400)
 def test_rccl_exchange_with_one_rank_reproduces_the_plain_chain():
-    """The DEVICE collective path of sharded runs (functionalmf_amd/parallel.py: all_gather_into_tensor on the
-    context's own W / V buffers and the 8-byte all-reduce of the residual sum of squares, issued under
-    torch.cuda.ExternalStream(ctx stream); the nu2 draw split around the all-reduce, btf_draw_scalars which | 8 then
-    | 16) on real hardware: a one-rank RCCL ("nccl") group with BTF_EXERCISE_EXCHANGE=1 issues every collective of
-    an N-rank run.  Host-RNG half-sweeps against the oracle, then whole rng="device" sweeps (Gaussian complete,
+    """The DEVICE collective path of sharded runs (btf_allgather_W / btf_allgather_V on the context's own W / V
+    buffers and btf_allreduce_sse, the 8-byte all-reduce of the residual sum of squares: the library's own RCCL calls on
+    the context's communicator and stream, bootstrapped by functionalmf_amd/parallel.py over the process group; the nu2
+    draw split around the all-reduce, btf_draw_scalars which | 8 then | 16) on real hardware: a one-rank RCCL ("nccl")
+    group with BTF_EXERCISE_EXCHANGE=1 issues every collective of an N-rank run.  Host-RNG half-sweeps against the oracle, then whole rng="device" sweeps (Gaussian complete,
     Gaussian with held-out cells, Binomial): the chain with the exchanges in must equal the plain one - a collective
     or a draw kernel running out of order on the stream would change it."""
     import os
