@@ -86,6 +86,22 @@ def synth_rows(seed, rows, M, T, R, K, Vt, noise=0.5, cols=None):
     return out, W
 
 
+def synth_legacy(seed, N, M, T, R, K, noise=0.5):
+    """SURVEY 8(d)'s synthetic tensor exactly as specified, for the unsharded runs: ONE legacy stream
+    (np.random.seed(seed), MT19937 + polar normals, as examples/gaussian_tensor_filtering.py:14-19 draws its data):
+    W_true ~ N(0,1) (N,K) with the upper triangle zeroed, V_true = 0.1 cumsum(N(0,1) (M,T,K), axis=1),
+    Y = Mu[..., None] + N(0, noise^2) (N,M,T,R).  Returns Y, W_true, V_true."""
+    rs = np.random.RandomState(seed)
+    Wt = rs.normal(0, 1, size=(N, K))
+    Wt[np.triu_indices(K, 1)] = 0
+    Vt = 0.1 * np.cumsum(rs.normal(0, 1, size=(M, T, K)), axis=1)
+    Y = np.einsum("nk,mtk->nmt", Wt, Vt)[..., None] + rs.normal(0, noise, size=(N, M, T, R))
+    return Y, Wt, Vt
+
+
+LEGACY_MAX_VALUES = 1 << 28     # the one-stream generator up to 2^28 values (C3: 2^25); beyond it - and for every rank slab - synth_rows
+
+
 def synth_V(seed, M, T, K):
     rs = np.random.RandomState(seed)
     return 0.1 * np.cumsum(rs.normal(0, 1, size=(M, T, K)), axis=1)
@@ -195,8 +211,12 @@ def main():
     # ---- synthetic data: only this rank's two slabs are ever materialised -------------
     Vt = synth_V(1, M, T, K)
     plan = ShardPlan(N, M, *(as_rank if as_rank else (rank, world)))
-    if world == 1 and not as_rank:
-        Y, _ = synth_rows(1, range(N), M, T, R, K, Vt)
+    legacy_data = world == 1 and not as_rank and N * M * T * R <= LEGACY_MAX_VALUES
+    if legacy_data:
+        Y, Wt_true, Vt = synth_legacy(1, N, M, T, R, K)         # legacy np.random.seed(1) stream
+        slabs = None
+    elif world == 1 and not as_rank:
+        Y, Wt_true = synth_rows(1, range(N), M, T, R, K, Vt)
         slabs = None
     else:
         rows, _ = synth_rows(1, range(plan.row0, plan.row0 + plan.nl), M, T, R, K, Vt)
@@ -216,11 +236,11 @@ def main():
             Y[rs.rand(N, M) < 0.05] = np.nan
             Y[rs.rand(N, M, T, R) < 0.05] = np.nan
         elif args.variant == "negbinom":
-            Mu = np.einsum("nk,mtk->nmt", synth_rows(1, range(N), M, T, 1, K, Vt, noise=0.0)[1], Vt)
+            Mu = np.einsum("nk,mtk->nmt", Wt_true, Vt)
             P = 1 / (1 + np.exp(-Mu))
             Y = rs.negative_binomial(4.0, 1 - np.repeat(P[..., None], R, axis=-1)).astype(float)
         else:
-            Mu = np.einsum("nk,mtk->nmt", synth_rows(1, range(N), M, T, 1, K, Vt, noise=0.0)[1], Vt)
+            Mu = np.einsum("nk,mtk->nmt", Wt_true, Vt)
             Ntr = np.full((N, M, T), 4.0)
             Y = (rs.binomial(4, 1 / (1 + np.exp(-Mu))).astype(float), Ntr)
     np.random.seed(1)
@@ -402,6 +422,14 @@ def main():
         fence()
         banded_per_s = nb / (time.perf_counter() - t0)
         model._ctx.call("btf_set_option", _native.OPT_SAMPLER, _native.SAMPLERS["spectral"])
+    # ... and the mode that meets north_star's bar (1) bit for bit - rng="host", sampler="banded", compat="reference": the
+    # legacy numpy stream feeds every draw, a fixed seed walks the reference's chain - timed in a leg of its own
+    host_rng = None
+    if world == 1 and not as_rank and not args.lean and args.variant == "complete" and args.sampler == "auto" and legacy_data:
+        try:
+            host_rng = host_rng_leg(Y, N, M, T, K, local_rank, stream, fence)
+        except Exception as e:         # pragma: no cover  (never let the extra leg cost the headline line)
+            host_rng = {"error": repr(e)}
     b_wv = bpc * (cells_local + cells_local_v)                     # B_WV of SURVEY 8(d), per GPU
     if args.variant in ("binomial", "negbinom"):                   # + the PG draw: trials in, omega out (48 B/cell in all)
         b_wv += 16.0 * cells_local
@@ -420,7 +448,7 @@ def main():
         "scaling": "weak" if (weak or world == 1) else "strong",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
+        "data": "synthetic" + (" (SURVEY 8(d): legacy np.random.seed(1) stream)" if legacy_data else " (per-row / per-block streams: rank slabs)"),
         "config": {"workload": "%s_btf %s (%d,%d,%d,%d) nembeds=%d tf_order=2 %s data, W+V update, rng=device%s"
                                % ({"binomial": "binomial", "negbinom": "negbinom"}.get(args.variant, "gaussian"), args.config, N, M, T,
                                   {"binomial": 1}.get(args.variant, R), K, args.variant + (" (4 trials per cell)" if args.variant == "binomial" else ""),
@@ -451,6 +479,8 @@ def main():
                      "copy_ceiling_GBs": copy_ceiling(torch), "read_ceiling_GBs": read_ceiling(local_rank)},
         "kernels_us": kernels_us,
     }
+    if host_rng is not None:
+        out["host_rng"] = host_rng
     # ---- the roofline object against the committed profiles of THIS workload (profiles/README.md) --------------------------
     #  traffic: HBM bytes per accumulation launch from the PMC passes (never another workload's figure);
     #  rocprof_avg_us: rocprofv3 --kernel-trace --stats AverageNs of the accumulation kernels in a `--lean` run of this command
@@ -542,6 +572,48 @@ def main():
     if world > 1 or exercise:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_rng_leg(Y, N, M, T, K, device, stream, fence, steps=40, sweeps=20):
+    """The reference-reproducible mode beside `value`: rng="host" (every normal and gamma from the legacy global numpy stream,
+    in the reference's order: SURVEY 8(a) Q4), sampler="banded" (P'L^-T z of a declared elimination order, fast_mvn.py:38-47),
+    compat="reference".  This is the instantiation the golden fixtures pin bit for bit (G1-G6); it is host-bound by construction -
+    82 k legacy polar normals per step and their upload - and is the default a user of INTEGRATION.md section A gets."""
+    from functionalmf_amd.factor import GaussianBayesianTensorFiltering
+    np.random.seed(1)
+    m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, nu2_init=1.0, rng="host",
+                                        compat="reference", sampler="banded", device=device, stream=stream)
+    for _ in range(3):
+        m.resample(Y)
+
+    def step():
+        m._resample_W(Y)
+        m._resample_V(Y)
+    for _ in range(5):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    m.sync()
+    fence()
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(sweeps):
+        m.resample(Y)
+    m.sync()
+    fence()
+    dts = time.perf_counter() - t0
+    nz = K * (K + 1) // 2 + (N - K) * K + M * K * T
+    t0 = time.perf_counter()
+    for _ in range(10):
+        np.random.normal(size=nz)
+    tz = (time.perf_counter() - t0) / 10
+    return {"mode": "rng=host, sampler=banded, compat=reference: the fixed-seed chain of the reference (bit-level fixtures G1-G6)",
+            "wv_steps_per_s": round(steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+            "full_sweeps_per_s": round(sweeps / dts, 1), "sweeps": sweeps, "v_sampler": m.v_sampler(),
+            "host_normals_per_step": nz, "legacy_normals_ms_per_step": round(1e3 * tz, 3),
+            "bound": "host: the legacy MT19937 / polar-method stream the reference draws from, then one upload per half-sweep"}
 
 
 def c4_leg(N, M, T, K, Vt, device, stream, fence, torch, steps=200):

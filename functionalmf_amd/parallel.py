@@ -154,6 +154,18 @@ class Exchange:
         self.ctx.call("btf_comm_info", out)
         return dict(zip(("active", "rank", "world", "gather_rank", "gather_world", "rehearsal", "rccl_version", "comm_count"), out))
 
+    def device_views(self):
+        """The context's W / V device buffers as torch tensors over the SAME memory (btf_dev_W / btf_dev_V, including the
+        padding the in-place all-gather uses): for a caller that prefers its own collectives to btf_allgather_W / _V - it
+        must issue them on the context's stream (btf_stream) or order its stream against it."""
+        import torch
+        p, (N, M, T, K, _) = self.plan, self.ctx.dims
+        lib = self.ctx.lib
+        dev = torch.device("cuda", self.ctx.device)
+        Wt = torch.as_tensor(_DevView(lib.btf_dev_W(self.ctx.h), (p.world * p.row_chunk * K,)), device=dev)
+        Vt = torch.as_tensor(_DevView(lib.btf_dev_V(self.ctx.h), (p.world * p.col_chunk * T * K,)), device=dev)
+        return Wt, Vt
+
     def _stream(self):
         """The ctx's HIP stream as a torch stream (event timing of the collectives only)."""
         import torch

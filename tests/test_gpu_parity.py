@@ -496,8 +496,9 @@ def test_binomial_chain_recovers_probabilities():
 
 
 def test_device_buffers_are_visible_to_torch_distributed(tmp_path):
-    """The RCCL exchange wraps the ctx's W / V device buffers as torch tensors and gathers in
-    place.  On a 1-GPU box: 1-rank nccl group, check aliasing both ways and the collective."""
+    """A caller that prefers its own collectives wraps the ctx's W / V device buffers (btf_dev_W / btf_dev_V) as torch
+    tensors and gathers in place (parallel.Exchange.device_views; the library's own exchange is btf_allgather_W / _V).
+    On a 1-GPU box: 1-rank nccl group, check aliasing both ways and the collective."""
     import os
     import torch
     import torch.distributed as dist
@@ -516,7 +517,7 @@ def test_device_buffers_are_visible_to_torch_distributed(tmp_path):
                                                 stream=torch.cuda.current_stream().cuda_stream)
         W0 = model.W.copy()
         model._push_state()
-        Wt, Vt = model._exchange._views()
+        Wt, Vt = model._exchange.device_views()
         assert Wt.is_cuda and Wt.dtype == torch.float64
         assert np.array_equal(Wt[:N * K].cpu().numpy().reshape(N, K), W0)          # same memory, read
         Wt[:N * K] += 1.0                                                            # ... and write
@@ -524,7 +525,7 @@ def test_device_buffers_are_visible_to_torch_distributed(tmp_path):
         model._W_dev_new = True
         assert np.array_equal(model.W, W0 + 1.0)
         n = model._plan.row_chunk * K
-        dist.all_gather_into_tensor(Wt[:n], Wt[0:n])                                 # in-place form used by after_W
+        dist.all_gather_into_tensor(Wt[:n], Wt[0:n])                                 # the in-place form btf_allgather_W issues
         torch.cuda.synchronize()
         model._W_dev_new = True
         assert np.array_equal(model.W, W0 + 1.0)
@@ -1195,6 +1196,27 @@ def test_spectral_v_step_vs_reference(golden, tag, monkeypatch):
     # held: whole curves missing (the reference examples' pattern) - complete-data kernels plus corrections
     assert model.likelihood_form() == ("curve_counts" if tag == "held" else "complete")
     assert relerr(model.V, Vref) < V_TOL
+
+
+@pytest.mark.parametrize("tag", ["g2", "k5", "tf0", "tf1", "tf3", "short", "held"])
+@pytest.mark.parametrize("fused", [0, 1])
+def test_spectral_mean_vs_dense_lapack_on_the_references_system(golden, tag, fused, monkeypatch):
+    """The benchmarked square root pinned to dense LAPACK: with z = 0 the spectral kernel's draw is the conditional mean,
+    and G8 holds np.linalg.solve(Q_j, mu_part_j) on the Q and mu_part the reference's own _resample_V assembled
+    (fast_mvn.py:47; tests/golden/make_golden_spectral.py), with cond(Q_j).  Column by column to 50 cond(Q_j) eps; the
+    stand-alone kernel and (where the shape admits it) the fused tail of the V accumulation launch."""
+    from functionalmf_amd import _native
+    g8 = golden("g8_spectral.npz")
+    model, Y, st, (N, M, T, R, K, tf), z, _ = _spectral_model(golden, tag)
+    model._ctx.call("btf_set_option", _native.OPT_FUSED_STEP, fused)
+    monkeypatch.setattr(model, "_v_normals", lambda: 0 * z)
+    model._resample_V(Y)
+    assert model.v_sampler() == "spectral"
+    dense, cond = g8[tag + "_V_mean_dense"], g8[tag + "_cond"]
+    V = model.V
+    for j in range(M):
+        err = np.abs(V[j] - dense[j]).max() / np.abs(dense[j]).max()
+        assert err <= 50 * cond[j] * np.finfo(float).eps, (tag, j, err, cond[j])
 
 
 def test_spectral_jitter_retry_matches_reference_schedule(golden):

@@ -285,6 +285,23 @@ def test_v_step_spectral_square_root_vs_reference(golden, tag):
     assert relerr(c["V"], d["V"]) < tol
 
 
+@pytest.mark.parametrize("tag", ["g2", "k5", "tf0", "tf1", "tf3", "short", "held"])
+def test_spectral_mean_is_the_dense_lapack_mean_of_the_references_system(golden, tag):
+    """G8's *_V_mean_dense is np.linalg.solve(Q_j, mu_part_j) on the precision and mu_part the REFERENCE's _resample_V
+    assembled (make_golden_spectral.py records them at fast_mvn.py:47); the generator already asserts its spectral shim
+    against that solve.  Here: the oracle's spectral square root at z = 0 hits the same means, column by column, to
+    50 cond(Q_j) eps."""
+    g8 = golden("g8_spectral.npz")
+    Y, st, (N, M, T, R, K, tf), z, _ = _spectral_case(golden, tag)
+    dense, cond = g8[tag + "_V_mean_dense"], g8[tag + "_cond"]
+    assert dense.shape == (M, T, K) and cond.shape == (M,)
+    a = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
+    orc.v_step(a, Y, orc.trend_penalty(T, tf), perm="spectral", z=0 * z)
+    for j in range(M):
+        err = np.abs(a["V"][j] - dense[j]).max() / np.abs(dense[j]).max()
+        assert err <= 50 * cond[j] * np.finfo(float).eps, (tag, j, err, cond[j])
+
+
 def test_spectral_square_root_has_the_right_covariance(golden):
     """S S' = Q^-1 for the spectral square root (unit normals pick out the columns of S)."""
     Y, st, (N, M, T, R, K, tf), z, _ = _spectral_case(golden, "k5")
