@@ -79,6 +79,14 @@ class ShardPlan:
         return full[:axis_len]
 
 
+class _DevView:
+    """__cuda_array_interface__ holder so torch can wrap a raw device pointer."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
 class Exchange:
     """The per-half-sweep exchange.  world == 1: no-ops.
 
