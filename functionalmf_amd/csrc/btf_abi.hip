@@ -88,6 +88,7 @@ struct btf_ctx {
   long long* acc_stamps = nullptr;
 #endif
   double* pband = nullptr;
+  double* pimg = nullptr; unsigned long long pimg_version = 0;       // the band as LDS images [P | Pm] (dataflow tails of the fused V launch)
   // what the precomputed prior band (fused V launch, btf_fused.h) was formed from: every change of Tau2 / lam2 / the shard
   // moves prior_version on; the band is rebuilt (prior_band_kernel) when pband_version lags behind
   unsigned long long prior_version = 1, pband_version = 0, last_v_prior_version = 0;
@@ -384,7 +385,20 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
     }
     if constexpr (K <= 8) {
       if (fw) p.launch(accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_W>, grid, dim3(16 * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, *fw);
-      else p.launch(accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_V>, grid, dim3(16 * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, *fv);
+      else {
+        // the barrier-free (dataflow) tail where it applies: one chunk per tile (the sums never leave the workgroup), the
+        // precomputed band, no scalar drawn by a side workgroup of this launch, every value in one reduction round
+        // (nembeds <= 6), its LDS footprint beside the partial sums; BTF_VF_DATAFLOW=0: the barrier form (A/B aid)
+        static const bool df_on = [] { const char* e = std::getenv("BTF_VF_DATAFLOW"); return !e || std::atoi(e) != 0; }();
+        FuseV f2 = *fv;
+        constexpr int RG = K < 4 ? 4 : (K > 6 ? 6 : K);        // accum_kernel's ACC_RG of the 16-wave complete-data instance
+        f2.dataflow = (df_on && f2.a.pband && f2.pimg && !f2.cnt && !f2.hp.flag && K <= 6 &&
+                       vf_df_fits(f2.a.T, K, f2.a.TF, f2.a.nD, 16, RG)) ? 1 : 0;
+        if constexpr (K <= 6) {
+          if (f2.dataflow) { p.launch(accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_VDF>, grid, dim3(16 * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, f2); return; }
+        }
+        p.launch(accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_V>, grid, dim3(16 * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, f2);
+      }
     }
     return;
   }
@@ -949,7 +963,7 @@ void btf_destroy(btf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->A_wT, c->C_wT, c->A_v, c->C_v, c->B_wT, c->B_v, c->W, c->V, c->Tau2, c->part,
                   c->gpart, c->zbuf, c->bsum, c->gband, c->status, c->tries, c->st_ptr, c->st_row, c->st_coef,
-                  c->srcmap_w, c->srcmap_v, c->pband, c->dbg, c->gpart_w, c->gpart_v, c->gsum_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->A8_wT, c->A8_v, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_llp, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val, c->sse_cols, c->vs_rec, c->vc_scratch, c->gs_cptr, c->gs_cidx, c->gs_cval};
+                  c->srcmap_w, c->srcmap_v, c->pband, c->pimg, c->dbg, c->gpart_w, c->gpart_v, c->gsum_v, c->eig, c->cv_cptr, c->cv_crow, c->cv_cdef, c->cv_rptr, c->cv_rcol, c->cv_rdef, c->eig_cols, c->cv_dcols, c->A8_wT, c->A8_v, c->gs_cons, c->gs_cc, c->gs_rc, c->gs_av, c->gs_mask, c->gs_info, c->gs_thetas, c->gs_ntheta, c->gs_ll, c->gs_llp, c->gs_hh, c->gs_cur, c->gs_nacc, c->gs_u, c->st_drow, c->st_dcoef, c->essX0, c->essNu, c->ess_st, c->ess_theta, c->ess_done, c->ess_part, c->Ta, c->Tb, c->Tc, c->lsum, c->dr_ptr, c->dr_col, c->dr_val, c->sse_cols, c->vs_rec, c->vc_scratch, c->gs_cptr, c->gs_cidx, c->gs_cval};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_lsum) (void)hipHostFree(c->pin_lsum);
@@ -980,6 +994,7 @@ int btf_set_shard(btf_ctx* c, int row0, int nrows_local, int col0, int ncols_loc
   c->hrow = c->hcol = -1;
   ++c->prior_version;
   if (c->pband) { (void)hipFree(c->pband); c->pband = nullptr; c->pband_version = 0; }      // (sized for the old column block)
+  if (c->pimg) { (void)hipFree(c->pimg); c->pimg = nullptr; c->pimg_version = 0; }
   c->nb_bwt_written = false;      // (the skip of nb_bwt_target is only valid for the shard geometry B_wT was written under)
   return BTF_OK;
 }
@@ -1404,7 +1419,7 @@ enum { ACC_ALL = 2, ACC_LOCAL = 0 };
 // ---- the two-launch W+V step (btf_fused.h) ----------------------------------------------------------------------
 // words: one 128-byte line per flag / counter, then the tiles' tickets of the W launch, then those of the V launch
 enum { FZ_EIG = 0, FZ_SC = 32, FZ_LAM = 64, FZ_GRAM = 96, FZ_GSUM = 128, FZ_TICKETS = 160 };
-constexpr int FZ_PUB_EIG = 0, FZ_PUB_HYP = 128, FZ_PUB_GSUM = 136, FZ_PUB_DOUBLES = 200;
+constexpr int FZ_PUB_EIG = 0, FZ_PUB_HYP = 128, FZ_PUB_GSUM = 136, FZ_PUB_GRAN = 200, FZ_PUB_DOUBLES = 224;
 int ensure_fused(btf_ctx* c) {
   const int tw = c->ldw / ACC_TILE, tv = c->ldv / ACC_TILE;
   if (c->fz_words && c->fz_tiles_w == tw && c->fz_tiles_v == tv) return BTF_OK;
@@ -1412,7 +1427,10 @@ int ensure_fused(btf_ctx* c) {
   const size_t nwords = (size_t)((FZ_TICKETS + tw + tv + 31) / 32) * 32;
   if ((rc = dev_alloc(c, &c->fz_words, nwords))) return rc;
   HIPCHK(c, hipMemsetAsync(c->fz_words, 0, nwords * sizeof(unsigned), c->stream));      // once: the last arrivers reset their tickets
-  if (!c->fz_pub) { if ((rc = dev_alloc(c, &c->fz_pub, (size_t)FZ_PUB_DOUBLES))) return rc; }
+  if (!c->fz_pub) {
+    if ((rc = dev_alloc(c, &c->fz_pub, (size_t)FZ_PUB_DOUBLES))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->fz_pub, 0, (size_t)FZ_PUB_DOUBLES * sizeof(double), c->stream));      // (the tagged granules: no stale tag may equal an epoch)
+  }
   c->fz_tiles_w = tw; c->fz_tiles_v = tv;
   c->fz_gram_total = 0; c->fz_w_total = 0;
   return BTF_OK;
@@ -1705,7 +1723,7 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
       Prof p(c, BTF_K_PRIOR);
       p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
                (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
-               (const double*)(c->dev_scalars ? c->hyp : nullptr), 1);
+               (const double*)(c->dev_scalars ? c->hyp : nullptr), 1, (double*)nullptr, 0, 0, 0);
       c->pband_version = c->prior_version;
       a.pband = c->pband;
     }
@@ -1718,7 +1736,7 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
       Prof p(c, BTF_K_PRIOR);
       p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
                (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
-               (const double*)(c->dev_scalars ? c->hyp : nullptr), 0);
+               (const double*)(c->dev_scalars ? c->hyp : nullptr), 0, (double*)nullptr, 0, 0, 0);
     }
     c->pband_version = 0;                 // (this form of the band is not the one the version stands for)
     a.pband = c->pband;
@@ -1914,7 +1932,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
           Prof p(c, BTF_K_PRIOR);
           p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
                    (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
-                   (const double*)(c->dev_scalars ? c->hyp : nullptr), 0);
+                   (const double*)(c->dev_scalars ? c->hyp : nullptr), 0, (double*)nullptr, 0, 0, 0);
         }
         c->pband_version = 0;
         sa.pband = c->pband;
@@ -1929,19 +1947,31 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
           // entries at kernel start.  Not when lam2 is drawn by a side workgroup of this very launch - those tails form it
           const int TD1 = T * (c->TF + 2);
           if (!c->pband) { if ((rc = dev_alloc(c, &c->pband, (size_t)c->ml * TD1))) return rc; c->pband_version = 0; }
-          if (c->pband_version != c->prior_version) {
+          // ... and, where the dataflow tail applies, the same band as LDS images [P | Pm] (v_fused_df copies them as they lie)
+          const bool img = c->TF == 2 && K <= 6 && vf_df_fits(T, K, c->TF, c->nD, 16, K < 4 ? 4 : K);
+          const int PB = df_layout(T, K, c->TF + 1).PB;
+          if (img && !c->pimg) {
+            if ((rc = dev_alloc(c, &c->pimg, (size_t)c->ml * 2 * PB))) return rc;
+            HIPCHK(c, hipMemsetAsync(c->pimg, 0, (size_t)c->ml * 2 * PB * sizeof(double), c->stream));      // (the zero rows: once)
+            c->pimg_version = 0;
+          }
+          if (c->pband_version != c->prior_version || (img && c->pimg_version != c->prior_version)) {
             Prof p(c, BTF_K_PRIOR);
             p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
                      (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
-                     (const double*)(c->dev_scalars ? c->hyp : nullptr), 1);
+                     (const double*)(c->dev_scalars ? c->hyp : nullptr), 1, img ? c->pimg : (double*)nullptr, T, c->TF + 2, PB);
             c->pband_version = c->prior_version;
+            c->pimg_version = img ? c->prior_version : 0;
           }
           fv.a.pband = c->pband;
+          if (img && c->pimg_version == c->prior_version) fv.pimg = c->pimg;
         }
         fv.cnt = nch_all > 1 ? c->fz_words + FZ_TICKETS + c->fz_tiles_w : nullptr;
         { static const int be = [] { const char* e = std::getenv("BTF_BAND_EARLY"); return e ? std::atoi(e) : 0; }(); fv.band_early = be; }      // (A/B aid)
         fv.eig_pub = c->fz_pub + FZ_PUB_EIG; fv.eig_flag = c->fz_words + FZ_EIG; fv.epoch = c->fz_epoch;
         side.pub = c->fz_pub + FZ_PUB_EIG; side.flag = c->fz_words + FZ_EIG; side.epoch = c->fz_epoch;
+        side.gran = reinterpret_cast<unsigned long long*>(c->fz_pub + FZ_PUB_GRAN);
+        fv.eig_gran = side.gran;
         if (sw.lam.hyp) {
           sw.lam.pub = c->fz_pub + FZ_PUB_HYP; sw.lam.flag = c->fz_words + FZ_LAM; sw.lam.epoch = c->fz_epoch;
           fv.hp = HypPub{c->fz_pub + FZ_PUB_HYP, c->fz_words + FZ_LAM, c->fz_epoch, 4};
@@ -1966,7 +1996,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
           Prof p(c, BTF_K_PRIOR);
           p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
                    (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
-                   (const double*)(c->dev_scalars ? c->hyp : nullptr), 1);
+                   (const double*)(c->dev_scalars ? c->hyp : nullptr), 1, (double*)nullptr, 0, 0, 0);
           c->pband_version = c->prior_version;
           sa.pband = c->pband;
         }

@@ -107,6 +107,20 @@ __device__ inline double philox_normal(uint64_t seed, uint64_t stream, uint64_t 
   return (index & 1) ? rad * s : rad * c;
 }
 
+// Both normals of Philox block `pair` (indices 2 pair, 2 pair + 1 of the stream) for the price of one: the same
+// operations on the same values as two philox_normal calls - bit-identical results.
+__device__ inline void philox_normal_pair(uint64_t seed, uint64_t stream, uint64_t pair, double& z0, double& z1) {
+  uint32_t r[4];
+  Philox::gen(seed, stream, pair, r);
+  double u1 = u01(r[0], r[1]);
+  double u2 = u01(r[2], r[3]);
+  double rad = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincospi(2.0 * u2, &s, &c);
+  z0 = rad * c;
+  z1 = rad * s;
+}
+
 // offset of row i's normals in the flat W-step stream: sum_{i'<i} min(i'+1, K)
 __host__ __device__ inline long long w_z_offset(int i, int K) {
   return i < K ? (long long)i * (i + 1) / 2 : (long long)K * (K + 1) / 2 + (long long)(i - K) * K;

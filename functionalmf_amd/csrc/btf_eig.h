@@ -293,7 +293,10 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
 // side task of a streaming launch (accum_kernel): out == nullptr: none
 // (Usrc != nullptr: no partials exist - the side workgroup forms the Gram of Usrc's nrows rows itself)
 // (pub / flag / epoch: the fused V launch's tails read the eigen-system inside the launch - btf_fused.h)
-struct EigSide { const double* gpart; int ngp; int K; double* out; const double* Usrc; int nrows; double* pub; unsigned* flag; unsigned epoch; };
+// (gran: the eigenvalues once more as self-validating 8-byte granules {half of g_k, epoch}, two per eigenvalue - the chain
+//  waves of the dataflow tails get value and "it is this launch's" in ONE round trip instead of flag, then payload)
+struct EigSide { const double* gpart; int ngp; int K; double* out; const double* Usrc; int nrows; double* pub; unsigned* flag; unsigned epoch;
+                 unsigned long long* gran; };
 
 static __global__ __launch_bounds__(WAVE) void gram_eig_kernel(const double* __restrict__ gpart, int ngp, int K,
                                                         double* __restrict__ out, int warm) {

@@ -330,6 +330,9 @@ struct FuseV {
   const unsigned* eig_flag; unsigned epoch;
   HypPub hp;               // lam2 drawn by a side workgroup of this launch (flag == nullptr: none)
   int band_early;          // 1: the prior band is formed before the stream (v_fused_band_early)
+  int dataflow;            // 1: the barrier-free tail (v_fused_df): one chunk, precomputed band, nembeds <= 6 (launch_accum decides)
+  const unsigned long long* eig_gran;   // [2 K] the eigenvalues as tagged granules {half of g_k, epoch} (EigSide.gran)
+  const double* pimg;      // [ml][2 PB] the LDS image [P | Pm] of every column's band (prior_band_image_kernel): dataflow tails copy it
 };
 template <> __device__ __forceinline__ unsigned* fuse_tickets<FUSE_V>(const FuseV& fz) { return fz.cnt; }
 template <> __device__ __forceinline__ int fuse_chunks<FUSE_V>(const FuseV& fz) { return fz.a.nch; }
@@ -339,6 +342,7 @@ constexpr int VF_MAILBOX = 128;                          // doubles at the top o
 // what a thread of a column's virtual workgroup fetches between its stream and the cross-wave reduction - the loads fly
 // while the slower waves finish their rows and the sums are reduced: the stencil of its band entry, its Tau2 values
 template <> struct FusePre<FUSE_V> { typedef struct VPre type; };
+template <> struct FusePre<FUSE_VDF> { typedef struct VPre type; };
 static_assert(VF_MAILBOX == VF_MAILBOX_DOUBLES, "mailbox");
 // BTF_VF_BANDPRE (default): the prior band of the tile's columns comes PRECOMPUTED (prior_band_kernel, whenever Tau2 / lam2
 // changed: btf_abi.hip, pband_version) - one double per thread loaded at kernel start and parked in a register pair through
@@ -847,6 +851,587 @@ __device__ __forceinline__ void v_fused_tail(const FuseV& fv, int tile, double* 
     }
   }
   TAIL_STAMP(stamps, 7);
+}
+
+// =================================================================================================================
+// V tail, dataflow form (FuseV.dataflow; BTF_VF_DATAFLOW=0 keeps the barrier form above)
+// =================================================================================================================
+// The barrier form serialises, behind the LAST wave's stream: reduction -> sums into the sampler's layout -> rotation ->
+// the 2K elimination chains (31 pivots of ~240 cycles on ONE wave per column) -> w -> back-substitution -> rotation back.
+// But the factorisation of A_k = g_k I + P_j needs only the eigenvalues (the side workgroup has them 8.3 us into the
+// launch) and the prior band (precomputed) - not the column sums.  Here the chain wave of a column writes its partial
+// sums to LDS when ITS stream ends and factors at once, while the other waves are still streaming, then reduce and
+// rotate; the right-hand sides meet the finished factors in a forward substitution of four fused multiply-adds per pivot.
+// No workgroup barrier behind the stream: a wave at an s_barrier would wait for the chain waves.  The stages are ordered
+// by counters in LDS (one relaxed add per producing wave behind a workgroup-scope release; consumers poll with s_sleep):
+// every wait names producers that signal unconditionally and every wave's program is a straight line of stages, so the
+// grid drains whatever the data hold (a failed factorisation or a missed flag skips the arithmetic, not the signals).
+// Same values through the same operations as v_fused_tail / v_spectral_kernel: bit-identical draws
+// (tests/test_gpu_fused.py).
+//
+// What the measurements of this form taught (scripts/chain_probe.hip, scripts/stamps_df_ab.sh): a lone wave issues one
+// instruction per ~9 cycles WHATEVER it is (f64 arithmetic, an LDS read, a move) - the chains cost their instruction
+// count, so (1) the chain wave does nothing but chains: the band arrives as a ready LDS image copied by another wave, the
+// records are 32-byte quads [l1 l2 l3 | 1/D -> w -> x] and the right-hand sides come paired with the scaled normals
+// [r(i+S) z(i) sqrt(1/D(i))] - three reads, four fused multiply-adds and one write per forward pivot, two reads, three
+// and one per backward pivot; (2) the workers of a column are the waves on the SIMDs no chain wave runs on.
+//
+// Roles in a tile of NG = 128 / T columns (16 waves, wave p on SIMD p % 4): p < NG is the CHAIN wave of column p; the
+// workers of column c are the waves p % NG == c on the other SIMDs (T = 32: every other wave), four at T = 64; the four
+// virtual waves of the final stage (rotation back, store, residual part, Gram share - v_spectral_kernel's thread
+// geometry, for its fixed-order sums) are p / NG = 0..3.  LDS (doubles): [0, 16 RG 128) the waves' partial sums,
+// overlaid - once every worker has read its sums - by the columns' working arrays (mraw, mt, the (r, z) pairs, heads,
+// Gram scratch); below the mailbox, per column: P | Pm, the record quads, the separator windows, flag words - the chain
+// waves' working set, disjoint from the partials so that they never wait for a reader.  Mailbox (top 128 doubles):
+// eigen-system [0, K + K K), 64 counter words from double 96.
+enum { DFC_PART = 0, DFC_READ = 1, DFC_EIG = 2, DFC_BAD = 3, DFC_GROUP0 = 8, DFC_PER_GROUP = 12 };
+enum { DFG_IN = 0, DFG_ROT, DFG_FAC, DFG_ZS, DFG_X, DFG_G1, DFG_G2, DFG_SSE, DFG_BAND, DFG_PROG, DFG_ZRAW };
+struct DfLayout { int PB, P, Pm, Q, win, flag, size; };
+__host__ __device__ inline DfLayout df_layout(int T, int K, int S) {
+  DfLayout D;
+  D.PB = ((T + S + 1) * (S + 1) + 1) & ~1;
+  int o = 0;
+  D.P = o; o += D.PB;
+  D.Pm = o; o += D.PB;
+  D.Q = o; o += T * K * 4;
+  D.win = o; o += (2 * K * (S * (S + 1) + S) + 1) & ~1;
+  D.flag = o; o += 8;
+  D.size = (o + 3) & ~3;                                     // (32-byte granules: the quads stay aligned)
+  return D;
+}
+// the workers' arrays, per column, overlaid on the partial sums
+struct DfWork { int mraw, mt, rz, head, gs, stride; };
+__host__ __device__ inline DfWork df_work(int T, int K, int S) {
+  DfWork W;
+  int o = 0;
+  W.mraw = o; o += T * K;                                    // raw sums, depth-major; later the output staging
+  W.mt = o; o += K * (T + S + 1);                            // rotated right-hand sides (the residual part reads them)
+  o = (o + 1) & ~1;
+  W.rz = o; o += 2 * T * K;                                  // [k][pivot][r(i+S), z sqrt(1/D)]
+  W.head = o; o += 2 * K * 4;                                // [side][k][r(0), r(1), r(2), -]
+  W.gs = o; o += VS_THREADS;                                 // Gram-share scratch
+  W.stride = (o + 3) & ~3;
+  return W;
+}
+// does the dataflow tail apply?  (T a whole number of columns per tile, K <= rg values in one reduction round, the chain
+// region beside the partial sums and beside the overlaid working arrays)
+__host__ __device__ inline bool vf_df_fits(int T, int K, int TF, int nD, int waves, int rg) {
+  const int ng = vf_cols_per_tile(T);
+  if (!(ng > 0 && ng * VF_GROUP_WAVES <= waves && K <= rg && K + K * K <= 96 && TF == 2)) return false;
+  if (waves != 16) return false;
+  if (2 * df_layout(T, K, TF + 1).PB > 2 * 8 * WAVE) return false;      // the band image: eight double2 per lane of the copying wave
+  const int nwt = (ng == 1 ? 12 : (ng == 2 ? 4 : 3)) * WAVE; // worker threads per column (v_fused_df): two elements each at most
+  if (T * K > 2 * nwt || T * K > 768) return false;
+  const int room = vf_red_doubles(false) - VF_MAILBOX - ng * df_layout(T, K, TF + 1).size;
+  return waves * rg * ACC_TILE <= room && ng * df_work(T, K, TF + 1).stride <= room;
+}
+template <> __device__ __forceinline__ int fuse_chain_waves<FUSE_VDF>(const FuseV& fz) { return ACC_TILE / fz.a.T; }
+template <> __device__ __forceinline__ const unsigned long long* fuse_eig_gran<FUSE_VDF>(const FuseV& fz) { return fz.eig_gran; }
+template <> __device__ __forceinline__ const double* fuse_nu2_ptr<FUSE_VDF>(const FuseV& fz) { return (fz.a.hyp && fz.a.hyp_noise) ? fz.a.hyp + HYP_NU2 : nullptr; }
+template <> __device__ __forceinline__ unsigned* fuse_tickets<FUSE_VDF>(const FuseV& fz) { return nullptr; }
+template <> __device__ __forceinline__ int fuse_chunks<FUSE_VDF>(const FuseV& fz) { return 1; }
+template <> __device__ __forceinline__ int fuse_owners<FUSE_VDF>(const FuseV&) { return 0; }
+
+__device__ __forceinline__ void df_signal(unsigned* c) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// bounded (a producer is a wave of this very workgroup and signals whatever happens: the bound only turns a bug into a
+// status code instead of a hung GPU)
+#ifndef BTF_DF_SLEEP
+#define BTF_DF_SLEEP 1
+#endif
+template <int SLEEP = BTF_DF_SLEEP>
+__device__ __forceinline__ void df_wait(unsigned* c, unsigned target, unsigned* bad) {
+  bool seen = false;
+  for (unsigned spins = 0; spins < (1u << 22) / SLEEP; ++spins) {
+    if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) { seen = true; break; }
+    __builtin_amdgcn_s_sleep(SLEEP);
+  }
+  if (!seen && (threadIdx.x & 63) == 0) __hip_atomic_store(bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// kernel start (every thread): the counters to zero behind one barrier, then ONE worker wave per column asks for the
+// column's band image - 2 PB / 128 double2 per lane, as it lies
+template <int K, int S>
+__device__ __forceinline__ void v_df_begin(const FuseV& fv, int tile, double* lds, VDfPre& pre) {
+  unsigned* cw = reinterpret_cast<unsigned*>(lds + vf_red_doubles(false) - VF_MAILBOX + 96);
+  if (threadIdx.x < 64) cw[threadIdx.x] = 0u;
+  __syncthreads();
+  v_df_band_load<K, S>(fv, tile, pre);
+}
+template <int K, int S>
+__device__ __forceinline__ void v_df_band_load(const FuseV& fv, int tile, VDfPre& pre) {
+  const VSpecArgs& a = fv.a;
+  const int T = a.T, NG = ACC_TILE / T;
+  const int lane = threadIdx.x & 63;
+  const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = pw - NG, j = tile * NG + cg;               // waves NG .. 2 NG - 1: the columns' band copiers
+#pragma unroll
+  for (int u = 0; u < 8; ++u) pre.pv[u] = make_double2(0.0, 0.0);
+  if (pw >= NG && pw < 2 * NG && j < a.ml) {
+    const int PB = df_layout(T, K, S).PB;
+    const double2* src = reinterpret_cast<const double2*>(fv.pimg + (size_t)j * 2 * PB);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (lane + 64 * u < PB) pre.pv[u] = src[lane + 64 * u];
+  }
+}
+// ... and, once the first rows of its stream have been consumed (loads return in order: the image is back), stores it
+// into the column's corner of the LDS and tells the chain wave
+template <int K, int S>
+__device__ __forceinline__ void v_df_band_store(const FuseV& fv, int tile, double* lds, const VDfPre& pre) {
+  const VSpecArgs& a = fv.a;
+  const int T = a.T, NG = ACC_TILE / T;
+  const int lane = threadIdx.x & 63;
+  const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = pw - NG;
+  if (!(pw >= NG && pw < 2 * NG && tile * NG + cg < a.ml)) return;
+  const DfLayout D = df_layout(T, K, S);
+  double2* dst = reinterpret_cast<double2*>(lds + vf_red_doubles(false) - VF_MAILBOX - (size_t)(cg + 1) * D.size + D.P);
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (lane + 64 * u < D.PB) dst[lane + 64 * u] = pre.pv[u];
+  unsigned* cw = reinterpret_cast<unsigned*>(lds + vf_red_doubles(false) - VF_MAILBOX + 96);
+  df_signal(cw + DFC_GROUP0 + cg * DFC_PER_GROUP + DFG_BAND);
+}
+
+template <int K, int S, int WAVES, int RG, int NVV>
+__device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* lds, const double (&acc)[NVV][2], long long* stamps,
+                                           const DfEarly& early) {
+  static_assert(NVV == K && K <= RG, "one reduction round");
+  static_assert(S == 3 && WAVES == 16, "tf_order 2, 16 waves");
+  VSpecArgs a = fv.a;
+  const int T = a.T, n = T * K, KK = tri(K);
+  constexpr int D1 = S + 1, WN = S * (S + 1) + S;
+  constexpr int NT = VF_GROUP_WAVES * WAVE;               // threads of the final stage's virtual workgroup (= VS_THREADS)
+  const int NG = ACC_TILE / T;
+  const int Tp = T + S + 1;
+  int nl, nr, ns;
+  spectral_split(T, S, nl, nr, ns);
+  const int lane = threadIdx.x & 63;
+  const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = pw % NG, vw = pw / NG;
+  const int j = tile * NG + cg, jg = a.col0 + j;
+  const bool live = j < a.ml;                              // (wave-uniform; a ragged last tile has dead column groups)
+  // The workers of a column are the waves on the SIMDs NO chain wave runs on (wave p sits on SIMD p % 4; the chain waves
+  // are p = 0 .. NG-1): every instruction a neighbour on its SIMD issues is one the chain wave waits for.  (T = 32: chain
+  // waves on all four SIMDs - every other wave works.)  The remaining waves write their partial sums and sleep until
+  // the final stage needs them, or leave.
+  const bool heavy = pw >= NG && (NG == 4 || (pw & 3) >= NG);
+  const int NWK = NG == 1 ? 12 : (NG == 2 ? 4 : 3), NWT = NWK * WAVE;      // workers per column, their threads
+  const int wk = NG == 1 ? (pw >> 2) * 3 + (pw & 3) - 1 : (NG == 2 ? (pw >> 2) : (pw >> 2) - 1);
+  const int first_worker = NG == 4 ? 4 : NG;              // it fetches the eigen-system for everybody
+  const DfLayout D = df_layout(T, K, S);
+  const DfWork Wk = df_work(T, K, S);
+  double* mailbox = lds + vf_red_doubles(false) - VF_MAILBOX;
+  unsigned* cw = reinterpret_cast<unsigned*>(mailbox + 96);
+  unsigned* cgw = cw + DFC_GROUP0 + cg * DFC_PER_GROUP;
+  double* top = lds + vf_red_doubles(false) - VF_MAILBOX - (size_t)(cg + 1) * D.size;
+  double* P = top + D.P;
+  double* Pm = top + D.Pm;
+  double* Q = top + D.Q;                                   // [k][pivot][l1 l2 l3 | 1/D -> w -> x]
+  double* win = top + D.win;
+  double* flag = top + D.flag;
+  double* base = lds + (size_t)cg * Wk.stride;
+  double* mraw = base + Wk.mraw;
+  double* mt = base + Wk.mt;
+  double* rz = base + Wk.rz;
+  double* head = base + Wk.head;
+  const double* gsh = mailbox;                             // eigenvalues, eigenvectors of W'W as published
+  const double* Ush = mailbox + K;
+
+  // ---- every wave, the moment its stream ends: its partial sums, then one count ----
+#pragma unroll
+  for (int v = 0; v < K; ++v)
+    *reinterpret_cast<double2*>(&lds[((size_t)pw * RG + v) * ACC_TILE + 2 * lane]) = make_double2(acc[v][0], acc[v][1]);
+  df_signal(cw + DFC_PART);
+  if (a.hyp && a.hyp_noise) {
+    // (the chain waves fetched nu2 with their last rows - when their stream was long enough to have such a point)
+    const double nu2 = (vw == 0 && early.nu2 > 0.0) ? early.nu2 : a.hyp[HYP_NU2];
+    a.s = 1.0 / nu2; a.sR = a.s * a.Rrep;
+  }
+
+  if (vw == 0) {
+    // =========================== the column's chain wave ===========================
+    if (!live) return;
+    const int nchain = nr > 0 ? 2 * K : K;
+    const bool chain = lane < nchain;
+    const int side = lane >= K ? 1 : 0;
+    const int k = chain ? lane - side * K : 0;
+    // the eigenvalue of the lane's system straight from the side workgroup's tagged granules {half of g_k, epoch}: value and
+    // "it is this launch's" in ONE round trip, by this wave itself (it must not wait for a wave that is still streaming)
+    unsigned long long ghi = early.ghi, glo = early.glo;     // (fetched behind the last rows' loads: usually this launch's already)
+    bool okw = __all((unsigned)ghi == fv.epoch && (unsigned)glo == fv.epoch) != 0;
+    for (unsigned spins = 0; !okw && spins < (1u << 20); ++spins) {
+      ghi = __hip_atomic_load(fv.eig_gran + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      glo = __hip_atomic_load(fv.eig_gran + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      okw = __all((unsigned)ghi == fv.epoch && (unsigned)glo == fv.epoch) != 0;
+      if (!okw) __builtin_amdgcn_s_sleep(4);
+    }
+    if (!okw && lane == 0) {
+      __hip_atomic_store(cw + DFC_BAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (atomicCAS(&a.status[0], 0, 2) == 0) a.status[1] = -1;
+    }
+    const double g0 = okw ? __longlong_as_double((long long)(((ghi >> 32) << 32) | (glo >> 32))) : 1.0;
+    df_wait(cgw + DFG_BAND, 1u, cw + DFC_BAD);             // (the band image was stored early in the stream: long there)
+    TAIL_STAMP(stamps, 3);                                 // (diagnostic builds: the eigenvalues are here, the factorisation starts)
+    const double* Pv = side ? Pm : P;
+    double* cq = Q + (size_t)(k * T + (side ? nl : 0)) * 4;
+    const int n_elim = side ? nr : nl;
+    const int n_common = nr > 0 ? (nl < nr ? nl : nr) : nl;
+    double shift = 0.0, eps = a.eps0;
+    int tried = 0;
+    bool ok;
+    double gk;
+    while (true) {
+      bool good = true;
+      gk = fma(g0, a.sR, shift);
+      if (chain) {
+        // factor: window c[b][d] = A[i+b+d][i+b]; per pivot the new band row in, the quad [l1 l2 l3 1/D] out
+        double c[S + 1][S + 1];
+#pragma unroll
+        for (int b = 0; b < S; ++b) {
+          const double2 p0 = *reinterpret_cast<const double2*>(Pv + b * 4), p1 = *reinterpret_cast<const double2*>(Pv + b * 4 + 2);
+          c[b][0] = p0.x + gk; c[b][1] = p0.y; c[b][2] = p1.x; c[b][3] = p1.y;
+        }
+        bool bad = false;
+        auto pivot = [&](int i) {
+          const double2 p0 = *reinterpret_cast<const double2*>(Pv + (i + S) * 4), p1 = *reinterpret_cast<const double2*>(Pv + (i + S) * 4 + 2);
+          c[S][0] = p0.x + gk; c[S][1] = p0.y; c[S][2] = p1.x; c[S][3] = p1.y;
+          const double d0 = c[0][0];
+          bad |= !(d0 > 0.0);
+          const double inv = rcp_cubic(d0);
+          double l[S + 1];
+#pragma unroll
+          for (int d = 1; d <= S; ++d) l[d] = c[0][d] * inv;
+#pragma unroll
+          for (int b = 1; b <= S; ++b)
+#pragma unroll
+            for (int aa = b; aa <= S; ++aa) c[b][aa - b] = fma(-l[aa], c[0][b], c[b][aa - b]);
+          *reinterpret_cast<double2*>(cq + i * 4) = make_double2(l[1], l[2]);
+          *reinterpret_cast<double2*>(cq + i * 4 + 2) = make_double2(l[3], inv);
+#pragma unroll
+          for (int b = 0; b < S; ++b)
+#pragma unroll
+            for (int d = 0; d <= S; ++d) c[b][d] = c[b + 1][d];
+        };
+#pragma unroll 4
+        for (int i = 0; i < n_common; ++i) pivot(i);
+        if (n_elim > n_common) pivot(n_common);
+        good = !bad;
+        if (ns > 0) {                                      // park the window for the separator system
+          double* wp = win + (size_t)(side * K + k) * WN;
+#pragma unroll
+          for (int b = 0; b < S; ++b)
+#pragma unroll
+            for (int d = 0; d <= S; ++d) wp[b * (S + 1) + d] = c[b][d];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (ns > 0 && lane < K) {
+        // separator system: both halves' Schur complements carry the original entries once too often
+        const double* wl = win + (size_t)k * WN;
+        const double* wr = win + (size_t)(K + k) * WN;
+        double Sg[S][S];
+#pragma unroll
+        for (int b = 0; b < S; ++b)
+#pragma unroll
+          for (int aa = b; aa < S; ++aa)
+            Sg[aa][b] = wl[b * (S + 1) + aa - b] + wr[(S - 1 - aa) * (S + 1) + aa - b] - (P[(nl + b) * D1 + aa - b] + (aa == b ? gk : 0.0));
+        double* sq = Q + (size_t)(k * T + nl + nr) * 4;
+#pragma unroll
+        for (int cc = 0; cc < S; ++cc) {
+          const double d0 = Sg[cc][cc];
+          good &= d0 > 0.0;
+          const double inv = rcp_cubic(d0);
+#pragma unroll
+          for (int d = 1; d <= S; ++d) {
+            double l = 0.0;
+            if (cc + d < S) {
+              l = Sg[cc + d][cc] * inv;
+#pragma unroll
+              for (int b2 = 1; b2 <= d; ++b2) Sg[cc + d][cc + b2] = fma(-l, Sg[cc + b2][cc], Sg[cc + d][cc + b2]);
+            }
+            sq[cc * 4 + d - 1] = l;
+          }
+          sq[cc * 4 + 3] = inv;
+        }
+      }
+      ok = __builtin_amdgcn_readfirstlane(__ballot(!good) == 0ULL ? 1 : 0) != 0;
+      if (ok || tried >= a.attempts) break;
+      shift += eps;   // fast_mvn.py:64-68: cumulative eps, eps *= 10
+      eps *= 10.0;
+      ++tried;
+    }
+    ok = ok && okw;
+    if (lane == 0) {
+      flag[0] = ok ? 1.0 : 0.0;
+      flag[1] = (double)tried;
+      a.tries[j] = tried;
+      if (!ok && okw && atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = jg;
+    }
+    df_signal(cgw + DFG_FAC);                              // the reciprocals are there: the workers scale the normals
+    TAIL_STAMP(stamps, 4);
+    // ---- the right-hand sides meet the factors: forward substitution with w folded in, separator, back-substitution ----
+    df_wait(cgw + DFG_ROT, (unsigned)NWK, cw + DFC_BAD);
+    df_wait(cgw + DFG_ZS, (unsigned)NWK, cw + DFC_BAD);
+    TAIL_STAMP(stamps, 5);                                 // (the workers' right-hand sides and scaled normals are in)
+    if (ok) {
+      double r[S + 1];
+      if (chain) {
+        // u(i) = r(i) as updated by the pivots before it (ascending, as spectral_pivot updates them); w(i) = u(i) / D(i) + z sqrt(1 / D(i))
+        const double* hd = head + (size_t)(side * K + k) * 4;
+        const double* pz = rz + (size_t)(k * T + (side ? nl : 0)) * 2;
+        {
+          const double2 h0 = *reinterpret_cast<const double2*>(hd);
+          r[0] = h0.x; r[1] = h0.y; r[2] = hd[2];
+        }
+        auto fstep = [&](int i) {
+          const double2 q0 = *reinterpret_cast<const double2*>(cq + i * 4), q1 = *reinterpret_cast<const double2*>(cq + i * 4 + 2);
+          const double2 z2 = *reinterpret_cast<const double2*>(pz + i * 2);
+          r[S] = z2.x;
+          const double u = r[0];
+          r[1] = fma(-q0.x, u, r[1]);
+          r[2] = fma(-q0.y, u, r[2]);
+          r[3] = fma(-q1.x, u, r[3]);
+          cq[i * 4 + 3] = fma(u, q1.y, z2.y);
+#pragma unroll
+          for (int b = 0; b < S; ++b) r[b] = r[b + 1];
+        };
+#pragma unroll 4
+        for (int i = 0; i < n_common; ++i) fstep(i);
+        if (n_elim > n_common) fstep(n_common);
+        if (ns > 0) {
+          double* wp = win + (size_t)(side * K + k) * WN;
+#pragma unroll
+          for (int b = 0; b < S; ++b) wp[S * (S + 1) + b] = r[b];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (ns > 0 && lane < K) {
+        const double* wl = win + (size_t)k * WN;
+        const double* wr = win + (size_t)(K + k) * WN;
+        double* sq = Q + (size_t)(k * T + nl + nr) * 4;
+        const double* sz = rz + (size_t)(k * T + nl + nr) * 2;      // [rotated right-hand side at depth nl + c, scaled normal of separator pivot c]
+        double us[S];
+#pragma unroll
+        for (int b = 0; b < S; ++b) us[b] = wl[S * (S + 1) + b] + wr[S * (S + 1) + S - 1 - b] - sz[b * 2];
+#pragma unroll
+        for (int cc = 0; cc < S; ++cc) {
+#pragma unroll
+          for (int d = 1; d <= S; ++d)
+            if (cc + d < S) us[cc + d] = fma(-sq[cc * 4 + d - 1], us[cc], us[cc + d]);
+          sq[cc * 4 + 3] = fma(us[cc], sq[cc * 4 + 3], sz[cc * 2 + 1]);
+        }
+        // ... and its S x S unit upper solve
+#pragma unroll
+        for (int cc = S - 1; cc >= 0; --cc) {
+          double acc2 = sq[cc * 4 + 3];
+#pragma unroll
+          for (int d = 1; d <= S; ++d) if (cc + d < S) acc2 = fma(-sq[cc * 4 + d - 1], sq[(cc + d) * 4 + 3], acc2);
+          sq[cc * 4 + 3] = acc2;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (chain) {
+        double x1 = 0.0, x2 = 0.0, x3 = 0.0;
+        if (ns > 0) {
+          const double* sq = Q + (size_t)(k * T + nl + nr) * 4;
+          x1 = sq[(side ? S - 1 : 0) * 4 + 3]; x2 = sq[(side ? S - 2 : 1) * 4 + 3]; x3 = sq[(side ? S - 3 : 2) * 4 + 3];
+        }
+        // x(i) = w(i) - sum_d L[i+d, i] x(i+d), the term of x(i+1) last (spectral_backward's order)
+#pragma unroll 4
+        for (int i = n_elim - 1; i >= 0; --i) {
+          const double2 q0 = *reinterpret_cast<const double2*>(cq + i * 4), q1 = *reinterpret_cast<const double2*>(cq + i * 4 + 2);
+          double acc2 = q1.y;
+          acc2 = fma(-q1.x, x3, acc2);
+          acc2 = fma(-q0.y, x2, acc2);
+          acc2 = fma(-q0.x, x1, acc2);
+          x3 = x2; x2 = x1; x1 = acc2;
+          cq[i * 4 + 3] = acc2;
+        }
+      }
+    }
+    df_signal(cgw + DFG_X);
+    TAIL_STAMP(stamps, 6);
+  } else {
+    // =========================== the other waves ===========================
+    if (!heavy) {
+      // not a worker of the sums: these waves (on the chain waves' SIMDs) draw the column's normals - pure arithmetic, one
+      // Philox block, one logarithm, one sincos per PAIR z[2m], z[2m+1] (philox_normal_pair: the bits of two philox_normal
+      // calls; j n is even) - in the time the slower waves still stream, stage them beside the right-hand sides once the
+      // partial sums have been read, and sleep until the final stage needs them (long sleeps: the SIMD is the chain wave's)
+      if (!live) return;
+      const int lw = NG == 1 ? (pw >> 2) - 1 : (pw >> 2) - 1;    // NG = 1: waves 4, 8, 12; NG = 2: waves 4 + cg, 8 + cg, 12 + cg
+      double zp[2][2] = {{0.0, 0.0}, {0.0, 0.0}};               // (two pairs per lane at most: T K <= 768)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int i0 = 2 * ((lw + 3 * m) * WAVE + lane);
+        if (i0 < n) {
+          if (a.z) { const double2 zz = *reinterpret_cast<const double2*>(a.z + (size_t)jg * n + i0); zp[m][0] = zz.x; zp[m][1] = zz.y; }
+          else philox_normal_pair(a.seed, a.stream, ((unsigned long long)jg * n + i0) >> 1, zp[m][0], zp[m][1]);
+        }
+      }
+      df_wait<8>(cw + DFC_READ, (unsigned)(NG * NWK), cw + DFC_BAD);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int i0 = 2 * ((lw + 3 * m) * WAVE + lane);
+        if (i0 < n) { rz[(size_t)i0 * 2 + 1] = zp[m][0]; rz[(size_t)(i0 + 1) * 2 + 1] = zp[m][1]; }
+      }
+      df_signal(cgw + DFG_ZRAW);
+      if (vw >= VF_GROUP_WAVES) return;
+      df_wait<16>(cgw + DFG_X, 1u, cw + DFC_BAD);
+    } else {
+      const int wt = wk * WAVE + lane;
+      if (pw == first_worker) {
+        // one wave of the workgroup fetches the eigen-system for the rotations (group 0 always exists)
+        bool okw = true;
+        if (lane == 0) okw = poll_flag(fv.eig_flag, fv.epoch);
+        okw = __builtin_amdgcn_readfirstlane(okw ? 1 : 0) != 0;
+        if (okw) {
+          for (int idx = lane; idx < K + K * K; idx += WAVE) mailbox[idx] = load_sc1(fv.eig_pub + idx);
+        } else if (lane == 0) {
+          __hip_atomic_store(cw + DFC_BAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        df_signal(cw + DFC_EIG);
+      }
+      // the column sums: every wave's partials are in (the slowest streaming wave decides), fixed order over the waves
+      df_wait(cw + DFC_PART, (unsigned)WAVES, cw + DFC_BAD);
+      if (stamps && pw == first_worker && lane == 0) stamps[1] = wall_clock64();      // (diagnostic builds: the slowest wave's stream has ended)
+      double sreg[2] = {0.0, 0.0};
+      if (live) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int e = wt + m * NWT;
+          if (e < n) {
+            const int k = e / T, t = e - k * T;
+            const double* p = lds + (size_t)k * ACC_TILE + cg * T + t;
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) s += p[(size_t)w * RG * ACC_TILE];
+            sreg[m] = s;
+          }
+        }
+      }
+      df_signal(cw + DFC_READ);
+      if (!live) return;
+      df_wait(cw + DFC_READ, (unsigned)(NG * NWK), cw + DFC_BAD);   // nobody reads partial sums any more: the working arrays may overlay them
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int e = wt + m * NWT;
+        if (e < n) {
+          const int k = e / T, t = e - k * T;
+          mraw[t * K + k] = 0.0 + sreg[m];
+        }
+      }
+      df_signal(cgw + DFG_IN);
+      df_wait(cgw + DFG_IN, (unsigned)NWK, cw + DFC_BAD);
+      df_wait(cw + DFC_EIG, 1u, cw + DFC_BAD);
+      // rotated right-hand sides, delivered where the chains will read them: r(t) of system k is r(i + S) of the ascending
+      // chain's pivot i = t - S (its first S values go to the head), of the descending chain's pivot i = T-1-t - S, and the
+      // separator's right-hand side at the depths nl .. nl + S - 1
+      for (int idx = wt; idx < K * T; idx += NWT) {
+        const int k = idx / T, t = idx - k * T;
+        double s = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) s = fma(Ush[kk * K + k], mraw[t * K + kk], s);
+        s *= a.s;
+        mt[k * Tp + t] = s;
+        const int m = T - 1 - t;
+        if (t < S) head[(size_t)k * 4 + t] = s; else if (t - S < nl) rz[(size_t)(k * T + t - S) * 2] = s;
+        if (nr > 0) { if (m < S) head[(size_t)(K + k) * 4 + m] = s; else if (m - S < nr) rz[(size_t)(k * T + nl + m - S) * 2] = s; }
+        if (ns > 0 && t >= nl && t < nl + S) rz[(size_t)(k * T + nl + nr + t - nl) * 2] = s;
+      }
+      df_signal(cgw + DFG_ROT);
+      // the normals: staged raw by the column's other waves (above); T = 32 has no such waves - the workers draw them here
+      if (NG == 4) {
+        const int i0 = 2 * wt;
+        double z0 = 0.0, z1 = 0.0;
+        if (i0 < n) {
+          if (a.z) { const double2 zz = *reinterpret_cast<const double2*>(a.z + (size_t)jg * n + i0); z0 = zz.x; z1 = zz.y; }
+          else philox_normal_pair(a.seed, a.stream, ((unsigned long long)jg * n + i0) >> 1, z0, z1);
+          rz[(size_t)i0 * 2 + 1] = z0; rz[(size_t)(i0 + 1) * 2 + 1] = z1;
+        }
+        df_signal(cgw + DFG_ZRAW);
+      }
+      df_wait(cgw + DFG_ZRAW, 3u, cw + DFC_BAD);
+      // z sqrt(1 / D) once the chain wave has the reciprocals (pivot order: z[j][k T + i] multiplies pivot i of system k)
+      df_wait(cgw + DFG_FAC, 1u, cw + DFC_BAD);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int idx = wt + m * NWT;
+        if (idx < n) rz[(size_t)idx * 2 + 1] = rz[(size_t)idx * 2 + 1] * sqrt(Q[(size_t)idx * 4 + 3]);
+      }
+      df_signal(cgw + DFG_ZS);
+      if (vw >= VF_GROUP_WAVES) return;
+      df_wait(cgw + DFG_X, 1u, cw + DFC_BAD);
+    }
+  }
+  // =========================== final stage: the column's four virtual waves ===========================
+  // rotate back, write V[j] (depth-major), residual part, Gram share - v_spectral_kernel's geometry (tid = vw 64 + lane)
+  const bool bad = __hip_atomic_load(cw + DFC_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+  const bool ok = flag[0] != 0.0 && !bad;
+  const int tid = vw * WAVE + lane;
+  double* xout = mraw;
+  double sse_acc = 0.0;
+  const double inv_s2 = -2.0 / a.s;
+  const double* xs = Q + 3;
+  if (ok) {
+    for (int idx = tid; idx < n; idx += NT) {
+      const int t = idx / K, k = idx - t * K;
+      const int pos = t < nl ? t : (t < nl + ns ? nl + nr + (t - nl) : nl + (T - 1 - t));
+      double s = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) s = fma(Ush[k * K + kk], xs[(size_t)(kk * T + pos) * 4], s);
+      xout[idx] = s;
+      a.V[(size_t)jg * n + idx] = s;
+      if (a.sse_out) {
+        const double xt = xs[(size_t)(k * T + pos) * 4];
+        sse_acc = fma(xt, fma(a.Rrep * gsh[k], xt, inv_s2 * mt[k * Tp + t]), sse_acc);
+      }
+    }
+  }
+  if (a.sse_out) {
+    const double v = wave_sum(sse_acc);
+    if (lane == 0) flag[2 + vw] = v;
+    df_signal(cgw + DFG_SSE);
+    if (vw == 0) {
+      df_wait(cgw + DFG_SSE, (unsigned)VF_GROUP_WAVES, cw + DFC_BAD);
+      if (ok && lane == 0) a.sse_out[j] = (flag[2] + flag[3]) + (flag[4] + flag[5]);
+    }
+  }
+  if (a.gout) {
+    df_signal(cgw + DFG_G1);
+    df_wait(cgw + DFG_G1, (unsigned)VF_GROUP_WAVES, cw + DFC_BAD);      // the fresh column stands in xout
+    int ng = NT / KK;
+    if (ng > 16) ng = 16;
+    if (ng < 1) ng = 1;
+    const int g = tid / KK, q = tid - g * KK;
+    int p = 0;
+    while ((p + 1) * (p + 2) / 2 <= q) ++p;
+    const int pq = q - p * (p + 1) / 2;
+    double* scratch = base + Wk.gs;
+    if (ok && g < ng) {
+      double s = 0.0;
+      for (int t = g; t < T; t += ng) s = fma(xout[t * K + p], xout[t * K + pq], s);
+      scratch[g * KK + q] = s;
+    }
+    df_signal(cgw + DFG_G2);
+    if (tid < KK) {                                          // (virtual wave 0: KK <= 36 < 64)
+      df_wait(cgw + DFG_G2, (unsigned)VF_GROUP_WAVES, cw + DFC_BAD);
+      if (ok) {
+        double s = 0.0;
+        for (int b = 0; b < ng; ++b) s += scratch[b * KK + tid];
+        a.gout[(size_t)j * KK + tid] = s;
+      }
+    }
+  }
+  if (vw == 0) TAIL_STAMP(stamps, 7);
 }
 
 }  // namespace btf

@@ -318,13 +318,14 @@ template <int NW> __device__ void sweep_lam_side(const LamSide& lm, double* red)
 // workgroup that finishes a 128-row tile last sums the chunks and draws the rows (w_solve_kernel's work); FUSE_V - the
 // columns of a 128-output tile are sampled where their sums are (v_spectral_kernel's work).  The extra kernel argument
 // is empty for FUSE_NONE.
-enum { FUSE_NONE = 0, FUSE_W = 1, FUSE_V = 2 };
+enum { FUSE_NONE = 0, FUSE_W = 1, FUSE_V = 2, FUSE_VDF = 3 };      // FUSE_VDF: FUSE_V with the barrier-free (dataflow) tail only - an instance of its own
 struct FuseNone {};
 struct FuseW;
 struct FuseV;
 template <int FUSE> struct FuseSel { typedef FuseNone type; };
 template <> struct FuseSel<FUSE_W> { typedef FuseW type; };
 template <> struct FuseSel<FUSE_V> { typedef FuseV type; };
+template <> struct FuseSel<FUSE_VDF> { typedef FuseV type; };
 template <int K, int WAVES> __device__ __forceinline__ void w_fused_owner(const FuseW& fw, int tile, double* lds, long long* stamps);
 template <int FUSE> __device__ __forceinline__ int fuse_owners(const typename FuseSel<FUSE>::type& fz);
 struct VPre;
@@ -344,6 +345,20 @@ template <int K, int S> __device__ __forceinline__ void v_fused_band_store(const
 #endif
 template <int FUSE> struct FusePre { struct type {}; };
 constexpr int VF_MAILBOX_DOUBLES = 128;
+// the dataflow form of the fused V tail (btf_fused.h, v_fused_df): no workgroup barrier behind the stream - the chain waves
+// factor while the other waves are still streaming / reducing; LDS counters order the stages
+struct VDfPre { double2 pv[8]; };
+template <int FUSE> __device__ __forceinline__ int fuse_chain_waves(const typename FuseSel<FUSE>::type& fz) { return 0; }
+template <int FUSE> __device__ __forceinline__ const double* fuse_nu2_ptr(const typename FuseSel<FUSE>::type& fz) { return nullptr; }
+// what a chain wave fetched BEHIND its last rows' loads (in order: back right after them, no wait of its own): the tagged
+// eigenvalue granules of its lane's system, the device-resident nu2
+struct DfEarly { unsigned long long ghi, glo; double nu2; };
+template <int FUSE> __device__ __forceinline__ const unsigned long long* fuse_eig_gran(const typename FuseSel<FUSE>::type& fz) { return nullptr; }
+template <int K, int S> __device__ __forceinline__ void v_df_begin(const FuseV& fv, int tile, double* lds, VDfPre& pre);
+template <int K, int S> __device__ __forceinline__ void v_df_band_load(const FuseV& fv, int tile, VDfPre& pre);
+template <int K, int S> __device__ __forceinline__ void v_df_band_store(const FuseV& fv, int tile, double* lds, const VDfPre& pre);
+template <int K, int S, int WAVES, int RG, int NVV>
+__device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* lds, const double (&acc)[NVV][2], long long* stamps, const DfEarly& early);
 template <int FUSE> __device__ __forceinline__ unsigned* fuse_tickets(const typename FuseSel<FUSE>::type& fz);
 template <int FUSE> __device__ __forceinline__ int fuse_chunks(const typename FuseSel<FUSE>::type& fz);
 // a tile's arrival ticket: call after drain_stores() + __syncthreads(); tells every thread whether this workgroup came
@@ -405,7 +420,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   constexpr int ACC_RG = ACC_RGW > ACC_RG0 ? ACC_RGW : ACC_RG0;
   // (FUSE_V: the same array also holds the sampler's layout of the tile's columns - btf_fused.h - and is sized for it)
   constexpr int RED_SLOT = ACC_RG * ACC_TILE;
-  constexpr int RED_SLOTS = FUSE == FUSE_V ? (vf_red_doubles(UNRV == 3) + RED_SLOT - 1) / RED_SLOT : ACC_WAVES;
+  constexpr int RED_SLOTS = (FUSE == FUSE_V || FUSE == FUSE_VDF) ? (vf_red_doubles(UNRV == 3) + RED_SLOT - 1) / RED_SLOT : ACC_WAVES;
   static_assert(RED_SLOTS >= ACC_WAVES, "reduction scratch");
   __shared__ double red[RED_SLOTS][ACC_RG][ACC_TILE];
   static_assert(FUSE != FUSE_W || (w_tail_lds_doubles(K) <= WAVES * ACC_RG * ACC_TILE && w_owner_lds_budget(K) == WAVES * ACC_RG * ACC_TILE), "W owner scratch");
@@ -482,6 +497,11 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
           gram_eig_wave<EIG_KC>(gsum, 1, K, side.out, sc, true, side.pub);
           if (side.flag) {                     // the tails of this launch wait for it (btf_fused.h): one storing wave
             drain_stores();
+            if (side.gran && lane < K) {       // the eigenvalues as tagged granules (one 8-byte sc1 store each: never torn)
+              const unsigned long long gb = (unsigned long long)__double_as_longlong(load_sc1(side.pub + lane));
+              __hip_atomic_store(side.gran + 2 * lane, ((gb >> 32) << 32) | (unsigned long long)side.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(side.gran + 2 * lane + 1, (gb << 32) | (unsigned long long)side.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (lane == 0) publish_epoch(side.flag, side.epoch);
           }
           ACC_SIDE_STAMP(3);
@@ -571,6 +591,13 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   const int r1 = min(r0 + rows_per_block, cm.row_end);
 
   // (fused V launch: the prior band of the tile's columns while the memory system is still idle - btf_fused.h)
+  // (dataflow tail: counters zeroed behind one barrier at kernel start; the chain waves fetch the whole band of their column)
+  constexpr bool dataflow = FUSE == FUSE_VDF;
+  static_assert(!dataflow || (UNRV != 3 && NV <= ACC_RG && OPL == 2), "the dataflow tail: one reduction round, two rows in flight");
+  bool df_band_done = false;
+  DfEarly df_early{0ULL, 0ULL, 0.0};
+  VDfPre dfpre;
+  if constexpr (dataflow) v_df_begin<K, 3>(fz, tile, &red[0][0][0], dfpre);
   bool band_early = false;
   if constexpr (FUSE == FUSE_V) band_early = v_fused_band_early<K, 3>(fz, tile, &red[0][0][0], UNRV == 3);
   typename FusePre<FUSE>::type vpre;
@@ -743,6 +770,42 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       }
       v_fused_prefetch_loads<K, 3>(fz, tile, vpre, band_early);
     }
+    if constexpr (dataflow) {
+      // dataflow tail (btf_fused.h): the band image the columns' copying waves asked for at kernel start came back with the
+      // first rows' loads (in order): into the LDS now, nothing parked through the stream ...
+      if (rb < full_end - STEP) {
+        Rows A;
+        load_rows(rb, A, std::true_type{}, ntc);
+        compute(rb, A);
+        rb += STEP;
+        v_df_band_store<K, 3>(fz, tile, &red[0][0][0], dfpre);
+        df_band_done = true;
+      }
+      for (; rb < full_end - STEP; rb += STEP) {
+        Rows A;
+        load_rows(rb, A, std::true_type{}, ntc);
+        compute(rb, A);
+      }
+      if (rb < full_end) {
+        // ... and the chain waves' speculative loads (the tagged eigenvalue granules of the lane's system, nu2) go out BEHIND
+        // the last whole row group's loads: back right after them, no wait of their own
+        Rows A;
+        load_rows(rb, A, std::true_type{}, ntc);
+        asm volatile("" ::: "memory");
+        const int ncw = fuse_chain_waves<FUSE>(fz);
+        if (wave < ncw) {
+          const int kk = lane < K ? lane : (lane < 2 * K ? lane - K : 0);
+          const unsigned long long* gp = fuse_eig_gran<FUSE>(fz);
+          df_early.ghi = __hip_atomic_load(gp + 2 * kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          df_early.glo = __hip_atomic_load(gp + 2 * kk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double* np = fuse_nu2_ptr<FUSE>(fz);
+          if (np) df_early.nu2 = *np;
+        }
+        asm volatile("" ::: "memory");
+        compute(rb, A);
+        rb += STEP;
+      }
+    }
     for (; rb < full_end; rb += STEP) {
       Rows A;
       load_rows(rb, A, std::true_type{}, ntc);
@@ -760,6 +823,14 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   };
   if (nt) run_stream(std::true_type{}); else run_stream(std::false_type{});
   ACC_STAMP(2);
+  if constexpr (dataflow) {
+    if (!df_band_done) {                                    // (a row range too short for the in-stream store: fetched again, now)
+      v_df_band_load<K, 3>(fz, tile, dfpre);
+      v_df_band_store<K, 3>(fz, tile, &red[0][0][0], dfpre);
+    }
+    v_fused_df<K, 3, WAVES, ACC_RG, NV>(fz, tile, &red[0][0][0], acc, ACC_TAIL_STAMPS, df_early);
+    return;
+  }
   // (fused V launch: the tail's global loads and its wait for the side workgroups go out here, under the wave skew and
   //  the reduction - btf_fused.h)
   if constexpr (FUSE == FUSE_V) {
@@ -1404,7 +1475,8 @@ __device__ __forceinline__ void vband_load_hyp(VBandArgs& a) {
 static __global__ void prior_band_kernel(const double* __restrict__ Tau2, double lam2, int nD,
                                   const int* __restrict__ st_ptr, const int* __restrict__ st_row,
                                   const double* __restrict__ st_coef, int TD1, int col0, int ml,
-                                  double* __restrict__ pband, const double* __restrict__ hyp, int spectral_form) {
+                                  double* __restrict__ pband, const double* __restrict__ hyp, int spectral_form,
+                                  double* __restrict__ pimg, int img_T, int img_D1, int img_PB) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= ml * TD1) return;
   if (hyp) lam2 = hyp[HYP_LAM2];
@@ -1422,6 +1494,14 @@ static __global__ void prior_band_kernel(const double* __restrict__ Tau2, double
     for (int e = st_ptr[e0]; e < st_ptr[e0 + 1]; ++e) s += st_coef[e] / (lam2 * tau[st_row[e]]);
   }
   pband[idx] = s;
+  // the same band as the LDS image [P | Pm] of the column (dataflow tails of the fused V launch, btf_fused.h: a wave copies
+  // it as it lies): entry (t, d) and its mirror image Pm[T-1-t-d][d]; the zero rows were zeroed once, at allocation
+  if (pimg) {
+    const int t = e0 / img_D1, d = e0 - t * img_D1;
+    double* im = pimg + (size_t)j * 2 * img_PB;
+    im[e0] = s;
+    if (t + d < img_T) im[img_PB + (img_T - 1 - t - d) * img_D1 + d] = s;
+  }
 }
 
 // generic banded factor + solves on a band at `Bc` (LDS or global), single wave.

@@ -182,6 +182,76 @@ __device__ __forceinline__ bool spectral_forward(const double* __restrict__ Pv, 
   return !bad;
 }
 
+// The same chain in two passes (the dataflow tail of the fused V launch, btf_fused.h): the factorisation alone - it needs
+// the band and g_k only, so it can run while the right-hand sides are still being summed - and, later, the forward
+// substitution from the recorded factor entries with the draw's  w = D^-1 u + D^-1/2 z  folded in.  Every value goes
+// through the operations of spectral_pivot in the same order (l = c0d * inv; r_d <- fma(-l_d, u, r_d) by ascending
+// pivot; w = fma(u, inv, z sqrt(inv))): bit-identical records.
+template <int S>
+struct SpecWinC { double c[S + 1][S + 1]; };
+
+template <int S>
+__device__ __forceinline__ void spectral_factor_pivot(const double* __restrict__ Pv, double* __restrict__ rec, int i, double gk,
+                                                      SpecWinC<S>& w, bool& bad) {
+#pragma unroll
+  for (int d = 0; d <= S; ++d) w.c[S][d] = Pv[(i + S) * (S + 1) + d];
+  w.c[S][0] += gk;
+  const double d0 = w.c[0][0];
+  bad |= !(d0 > 0.0);
+  const double inv = rcp_cubic(d0);
+  double l[S + 1];
+#pragma unroll
+  for (int d = 1; d <= S; ++d) l[d] = w.c[0][d] * inv;
+#pragma unroll
+  for (int b = 1; b <= S; ++b)
+#pragma unroll
+    for (int a = b; a <= S; ++a) w.c[b][a - b] = fma(-l[a], w.c[0][b], w.c[b][a - b]);
+#pragma unroll
+  for (int d = 1; d <= S; ++d) rec[i * (S + 2) + d - 1] = l[d];
+  rec[i * (S + 2) + S] = inv;
+#pragma unroll
+  for (int b = 0; b < S; ++b)
+#pragma unroll
+    for (int d = 0; d <= S; ++d) w.c[b][d] = w.c[b + 1][d];
+}
+
+template <int S>
+__device__ __forceinline__ bool spectral_factor(const double* __restrict__ Pv, double* __restrict__ rec, int n_elim, int n_common,
+                                                double gk, SpecWinC<S>& w) {
+#pragma unroll
+  for (int b = 0; b < S; ++b) {
+#pragma unroll
+    for (int d = 0; d <= S; ++d) w.c[b][d] = Pv[b * (S + 1) + d];
+    w.c[b][0] += gk;
+  }
+  bool bad = false;
+#pragma unroll 4
+  for (int i = 0; i < n_common; ++i) spectral_factor_pivot<S>(Pv, rec, i, gk, w, bad);
+  if (n_elim > n_common) spectral_factor_pivot<S>(Pv, rec, n_common, gk, w, bad);
+  return !bad;
+}
+
+// forward substitution from the records; zs[i] = z_i sqrt(1 / D_i) (made by other waves from the recorded reciprocals);
+// slot S+1 of the record receives w_i.  r[0 .. S-1] on return: the reduced right-hand side behind the last pivot.
+template <int S>
+__device__ __forceinline__ void spectral_forward_rhs(const double* __restrict__ rv, const double* __restrict__ zs, double* __restrict__ rec,
+                                                     int n_elim, int n_common, double (&r)[S + 1]) {
+#pragma unroll
+  for (int b = 0; b < S; ++b) r[b] = rv[b];
+  auto step = [&](int i) {
+    r[S] = rv[i + S];
+    const double u = r[0];
+#pragma unroll
+    for (int d = 1; d <= S; ++d) r[d] = fma(-rec[i * (S + 2) + d - 1], u, r[d]);
+    rec[i * (S + 2) + S + 1] = fma(u, rec[i * (S + 2) + S], zs[i]);
+#pragma unroll
+    for (int b = 0; b < S; ++b) r[b] = r[b + 1];
+  };
+#pragma unroll 4
+  for (int i = 0; i < n_common; ++i) step(i);
+  if (n_elim > n_common) step(n_common);
+}
+
 // x = L^-T w for one chain, in place in the records (slot S+1): x_i = w_i - sum_d L[i+d, i] x_{i+d}, the term
 // of x_{i+1} last (the dependent chain).  x[1..S] on entry: the unknowns behind the chain's last pivot.
 template <int S>
