@@ -65,6 +65,7 @@ struct btf_ctx {
   int* st_drow = nullptr; double* st_dcoef = nullptr; bool st_dense_ok = false;   // VS_MAXE slots per (t,d) (spectral sampler)
   int* srcmap_w = nullptr; int* srcmap_v = nullptr;   // per-output source index of the cached weights
   bool stale_w = false, stale_v = false;
+  int v_part_mode = 0;               // accumulation mode of the V half-sweep's partials in c->part (2: Gram blocks at the source columns)
   double ssw = 0.0, nobs = 0.0, sa2 = 0.0;      // within-cell SS, observation count, sum S1^2/cnt (Gaussian data)
   double nobs_global = -1.0;                    // sharded runs: observation count over all ranks (btf_set_global_nobs)
   bool w_part_valid = false; int w_part_mode = 0, w_part_nch = 0, w_part_rpb = 0; bool w_part_gv = false;   // W-step partials current?
@@ -1627,6 +1628,7 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     const bool whole = c->nl == c->N && c->ml == c->M;
     WSolveArgs a{};
     a.part = c->part; a.nch = nch; a.ld = c->ldw; a.weighted = wt ? 1 : 0;
+    a.gsrc = (wt && want_mode == 2) ? c->srcmap_w : nullptr;     // (stale cached weights: Gram sums at the source row's column)
     a.gpart = use_gv ? c->gpart_v : c->gpart; a.ngp = use_gv ? c->ngp_v : c->ngp_gram;
     if (use_gv && c->w_part_gsum) { a.gpart = c->gsum_v; a.ngp = 1; }      // (summed by a side workgroup of the accumulation launch)
     const int wrows = ws_rows_for(c->nl);
@@ -1688,6 +1690,7 @@ static int v_banded_dispatch(btf_ctx* c, int choice, const double* dz, uint64_t 
     lds_bytes = lds_fixed;
   }
   a.part = c->part; a.nch = nch; a.ld = c->ldv; a.weighted = wt ? 1 : 0;
+  a.gsrc = (wt && c->v_part_mode == 2) ? c->srcmap_v : nullptr;   // (stale cached weights: Gram blocks at the source column)
   a.gpart = use_gw ? c->gpart_w : c->gpart; a.ngp = use_gw ? c->ngp_w : c->ngp_gram;
   a.s = c->binomial ? 1.0 : 1.0 / c->nu2;
   a.sR = a.s * c->R;
@@ -1829,6 +1832,7 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
   const int K = c->K, KK = c->KK, T = c->T, n = T * K;
   const bool wt = lik_weighted(c), cv = c->weighted && !wt;
   const int mode = !wt ? 0 : (compat == BTF_COMPAT_REFERENCE && c->stale_v && c->srcmap_v ? 2 : 1);
+  c->v_part_mode = mode;
   const int NV = wt ? K + KK : K;
   const int tiles = c->ldv / ACC_TILE;
   const int rpb = pick_rpb(c->N, tiles, c->rpb_v, wt, acc_slots(c, K, mode), v_side_reserve(c, wt));

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(VB_THREADS) void v_banded_chunk_kernel(VBandArgs a,
   }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = blockIdx.x, jg = a.col0 + j;
+  const int jq = a.gsrc ? a.gsrc[j * a.T] / a.T : j;      // (stale cached weights: the column whose Gram blocks this one reuses - VBandArgs.gsrc)
   const int KK = tri(K), T = a.T, n = T * K, D1 = a.TF + 2, bw = (a.TF + 1) * K, R1 = bw + 1;
   const int NV = a.weighted ? K + KK : K;
   const VcLayout C = vc_layout(T, K, a.TF, a.weighted, CH);
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(VB_THREADS) void v_banded_chunk_kernel(VBandArgs a,
         const int t1 = (c0 + nview - 1) / K, cnt = t1 - t0 + 1;
         for (int e = tid; e < cnt * KK; e += VB_THREADS) {
           const int q = e / cnt, tt = e - q * cnt;
-          Ql[tt * KK + q] = chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t0 + tt) * a.s;
+          Ql[tt * KK + q] = chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)jq * T + t0 + tt) * a.s;
         }
         __syncthreads();
       }

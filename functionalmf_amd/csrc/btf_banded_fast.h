@@ -640,6 +640,7 @@ __global__ __launch_bounds__(VB_THREADS) void v_banded_fast_kernel(VBandArgs a, 
   }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = blockIdx.x, jg = a.col0 + j;
+  const int jq = a.gsrc ? a.gsrc[j * a.T] / a.T : j;      // (stale cached weights: the column whose Gram blocks this one reuses - VBandArgs.gsrc)
   const int KK = tri(K), T = a.T, n = T * K, D1 = a.TF + 2, bw = (a.TF + 1) * K, R1 = bw + 1;
   const int NV = a.weighted ? K + KK : K;
 
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(VB_THREADS) void v_banded_fast_kernel(VBandArgs a, 
   if (a.weighted) {
     for (int idx = tid; idx < T * KK; idx += VB_THREADS) {
       const int t = idx / KK, q = idx - t * KK;
-      Ql[idx] = chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t) * a.s;
+      Ql[idx] = chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)jq * T + t) * a.s;
     }
   } else {
     reduce_gram(a.gpart, a.ngp, KK, a.sR, Bc, Ql);   // Bc is free scratch until the assembly

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
   }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = blockIdx.x, jg = a.col0 + j;
+  const int jq = a.gsrc ? a.gsrc[j * a.T] / a.T : j;      // (stale cached weights: the column whose Gram blocks this one reuses - VBandArgs.gsrc)
   const int KK = tri(K), T = a.T, n = T * K, D1 = a.TF + 2, bw = (a.TF + 1) * K, R1 = bw <= 15 ? 16 : bw + 1;   // = tw_layout's stride
   const int NV = a.weighted ? K + KK : K;
   const bool ql_global = a.weighted && a.ql_global;          // (see tw_layout: weighted == 2)
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
       qhas[u] = e < T * KK;
       const int ec = qhas[u] ? e : 0;
       const int q = ec / T, t = ec - q * T;
-      qp[u] = a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t;
+      qp[u] = a.part + (size_t)(K + q) * a.ld + (size_t)jq * T + t;
       qdst[u] = t * KK + q;
     }
   }
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
         has[u] = e < tot;
         const int ec = has[u] ? e : 0;
         const int q = ec / T, t = ec - q * T;
-        pp[u] = a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t;
+        pp[u] = a.part + (size_t)(K + q) * a.ld + (size_t)jq * T + t;
         dst[u] = t * KK + q;
       }
       int c = 0;
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(VT_THREADS) void v_banded_twist_kernel(VBandArgs a,
         if (src >= 0) v = lds[src];
         else {
           const int ge = -2 - src, q = ge / T, t = ge - q * T;
-          v = chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t) * a.s;
+          v = chunk_sum(a.part + (size_t)(K + q) * a.ld + (size_t)jq * T + t) * a.s;
         }
         if (dia >= 0) v += lds[dia] + shift;
         lds[dst] = v;

@@ -615,9 +615,31 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   const bool nt = __builtin_amdgcn_readfirstlane(cm.nt) != 0;      // (uniform: the loop is compiled for both forms of the load)
 #endif
   int s0 = 0, s1 = 0;
+  // MODE 2 (the stale cached weights of compat="reference"): every output that shares a source shares the source's Gram -
+  // factor.py:349-357 reuses Xt / Lt for the rows >= K, :394-400 Q_likelihood until the NaN pattern changes - so the
+  // K(K+1)/2 outer-product sums are accumulated only where an output IS a source (its own weights); a tile without any
+  // (all but the first at C4: every wave of a workgroup covers the tile's 128 outputs, so this is workgroup-uniform) runs
+  // the K-sum stream with the rescaled statistic, reduces one round instead of four and writes a quarter of the partials.
+  // The consumers read a dependent output's Gram at its source's column (WSolveArgs.gsrc / VBandArgs.gsrc): the same
+  // sums in the same order, accumulated once.
+  bool gram_on = true;
   if constexpr (MODE == 2) {
     s0 = srcmap[col];
     if constexpr (OPL == 2) s1 = srcmap[col + 1];
+    const bool own = s0 == (int)col || (OPL == 2 && s1 == (int)col + 1);
+    gram_on = __builtin_amdgcn_readfirstlane(__any(own) ? 1 : 0) != 0;
+  }
+  // ... and how the source's weight of a row is fetched (wave-uniform choice, made once): 1 - every output of the wave has
+  // the SAME source (the W half-sweep: row K-1 for all later rows): one scalar load per row; 2 - the lane's two outputs have
+  // neighbouring sources (the V half-sweep: (j, t), (j, t+1) -> (src j, t), (src j, t+1)): one 16-byte load like the lane's
+  // own weights; 0 - two gathers per lane and row (what every case used to pay: the vector-memory issue rate, not the bytes,
+  // bounded this mode - 19.6 us for 75.5 MB at C4)
+  int cs_form = 0, cs_src = 0;
+  if constexpr (MODE == 2 && OPL == 2) {
+    cs_src = __builtin_amdgcn_readfirstlane(s0);
+    if (__all(s0 == cs_src && s1 == cs_src)) cs_form = 1;
+    else if (__all(s1 == s0 + 1 && (s0 & 1) == 0)) cs_form = 2;
+    cs_form = __builtin_amdgcn_readfirstlane(cs_form);
   }
 
   int ublk0 = r0;                                             // first row of the block of U staged in `ush` (ULDS)
@@ -663,7 +685,11 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
               else R.c[u] = *reinterpret_cast<const double2*>(Cx + (size_t)r * ld + col);
             }
           }
-          if constexpr (MODE == 2) R.cs[u] = make_double2((double)Cx[(size_t)r * ld + s0], (double)Cx[(size_t)r * ld + s1]);
+          if constexpr (MODE == 2) {
+            if (cs_form == 1) { const double w1 = (double)Cx[(size_t)r * ld + cs_src]; R.cs[u] = make_double2(w1, w1); }      // (uniform address: a scalar load)
+            else if (cs_form == 2 && sizeof(CT) == 8) R.cs[u] = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(Cx) + (size_t)r * ld + s0);
+            else R.cs[u] = make_double2((double)Cx[(size_t)r * ld + s0], (double)Cx[(size_t)r * ld + s1]);
+          }
         }
       } else {
         R.x[u] = make_double2(0.0, 0.0);
@@ -691,7 +717,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
         acc[k][0] = fma(R.x[u].x, uk, acc[k][0]);
         if constexpr (OPL == 2) acc[k][1] = fma(R.x[u].y, uk, acc[k][1]);
       }
-      if constexpr (MODE >= 1) {
+      if (MODE >= 1 && (MODE != 2 || gram_on)) {
         // outer products on the fly: (c u_p) u_q, K more multiplies per output instead of KK more scalar operands
         // per row - the scalar loads of a precomputed table (KK doubles per row, more than the SGPR file holds for
         // the rows in flight) were issued just in time and stalled every wave four times per row
@@ -849,6 +875,9 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   for (int r = 0; r < NFS; ++r) fsum[r] = 0.0;
 #pragma unroll
   for (int g = 0; g < NV; g += ACC_RG) {
+    // (MODE 2 without a source output in the tile: the Gram slots were never accumulated and nobody reads them here - rounds
+    //  that hold nothing but Gram values are skipped, uniformly)
+    if (MODE == 2 && !gram_on && g >= K) break;
 #pragma unroll
     for (int v = 0; v < ACC_RG; ++v) {
       if (g + v < NV) {
@@ -858,7 +887,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
     }
     __syncthreads();
     if constexpr (!ULDS) { if (g == 0) ACC_STAMP(1); }         // (diagnostic builds: every wave has finished its rows)
-    if (tv < ACC_RG && g + tv < NV) {
+    if (tv < ACC_RG && g + tv < NV && !(MODE == 2 && !gram_on && g + tv >= K)) {
       double s = 0.0;
 #pragma unroll
       for (int w = 0; w < NWR; ++w) s += red[w][tv][tc];
@@ -1029,6 +1058,9 @@ __global__ __launch_bounds__(WAVE) void colgram_kernel(const double* __restrict_
 // ============================================================================
 struct WSolveArgs {
   const double* part; int nch; int ld;
+  // compat="reference", stale cached weights (MODE 2 accumulation): the Gram sums of row il stand in the partials' column
+  // gsrc[il] - the row whose weights it shares (factor.py:349-357) - and were accumulated there ONCE; nullptr: its own
+  const int* gsrc;
   const double* gpart; int ngp;
   int weighted;
   double s;        // 1/nu2 (Gaussian) or 1 (Binomial)
@@ -1203,6 +1235,8 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
     for (int v = 0; v < NVMAX; ++v) part[v] = 0.0;
     const size_t cst = (size_t)NV * a.ld;               // chunk stride
     const bool live1 = il < a.nl;
+    // (stale cached weights: the Gram sums of this row stand at its source's column of the partials)
+    const ptrdiff_t goff = (a.gsrc && live1) ? (ptrdiff_t)a.gsrc[il] - (ptrdiff_t)il : 0;
     int c = grp * SUB + sub;
     // (slot u of the first batch exists if chunk c + u CS does: at C3 the 64 (wave, subgroup) pairs of a row own ONE chunk
     //  each, and a batch that asked for all UNR of them never left before the normals - 1.6 us of Philox in front of the
@@ -1217,7 +1251,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
         const bool has = c + u * CS < a.nch;
         nfirst += has ? 1 : 0;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) x0[u][v] = has ? p[(size_t)u * CS * cst + (size_t)v * a.ld] : 0.0;
+        for (int v = 0; v < NV; ++v) x0[u][v] = has ? p[(ptrdiff_t)((size_t)u * CS * cst + (size_t)v * a.ld) + (v >= K ? goff : 0)] : 0.0;
       }
     }
     if (live1) {
@@ -1245,7 +1279,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
-          for (int v = 0; v < NV; ++v) x[u][v] = p[(size_t)u * CS * cst + (size_t)v * a.ld];
+          for (int v = 0; v < NV; ++v) x[u][v] = p[(ptrdiff_t)((size_t)u * CS * cst + (size_t)v * a.ld) + (v >= K ? goff : 0)];
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
@@ -1254,7 +1288,7 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
       for (; c < a.nch; c += CS) {
         const double* p = a.part + (size_t)c * cst + il;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) part[v] += p[(size_t)v * a.ld];
+        for (int v = 0; v < NV; ++v) part[v] += p[(ptrdiff_t)((size_t)v * a.ld) + (v >= K ? goff : 0)];
       }
     }
     // (the staging area of the Gram partials is `red` itself: this wave's sums wait in registers meanwhile)
@@ -1431,6 +1465,9 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
 struct VBandArgs {
   // likelihood part
   const double* part; int nch; int ld;   // accum partials [nch][NV][ld], column j at offset j*T
+  // compat="reference", stale cached weights (MODE 2 accumulation): the Gram blocks of local column j stand at the partials'
+  // column gsrc[j * T] / T - the column whose Q_likelihood it reuses (factor.py:394-400), accumulated there ONCE; nullptr: its own
+  const int* gsrc;
   const double* gpart; int ngp;          // Gram partials (complete-data path)
   int weighted;
   double s, sR;
@@ -1602,7 +1639,7 @@ __global__ __launch_bounds__(WAVE) void v_banded_kernel(VBandArgs a) {
   if (a.weighted) {
     for (int idx = lane; idx < T * KK; idx += WAVE) {
       const int t = idx / KK, q = idx - t * KK;
-      const double* p = a.part + (size_t)(K + q) * a.ld + (size_t)j * T + t;
+      const double* p = a.part + (size_t)(K + q) * a.ld + (size_t)(a.gsrc ? a.gsrc[j * T] / T : j) * T + t;
       double s = 0.0;
       for (int c = 0; c < a.nch; ++c) s += p[(size_t)c * NV * a.ld];
       Ql[idx] = s * a.s;
