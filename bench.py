@@ -507,6 +507,14 @@ def main():
             big = hbm_resident_reference()
             if big:
                 rl["hbm_resident"] = big
+    if v_fused and world == 1 and not as_rank and "v_accum" in kernels_us:
+        # the LARGEST launch of the step is not the plain stream but the V accumulation launch that carries its sampler as a
+        # tail: the same algorithmic bytes over stream + tail (latency-bound chains behind the stream: DESIGN.md 4.3)
+        va = kernels_us["v_accum"]
+        rl["largest_launch"] = {"kernel": "accum_kernel FUSE_V%s (V accumulation + spectral sampler tail)" % ("DF" if os.environ.get("BTF_VF_DATAFLOW", "1") != "0" else ""),
+                                "avg_launch_us": va, "algorithmic_bytes": bpc * cells_local_v,
+                                "frac": round(bpc * cells_local_v / (va * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                "timing": "live HIP events"}
     if args.variant in ("binomial", "negbinom"):
         out["config"]["pg_sampler"] = getattr(model, "pg_sampler", "series")
     if world > 1 or exercise:

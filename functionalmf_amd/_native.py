@@ -24,7 +24,7 @@ COMPAT = {"reference": 0, "exact": 1}
 KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw", "nb_loglik",
                 "prior_band", "gram_eig", "hyper", "ess"]
 COMM_ID_BYTES = 128               # BTF_COMM_ID_BYTES of include/btf.h
-OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT, OPT_CURVE_COUNTS, OPT_SPLIT_ACCUM, OPT_FUSED_SWEEP, OPT_FUSED_STEP = 0, 1, 2, 3, 4, 5, 6, 7
+OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT, OPT_CURVE_COUNTS, OPT_SPLIT_ACCUM, OPT_FUSED_SWEEP, OPT_FUSED_STEP, OPT_FUSED_DATAFLOW = 0, 1, 2, 3, 4, 5, 6, 7, 8
 ESS_HOST_LIKELIHOOD = -1          # BTF_ESS_HOST_LIKELIHOOD of include/btf.h
 SAMPLERS = {"banded": 0, "spectral": 1, "chain": 2, "generic": 3, "banded_nopanel": 4}
 

@@ -161,6 +161,7 @@ struct btf_ctx {
   unsigned long long sweep_w = 0, sweep_v = 0;
   // the two-launch W+V step (BTF_OPT_FUSED_STEP, btf_fused.h): tickets / flags (zeroed once; 32 words = one 128-byte line
   // per flag), the write-through copies the tails read, the epoch of the hand-offs (one per fused launch, never reused)
+  int fused_dataflow = 1;            // BTF_OPT_FUSED_DATAFLOW: 1 (default) the fused V launch runs the barrier-free tail where it applies
   int fused_step = 1;                // BTF_OPT_FUSED_STEP: 0 four launches, 1 (default) the V launch carries its sampler, 2 the W launch its solve too
   unsigned* fz_words = nullptr; int fz_tiles_w = 0, fz_tiles_v = 0;
   double* fz_pub = nullptr;
@@ -389,8 +390,8 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
       else {
         // the barrier-free (dataflow) tail where it applies: one chunk per tile (the sums never leave the workgroup), the
         // precomputed band, no scalar drawn by a side workgroup of this launch, every value in one reduction round
-        // (nembeds <= 6), its LDS footprint beside the partial sums; BTF_VF_DATAFLOW=0: the barrier form (A/B aid)
-        static const bool df_on = [] { const char* e = std::getenv("BTF_VF_DATAFLOW"); return !e || std::atoi(e) != 0; }();
+        // (nembeds <= 6), its LDS footprint beside the partial sums; BTF_OPT_FUSED_DATAFLOW 0: the barrier form
+        const bool df_on = c->fused_dataflow != 0;
         FuseV f2 = *fv;
         constexpr int RG = K < 4 ? 4 : (K > 6 ? 6 : K);        // accum_kernel's ACC_RG of the 16-wave complete-data instance
         f2.dataflow = (df_on && f2.a.pband && f2.pimg && !f2.cnt && !f2.hp.flag && K <= 6 &&
@@ -934,6 +935,7 @@ int btf_create(btf_ctx** out, int nrows, int ncols, int ndepth, int nembeds, int
   if (e != hipSuccess) { g_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete c; return BTF_EHIP; }
   { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->ncu = n; }
   { const char* e = std::getenv("BTF_FUSED_STEP"); if (e) c->fused_step = std::max(0, std::min(2, std::atoi(e))); }      // (A/B aid; BTF_OPT_FUSED_STEP is the interface)
+  { const char* e = std::getenv("BTF_VF_DATAFLOW"); if (e) c->fused_dataflow = std::atoi(e) != 0 ? 1 : 0; }             // (A/B aid; BTF_OPT_FUSED_DATAFLOW is the interface)
   if (stream) { c->stream = (hipStream_t)stream; }
   else {
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -3601,6 +3603,9 @@ int btf_set_option(btf_ctx* c, int option, int value) {
     case BTF_OPT_FUSED_STEP:
       if (value < 0 || value > 2) return fail(c, BTF_EINVAL, "BTF_OPT_FUSED_STEP: 0, 1 or 2");
       c->fused_step = value;
+      return BTF_OK;
+    case BTF_OPT_FUSED_DATAFLOW:
+      c->fused_dataflow = value != 0 ? 1 : 0;
       return BTF_OK;
     case BTF_OPT_FUSED_SWEEP:
       c->fused_sweep = value != 0;

@@ -94,6 +94,12 @@ enum {
                                 accumulation launch that wait for their tile's streaming workgroups: two launches.
                                 All three walk the same chain bit for bit (tests/test_gpu_fused.py).  Measured on MI355X at
                                 (512,256,64) nembeds 5: 41.2 / 38.7 / 42.2 us per step. */
+  BTF_OPT_FUSED_DATAFLOW = 8,/* 1 (default): where the fused V launch of BTF_OPT_FUSED_STEP >= 1 allows it - one chunk per tile, the
+                                precomputed prior band, nembeds <= 6 - its tail is the BARRIER-FREE form (csrc/btf_fused.h,
+                                v_fused_df): the chain wave of a column factors A_k = g_k I + P_j (fast_mvn.py:38) the moment its own
+                                stream ends, while the other waves still stream, reduce and rotate; LDS counters order the
+                                stages.  Bit-identical to the barrier tail and to the four-launch form.  Measured at
+                                (512,256,64) nembeds 5: 20.4 us per V launch against 21.0.  0: the barrier tail. */
   BTF_OPT_SPLIT_ACCUM = 5,   /* sharded Gaussian contexts: 1 - the streaming accumulation of a half-sweep runs in two launches: the
                                 chunks that reduce over this rank's OWN block of the fixed factor (its columns of V for the W
                                 half-sweep, its rows of W for the V half-sweep) are queued right behind the kernel that drew

@@ -19,7 +19,7 @@ def _synth(N, M, T, R, K, seed=3):
     return np.einsum("nk,mtk->nmt", Wt, Vt)[..., None] + rs.normal(0, 0.5, size=(N, M, T, R))
 
 
-def _make(dims, fused, rng, compat, sampler="spectral", rpb=None, seed=11):
+def _make(dims, fused, rng, compat, sampler="spectral", rpb=None, seed=11, dataflow=None):
     from functionalmf_amd import _native
     from functionalmf_amd.factor import GaussianBayesianTensorFiltering
     N, M, T, R, K = dims
@@ -27,6 +27,8 @@ def _make(dims, fused, rng, compat, sampler="spectral", rpb=None, seed=11):
     m = GaussianBayesianTensorFiltering(N, M, T, nembeds=K, tf_order=2, sigma2_init=0.5, lam2_init=0.1, nu2_init=1.0,
                                         rng=rng, device_seed=5, compat=compat, sampler=sampler)
     m._ctx.call("btf_set_option", _native.OPT_FUSED_STEP, int(fused))      # 0: four launches, 1: V launch fused, 2: W launch too
+    if dataflow is not None:
+        m._ctx.call("btf_set_option", _native.OPT_FUSED_DATAFLOW, int(dataflow))   # the barrier-free tail of the fused V launch, or the barrier tail
     if rpb:
         m._ctx.call("btf_set_tuning", rpb[0], rpb[1])
     return m
@@ -176,3 +178,47 @@ def test_twisted_sampler_with_the_precomputed_band_walks_the_same_chain(rng):
     assert np.array_equal(a.W, b.W) and np.array_equal(a.V, b.V)
     la, lb = _launches(a), _launches(b)
     assert la.get("prior_band") == 1 and "prior_band" not in lb, (la, lb)
+
+
+def test_dataflow_tail_is_the_default_where_it_applies_and_equals_the_barrier_tail():
+    """The barrier-free tail of the fused V launch (csrc/btf_fused.h, v_fused_df: LDS counters instead of workgroup barriers,
+    the chain waves factoring while the other waves still stream) against the barrier tail (BTF_VF_DATAFLOW=0) and the
+    four-launch form, bit for bit, at the shapes it takes - two columns per tile (T = 64), four (T = 32), one (T = 128),
+    a ragged last tile, rows too few for the in-stream band store, nembeds 1 and 6 - with host and device normals."""
+    shapes = [(96, 6, 64, 2, 5), (70, 9, 32, 2, 3), (40, 3, 128, 1, 4), (130, 7, 64, 3, 1), (24, 5, 64, 1, 6), (600, 4, 64, 2, 5)]
+    for dims in shapes:
+        Y = _synth(*dims)
+        for rng in ("device", "host"):
+            outs = []
+            for mode, df in ((1, 1), (1, 0), (0, 1)):
+                m = _make(dims, mode, rng, "reference", dataflow=df)
+                np.random.seed(31)
+                for _ in range(3):
+                    m._resample_W(Y)
+                    m._resample_V(Y)
+                m.sync()
+                outs.append((m.W.copy(), m.V.copy()))
+            for W, V in outs[1:]:
+                assert np.array_equal(outs[0][0], W) and np.array_equal(outs[0][1], V), (dims, rng)
+            assert np.isfinite(outs[0][1]).all() and np.abs(outs[0][1]).max() > 0
+
+
+@pytest.mark.timeout(600)
+def test_in_launch_hand_offs_hold_over_thousands_of_launches():
+    """Stress of the in-launch hand-offs: 3000 W+V steps each of (a) the dataflow tail at C3 size - 128 + 1
+    workgroups per V launch, LDS counters inside every workgroup, the eigenvalue granules and the eigen-system published by
+    the side workgroup and read under full streaming load - and (b) the ticketed barrier tail with several chunks per tile in
+    both launches (write-through partials, last arriver per tile), against the four-launch chain: one stale partial, one
+    early read of a granule or one lost count anywhere in 3000 steps changes the final state, which must be bit-identical."""
+    cases = [((512, 256, 64, 4, 5), 1, None, 3000), ((640, 6, 64, 2, 5), 2, (64, 128), 3000)]
+    for dims, mode, rpb, steps in cases:
+        Y = _synth(*dims, seed=2)
+        ends = []
+        for fused in (mode, 0):
+            m = _make(dims, fused, "device", "reference", rpb=rpb)
+            for _ in range(steps):
+                m._resample_W(Y)
+                m._resample_V(Y)
+            m.sync()
+            ends.append((m.W.copy(), m.V.copy()))
+        assert np.array_equal(ends[0][0], ends[1][0]) and np.array_equal(ends[0][1], ends[1][1]), dims
