@@ -34,6 +34,15 @@ __device__ __forceinline__ double rsq_nr(double x) {       // 1/sqrt(x) to full 
   return fma(0.5 * e, r, r);
 }
 
+// 1/d to full precision from v_rcp_f64 (rel. error < 2^-23) and a cubic correction (btf_spectral.h's rcp_cubic): four
+// instructions where an IEEE division is ~30 - the refinement below divides once per matrix element and iteration
+__device__ __forceinline__ double eig_rcp(double d) {
+  const double r = __builtin_amdgcn_rcp(d);
+  const double e = fma(-d, r, 1.0);
+  const double p = fma(e, e, e);
+  return fma(p, r, r);
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -56,9 +65,27 @@ __device__ __forceinline__ void eig_for(int K, F f) {
 // their LDS reads go out together; a lone wave otherwise pays one LDS round trip per term (K = 10, warm path: ~20 us).
 // pub != nullptr: the eigenvalues and vectors (K + K K doubles) are also stored write-through (sc1) there, for consumers
 // inside the same launch (btf_fused.h); the caller drains the stores and raises the flag
+// What a caller may fetch AHEAD of the call (beside its own loads of the Gram partials: one global round trip for both
+// instead of two dependent ones in front of the first iteration): the warm-start counter and this lane's (up to two)
+// entries of the previous eigenvectors.
+struct EigWarm { double count, x0, x1; bool have; };
+template <int KC>
+__device__ __forceinline__ EigWarm eig_warm_fetch(const double* __restrict__ out, int Krt) {
+  const int K = KC > 0 ? KC : Krt, K2 = K * K, lane = threadIdx.x & 63;
+  EigWarm w;
+  w.count = out[K + K2 + 1];
+  w.x0 = lane < K2 ? out[K + lane] : 0.0;
+  w.x1 = lane + WAVE < K2 ? out[K + lane + WAVE] : 0.0;
+  w.have = true;
+  return w;
+}
+// gran / epoch: the eigenvalues also go out as self-validating 8-byte granules {half of lambda, epoch} - FIRST, straight
+// from the registers that hold them: a consumer that needs nothing but the eigenvalues (the chain waves of the dataflow
+// tails, btf_fused.h) has them before the eigenvectors' stores have even been issued
 template <int KC = 0>
 __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, int Krt, double* __restrict__ out,
-                                     double* __restrict__ scratch, bool warm_ok = true, double* pub = nullptr) {
+                                     double* __restrict__ scratch, bool warm_ok = true, double* pub = nullptr,
+                                     EigWarm pre = EigWarm{0.0, 0.0, 0.0, false}, unsigned long long* gran = nullptr, unsigned epoch = 0u) {
   const int K = KC > 0 ? KC : Krt;
   __builtin_amdgcn_s_setprio(3);       // beside a streaming kernel: win the issue arbitration, the stream waits on memory anyway
   const int lane = threadIdx.x & 63;
@@ -95,14 +122,14 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
   //      X <- X + X E.  Four K^3 products per iteration, quadratic convergence, and the R term pulls X back to
   //      orthogonality, so nothing drifts from call to call.  Between two Gibbs sweeps the Gram moves by ~1e-3, so
   //      two or three iterations reach 1e-15.  Anything else (first call, no convergence) takes the Jacobi path.
-  const double wcount = out[K + K2 + 1];
+  const double wcount = pre.have ? pre.count : out[K + K2 + 1];
   const bool warm = warm_ok && wcount >= 1.0 && K > 1;
   double* lamv = reinterpret_cast<double*>(csg);                   // K eigenvalue estimates (csg is idle here)
   bool refined = false;
   int xcur = 0;
   if (warm) {
-    if (h0) Ub0[e0] = out[K + e0];
-    if (h1) Ub0[e1] = out[K + e1];
+    if (h0) Ub0[e0] = pre.have ? pre.x0 : out[K + e0];
+    if (h1) Ub0[e1] = pre.have ? pre.x1 : out[K + e1];
     wave_lds_sync();
     float prev_err = 3.0e38f;
     for (int it = 0; it < 8; ++it) {
@@ -130,8 +157,8 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
       if (h1) {
         eig_for<KC>(K, [&](int k) { S1 = fma(X[k * K + r1], Ab1[k * K + c1], S1); });
       }
-      if (h0 && r0 == c0) lamv[r0] = S0 / (1.0 - R0);
-      if (h1 && r1 == c1) lamv[r1] = S1 / (1.0 - R1);
+      if (h0 && r0 == c0) lamv[r0] = S0 * eig_rcp(1.0 - R0);
+      if (h1 && r1 == c1) lamv[r1] = S1 * eig_rcp(1.0 - R1);
       wave_lds_sync();
       double lmax = 0.0;
       eig_for<KC>(K, [&](int k) { lmax = fmax(lmax, fabs(lamv[k])); });
@@ -149,11 +176,11 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
       const double delta = 2.0 * K * (double)err;                            // cluster threshold (bounds ||S - D|| + ||G|| ||R||)
       if (h0) {
         const double gap = lamv[c0] - lamv[r0];
-        Ab1[e0] = (r0 == c0 || !(fabs(gap) > delta)) ? 0.5 * R0 : (S0 + lamv[c0] * R0) / gap;
+        Ab1[e0] = (r0 == c0 || !(fabs(gap) > delta)) ? 0.5 * R0 : (S0 + lamv[c0] * R0) * eig_rcp(gap);
       }
       if (h1) {
         const double gap = lamv[c1] - lamv[r1];
-        Ab1[e1] = (r1 == c1 || !(fabs(gap) > delta)) ? 0.5 * R1 : (S1 + lamv[c1] * R1) / gap;
+        Ab1[e1] = (r1 == c1 || !(fabs(gap) > delta)) ? 0.5 * R1 : (S1 + lamv[c1] * R1) * eig_rcp(gap);
       }
       wave_lds_sync();
       // X <- X + X E
@@ -179,8 +206,8 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
   }
   const int Ke = K + (K & 1);            // players of the round-robin tournament (a phantom one if K is odd)
   const int Km = Ke - 1;
-  // circle method (player Km fixed, the others rotate): partner of every index in every round, once
-  for (int e = lane; e < Km * K; e += WAVE) {
+  // circle method (player Km fixed, the others rotate): partner of every index in every round, once (Jacobi path only)
+  for (int e = lane; !refined && e < Km * K; e += WAVE) {
     const int round = e / K, i = e - round * K;
     int x = 2 * round - i;
     x += x < 0 ? Km : 0;
@@ -275,6 +302,11 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
       if (v > bv) { bv = v; bigr = r; }
     });
     const double sgn = U[bigr * K + lane] < 0.0 ? -1.0 : 1.0;
+    if (gran) {
+      const unsigned long long gb = (unsigned long long)__double_as_longlong(lam);
+      __hip_atomic_store(gran + 2 * rank, ((gb >> 32) << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(gran + 2 * rank + 1, (gb << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     out[rank] = lam;
     if (pub) store_sc1(pub + rank, lam);
     for (int r = 0; r < K; ++r) {

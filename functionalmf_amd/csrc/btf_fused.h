@@ -928,6 +928,11 @@ __host__ __device__ inline bool vf_df_fits(int T, int K, int TF, int nD, int wav
 template <> __device__ __forceinline__ int fuse_chain_waves<FUSE_VDF>(const FuseV& fz) { return ACC_TILE / fz.a.T; }
 template <> __device__ __forceinline__ const unsigned long long* fuse_eig_gran<FUSE_VDF>(const FuseV& fz) { return fz.eig_gran; }
 template <> __device__ __forceinline__ const double* fuse_nu2_ptr<FUSE_VDF>(const FuseV& fz) { return (fz.a.hyp && fz.a.hyp_noise) ? fz.a.hyp + HYP_NU2 : nullptr; }
+template <> __device__ __forceinline__ void fuse_touch_args<FUSE_VDF>(const FuseV& fz) {
+  // one field per 64-byte line of the argument block the tail reads (forced to be loaded HERE: inputs of an empty asm)
+  asm volatile("" :: "s"(fz.a.nch), "s"(fz.a.nD), "s"(fz.a.st_drow), "s"(fz.a.ml), "s"(fz.a.attempts), "s"(fz.a.Rrep), "s"(fz.a.eig_cols),
+               "s"(fz.a.pband), "s"(fz.epoch), "s"(fz.eig_gran), "s"(fz.a.sse_out), "s"(fz.a.gout), "s"(fz.a.eps0), "s"(fz.a.seed));
+}
 template <> __device__ __forceinline__ unsigned* fuse_tickets<FUSE_VDF>(const FuseV& fz) { return nullptr; }
 template <> __device__ __forceinline__ int fuse_chunks<FUSE_VDF>(const FuseV& fz) { return 1; }
 template <> __device__ __forceinline__ int fuse_owners<FUSE_VDF>(const FuseV&) { return 0; }
@@ -1012,7 +1017,8 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
   spectral_split(T, S, nl, nr, ns);
   const int lane = threadIdx.x & 63;
   const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int cg = pw % NG, vw = pw / NG;
+  const int lgNG = T == 128 ? 0 : (T == 64 ? 1 : 2);       // NG = 1, 2, 4: shifts instead of divisions
+  const int cg = pw & (NG - 1), vw = pw >> lgNG;
   const int j = tile * NG + cg, jg = a.col0 + j;
   const bool live = j < a.ml;                              // (wave-uniform; a ragged last tile has dead column groups)
   // The workers of a column are the waves on the SIMDs NO chain wave runs on (wave p sits on SIMD p % 4; the chain waves

@@ -350,6 +350,7 @@ constexpr int VF_MAILBOX_DOUBLES = 128;
 struct VDfPre { double2 pv[8]; };
 template <int FUSE> __device__ __forceinline__ int fuse_chain_waves(const typename FuseSel<FUSE>::type& fz) { return 0; }
 template <int FUSE> __device__ __forceinline__ const double* fuse_nu2_ptr(const typename FuseSel<FUSE>::type& fz) { return nullptr; }
+template <int FUSE> __device__ __forceinline__ void fuse_touch_args(const typename FuseSel<FUSE>::type& fz) {}
 // what a chain wave fetched BEHIND its last rows' loads (in order: back right after them, no wait of its own): the tagged
 // eigenvalue granules of its lane's system, the device-resident nu2
 struct DfEarly { unsigned long long ghi, glo; double nu2; };
@@ -485,6 +486,9 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       const bool task = b > 0 && wave < TPW && t < sidec.ncols;
       const int col = task ? sidec.cols[t] : 0;
       if (task) curve_column_sum_wave<K>(sidec.cv, sidec.W, col, gown + wave * 64);    // (its loads fly with reduce_gram's)
+      // (workgroup 0's first wave: the previous eigen-system, the warm start of the solve - fetched with the Gram partials)
+      EigWarm eig_pre{0.0, 0.0, 0.0, false};
+      if (b == 0 && wave == 0) eig_pre = eig_warm_fetch<EIG_KC>(side.out, K);
       if (side.Usrc) {         // (sharded runs: W has just been all-gathered, nobody summed its Gram)
         gram_mfma_block<K, WAVES>(side.Usrc, side.nrows, 0, 1, rsc, gsum);
         __syncthreads();
@@ -494,14 +498,9 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       if (b == 0) {
         ACC_SIDE_STAMP(1);
         if (wave == 0) {
-          gram_eig_wave<EIG_KC>(gsum, 1, K, side.out, sc, true, side.pub);
+          gram_eig_wave<EIG_KC>(gsum, 1, K, side.out, sc, true, side.pub, eig_pre, side.flag ? side.gran : nullptr, side.epoch);
           if (side.flag) {                     // the tails of this launch wait for it (btf_fused.h): one storing wave
             drain_stores();
-            if (side.gran && lane < K) {       // the eigenvalues as tagged granules (one 8-byte sc1 store each: never torn)
-              const unsigned long long gb = (unsigned long long)__double_as_longlong(load_sc1(side.pub + lane));
-              __hip_atomic_store(side.gran + 2 * lane, ((gb >> 32) << 32) | (unsigned long long)side.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(side.gran + 2 * lane + 1, (gb << 32) | (unsigned long long)side.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             if (lane == 0) publish_epoch(side.flag, side.epoch);
           }
           ACC_SIDE_STAMP(3);
@@ -826,6 +825,10 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
           df_early.glo = __hip_atomic_load(gp + 2 * kk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const double* np = fuse_nu2_ptr<FUSE>(fz);
           if (np) df_early.nu2 = *np;
+          // (the tail reads a few hundred bytes of kernel arguments the stream never touches, and the stream's own scalar
+          //  loads - the factor rows - have long pushed them out of the scalar cache: touch their lines now, one scalar load
+          //  each, so that the chain wave does not start its tail with a chain of scalar-cache misses)
+          fuse_touch_args<FUSE>(fz);
         }
         asm volatile("" ::: "memory");
         compute(rb, A);
