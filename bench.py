@@ -135,6 +135,8 @@ def parse_args(argv=None):
                     "message size; adds a `projected` block (never `value`: that stays this GPU's own rate)")
     ap.add_argument("--overlap", action="store_true", help="sharded runs: all-gathers on a communication stream, own-block chunks of the "
                     "next accumulation ahead of them (BTF_OPT_SPLIT_ACCUM); default: collectives in line on the ctx's stream")
+    ap.add_argument("--python-loop", action="store_true", help="drive the timed W+V steps from Python, call by call (default on one GPU with "
+                    "Gaussian data: one btf_wv_steps call queues them all)")
     ap.add_argument("--master-port", type=int, default=29533)
     return ap.parse_args(argv)
 
@@ -282,21 +284,42 @@ def main():
         def step():
             model._resample_W(data)
             model._resample_V(data)
+    # One GPU, Gaussian data: the K timed W+V steps are queued by ONE call into the C side (model.wv_steps -> btf_wv_steps:
+    # the same launches with the same seeds as K Python-driven steps - tests/test_gpu_parity.py checks the chains coincide -
+    # without a round trip through the interpreter between the launches).  The Python-driven loop is timed too, beside it
+    # (config.python_driven_sweeps_per_s).
+    c_driven = world == 1 and not as_rank and args.variant in ("complete", "heldout", "curves5", "missing5") and not args.python_loop
+
+    def run_steps(k):
+        if c_driven:
+            model.wv_steps(data, k)
+        else:
+            for _ in range(k):
+                step()
 
     def fence():
         if world > 1 or exercise:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     model.sync()                      # raises if any factorisation failed inside the timed region
+    py_per_s = None
+    if c_driven and not args.lean:    # the same K steps driven from Python, call by call
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0p = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        py_per_s = args.steps / (time.perf_counter() - t0p)
+        model.sync()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -457,6 +480,8 @@ def main():
                    "median_ms_per_step": round(float(np.median(per_step_ms)), 4), "median_over_steps": int(nmed),
                    "burn_in_sweeps": args.burn,
                    "full_resample_sweeps_per_s": None if full_per_s is None else round(full_per_s, 2),
+                   "step_loop": "C side (btf_wv_steps: one call queues the K steps)" if c_driven else "Python (one _resample_W / _resample_V call pair per step)",
+                   "python_driven_sweeps_per_s": None if py_per_s is None else round(py_per_s, 2),
                    "v_sampler": sampler, "banded_sweeps_per_s": None if banded_per_s is None else round(banded_per_s, 2),
                    "likelihood_form": form,
                    "launches_per_step": 4 - int(v_fused) - int(w_fused),

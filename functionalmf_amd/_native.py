@@ -104,6 +104,7 @@ SIGNATURES = {
     "btf_queue_lam2": (C.c_int, [_ctx, C.c_uint64, C.c_int]),
     "btf_gibbs_sweeps": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_double,
                                    C.c_double, C.c_double, C.c_double, C.c_int]),
+    "btf_wv_steps": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_int]),
     "btf_gass_set_constraints": (C.c_int, [_ctx, _c_dp, C.c_int, _c_dp, C.c_int]),
     "btf_gass_begin": (C.c_int, [_ctx, C.c_int, C.c_int, _c_dp, _c_dp, C.c_uint64, C.c_double, C.c_int, C.c_int]),
     "btf_gass_grid": (C.c_int, [_ctx, C.c_int, _c_ip, C.POINTER(C.c_uint8), _c_dp, _c_dp]),

@@ -355,6 +355,10 @@ inline int unr3_min_rpb() {
   static const int v = [] { const char* e = std::getenv("BTF_UNR3_RPB"); return e ? std::atoi(e) : 2048; }();
   return v;
 }
+inline bool lean_on() {
+  static const bool v = [] { const char* e = std::getenv("BTF_ACC_LEAN"); return !e || std::atoi(e) != 0; }();      // (A/B aid)
+  return v;
+}
 template <int K>
 void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* Cx, const unsigned char* C8, const double* U,
                   const int* srcmap, int Rdim, int ld, int rpb, int nch, EigSide side = EigSide{nullptr, 0, 0, nullptr},
@@ -415,6 +419,10 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
     else p.launch(accum_kernel<K, 1, acc_waves(K, 1), unsigned char>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, C8, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
   } else if (mode == 2) p.launch(accum_kernel<K, 2>, grid, dim3(acc_waves(K, 2) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
   else if (mode == 1) p.launch(accum_kernel<K, 1>, grid, dim3(acc_waves(K, 1) * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
+  else if (K <= 8 && acc_waves(K, 0) == 16 && rpb < unr3_min_rpb() && !tau.Tau2 && !sw.sc.hyp && !sw.lam.hyp && lean_on()) {
+    // the plain W+V step's launches carry no gamma-drawing side task: the instance compiled without them
+    if constexpr (K <= 8) p.launch(accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_LEAN>, grid, dim3(16 * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
+  }
   else if (K >= 10 && ACC_WAVES != acc_waves(10, 0) && !side.out && rpb < unr3_min_rpb()) {
     // nembeds 10: a launch without eigen side tasks (the W half-sweep's) takes the 16-wave instance
     if constexpr (K >= 10) p.launch(accum_kernel<K, 0, ACC_WAVES>, grid, dim3(ACC_WAVES * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, FuseNone{});
@@ -2504,6 +2512,19 @@ int btf_gibbs_sweeps(btf_ctx* c, int n, uint64_t seed_base, uint64_t draws0, int
       c->col_count = c->col_every;
       if (c->col_slot >= c->smp_n) c->col_every = 0;
     }
+  }
+  return BTF_OK;
+}
+
+int btf_wv_steps(btf_ctx* c, int n, uint64_t seed_base, uint64_t draws0, int compat, double eps0, int attempts) {
+  if (!c || n < 0) return BTF_EINVAL;
+  if (c->nl != c->N || c->ml != c->M) return fail(c, BTF_ESTATE, "btf_wv_steps: unsharded contexts (a sharded step has an exchange behind each half-sweep)");
+  if (!c->have_data || !c->have_W || !c->have_V || !c->have_hyper) return fail(c, BTF_ESTATE, "set data, W, V and hyper-parameters first");
+  int rc;
+  for (int s = 0; s < n; ++s) {
+    const uint64_t d = seed_base + draws0 + 2ULL * (uint64_t)s;
+    if ((rc = btf_resample_W(c, nullptr, d + 1, compat))) return rc;
+    if ((rc = btf_resample_V(c, nullptr, d + 2, compat, eps0, attempts))) return rc;
   }
   return BTF_OK;
 }

@@ -82,7 +82,9 @@ __device__ __forceinline__ EigWarm eig_warm_fetch(const double* __restrict__ out
 // gran / epoch: the eigenvalues also go out as self-validating 8-byte granules {half of lambda, epoch} - FIRST, straight
 // from the registers that hold them: a consumer that needs nothing but the eigenvalues (the chain waves of the dataflow
 // tails, btf_fused.h) has them before the eigenvectors' stores have even been issued
-template <int KC = 0>
+// EXT: the prefetched warm start and the granules are compiled in (the side task of the fused V launch at nembeds <= 8); the
+// plain form keeps the register footprint the run-time-K instances (nembeds 9, 10 on 16 waves) were tuned to
+template <int KC = 0, bool EXT = false>
 __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, int Krt, double* __restrict__ out,
                                      double* __restrict__ scratch, bool warm_ok = true, double* pub = nullptr,
                                      EigWarm pre = EigWarm{0.0, 0.0, 0.0, false}, unsigned long long* gran = nullptr, unsigned epoch = 0u) {
@@ -122,14 +124,14 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
   //      X <- X + X E.  Four K^3 products per iteration, quadratic convergence, and the R term pulls X back to
   //      orthogonality, so nothing drifts from call to call.  Between two Gibbs sweeps the Gram moves by ~1e-3, so
   //      two or three iterations reach 1e-15.  Anything else (first call, no convergence) takes the Jacobi path.
-  const double wcount = pre.have ? pre.count : out[K + K2 + 1];
+  const double wcount = (EXT && pre.have) ? pre.count : out[K + K2 + 1];
   const bool warm = warm_ok && wcount >= 1.0 && K > 1;
   double* lamv = reinterpret_cast<double*>(csg);                   // K eigenvalue estimates (csg is idle here)
   bool refined = false;
   int xcur = 0;
   if (warm) {
-    if (h0) Ub0[e0] = pre.have ? pre.x0 : out[K + e0];
-    if (h1) Ub0[e1] = pre.have ? pre.x1 : out[K + e1];
+    if (h0) Ub0[e0] = (EXT && pre.have) ? pre.x0 : out[K + e0];
+    if (h1) Ub0[e1] = (EXT && pre.have) ? pre.x1 : out[K + e1];
     wave_lds_sync();
     float prev_err = 3.0e38f;
     for (int it = 0; it < 8; ++it) {
@@ -302,7 +304,7 @@ __device__ inline void gram_eig_wave(const double* __restrict__ gsrc, int ngp, i
       if (v > bv) { bv = v; bigr = r; }
     });
     const double sgn = U[bigr * K + lane] < 0.0 ? -1.0 : 1.0;
-    if (gran) {
+    if (EXT && gran) {
       const unsigned long long gb = (unsigned long long)__double_as_longlong(lam);
       __hip_atomic_store(gran + 2 * rank, ((gb >> 32) << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(gran + 2 * rank + 1, (gb << 32) | (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

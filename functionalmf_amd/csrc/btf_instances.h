@@ -40,6 +40,8 @@ namespace btf {
   P void accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_V> BTF_ACC_ARGS_F(double, double, FuseV);
 #define BTF_FUSED_VDF_SET(P, K)                                                                          \
   P void accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_VDF> BTF_ACC_ARGS_F(double, double, FuseV);
+#define BTF_LEAN_SET(P, K)                                                                               \
+  P void accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_LEAN> BTF_ACC_ARGS(double, double);
 #define BTF_FUSED_UNR3_SET(P, K)                                                                         \
   P void accum_kernel<K, 0, 16, double, double, 3, 2, FUSE_W> BTF_ACC_ARGS_F(double, double, FuseW);     \
   P void accum_kernel<K, 0, 16, double, double, 3, 2, FUSE_V> BTF_ACC_ARGS_F(double, double, FuseV);
@@ -50,6 +52,8 @@ namespace btf {
   BTF_FUSED_V_SET(P, 5) BTF_FUSED_V_SET(P, 6) BTF_FUSED_V_SET(P, 7) BTF_FUSED_V_SET(P, 8)                \
   BTF_FUSED_VDF_SET(P, 1) BTF_FUSED_VDF_SET(P, 2) BTF_FUSED_VDF_SET(P, 3) BTF_FUSED_VDF_SET(P, 4)        \
   BTF_FUSED_VDF_SET(P, 5) BTF_FUSED_VDF_SET(P, 6)                                                        \
+  BTF_LEAN_SET(P, 1) BTF_LEAN_SET(P, 2) BTF_LEAN_SET(P, 3) BTF_LEAN_SET(P, 4)                            \
+  BTF_LEAN_SET(P, 5) BTF_LEAN_SET(P, 6) BTF_LEAN_SET(P, 7) BTF_LEAN_SET(P, 8)                            \
   BTF_FUSED_UNR3_SET(P, 8)
 
 #define BTF_WSOLVE_SET(P, K)                                                                             \

@@ -299,10 +299,17 @@ __host__ __device__ constexpr int acc_waves(int K, int MODE) {
 #ifndef BTF_ACC_K10_EU
 #define BTF_ACC_K10_EU 0
 #endif
-#if BTF_ACC_K10_EU > 0
-#define BTF_ACC_EU_ATTR(K, MODE, WAVES) __attribute__((amdgpu_waves_per_eu((K) >= 10 && (MODE) == 0 ? BTF_ACC_K10_EU : 1, (K) >= 10 && (MODE) == 0 ? BTF_ACC_K10_EU : 8)))
+// the lean instance (FUSE_LEAN) may be asked to fit two 16-wave workgroups per CU (8 waves per SIMD: at most 64 VGPRs):
+// -DBTF_ACC_LEAN_EU=8 (A/B aid; 0: whatever the compiler picks)
+#ifndef BTF_ACC_LEAN_EU
+#define BTF_ACC_LEAN_EU 0
+#endif
+__host__ __device__ constexpr int acc_eu_min(int K, int MODE, int FUSE) { return (FUSE == 4 && BTF_ACC_LEAN_EU > 0) ? BTF_ACC_LEAN_EU : ((K >= 10 && MODE == 0 && BTF_ACC_K10_EU > 0) ? BTF_ACC_K10_EU : 1); }
+__host__ __device__ constexpr int acc_eu_max(int K, int MODE, int FUSE) { return (FUSE == 4 && BTF_ACC_LEAN_EU > 0) ? BTF_ACC_LEAN_EU : ((K >= 10 && MODE == 0 && BTF_ACC_K10_EU > 0) ? BTF_ACC_K10_EU : 8); }
+#if BTF_ACC_K10_EU > 0 || BTF_ACC_LEAN_EU > 0
+#define BTF_ACC_EU_ATTR(K, MODE, WAVES, FUSE) __attribute__((amdgpu_waves_per_eu(acc_eu_min(K, MODE, FUSE), acc_eu_max(K, MODE, FUSE))))
 #else
-#define BTF_ACC_EU_ATTR(K, MODE, WAVES)
+#define BTF_ACC_EU_ATTR(K, MODE, WAVES, FUSE)
 #endif
 // outputs per lane: two adjacent ones (one 16-byte load per row and lane) wherever the K + K(K+1)/2 accumulator pairs
 // fit the register file; the weighted modes of K >= 9 (54 / 65 values: 216 / 260 VGPRs for the pairs alone) keep ONE
@@ -318,7 +325,7 @@ template <int NW> __device__ void sweep_lam_side(const LamSide& lm, double* red)
 // workgroup that finishes a 128-row tile last sums the chunks and draws the rows (w_solve_kernel's work); FUSE_V - the
 // columns of a 128-output tile are sampled where their sums are (v_spectral_kernel's work).  The extra kernel argument
 // is empty for FUSE_NONE.
-enum { FUSE_NONE = 0, FUSE_W = 1, FUSE_V = 2, FUSE_VDF = 3 };      // FUSE_VDF: FUSE_V with the barrier-free (dataflow) tail only - an instance of its own
+enum { FUSE_NONE = 0, FUSE_W = 1, FUSE_V = 2, FUSE_VDF = 3, FUSE_LEAN = 4 };      // FUSE_LEAN: FUSE_NONE without the gamma-drawing side tasks (Tau2 chain, scalars, lam2) - the plain W+V step's W launch      // FUSE_VDF: FUSE_V with the barrier-free (dataflow) tail only - an instance of its own
 struct FuseNone {};
 struct FuseW;
 struct FuseV;
@@ -326,6 +333,7 @@ template <int FUSE> struct FuseSel { typedef FuseNone type; };
 template <> struct FuseSel<FUSE_W> { typedef FuseW type; };
 template <> struct FuseSel<FUSE_V> { typedef FuseV type; };
 template <> struct FuseSel<FUSE_VDF> { typedef FuseV type; };
+template <> struct FuseSel<FUSE_LEAN> { typedef FuseNone type; };
 template <int K, int WAVES> __device__ __forceinline__ void w_fused_owner(const FuseW& fw, int tile, double* lds, long long* stamps);
 template <int FUSE> __device__ __forceinline__ int fuse_owners(const typename FuseSel<FUSE>::type& fz);
 struct VPre;
@@ -402,12 +410,13 @@ __host__ __device__ constexpr int w_owner_lds_budget(int K);
 #define TAIL_STAMP(st, i) do { if ((st) && threadIdx.x == 0) (st)[i] = wall_clock64(); } while (0)
 template <int K, int MODE, int WAVES = acc_waves(K, MODE), typename CT = double, typename XT = double, int UNRV = 0,
           int OPL = acc_opl(K, MODE), int FUSE = FUSE_NONE>
-__global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void accum_kernel(
+__global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES, FUSE) void accum_kernel(
     const XT* __restrict__ X, const CT* __restrict__ Cx, const double* __restrict__ U,
     const int* __restrict__ srcmap, double* __restrict__ part, int Rdim, int ld,
     int rows_per_block, EigSide side, EigSideCols sidec, TauSide tau, GramSide gram, ChunkMap cm, SweepSide sw,
     typename FuseSel<FUSE>::type fz) {
   static_assert(FUSE == FUSE_NONE || (MODE == 0 && OPL == 2 && WAVES == 16), "the fused tails follow the complete-data stream");
+  constexpr bool PLAIN = FUSE == FUSE_NONE || FUSE == FUSE_LEAN;      // no tail: the partial sums go to HBM
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
@@ -452,6 +461,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
     }
     b -= nown;
   }
+  if constexpr (FUSE != FUSE_LEAN) {
   if (sw.sc.hyp) {
     if (b == 0) { sweep_scalar_side<WAVES>(sw.sc, &red[0][0][0]); return; }
     b -= 1;
@@ -459,6 +469,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   if (sw.lam.hyp) {
     if (b == 0) { sweep_lam_side<WAVES>(sw.lam, &red[0][0][0]); return; }
     b -= 1;
+  }
   }
   if (side.out) {
     // side task (spectral V sampler): the first workgroup is dispatched first; one wave of it solves the K x K
@@ -488,7 +499,8 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       if (task) curve_column_sum_wave<K>(sidec.cv, sidec.W, col, gown + wave * 64);    // (its loads fly with reduce_gram's)
       // (workgroup 0's first wave: the previous eigen-system, the warm start of the solve - fetched with the Gram partials)
       EigWarm eig_pre{0.0, 0.0, 0.0, false};
-      if (b == 0 && wave == 0) eig_pre = eig_warm_fetch<EIG_KC>(side.out, K);
+      // (not where the solver runs with a run-time K - nembeds 9, 10 on 16 waves: no register to park it in)
+      if constexpr (EIG_KC > 0) { if (b == 0 && wave == 0) eig_pre = eig_warm_fetch<EIG_KC>(side.out, K); }
       if (side.Usrc) {         // (sharded runs: W has just been all-gathered, nobody summed its Gram)
         gram_mfma_block<K, WAVES>(side.Usrc, side.nrows, 0, 1, rsc, gsum);
         __syncthreads();
@@ -498,7 +510,10 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       if (b == 0) {
         ACC_SIDE_STAMP(1);
         if (wave == 0) {
-          gram_eig_wave<EIG_KC>(gsum, 1, K, side.out, sc, true, side.pub, eig_pre, side.flag ? side.gran : nullptr, side.epoch);
+          // (the run-time-K form of the solver - nembeds 9, 10 on 16 waves - has no register to spare for the prefetched warm
+          //  start or the granules: nobody reads granules there, the dataflow tails stop at nembeds 6)
+          if constexpr (EIG_KC > 0) gram_eig_wave<EIG_KC, true>(gsum, 1, K, side.out, sc, true, side.pub, eig_pre, side.flag ? side.gran : nullptr, side.epoch);
+          else gram_eig_wave<EIG_KC>(gsum, 1, K, side.out, sc, true, side.pub);
           if (side.flag) {                     // the tails of this launch wait for it (btf_fused.h): one storing wave
             drain_stores();
             if (lane == 0) publish_epoch(side.flag, side.epoch);
@@ -515,6 +530,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
     }
     b -= nside;
   }
+  if constexpr (FUSE != FUSE_LEAN)
   if (tau.Tau2) {
     constexpr int CPW = TAU_SIDE_CPW;                       // columns per side workgroup
     const int ntw = (tau.M + CPW - 1) / CPW;
@@ -872,7 +888,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
   // cross-wave reduction through LDS, ACC_RG values per round, fixed order
   const int tv = threadIdx.x >> 7;   // value slot 0..3
   const int tc = threadIdx.x & 127;  // column inside the tile
-  constexpr int NFS = FUSE == FUSE_NONE ? 1 : (NV + ACC_RG - 1) / ACC_RG;
+  constexpr int NFS = PLAIN ? 1 : (NV + ACC_RG - 1) / ACC_RG;
   double fsum[NFS];                  // (fused tails: this thread's sums, one per round)
 #pragma unroll
   for (int r = 0; r < NFS; ++r) fsum[r] = 0.0;
@@ -894,8 +910,12 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES) void 
       double s = 0.0;
 #pragma unroll
       for (int w = 0; w < NWR; ++w) s += red[w][tv][tc];
-      if constexpr (FUSE == FUSE_NONE) {
+      if constexpr (PLAIN) {
+#ifdef BTF_PART_SC1      // (A/B aid: the partial sums written through - does the next kernel's cold read of them get shorter?)
+        store_sc1(&part[((size_t)chunk * NV + (g + tv)) * ld + (size_t)tile * ACC_TILE + tc], s);
+#else
         part[((size_t)chunk * NV + (g + tv)) * ld + (size_t)tile * ACC_TILE + tc] = s;
+#endif
       } else {
         // the tail of another workgroup of this launch reads them: write-through (one chunk, FUSE_V: they stay here)
         if (FUSE == FUSE_W || fuse_tickets<FUSE>(fz)) store_sc1(&part[((size_t)chunk * NV + (g + tv)) * ld + (size_t)tile * ACC_TILE + tc], s);

@@ -893,6 +893,27 @@ class GaussianBayesianTensorFiltering(BayesianTensorFiltering):
         self._tau_dev_new, self._tau_dirty = True, False
         self._lsum_valid = self._lsum_on_device = False
 
+    def wv_steps(self, data, n):
+        """n times (_resample_W, _resample_V) - the W+V update of factor.py:313-409.  With rng="device" on one GPU the
+        launches of all n steps are queued by a single call into the C side (btf_wv_steps: the same launches and seeds as the
+        Python loop, so the chains coincide); otherwise this IS the Python loop."""
+        if not (type(self) is GaussianBayesianTensorFiltering and self.rng == "device" and self._plan.world == 1
+                and not self._exchange.active and self.sample_W and self.sample_V):
+            for _ in range(int(n)):
+                self._resample_W(data)
+                self._resample_V(data)
+            return
+        self._bind_data(data)
+        self._set_noise()
+        self._push_state()
+        o = self.linalg_opts
+        self._ctx.call("btf_wv_steps", int(n), (self._device_seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF, int(self._draws),
+                       _native.COMPAT[self.compat], float(o["force_psd_eps"]), int(o["force_psd_attempts"]) if o["force_psd"] else 0)
+        self._draws += 2 * int(n)
+        self._W_dev_new = self._V_dev_new = True
+        self._lsum_valid = False
+        self._lsum_on_device = False
+
     def _set_noise(self):
         if not self._dev_scalars:
             self._ctx.call("btf_set_nu2", _scalar(self.nu2))

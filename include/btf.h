@@ -300,6 +300,11 @@ int btf_queue_scalars(btf_ctx* ctx, uint64_t seed, int which, double nu2_a, doub
  * errors of the factorisations surface at the next btf_sync. */
 int btf_gibbs_sweeps(btf_ctx* ctx, int nsweeps, uint64_t seed_base, uint64_t draws0, int compat, double nu2_a, double nu2_b,
                      double sigma2_a, double sigma2_b, double stability, double eps0, int attempts);
+/* n W+V updates - _resample_W then _resample_V (factor.py:313-409), device normals - queued by ONE call: what a host loop
+ * of btf_resample_W(NULL, seed_base + draws0 + 2 s + 1, compat); btf_resample_V(NULL, seed_base + draws0 + 2 s + 2, ...)
+ * over s = 0 .. n-1 does, without a round trip through the caller between the launches (the same launches, the same
+ * seeds: the same chain).  Unsharded contexts; no host synchronisation.                                              */
+int btf_wv_steps(btf_ctx* ctx, int n, uint64_t seed_base, uint64_t draws0, int compat, double eps0, int attempts);
 int btf_set_nu2(btf_ctx* ctx, double nu2);               /* Gaussian scalar noise variance */
 /* Device-resident scalar hyper-parameters (rng="device" only, unsharded
  * contexts).  After btf_device_scalars(ctx,1) the half-sweep, prior-band and Tau2 kernels read

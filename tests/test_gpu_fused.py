@@ -222,3 +222,30 @@ def test_in_launch_hand_offs_hold_over_thousands_of_launches():
             m.sync()
             ends.append((m.W.copy(), m.V.copy()))
         assert np.array_equal(ends[0][0], ends[1][0]) and np.array_equal(ends[0][1], ends[1][1]), dims
+
+
+@pytest.mark.parametrize("dims,variant", [((96, 6, 64, 2, 5), "complete"), ((70, 9, 32, 2, 3), "missing"), ((40, 3, 24, 1, 4), "complete")])
+def test_c_driven_wv_steps_walk_the_python_driven_chain(dims, variant):
+    """model.wv_steps(data, n) (btf_wv_steps: n W+V updates queued by one call into the C side - what bench.py times) against
+    n Python-driven (_resample_W, _resample_V) pairs: the same launches, the same seeds, the same chain bit for bit; and
+    the two may be mixed (the draw counter moves on by two per step either way)."""
+    Y = _synth(*dims)
+    if variant == "missing":
+        rs = np.random.RandomState(5)
+        Y[rs.rand(*Y.shape) < 0.1] = np.nan
+    a, b = _make(dims, 1, "device", "reference", sampler="auto"), _make(dims, 1, "device", "reference", sampler="auto")
+    a.wv_steps(Y, 7)
+    for _ in range(7):
+        b._resample_W(Y)
+        b._resample_V(Y)
+    a.sync()
+    b.sync()
+    assert np.array_equal(a.W, b.W) and np.array_equal(a.V, b.V)
+    a._resample_W(Y)
+    a._resample_V(Y)
+    a.wv_steps(Y, 3)
+    b.wv_steps(Y, 2)
+    for _ in range(2):
+        b._resample_W(Y)
+        b._resample_V(Y)
+    assert np.array_equal(a.W, b.W) and np.array_equal(a.V, b.V) and np.isfinite(a.V).all()
