@@ -24,6 +24,7 @@ COMPAT = {"reference": 0, "exact": 1}
 KERNEL_NAMES = ["stats", "w_accum", "w_solve", "v_accum", "v_banded", "gram", "products", "sse", "pg_draw", "nb_loglik",
                 "prior_band", "gram_eig", "hyper", "ess"]
 COMM_ID_BYTES = 128               # BTF_COMM_ID_BYTES of include/btf.h
+PEER_DESC_BYTES = 256             # BTF_PEER_DESC_BYTES
 OPT_SAMPLER, OPT_NB_HISTOGRAMS, OPT_FUSE_GRAM, OPT_PG_EXACT, OPT_CURVE_COUNTS, OPT_SPLIT_ACCUM, OPT_FUSED_SWEEP, OPT_FUSED_STEP, OPT_FUSED_DATAFLOW = 0, 1, 2, 3, 4, 5, 6, 7, 8
 ESS_HOST_LIKELIHOOD = -1          # BTF_ESS_HOST_LIKELIHOOD of include/btf.h
 SAMPLERS = {"banded": 0, "spectral": 1, "chain": 2, "generic": 3, "banded_nopanel": 4}
@@ -128,6 +129,8 @@ SIGNATURES = {
     "btf_comm_block": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_ip, _c_ip]),
     "btf_comm_init": (C.c_int, [_ctx, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int]),
     "btf_comm_rehearse": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "btf_peer_export": (C.c_int, [_ctx, C.POINTER(C.c_ubyte), C.c_int]),
+    "btf_peer_init": (C.c_int, [_ctx, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int]),
     "btf_comm_destroy": (C.c_int, [_ctx]),
     "btf_comm_info": (C.c_int, [_ctx, _c_ip]),
     "btf_allgather_W": (C.c_int, [_ctx]),

@@ -12,6 +12,7 @@
 #include "btf_instances.h"      // the large kernel families: extern templates, compiled in btf_instances.hip
 #include "btf_comm.h"           // RCCL, bound at run time
 #include <hip/hip_ext.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -149,6 +150,15 @@ struct btf_ctx {
   hipStream_t comm_stream = nullptr;                                  // the overlapped exchange runs its gathers here
   double* comm_scr = nullptr; size_t comm_scr_elems = 0;              // rehearsal: [send | recv] of the larger message
   double* comm_words = nullptr;                                       // 16 device doubles: btf_allreduce_sum's staging
+  // the peer-window transport (btf_comm.h): this rank's mailbox, the table of where every rank's buffers are mapped
+  // here, the mappings to close, the collective counter
+  PeerMailbox* peer_box = nullptr;
+  PeerTable* peer_tab = nullptr;
+  unsigned* peer_counters = nullptr;
+  std::vector<void*> peer_opened;
+  bool peer_on = false;
+  unsigned long long peer_epoch = 0;
+  long long peer_timeout_ticks = 0;
   bool tau_pending = false; unsigned long long tau_seed = 0; double tau_stability = 1e-6;   // btf_queue_Tau2
   // the four-launch sweep (BTF_OPT_FUSED_SWEEP): per-column residual parts left by the spectral V sampler, and a queued
   // nu2 / sigma2 draw that the next W accumulation launch carries as a side workgroup (btf_queue_scalars)
@@ -775,6 +785,7 @@ int check_status(btf_ctx* c) {
     int zero[2] = {0, -1};
     HIPCHK(c, hipMemcpy(c->status, zero, sizeof(zero), hipMemcpyHostToDevice));
     if (st[0] == 2) return fail(c, BTF_EHIP, "a hand-off inside a fused launch timed out (btf_fused.h): its producer workgroup never published");
+    if (st[0] == 3) return fail(c, BTF_EHIP, "the peer-window exchange timed out waiting for rank " + std::to_string(st[1]) + " (btf_comm.h; BTF_PEER_TIMEOUT_MS)");
     return fail(c, BTF_ENOTPD, "conditional precision not positive definite at index " + std::to_string(st[1]));
   }
   return BTF_OK;
@@ -3704,7 +3715,9 @@ namespace {
 
 int comm_ready(btf_ctx* c, RcclApi** api) {
   if (!c) return BTF_EINVAL;
-  if (!c->comm) return fail(c, BTF_ESTATE, "no communicator: btf_comm_init first");
+  *api = nullptr;
+  if (c->peer_on) { HIPCHK(c, hipSetDevice(c->dev)); return BTF_OK; }
+  if (!c->comm) return fail(c, BTF_ESTATE, "no communicator: btf_comm_init (or btf_peer_init) first");
   std::string why;
   if (!(*api = rccl_api(&why))) return fail(c, BTF_EHIP, why);
   HIPCHK(c, hipSetDevice(c->dev));
@@ -3719,8 +3732,30 @@ int comm_blocks_match(btf_ctx* c) {
                                    "'s equal chunks ceil(n / world) (btf_comm_block)");
   return BTF_OK;
 }
+// one collective of the peer-window transport (btf_comm.h): this rank's block [off, off + len) of W (which 0) or V (1)
+// into every peer's buffer, and / or the sum over the ranks of red_n doubles at red_src into red_dst (may alias)
+int peer_collective(btf_ctx* c, int which, size_t off, size_t len, const double* red_src, double* red_dst, int red_n, hipStream_t s) {
+  if (c->gather_world <= 1) {
+    if (red_n && red_dst != red_src) HIPCHK(c, hipMemcpyAsync(red_dst, red_src, (size_t)red_n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return BTF_OK;
+  }
+  PeerArgs a{};
+  a.tab = c->peer_tab; a.rank = c->gather_rank; a.world = c->gather_world; a.which = which;
+  a.wpp = len ? (int)std::min<size_t>(16, std::max<size_t>(1, (len * sizeof(double) + 65535) / 65536)) : 1;      // 64 KB a workgroup
+  a.epoch = ++c->peer_epoch; a.off = off; a.len = len;
+  a.red_src = red_src; a.red_dst = red_dst; a.red_n = red_n;
+  a.counters = c->peer_counters; a.status = c->status; a.timeout_ticks = c->peer_timeout_ticks;
+  hipLaunchKernelGGL(peer_exchange_kernel, dim3((unsigned)((a.world - 1) * a.wpp)), dim3(PEER_THREADS), 0, s, a);
+  HIPCHK(c, hipGetLastError());
+  return BTF_OK;
+}
 // one gather of `chunk` doubles per rank into `buf` (in place), or - rehearsal - of the whole message through scratch
 int comm_gather(btf_ctx* c, RcclApi* api, double* buf, size_t chunk, hipStream_t s) {
+  if (c->peer_on) {
+    const bool isW = buf == c->W;
+    const size_t unit = isW ? (size_t)c->K : (size_t)c->T * c->K;
+    return peer_collective(c, isW ? 0 : 1, (size_t)(isW ? c->row0 : c->col0) * unit, (size_t)(isW ? c->nl : c->ml) * unit, nullptr, nullptr, 0, s);
+  }
   if (c->comm_rehearse) {
     const size_t n = chunk * (size_t)c->gather_world;
     if (2 * n > c->comm_scr_elems) {
@@ -3806,8 +3841,101 @@ int btf_comm_rehearse(btf_ctx* c, int rank, int world) {
   return BTF_OK;
 }
 
+#define BTF_PEER_MAGIC 0x42544650
+int btf_peer_export(btf_ctx* c, unsigned char* out, int nbytes) {
+  if (!c) return BTF_EINVAL;
+  if (!out || nbytes != BTF_PEER_DESC_BYTES) return fail(c, BTF_EINVAL, "desc: a buffer of BTF_PEER_DESC_BYTES bytes");
+  static_assert(BTF_PEER_DESC_BYTES == PEER_DESC_BYTES, "include/btf.h and btf_comm.h disagree on the descriptor size");
+  int rc;
+  if ((rc = btf_comm_destroy(c))) return rc;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipExtMallocWithFlags((void**)&c->peer_box, sizeof(PeerMailbox), hipDeviceMallocFinegrained));
+  HIPCHK(c, hipMemset(c->peer_box, 0, sizeof(PeerMailbox)));
+  HIPCHK(c, hipDeviceSynchronize());
+  PeerDesc d;
+  std::memset(&d, 0, sizeof(d));
+  HIPCHK(c, hipIpcGetMemHandle(&d.W, c->W));
+  HIPCHK(c, hipIpcGetMemHandle(&d.V, c->V));
+  HIPCHK(c, hipIpcGetMemHandle(&d.box, c->peer_box));
+  d.pW = (unsigned long long)(uintptr_t)c->W; d.pV = (unsigned long long)(uintptr_t)c->V; d.pbox = (unsigned long long)(uintptr_t)c->peer_box;
+  d.pid = (long long)getpid(); d.dev = c->dev; d.magic = BTF_PEER_MAGIC;
+  d.wbytes = (long long)((size_t)(c->N + 64) * c->K * sizeof(double)); d.vbytes = (long long)((size_t)(c->M + 64) * c->T * c->K * sizeof(double));
+  std::memset(out, 0, (size_t)nbytes);
+  std::memcpy(out, &d, sizeof(d));
+  return BTF_OK;
+}
+
+int btf_peer_init(btf_ctx* c, int rank, int world, const unsigned char* descs, int nbytes) {
+  if (!c) return BTF_EINVAL;
+  if (world < 1 || world > PEER_MAX || rank < 0 || rank >= world) return fail(c, BTF_EINVAL, "need 0 <= rank < world <= 64 (W / V are padded for 64 ranks)");
+  if (!descs || nbytes != world * BTF_PEER_DESC_BYTES) return fail(c, BTF_EINVAL, "descs: world x BTF_PEER_DESC_BYTES bytes, rank-major (what every rank's btf_peer_export gave)");
+  if (!c->peer_box) return fail(c, BTF_ESTATE, "btf_peer_export first (it creates this rank's mailbox)");
+  HIPCHK(c, hipSetDevice(c->dev));
+  PeerTable tab;
+  std::memset(&tab, 0, sizeof(tab));
+  const long long me = (long long)getpid();
+  for (int r = 0; r < world; ++r) {
+    PeerDesc d;
+    std::memcpy(&d, descs + (size_t)r * BTF_PEER_DESC_BYTES, sizeof(d));
+    if (d.magic != BTF_PEER_MAGIC) return fail(c, BTF_EINVAL, "descriptor " + std::to_string(r) + " is not a btf_peer_export result");
+    if (r == rank) {
+      if (d.pid != me || d.pbox != (unsigned long long)(uintptr_t)c->peer_box) return fail(c, BTF_EINVAL, "descriptor " + std::to_string(r) + " is not this context's own export");
+      tab.W[r] = c->W; tab.V[r] = c->V; tab.box[r] = c->peer_box;
+      continue;
+    }
+    if (d.wbytes != (long long)((size_t)(c->N + 64) * c->K * sizeof(double)) || d.vbytes != (long long)((size_t)(c->M + 64) * c->T * c->K * sizeof(double)))
+      return fail(c, BTF_EINVAL, "rank " + std::to_string(r) + "'s W / V buffers have another shape than this rank's");
+    if (d.pid == me) {        // another context of this process: its pointers are ours too
+      if (d.dev != c->dev) {
+        int can = 0;
+        HIPCHK(c, hipDeviceCanAccessPeer(&can, c->dev, d.dev));
+        if (!can) return fail(c, BTF_EHIP, "device " + std::to_string(c->dev) + " cannot map device " + std::to_string(d.dev));
+        const hipError_t e = hipDeviceEnablePeerAccess(d.dev, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(c, BTF_EHIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+      }
+      tab.W[r] = (double*)(uintptr_t)d.pW; tab.V[r] = (double*)(uintptr_t)d.pV; tab.box[r] = (PeerMailbox*)(uintptr_t)d.pbox;
+      continue;
+    }
+    void* p[3] = {nullptr, nullptr, nullptr};
+    const hipIpcMemHandle_t* h[3] = {&d.W, &d.V, &d.box};
+    for (int i = 0; i < 3; ++i) {
+      const hipError_t e = hipIpcOpenMemHandle(&p[i], *h[i], hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess)
+        return fail(c, BTF_EHIP, "hipIpcOpenMemHandle of rank " + std::to_string(r) + "'s buffers: " + hipGetErrorString(e) +
+                                     " (the ranks must be processes of one node whose GPUs can map each other)");
+      c->peer_opened.push_back(p[i]);
+    }
+    tab.W[r] = (double*)p[0]; tab.V[r] = (double*)p[1]; tab.box[r] = (PeerMailbox*)p[2];
+  }
+  int rc;
+  if ((rc = dev_alloc(c, &c->peer_tab, (size_t)1))) return rc;
+  if ((rc = dev_alloc(c, &c->peer_counters, (size_t)PEER_MAX + 1))) return rc;
+  if (!c->comm_words) { if ((rc = dev_alloc(c, &c->comm_words, (size_t)16))) return rc; }
+  HIPCHK(c, hipMemcpy(c->peer_tab, &tab, sizeof(tab), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemset(c->peer_counters, 0, (PEER_MAX + 1) * sizeof(unsigned)));
+  const char* ms = std::getenv("BTF_PEER_TIMEOUT_MS");
+  const long long msv = ms && *ms ? std::atoll(ms) : 20000;
+  c->peer_timeout_ticks = std::max<long long>(1, msv) * 100000;          // wall_clock64 ticks at 100 MHz
+  c->peer_epoch = 0;
+  c->comm_rank = c->gather_rank = rank; c->comm_world = c->gather_world = world; c->comm_rehearse = false;
+  c->peer_on = true;
+  return BTF_OK;
+}
+
 int btf_comm_destroy(btf_ctx* c) {
   if (!c) return BTF_EINVAL;
+  if (c->peer_box || c->peer_on) {
+    (void)hipSetDevice(c->dev);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    for (void* p : c->peer_opened) (void)hipIpcCloseMemHandle(p);
+    c->peer_opened.clear();
+    if (c->peer_box) { (void)hipFree(c->peer_box); c->peer_box = nullptr; }
+    if (c->peer_tab) { (void)hipFree(c->peer_tab); c->peer_tab = nullptr; }
+    if (c->peer_counters) { (void)hipFree(c->peer_counters); c->peer_counters = nullptr; }
+    c->peer_on = false; c->peer_epoch = 0;
+  }
   if (c->comm) {
     std::string why;
     RcclApi* api = rccl_api(&why);
@@ -3826,7 +3954,7 @@ int btf_comm_destroy(btf_ctx* c) {
 
 int btf_comm_info(btf_ctx* c, int32_t* out) {
   if (!c || !out) return BTF_EINVAL;
-  out[0] = c->comm ? 1 : 0; out[1] = c->comm_rank; out[2] = c->comm_world; out[3] = c->gather_rank; out[4] = c->gather_world;
+  out[0] = c->peer_on ? 2 : c->comm ? 1 : 0; out[1] = c->comm_rank; out[2] = c->comm_world; out[3] = c->gather_rank; out[4] = c->gather_world;
   out[5] = c->comm_rehearse ? 1 : 0;
   int v = 0;
   std::string why;
@@ -3855,6 +3983,7 @@ int btf_allreduce_sse(btf_ctx* c) {
   int rc;
   if ((rc = comm_ready(c, &api))) return rc;
   if (!c->hyp) return fail(c, BTF_ESTATE, "no device-resident scalars yet (btf_device_scalars)");
+  if (c->peer_on) return peer_collective(c, 2, 0, 0, c->hyp + HYP_SSE, c->hyp + HYP_SSE, 1, c->stream);
   RCCLCHK(c, api, api->AllReduce(c->hyp + HYP_SSE, c->hyp + HYP_SSE, 1, ncclDouble, ncclSum, c->comm, c->stream));
   return BTF_OK;
 }
@@ -3865,7 +3994,8 @@ int btf_allreduce_sum(btf_ctx* c, double* vals, int n) {
   if ((rc = comm_ready(c, &api))) return rc;
   if (!vals || n < 1 || n > 16) return fail(c, BTF_EINVAL, "1 to 16 doubles");
   HIPCHK(c, hipMemcpyAsync(c->comm_words, vals, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  RCCLCHK(c, api, api->AllReduce(c->comm_words, c->comm_words, (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
+  if (c->peer_on) { if ((rc = peer_collective(c, 2, 0, 0, c->comm_words, c->comm_words, n, c->stream))) return rc; }
+  else RCCLCHK(c, api, api->AllReduce(c->comm_words, c->comm_words, (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
   HIPCHK(c, hipMemcpyAsync(vals, c->comm_words, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return BTF_OK;

@@ -7,6 +7,7 @@
 // it one HIP runtime, per process, the same rule _native.load() follows for libamdhip64) and only then loads the one on
 // the library search path (this library's RUNPATH is the ROCm lib directory).  BTF_RCCL_PATH overrides both.
 #pragma once
+#include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      // types and prototypes only: every call goes through the table below
 #include <dlfcn.h>
 
@@ -78,6 +79,141 @@ inline int comm_block_len(int n, int rank, int world) {
   const int lo = comm_block_lo(n, rank, world);
   const int c = comm_chunk(n, world);
   return (n - lo) < c ? (n - lo) : c;
+}
+
+
+// ---- the peer-window transport -----------------------------------------------------------------------------------------
+// The same collectives without a communication library: every rank maps the W / V buffers and a small mailbox of every
+// other rank (hipIpc handles - the ranks are processes of one node; or raw pointers when two contexts share a process)
+// and ONE kernel per collective pushes this rank's block straight into the peers' buffers over xGMI (a store to a
+// mapped peer address), flags it, and waits for the peers' blocks to land here.  Messages are 20 KB to 2.6 MB and the
+// step around them is 40-110 us, so what counts is latency: one launch and two flag round trips, no ring, no proxy thread.
+// Also the only device-side transport that lets several ranks share ONE GPU (RCCL refuses that), which is how the N > 1
+// path of the C ABI is tested on a one-GPU box (tests/test_gpu_comm.py).
+//
+// Protocol of collective number e (every rank issues the same sequence of collectives, as with RCCL), for each peer r:
+//   1. mailbox(r).arrive[me] = e     - this kernel started, so everything queued before it on my stream - every reader
+//                                      of my W / V - is done: r may overwrite its block in my buffers
+//   2. wait mailbox(me).arrive[r] >= e, then copy my block into r's buffer (and my all-reduce operands into
+//      mailbox(r).red[me]), __threadfence_system(), and the last workgroup of the copy stores mailbox(r).done[me] = e
+//   3. wait mailbox(me).done[r] >= e - r's block is here; the kernel ends, and with it the stream-ordered collective
+// The mailbox is fine-grained device memory (flag loads and stores at system scope reach it past the L2s); W / V are
+// ordinary allocations: the writer's fence writes its L2 back before the flag, the readers are later kernels (the
+// launch boundary invalidates theirs).  Every wait is bounded (BTF_PEER_TIMEOUT_MS, default 20 s): a dead peer turns
+// into status code 3 and BTF_EHIP at the next check, never into a hung GPU (and once the status word is set, every
+// later wait of this context returns at once).
+// One process per rank is the deployment; several contexts of ONE process work too (raw pointers instead of handles)
+// as long as their streams get a hardware queue each - the HIP runtime multiplexes a process's streams over 4
+// (GPU_MAX_HW_QUEUES), and a waiting exchange kernel holds its queue.
+constexpr int PEER_MAX = 64;
+constexpr int PEER_RED = 16;
+constexpr int PEER_THREADS = 256;
+constexpr int PEER_DESC_BYTES = 256;          // BTF_PEER_DESC_BYTES of include/btf.h
+
+struct PeerMailbox {
+  unsigned long long arrive[PEER_MAX];
+  unsigned long long done[PEER_MAX];
+  double red[PEER_MAX][PEER_RED];
+};
+struct PeerDesc {                              // what a rank publishes: btf_peer_export
+  hipIpcMemHandle_t W, V, box;
+  unsigned long long pW, pV, pbox;             // the same three as raw pointers: valid inside the exporting process
+  long long pid;
+  int dev, magic;
+  long long wbytes, vbytes;
+};
+static_assert(sizeof(PeerDesc) <= PEER_DESC_BYTES, "PeerDesc outgrew BTF_PEER_DESC_BYTES");
+struct PeerTable {                             // device resident: where each rank's buffers are mapped HERE
+  double* W[PEER_MAX];
+  double* V[PEER_MAX];
+  PeerMailbox* box[PEER_MAX];
+};
+struct PeerArgs {
+  const PeerTable* tab;
+  int rank, world, which, wpp;                 // which: 0 W, 1 V, 2 no block; wpp: workgroups per peer
+  unsigned long long epoch;
+  size_t off, len;                             // my block, in doubles
+  const double* red_src; double* red_dst; int red_n;
+  unsigned* counters;                          // [PEER_MAX + 1] zero between launches: per-peer copy counts, [PEER_MAX] operands read
+  int* status;
+  long long timeout_ticks;                     // of the 100 MHz wall clock
+};
+
+__device__ inline bool peer_wait(const unsigned long long* p, unsigned long long e, long long ticks, int* status, int who) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
+    __builtin_amdgcn_s_sleep(16);
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;      // already failed: drain
+    if (wall_clock64() - t0 > ticks) {
+      if (atomicCAS(status, 0, 3) == 0) status[1] = who;
+      return false;
+    }
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(PEER_THREADS) void peer_exchange_kernel(PeerArgs a) {
+  const int q = (int)blockIdx.x / a.wpp, part = (int)blockIdx.x % a.wpp, tid = (int)threadIdx.x;
+  const int r = (a.rank + 1 + q) % a.world;                  // ranks start on different peers
+  PeerMailbox* mine = a.tab->box[a.rank];
+  PeerMailbox* theirs = a.tab->box[r];
+  __shared__ int ok;
+  if (tid == 0) {
+    if (part == 0) __hip_atomic_store(&theirs->arrive[a.rank], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    ok = peer_wait(&mine->arrive[r], a.epoch, a.timeout_ticks, a.status, r) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool go = ok != 0;
+  if (go) {
+    if (a.len) {
+      const double* src = (a.which == 0 ? a.tab->W[a.rank] : a.tab->V[a.rank]) + a.off;
+      double* dst = (a.which == 0 ? a.tab->W[r] : a.tab->V[r]) + a.off;
+      const size_t first = (size_t)part * PEER_THREADS + tid, stride = (size_t)a.wpp * PEER_THREADS;
+      if ((a.off & 1) == 0) {                                // 16-byte aligned block: pairs
+        const size_t pairs = a.len / 2;
+        for (size_t i = first; i < pairs; i += stride) reinterpret_cast<double2*>(dst)[i] = reinterpret_cast<const double2*>(src)[i];
+        if ((a.len & 1) && part == 0 && tid == 0) dst[a.len - 1] = src[a.len - 1];
+      } else {
+        for (size_t i = first; i < a.len; i += stride) dst[i] = src[i];
+      }
+    }
+    if (a.red_n && part == 0 && tid < a.red_n)
+      __hip_atomic_store(&theirs->red[a.rank][tid], a.red_src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    if (a.red_n && part == 0) __hip_atomic_fetch_add(&a.counters[PEER_MAX], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned before = __hip_atomic_fetch_add(&a.counters[q], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == (unsigned)a.wpp - 1) {
+      a.counters[q] = 0;
+      if (go) __hip_atomic_store(&theirs->done[a.rank], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    ok = go && peer_wait(&mine->done[r], a.epoch, a.timeout_ticks, a.status, r) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!a.red_n || blockIdx.x != 0) return;
+  // the sum, in rank order on every rank (the same bits everywhere): workgroup 0, once every peer's operands are here and
+  // every workgroup of this launch has read red_src (red_dst may be the same address)
+  __shared__ int all;
+  if (tid == 0) all = 1;
+  __syncthreads();
+  if (tid < a.world && tid != a.rank && !peer_wait(&mine->done[tid], a.epoch, a.timeout_ticks, a.status, tid)) all = 0;
+  if (tid == 0) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(&a.counters[PEER_MAX], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(a.world - 1)) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > a.timeout_ticks) { all = 0; break; }
+    }
+    a.counters[PEER_MAX] = 0;
+  }
+  __syncthreads();
+  if (tid < a.red_n && all) {
+    double s = 0.0;
+    for (int p = 0; p < a.world; ++p)
+      s += p == a.rank ? a.red_src[tid] : __hip_atomic_load(&mine->red[p][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    a.red_dst[tid] = s;
+  }
 }
 
 }  // namespace btf

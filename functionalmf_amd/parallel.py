@@ -94,8 +94,12 @@ class Exchange:
     btf_allgather_W / btf_allgather_V / btf_allreduce_sse of include/btf.h, RCCL calls on the context's communicator,
     buffers and stream (csrc/btf_comm.h).  torch.distributed is then only the channel that carries rank 0's 128-byte
     communicator id to the other ranks (any backend; what MPI_Bcast is to an NCCL program) - a C caller uses its own.
+    transport "peer": the same four calls of the C ABI on the library's peer-window transport (btf_peer_export /
+    btf_peer_init, csrc/btf_comm.h): every rank maps the other ranks' W / V buffers (hipIpc) and one kernel per collective
+    stores this rank's block straight into them.  The process group carries the 256-byte descriptors once.  The default
+    when the ranks of a "gloo" group have a device context each (several ranks on ONE GPU, where RCCL refuses to run).
     transport "host": the exchange staged through host copies over torch.distributed (any backend) - what the CPU tests
-    (gloo) and the tests that put several ranks on ONE GPU use, since RCCL refuses two ranks on one device."""
+    (gloo) use."""
 
     def __init__(self, plan, ctx=None, group=None, overlap=True, rehearse=False, transport=None):
         self.plan, self.ctx, self.group = plan, ctx, group
@@ -128,11 +132,13 @@ class Exchange:
             raise RuntimeError("shard does not match the process group")
         want = transport or os.environ.get("BTF_EXCHANGE_TRANSPORT") or \
             ("rccl" if dist.get_backend(group) == "nccl" else "host")
-        if want not in ("rccl", "host"):
-            raise ValueError("transport must be 'rccl' or 'host'")
+        if want not in ("rccl", "peer", "host"):
+            raise ValueError("transport must be 'rccl', 'peer' or 'host'")
         self.transport = want if ctx is not None else "host"
         if self.transport == "rccl":
             self._init_comm()
+        elif self.transport == "peer":
+            self._init_peer()
 
     # -- device path (RCCL under the C ABI) ----------------------------------------------
     def _init_comm(self):
@@ -153,6 +159,25 @@ class Exchange:
         dist.broadcast(t, src=src, group=self.group)
         ident = (C.c_ubyte * nb)(*t.cpu().tolist())
         self.ctx.call("btf_comm_init", self.plan.rank, self.plan.world, ident, nb)
+
+    def _init_peer(self):
+        """btf_peer_export on every rank -> all-gather of the descriptors over the process group -> btf_peer_init."""
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _native
+        nb, p = _native.PEER_DESC_BYTES, self.plan
+        desc = (C.c_ubyte * nb)()
+        self.ctx.call("btf_peer_export", desc, nb)
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        dev = torch.device("cuda", self.ctx.device) if on_gpu else "cpu"
+        mine = torch.tensor(list(desc), dtype=torch.uint8, device=dev)
+        out = [torch.empty_like(mine) for _ in range(p.world)]
+        dist.all_gather(out, mine, group=self.group)
+        flat = [b for t in out for b in t.cpu().tolist()]
+        descs = (C.c_ubyte * (nb * p.world))(*flat)
+        self.ctx.call("btf_peer_init", p.rank, p.world, descs, nb * p.world)
+        dist.barrier(group=self.group)          # every rank has mapped every mailbox before the first collective
 
     def comm_info(self):
         """{has communicator, rank, world, gather rank, gather world, rehearsal, RCCL version, ncclCommCount} of the
@@ -206,7 +231,7 @@ class Exchange:
 
     def _staged(self):
         """True when the exchange goes through host copies (transport "host")."""
-        return self.transport != "rccl"
+        return self.transport not in ("rccl", "peer")
 
     def _staged_gather(self, getter, setter, shape, block0, blocklen, gather):
         import ctypes as C

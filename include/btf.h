@@ -193,8 +193,23 @@ int btf_comm_join(btf_ctx* ctx, void* comm_stream);
  * all-gather moves the full gathered message (world x chunk doubles) from one scratch buffer to another, so the step
  * pays RCCL's call and the message's bytes but the blocks of the other ranks are never refreshed: not a sampler.
  * btf_comm_info: out[8] = {has communicator, its rank, its size, gather rank, gather world, rehearsal, RCCL version
- * code, ncclCommCount}.                                                                                              */
+ * code, ncclCommCount}; out[0] is 2 for the peer-window transport below.
+ *
+ * The peer-window transport (csrc/btf_comm.h) runs the same four collectives without RCCL: every rank maps the W / V
+ * buffers and a mailbox of every other rank (hipIpc handles: processes of one node whose GPUs can map each other) and one
+ * kernel per collective stores this rank's block straight into the peers' buffers, flags it and waits for theirs - one
+ * launch, two flag round trips.  It is also the only device-side transport for several ranks on ONE GPU.
+ *   every rank:  btf_peer_export(ctx, desc, BTF_PEER_DESC_BYTES)
+ *   the caller:  all-gathers the descriptors over its channel (MPI_Allgather, torch.distributed)
+ *   every rank:  btf_peer_init(ctx, rank, world, descs, world * BTF_PEER_DESC_BYTES)       (descs rank-major)
+ * after which btf_allgather_W / _V, btf_allreduce_sse and btf_allreduce_sum use it (btf_comm_info out[0] == 2), under
+ * the rule of every collective library: all ranks issue the same sequence of collectives.  Sums are taken in rank order
+ * on every rank (identical bits everywhere).  A peer that never arrives turns, after BTF_PEER_TIMEOUT_MS (default
+ * 20000), into BTF_EHIP at the next step's status check - not into a hung GPU.  btf_comm_destroy tears it down.          */
 #define BTF_COMM_ID_BYTES 128
+#define BTF_PEER_DESC_BYTES 256
+int btf_peer_export(btf_ctx* ctx, unsigned char* desc, int nbytes);
+int btf_peer_init(btf_ctx* ctx, int rank, int world, const unsigned char* descs, int nbytes);
 int btf_comm_unique_id(unsigned char* id, int nbytes);
 int btf_comm_block(int n, int rank, int world, int32_t* lo, int32_t* len);
 int btf_comm_init(btf_ctx* ctx, int rank, int world, const unsigned char* id, int nbytes);

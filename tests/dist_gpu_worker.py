@@ -14,6 +14,7 @@ import numpy as np
 import torch.distributed as dist
 
 OVERLAP = os.environ.get("BTF_DIST_OVERLAP", "0") == "1"      # base section: all-gathers on the communication stream
+TRANSPORT = os.environ.get("BTF_EXCHANGE_TRANSPORT") or ("rccl" if os.environ.get("BTF_DIST_BACKEND", "gloo") == "nccl" else "host")
 # BTF_DIST_GPU_PER_RANK=1 (test_rccl_ranks_on_their_own_gpus: a box with >= 2 GPUs): rank r runs on cuda:LOCAL_RANK and the
 # collectives are real RCCL traffic between devices; otherwise every rank shares cuda:0
 DEV = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("BTF_DIST_GPU_PER_RANK", "0") == "1" else 0
@@ -213,7 +214,7 @@ def main():
     if "reference" in sections and world > 1:
         reference_section(rank, world)
     if "base" not in sections:
-        print("SHARD_GPU_OK rank", rank, flush=True)
+        print("SHARD_GPU_OK rank", rank, "exchange", TRANSPORT, flush=True)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -225,11 +226,15 @@ def main():
             N, M, T, nembeds=K, tf_order=tf, sigma2_init=st["sigma2"], lam2_init=st["lam2"], nu2_init=st["nu2"],
             W_init=st["W"], V_init=st["V"], Tau2_init=st["Tau2"], compat="exact", shard=(rank, world), device=DEV, overlap_exchange=OVERLAP)
         assert model._exchange.active and model._plan.world == world
-        # "nccl" process group: the exchange is the context's own RCCL communicator (C ABI); gloo: staged through the host
-        assert model._exchange.transport == ("rccl" if backend == "nccl" else "host"), model._exchange.transport
-        if backend == "nccl":
+        # "nccl" process group: the exchange is the context's own RCCL communicator (C ABI); gloo: staged through the host;
+        # BTF_EXCHANGE_TRANSPORT=peer: the library's peer-window transport (the ranks map each other's W / V: hipIpc)
+        assert model._exchange.transport == TRANSPORT, model._exchange.transport
+        if TRANSPORT == "rccl":
             info = model._exchange.comm_info()
             assert info["active"] == 1 and info["rank"] == rank and info["world"] == world and info["comm_count"] == world, info
+        elif TRANSPORT == "peer":
+            info = model._exchange.comm_info()
+            assert info["active"] == 2 and info["rank"] == rank and info["world"] == world and info["gather_world"] == world, info
         Delta = orc.trend_penalty(T, tf)
         ost = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in st.items()}
         for it in range(2):
@@ -324,7 +329,7 @@ def main():
         assert np.abs(a[3] - b[3]).max() / np.abs(b[3]).max() < 1e-9, ("omega", rdims)
         assert np.abs(a[0] - b[0]).max() / np.abs(b[0]).max() < 1e-7 and np.abs(a[1] - b[1]).max() / np.abs(b[1]).max() < 1e-5, rdims
     print("SHARD_GPU_OK rank", rank, "backend", dist.get_backend(), "world", dist.get_world_size(), "device", DEV,
-          "exchange", "ctx-owned RCCL communicator" if backend == "nccl" else "host-staged", flush=True)
+          "exchange", {"rccl": "ctx-owned RCCL communicator", "peer": "peer windows", "host": "host-staged"}[TRANSPORT], flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

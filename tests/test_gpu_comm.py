@@ -234,3 +234,113 @@ def test_device_likelihood_entry_points_reject_the_host_family():
     ll = C.c_double(1.0)
     assert lib.btf_ess_eval(h, 0, 0.3, 0, host, C.byref(ll)) == 0 and ll.value == 0.0
     ctx.close()
+
+
+def _peer_group(ctxs):
+    """btf_peer_export on every context, the descriptors side by side, btf_peer_init on every context: what MPI_Allgather
+    (or Exchange._init_peer) does between processes, here between the contexts of one."""
+    from functionalmf_amd import _native
+    nb, world = _native.PEER_DESC_BYTES, len(ctxs)
+    descs = (C.c_ubyte * (nb * world))()
+    for r, ctx in enumerate(ctxs):
+        one = (C.c_ubyte * nb)()
+        ctx.call("btf_peer_export", one, nb)
+        descs[r * nb:(r + 1) * nb] = list(one)
+    for r, ctx in enumerate(ctxs):
+        ctx.call("btf_peer_init", r, world, descs, nb * world)
+        assert _info(ctx)[:6] == [2, r, world, r, world, 0]
+
+
+@pytest.mark.parametrize("world,split", [(2, 0), (3, 0)])
+def test_peer_windows_run_the_sharded_chain_between_contexts(world, split):
+    """The peer-window transport (btf_peer_export / btf_peer_init): `world` contexts - here in one process, each on its own
+    stream, mapped into each other by raw pointers - hold the slabs of ranks 0 .. world-1 and run the sharded step with the
+    library's own collectives: after every half-sweep each rank's exchange kernel stores its block into the other ranks'
+    W / V and waits for theirs; the nu2 draw sums the per-rank residuals through the mailboxes.  Every rank must end
+    with the same replicated W, V and scalars, and they must be the unsharded chain's (same device seeds; the only
+    difference is the order of the residual sum).  (Few streams at a time: the runtime gives a process 4 hardware
+    queues, and a waiting exchange kernel holds its own - btf_comm.h; the process-per-rank form of this test, with the
+    gathers on the communication streams too, is test_peer_windows_between_processes_on_one_gpu.)"""
+    from functionalmf_amd import _native
+    g = load_golden("g2_c2_complete.npz")
+    st = state_from(g, "s0_")
+    ref, dims = _gaussian_ctx(g, st, dev_scalars=True)
+    N, M, T, R, K, tf = dims
+
+    def state(ctx):
+        W, V, sc = np.empty((N, K)), np.empty((M, T, K)), np.zeros(6)
+        ctx.call("btf_get_W", _native.dptr(W))
+        ctx.call("btf_get_V", _native.dptr(V))
+        ctx.call("btf_get_scalars", _native.dptr(sc))
+        ctx.call("btf_sync")
+        return W, V, sc[:4].copy()
+
+    for it in range(4):
+        seed = 300 + 10 * it
+        ref.call("btf_draw_scalars", seed, 1, 0.1, 0.1, 0.1, 0.1)
+        ref.call("btf_resample_W", None, seed + 1, _native.COMPAT["exact"])
+        ref.call("btf_resample_V", None, seed + 2, _native.COMPAT["exact"], 1e-6, 4)
+    W0, V0, s0 = state(ref)
+    ref.close()
+    assert np.all(np.isfinite(W0)) and np.all(np.isfinite(V0))
+    ctxs = [_gaussian_ctx(g, st, shard=(r, world), dev_scalars=True)[0] for r in range(world)]
+    _peer_group(ctxs)
+    Y = np.asarray(g["Y"]).reshape(N, M, T, R)
+    for ctx in ctxs:
+        ctx.call("btf_set_option", _native.OPT_SPLIT_ACCUM, split)
+        ctx.call("btf_set_global_nobs", float(np.isfinite(Y).sum()))      # the nu2 draw's count is over all ranks
+    for it in range(4):
+        seed = 300 + 10 * it
+        for ctx in ctxs:
+            ctx.call("btf_draw_scalars", seed, 1 | 8, 0.1, 0.1, 0.1, 0.1)
+        for ctx in ctxs:
+            ctx.call("btf_allreduce_sse")
+        for ctx in ctxs:
+            ctx.call("btf_draw_scalars", seed, 1 | 16, 0.1, 0.1, 0.1, 0.1)
+        for ctx in ctxs:
+            ctx.call("btf_resample_W", None, seed + 1, _native.COMPAT["exact"])
+        for ctx in ctxs:
+            ctx.call("btf_allgather_W")
+        for ctx in ctxs:
+            ctx.call("btf_resample_V", None, seed + 2, _native.COMPAT["exact"], 1e-6, 4)
+        for ctx in ctxs:
+            ctx.call("btf_allgather_V")
+
+    got = [state(ctx) for ctx in ctxs]
+    for W, V, sc in got[1:]:
+        assert np.array_equal(W, got[0][0]) and np.array_equal(V, got[0][1]) and np.array_equal(sc, got[0][2])     # replicas agree bit for bit
+    assert relerr(got[0][0], W0) < 1e-9 and relerr(got[0][1], V0) < 1e-9 and np.allclose(got[0][2], s0, rtol=1e-9)
+    vals = [np.array([1.0 + r, -2.0 * r, 0.5]) for r in range(world)]
+    # btf_allreduce_sum synchronises: every rank's call must be on its way before the first one waits -> threads
+    import threading
+    th = [threading.Thread(target=lambda c=c, v=v: c.call("btf_allreduce_sum", _native.dptr(v), 3)) for c, v in zip(ctxs, vals)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    want = [sum(1.0 + r for r in range(world)), sum(-2.0 * r for r in range(world)), 0.5 * world]
+    for v in vals:
+        assert v.tolist() == want
+    for ctx in ctxs:
+        ctx.call("btf_comm_destroy")
+        assert _info(ctx)[0] == 0
+        ctx.close()
+
+
+def test_peer_exchange_with_a_missing_rank_times_out_instead_of_hanging(monkeypatch):
+    """A rank whose peer never issues the collective: the exchange kernel gives up after BTF_PEER_TIMEOUT_MS and the
+    next status check reports BTF_EHIP naming the rank - the GPU is not left spinning."""
+    from functionalmf_amd import _native
+    monkeypatch.setenv("BTF_PEER_TIMEOUT_MS", "200")
+    g = load_golden("g2_c2_complete.npz")
+    st = state_from(g, "s0_")
+    ctxs = [_gaussian_ctx(g, st, shard=(r, 2))[0] for r in range(2)]
+    _peer_group(ctxs)
+    ctxs[0].call("btf_resample_W", None, 5, _native.COMPAT["exact"])
+    ctxs[0].call("btf_allgather_W")                      # rank 1 never comes
+    with pytest.raises(_native.BTFError) as e:
+        ctxs[0].call("btf_resample_V", None, 6, _native.COMPAT["exact"], 1e-6, 4)
+        ctxs[0].call("btf_sync")
+    assert "rank 1" in str(e.value) and "timed out" in str(e.value)
+    for ctx in ctxs:
+        ctx.close()

@@ -754,6 +754,30 @@ def test_sharded_reference_compat_reads_its_stale_weights_from_the_halo(world):
     assert out.stdout.count("SHARD_GPU_OK") == world, out.stdout[-2000:]
 
 
+@pytest.mark.timeout(500)
+@pytest.mark.parametrize("world,sections,overlap", [(2, "base", "0"), (3, "base,split,reference", "1")])
+def test_peer_windows_between_processes_on_one_gpu(world, sections, overlap):
+    """The N > 1 device exchange of the C ABI on hardware: `world` processes on cuda:0 (RCCL refuses that; gloo only
+    carries the descriptors) with BTF_EXCHANGE_TRANSPORT=peer - btf_peer_export / btf_peer_init map every rank's W / V
+    and mailbox into every other rank (hipIpc), and btf_allgather_W / _V / btf_allreduce_sse / _sum are one kernel each
+    that stores this rank's block into the peers' buffers and waits for theirs (csrc/btf_comm.h).  The whole worker:
+    host-RNG half-sweeps against the oracle, rng="device" chains (Gaussian complete / held-out, Binomial,
+    Negative-Binomial) against the unsharded chains, the split accumulation with the gathers on the communication stream,
+    compat="reference" with halo sources."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, BTF_EXCHANGE_TRANSPORT="peer", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               BTF_DIST_SECTION=sections, BTF_DIST_OVERLAP=overlap)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+           "--master-addr", "127.0.0.1", "--master-port", "29591", os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=460)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("SHARD_GPU_OK") == world, out.stdout[-2000:]
+    assert out.stdout.count("peer windows") == world, out.stdout[-2000:]
+
+
 @pytest.mark.timeout(400)
 def test_rccl_exchange_with_one_rank_reproduces_the_plain_chain():
     """The DEVICE collective path of sharded runs (btf_allgather_W / btf_allgather_V on the context's own W / V
