@@ -3741,7 +3741,9 @@ int peer_collective(btf_ctx* c, int which, size_t off, size_t len, const double*
   }
   PeerArgs a{};
   a.tab = c->peer_tab; a.rank = c->gather_rank; a.world = c->gather_world; a.which = which;
-  a.wpp = len ? (int)std::min<size_t>(16, std::max<size_t>(1, (len * sizeof(double) + 65535) / 65536)) : 1;      // 64 KB a workgroup
+  static const int wpp_cap = [] { const char* e = std::getenv("BTF_PEER_WPP"); const int v = e && *e ? std::atoi(e) : 64; return std::min(64, std::max(1, v)); }();
+  static const int wg_bytes = [] { const char* e = std::getenv("BTF_PEER_WG_BYTES"); const int v = e && *e ? std::atoi(e) : 16384; return std::max(4096, v); }();
+  a.wpp = len ? (int)std::min<size_t>((size_t)wpp_cap, std::max<size_t>(1, (len * sizeof(double) + wg_bytes - 1) / wg_bytes)) : 1;
   a.epoch = ++c->peer_epoch; a.off = off; a.len = len;
   a.red_src = red_src; a.red_dst = red_dst; a.red_n = red_n;
   a.counters = c->peer_counters; a.status = c->status; a.timeout_ticks = c->peer_timeout_ticks;

@@ -95,11 +95,11 @@ inline int comm_block_len(int n, int rank, int world) {
 //   1. mailbox(r).arrive[me] = e     - this kernel started, so everything queued before it on my stream - every reader
 //                                      of my W / V - is done: r may overwrite its block in my buffers
 //   2. wait mailbox(me).arrive[r] >= e, then copy my block into r's buffer (and my all-reduce operands into
-//      mailbox(r).red[me]), __threadfence_system(), and the last workgroup of the copy stores mailbox(r).done[me] = e
+//      mailbox(r).red[me]), write-through stores, drained (s_waitcnt vmcnt(0)), and the last workgroup of the copy stores mailbox(r).done[me] = e
 //   3. wait mailbox(me).done[r] >= e - r's block is here; the kernel ends, and with it the stream-ordered collective
 // The mailbox is fine-grained device memory (flag loads and stores at system scope reach it past the L2s); W / V are
-// ordinary allocations: the writer's fence writes its L2 back before the flag, the readers are later kernels (the
-// launch boundary invalidates theirs).  Every wait is bounded (BTF_PEER_TIMEOUT_MS, default 20 s): a dead peer turns
+// ordinary allocations: the writer stores them write-through and drains before the flag, the readers are later kernels
+// (the launch boundary invalidates their caches).  Every wait is bounded (BTF_PEER_TIMEOUT_MS, default 20 s): a dead peer turns
 // into status code 3 and BTF_EHIP at the next check, never into a hung GPU (and once the status word is set, every
 // later wait of this context returns at once).
 // One process per rank is the deployment; several contexts of ONE process work too (raw pointers instead of handles)
@@ -139,10 +139,24 @@ struct PeerArgs {
   long long timeout_ticks;                     // of the 100 MHz wall clock
 };
 
+// Flags and payload are system-scope (sc0 sc1) accesses: stores are written through to the memory they target - a peer
+// GPU's HBM over xGMI, or this GPU's - and acknowledged when they are there, so "s_waitcnt vmcnt(0)" is the whole release
+// (no L2 write-back per workgroup: 8-byte stores, like the in-launch hand-offs of btf_fused.h); polls bypass the caches.
+typedef __attribute__((address_space(1))) unsigned long long peer_u64;
+__device__ __forceinline__ void peer_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store((peer_u64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void peer_store(double* p, double v) { peer_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v)); }
+__device__ __forceinline__ unsigned long long peer_load(const unsigned long long* p) {
+  return __hip_atomic_load((const peer_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double peer_load(const double* p) { return __longlong_as_double((long long)peer_load(reinterpret_cast<const unsigned long long*>(p))); }
+__device__ __forceinline__ void peer_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ inline bool peer_wait(const unsigned long long* p, unsigned long long e, long long ticks, int* status, int who) {
   const long long t0 = wall_clock64();
-  while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
-    __builtin_amdgcn_s_sleep(16);
+  while (peer_load(p) < e) {
+    __builtin_amdgcn_s_sleep(2);
     if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;      // already failed: drain
     if (wall_clock64() - t0 > ticks) {
       if (atomicCAS(status, 0, 3) == 0) status[1] = who;
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_exchange_kernel(PeerArgs a)
   PeerMailbox* theirs = a.tab->box[r];
   __shared__ int ok;
   if (tid == 0) {
-    if (part == 0) __hip_atomic_store(&theirs->arrive[a.rank], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (part == 0) peer_store(&theirs->arrive[a.rank], a.epoch);      // (everything this stream queued earlier is done: kernel boundary)
     ok = peer_wait(&mine->arrive[r], a.epoch, a.timeout_ticks, a.status, r) ? 1 : 0;
   }
   __syncthreads();
@@ -169,25 +183,26 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_exchange_kernel(PeerArgs a)
       const double* src = (a.which == 0 ? a.tab->W[a.rank] : a.tab->V[a.rank]) + a.off;
       double* dst = (a.which == 0 ? a.tab->W[r] : a.tab->V[r]) + a.off;
       const size_t first = (size_t)part * PEER_THREADS + tid, stride = (size_t)a.wpp * PEER_THREADS;
-      if ((a.off & 1) == 0) {                                // 16-byte aligned block: pairs
-        const size_t pairs = a.len / 2;
-        for (size_t i = first; i < pairs; i += stride) reinterpret_cast<double2*>(dst)[i] = reinterpret_cast<const double2*>(src)[i];
-        if ((a.len & 1) && part == 0 && tid == 0) dst[a.len - 1] = src[a.len - 1];
-      } else {
-        for (size_t i = first; i < a.len; i += stride) dst[i] = src[i];
+      size_t i = first;
+      for (; i + 7 * stride < a.len; i += 8 * stride) {      // eight loads in flight a thread
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) peer_store(dst + i + u * stride, v[u]);
       }
+      for (; i < a.len; i += stride) peer_store(dst + i, src[i]);
     }
-    if (a.red_n && part == 0 && tid < a.red_n)
-      __hip_atomic_store(&theirs->red[a.rank][tid], a.red_src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.red_n && part == 0 && tid < a.red_n) peer_store(&theirs->red[a.rank][tid], a.red_src[tid]);
   }
-  __threadfence_system();
+  peer_drain();
   __syncthreads();
   if (tid == 0) {
-    if (a.red_n && part == 0) __hip_atomic_fetch_add(&a.counters[PEER_MAX], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned before = __hip_atomic_fetch_add(&a.counters[q], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (before == (unsigned)a.wpp - 1) {
-      a.counters[q] = 0;
-      if (go) __hip_atomic_store(&theirs->done[a.rank], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.red_n && part == 0) __hip_atomic_fetch_add(&a.counters[PEER_MAX], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned before = __hip_atomic_fetch_add(&a.counters[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == (unsigned)a.wpp - 1) {                     // every workgroup of this peer has drained its stores
+      __hip_atomic_store(&a.counters[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (go) peer_store(&theirs->done[a.rank], a.epoch);
     }
     ok = go && peer_wait(&mine->done[r], a.epoch, a.timeout_ticks, a.status, r) ? 1 : 0;
   }
@@ -201,17 +216,16 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_exchange_kernel(PeerArgs a)
   if (tid < a.world && tid != a.rank && !peer_wait(&mine->done[tid], a.epoch, a.timeout_ticks, a.status, tid)) all = 0;
   if (tid == 0) {
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(&a.counters[PEER_MAX], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(a.world - 1)) {
-      __builtin_amdgcn_s_sleep(4);
+    while (__hip_atomic_load(&a.counters[PEER_MAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(a.world - 1)) {
+      __builtin_amdgcn_s_sleep(2);
       if (wall_clock64() - t0 > a.timeout_ticks) { all = 0; break; }
     }
-    a.counters[PEER_MAX] = 0;
+    __hip_atomic_store(&a.counters[PEER_MAX], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (tid < a.red_n && all) {
     double s = 0.0;
-    for (int p = 0; p < a.world; ++p)
-      s += p == a.rank ? a.red_src[tid] : __hip_atomic_load(&mine->red[p][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int p = 0; p < a.world; ++p) s += p == a.rank ? a.red_src[tid] : peer_load(&mine->red[p][tid]);
     a.red_dst[tid] = s;
   }
 }
