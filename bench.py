@@ -790,8 +790,12 @@ def pmc_traffic(config, variant, suffix=""):
         # (the instances of THIS variant's likelihood form: the default run's short C4 leg leaves Binomial accumulation
         #  launches in a complete-data profile)
         unweighted = variant in ("complete", "heldout", "curves5")
-        vals = [v["hbm_bytes_per_launch_corrected"] for k, v in d.items()
+        vals = [(k, v["hbm_bytes_per_launch_corrected"]) for k, v in d.items()
                 if (mode := _plain_accum(k)) is not None and ((mode == "0") == unweighted)]
+        # (the timed W+V steps launch the FUSE_LEAN instance "..., 4>"; the full instance "..., 0>" beside it in the same
+        #  profile is the burn-in sweeps' launch, whose side tasks read the Tau2 chain as well)
+        lean = [x for x in vals if x[0].split("(")[0].rstrip().endswith(", 4>")]
+        vals = [x[1] for x in (lean or vals)]
         return (round(max(vals), 1), os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2 x FETCH + WRITE)") if vals else None
     except Exception:
         return None
@@ -816,12 +820,13 @@ def valu_insts(config, variant, kernel):
 
 def _plain_accum(name):
     """Is this kernel name a plain accumulation launch - accum_kernel<K, MODE, WAVES, TX, TC, UNR, OPL, FUSE> with FUSE == 0
-    (FUSE 1 / 2: the launch carries the W solves / the spectral sampler as its tail, csrc/btf_fused.h - its duration is
-    not the stream's)?  Returns the likelihood MODE as a string, or None."""
+    or 4 (FUSE_LEAN: the same stream compiled without the gamma-drawing side tasks; FUSE 1 / 2 / 3: the launch carries the W
+    solves / the spectral sampler as its tail, csrc/btf_fused.h - its duration is not the stream's)?  Returns the
+    likelihood MODE as a string, or None."""
     import re
     m = re.search(r"accum_kernel<\d+, (\d+), \d+, [^,]+, [^,]+, \d+, \d+, (\d+)>", name)
     if m:
-        return m.group(1) if m.group(2) == "0" else None
+        return m.group(1) if m.group(2) in ("0", "4") else None
     m = re.search(r"accum_kernel<\d+, (\d+), \d+, [^,]+, [^,]+, \d+, \d+>", name)      # (profiles of rounds 2-3: no FUSE argument)
     return m.group(1) if m else None
 
