@@ -475,7 +475,9 @@ def main():
         "config": {"workload": "%s_btf %s (%d,%d,%d,%d) nembeds=%d tf_order=2 %s data, W+V update, rng=device%s"
                                % ({"binomial": "binomial", "negbinom": "negbinom"}.get(args.variant, "gaussian"), args.config, N, M, T,
                                   {"binomial": 1}.get(args.variant, R), K, args.variant + (" (4 trials per cell)" if args.variant == "binomial" else ""),
-                                  "; %d-way row/column shards, RCCL all-gather of W and V" % world if world > 1 else ""),
+                                  "; %d-way row/column shards, %s all-gather of W and V" % (
+                                      world, {"rccl": "RCCL", "peer": "peer-window", "host": "host-staged"}.get(model._exchange.transport, "?"))
+                                  if world > 1 else ""),
                    "global_sweeps_per_s": round(sweeps_per_s, 2), "units_per_sweep": units,
                    "median_ms_per_step": round(float(np.median(per_step_ms)), 4), "median_over_steps": int(nmed),
                    "burn_in_sweeps": args.burn,
@@ -547,7 +549,7 @@ def main():
         # torch.distributed carried the communicator id, the barrier and the max over ranks of the clock
         out["config"].update({"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
                               "exchange_transport": model._exchange.transport,
-                              "communicator": model._exchange.comm_info() if model._exchange.transport == "rccl" else None,
+                              "communicator": model._exchange.comm_info() if model._exchange.transport in ("rccl", "peer") else None,
                               "collective_us": coll})
     if as_rank:
         # What ONE rank of a P-GPU run does per step, measured on one GPU: its kernels on its real slabs and the RCCL call
