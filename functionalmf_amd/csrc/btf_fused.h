@@ -899,7 +899,7 @@ __host__ __device__ inline DfLayout df_layout(int T, int K, int S) {
   D.size = (o + 3) & ~3;                                     // (32-byte granules: the quads stay aligned)
   return D;
 }
-// the workers' arrays, per column, overlaid on the partial sums
+// the workers' arrays, per column, behind the streaming waves' partial sums
 struct DfWork { int mraw, mt, rz, head, gs, stride; };
 __host__ __device__ inline DfWork df_work(int T, int K, int S) {
   DfWork W;
@@ -920,10 +920,10 @@ __host__ __device__ inline bool vf_df_fits(int T, int K, int TF, int nD, int wav
   if (!(ng > 0 && ng * VF_GROUP_WAVES <= waves && K <= rg && K + K * K <= 96 && TF == 2)) return false;
   if (waves != 16) return false;
   if (2 * df_layout(T, K, TF + 1).PB > 2 * 8 * WAVE) return false;      // the band image: eight double2 per lane of the copying wave
-  const int nwt = (ng == 1 ? 12 : (ng == 2 ? 4 : 3)) * WAVE; // worker threads per column (v_fused_df): two elements each at most
-  if (T * K > 2 * nwt || T * K > 768) return false;
+  const int nwt = ((waves - ng) / ng) * WAVE;                 // worker threads per column (v_fused_df: every streaming wave): one element each
+  if (T * K > nwt || T * K > 768) return false;
   const int room = vf_red_doubles(false) - VF_MAILBOX - ng * df_layout(T, K, TF + 1).size;
-  return waves * rg * ACC_TILE <= room && ng * df_work(T, K, TF + 1).stride <= room;
+  return (waves - ng) * K * ACC_TILE + ng * df_work(T, K, TF + 1).stride <= room;      // partial sums [w][k][128], the working arrays behind them
 }
 template <> __device__ __forceinline__ int fuse_chain_waves<FUSE_VDF>(const FuseV& fz) { return ACC_TILE / fz.a.T; }
 template <> __device__ __forceinline__ const unsigned long long* fuse_eig_gran<FUSE_VDF>(const FuseV& fz) { return fz.eig_gran; }
@@ -1021,14 +1021,13 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
   const int cg = pw & (NG - 1), vw = pw >> lgNG;
   const int j = tile * NG + cg, jg = a.col0 + j;
   const bool live = j < a.ml;                              // (wave-uniform; a ragged last tile has dead column groups)
-  // The workers of a column are the waves on the SIMDs NO chain wave runs on (wave p sits on SIMD p % 4; the chain waves
-  // are p = 0 .. NG-1): every instruction a neighbour on its SIMD issues is one the chain wave waits for.  (T = 32: chain
-  // waves on all four SIMDs - every other wave works.)  The remaining waves write their partial sums and sleep until
-  // the final stage needs them, or leave.
-  const bool heavy = pw >= NG && (NG == 4 || (pw & 3) >= NG);
-  const int NWK = NG == 1 ? 12 : (NG == 2 ? 4 : 3), NWT = NWK * WAVE;      // workers per column, their threads
-  const int wk = NG == 1 ? (pw >> 2) * 3 + (pw & 3) - 1 : (NG == 2 ? (pw >> 2) : (pw >> 2) - 1);
-  const int first_worker = NG == 4 ? 4 : NG;              // it fetches the eigen-system for everybody
+  // The chain wave of a column (p < NG) does not stream (accum_kernel): it draws the column's normals, waits for the
+  // eigenvalues and factors while the other 16 - NG waves stream.  Those are all workers of the sums afterwards: wave p
+  // works for column p % NG, one element of the column per thread.
+  const int NSW = WAVES - NG;                              // streaming waves: their partial sums, [w][k][128] from the bottom of the LDS
+  const int NWK = NSW >> lgNG, NWT = NWK * WAVE;           // workers per column (15 / 7 / 3), their threads
+  const int wk = vw - 1;                                   // worker index of a non-chain wave: p = NG + wk NG + cg
+  const int first_worker = NG;                             // it fetches the eigen-system for everybody
   const DfLayout D = df_layout(T, K, S);
   const DfWork Wk = df_work(T, K, S);
   double* mailbox = lds + vf_red_doubles(false) - VF_MAILBOX;
@@ -1040,22 +1039,15 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
   double* Q = top + D.Q;                                   // [k][pivot][l1 l2 l3 | 1/D -> w -> x]
   double* win = top + D.win;
   double* flag = top + D.flag;
-  double* base = lds + (size_t)cg * Wk.stride;
+  double* base = lds + (size_t)NSW * K * ACC_TILE + (size_t)cg * Wk.stride;      // the columns' working arrays: BEHIND the partial sums
   double* mraw = base + Wk.mraw;
   double* mt = base + Wk.mt;
   double* rz = base + Wk.rz;
   double* head = base + Wk.head;
   const double* gsh = mailbox;                             // eigenvalues, eigenvectors of W'W as published
   const double* Ush = mailbox + K;
-
-  // ---- every wave, the moment its stream ends: its partial sums, then one count ----
-#pragma unroll
-  for (int v = 0; v < K; ++v)
-    *reinterpret_cast<double2*>(&lds[((size_t)pw * RG + v) * ACC_TILE + 2 * lane]) = make_double2(acc[v][0], acc[v][1]);
-  df_signal(cw + DFC_PART);
   if (a.hyp && a.hyp_noise) {
-    // (the chain waves fetched nu2 with their last rows - when their stream was long enough to have such a point)
-    const double nu2 = (vw == 0 && early.nu2 > 0.0) ? early.nu2 : a.hyp[HYP_NU2];
+    const double nu2 = a.hyp[HYP_NU2];
     a.s = 1.0 / nu2; a.sR = a.s * a.Rrep;
   }
 
@@ -1066,10 +1058,20 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
     const bool chain = lane < nchain;
     const int side = lane >= K ? 1 : 0;
     const int k = chain ? lane - side * K : 0;
+    // the column's normals, raw, beside the places of the right-hand sides (one Philox block, one logarithm, one sincos
+    // per PAIR z[2m], z[2m+1]: philox_normal_pair, the bits of two philox_normal calls; n is even or the last odd element
+    // has a partner inside the column's record): the side workgroup needs ~7 us for the eigenvalues anyway
+    for (int i0 = 2 * lane; i0 < n; i0 += 2 * WAVE) {
+      double z0, z1;
+      if (a.z) { const double2 zz = *reinterpret_cast<const double2*>(a.z + (size_t)jg * n + i0); z0 = zz.x; z1 = zz.y; }
+      else philox_normal_pair(a.seed, a.stream, ((unsigned long long)jg * n + i0) >> 1, z0, z1);
+      rz[(size_t)i0 * 2 + 1] = z0;
+      if (i0 + 1 < n) rz[(size_t)(i0 + 1) * 2 + 1] = z1;
+    }
     // the eigenvalue of the lane's system straight from the side workgroup's tagged granules {half of g_k, epoch}: value and
-    // "it is this launch's" in ONE round trip, by this wave itself (it must not wait for a wave that is still streaming)
-    unsigned long long ghi = early.ghi, glo = early.glo;     // (fetched behind the last rows' loads: usually this launch's already)
-    bool okw = __all((unsigned)ghi == fv.epoch && (unsigned)glo == fv.epoch) != 0;
+    // "it is this launch's" in ONE round trip
+    unsigned long long ghi = 0ULL, glo = 0ULL;
+    bool okw = false;
     for (unsigned spins = 0; !okw && spins < (1u << 20); ++spins) {
       ghi = __hip_atomic_load(fv.eig_gran + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       glo = __hip_atomic_load(fv.eig_gran + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1179,12 +1181,16 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
       a.tries[j] = tried;
       if (!ok && okw && atomicCAS(&a.status[0], 0, 1) == 0) a.status[1] = jg;
     }
-    df_signal(cgw + DFG_FAC);                              // the reciprocals are there: the workers scale the normals
     TAIL_STAMP(stamps, 4);
+    // z sqrt(1 / D), all lanes (pivot order: z[j][k T + i] multiplies pivot i of system k): still under the others' stream
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int idx = lane; idx < n; idx += WAVE) rz[(size_t)idx * 2 + 1] = rz[(size_t)idx * 2 + 1] * sqrt(Q[(size_t)idx * 4 + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     // ---- the right-hand sides meet the factors: forward substitution with w folded in, separator, back-substitution ----
     df_wait(cgw + DFG_ROT, (unsigned)NWK, cw + DFC_BAD);
-    df_wait(cgw + DFG_ZS, (unsigned)NWK, cw + DFC_BAD);
-    TAIL_STAMP(stamps, 5);                                 // (the workers' right-hand sides and scaled normals are in)
+    TAIL_STAMP(stamps, 5);                                 // (the workers' right-hand sides are in)
     if (ok) {
       double r[S + 1];
       if (chain) {
@@ -1266,117 +1272,57 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
     df_signal(cgw + DFG_X);
     TAIL_STAMP(stamps, 6);
   } else {
-    // =========================== the other waves ===========================
-    if (!heavy) {
-      // not a worker of the sums: these waves (on the chain waves' SIMDs) draw the column's normals - pure arithmetic, one
-      // Philox block, one logarithm, one sincos per PAIR z[2m], z[2m+1] (philox_normal_pair: the bits of two philox_normal
-      // calls; j n is even) - in the time the slower waves still stream, stage them beside the right-hand sides once the
-      // partial sums have been read, and sleep until the final stage needs them (long sleeps: the SIMD is the chain wave's)
-      if (!live) return;
-      const int lw = NG == 1 ? (pw >> 2) - 1 : (pw >> 2) - 1;    // NG = 1: waves 4, 8, 12; NG = 2: waves 4 + cg, 8 + cg, 12 + cg
-      double zp[2][2] = {{0.0, 0.0}, {0.0, 0.0}};               // (two pairs per lane at most: T K <= 768)
+    // =========================== the other waves: stream ended ===========================
+    // the wave's partial sums of the tile's 128 outputs (both lanes' pairs), then one count
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int i0 = 2 * ((lw + 3 * m) * WAVE + lane);
-        if (i0 < n) {
-          if (a.z) { const double2 zz = *reinterpret_cast<const double2*>(a.z + (size_t)jg * n + i0); zp[m][0] = zz.x; zp[m][1] = zz.y; }
-          else philox_normal_pair(a.seed, a.stream, ((unsigned long long)jg * n + i0) >> 1, zp[m][0], zp[m][1]);
-        }
+    for (int v = 0; v < K; ++v)
+      *reinterpret_cast<double2*>(&lds[((size_t)(pw - NG) * K + v) * ACC_TILE + 2 * lane]) = make_double2(acc[v][0], acc[v][1]);
+    df_signal(cw + DFC_PART);
+    if (pw == first_worker) {
+      // one wave of the workgroup fetches the eigen-system for the rotations (group 0 always exists)
+      bool okw = true;
+      if (lane == 0) okw = poll_flag(fv.eig_flag, fv.epoch);
+      okw = __builtin_amdgcn_readfirstlane(okw ? 1 : 0) != 0;
+      if (okw) {
+        for (int idx = lane; idx < K + K * K; idx += WAVE) mailbox[idx] = load_sc1(fv.eig_pub + idx);
+      } else if (lane == 0) {
+        __hip_atomic_store(cw + DFC_BAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      df_wait<8>(cw + DFC_READ, (unsigned)(NG * NWK), cw + DFC_BAD);
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int i0 = 2 * ((lw + 3 * m) * WAVE + lane);
-        if (i0 < n) { rz[(size_t)i0 * 2 + 1] = zp[m][0]; rz[(size_t)(i0 + 1) * 2 + 1] = zp[m][1]; }
-      }
-      df_signal(cgw + DFG_ZRAW);
-      if (vw >= VF_GROUP_WAVES) return;
-      df_wait<16>(cgw + DFG_X, 1u, cw + DFC_BAD);
-    } else {
-      const int wt = wk * WAVE + lane;
-      if (pw == first_worker) {
-        // one wave of the workgroup fetches the eigen-system for the rotations (group 0 always exists)
-        bool okw = true;
-        if (lane == 0) okw = poll_flag(fv.eig_flag, fv.epoch);
-        okw = __builtin_amdgcn_readfirstlane(okw ? 1 : 0) != 0;
-        if (okw) {
-          for (int idx = lane; idx < K + K * K; idx += WAVE) mailbox[idx] = load_sc1(fv.eig_pub + idx);
-        } else if (lane == 0) {
-          __hip_atomic_store(cw + DFC_BAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        df_signal(cw + DFC_EIG);
-      }
-      // the column sums: every wave's partials are in (the slowest streaming wave decides), fixed order over the waves
-      df_wait(cw + DFC_PART, (unsigned)WAVES, cw + DFC_BAD);
-      if (stamps && pw == first_worker && lane == 0) stamps[1] = wall_clock64();      // (diagnostic builds: the slowest wave's stream has ended)
-      double sreg[2] = {0.0, 0.0};
-      if (live) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const int e = wt + m * NWT;
-          if (e < n) {
-            const int k = e / T, t = e - k * T;
-            const double* p = lds + (size_t)k * ACC_TILE + cg * T + t;
-            double s = 0.0;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) s += p[(size_t)w * RG * ACC_TILE];
-            sreg[m] = s;
-          }
-        }
-      }
-      df_signal(cw + DFC_READ);
-      if (!live) return;
-      df_wait(cw + DFC_READ, (unsigned)(NG * NWK), cw + DFC_BAD);   // nobody reads partial sums any more: the working arrays may overlay them
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int e = wt + m * NWT;
-        if (e < n) {
-          const int k = e / T, t = e - k * T;
-          mraw[t * K + k] = 0.0 + sreg[m];
-        }
-      }
-      df_signal(cgw + DFG_IN);
-      df_wait(cgw + DFG_IN, (unsigned)NWK, cw + DFC_BAD);
-      df_wait(cw + DFC_EIG, 1u, cw + DFC_BAD);
-      // rotated right-hand sides, delivered where the chains will read them: r(t) of system k is r(i + S) of the ascending
-      // chain's pivot i = t - S (its first S values go to the head), of the descending chain's pivot i = T-1-t - S, and the
-      // separator's right-hand side at the depths nl .. nl + S - 1
-      for (int idx = wt; idx < K * T; idx += NWT) {
-        const int k = idx / T, t = idx - k * T;
-        double s = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) s = fma(Ush[kk * K + k], mraw[t * K + kk], s);
-        s *= a.s;
-        mt[k * Tp + t] = s;
-        const int m = T - 1 - t;
-        if (t < S) head[(size_t)k * 4 + t] = s; else if (t - S < nl) rz[(size_t)(k * T + t - S) * 2] = s;
-        if (nr > 0) { if (m < S) head[(size_t)(K + k) * 4 + m] = s; else if (m - S < nr) rz[(size_t)(k * T + nl + m - S) * 2] = s; }
-        if (ns > 0 && t >= nl && t < nl + S) rz[(size_t)(k * T + nl + nr + t - nl) * 2] = s;
-      }
-      df_signal(cgw + DFG_ROT);
-      // the normals: staged raw by the column's other waves (above); T = 32 has no such waves - the workers draw them here
-      if (NG == 4) {
-        const int i0 = 2 * wt;
-        double z0 = 0.0, z1 = 0.0;
-        if (i0 < n) {
-          if (a.z) { const double2 zz = *reinterpret_cast<const double2*>(a.z + (size_t)jg * n + i0); z0 = zz.x; z1 = zz.y; }
-          else philox_normal_pair(a.seed, a.stream, ((unsigned long long)jg * n + i0) >> 1, z0, z1);
-          rz[(size_t)i0 * 2 + 1] = z0; rz[(size_t)(i0 + 1) * 2 + 1] = z1;
-        }
-        df_signal(cgw + DFG_ZRAW);
-      }
-      df_wait(cgw + DFG_ZRAW, 3u, cw + DFC_BAD);
-      // z sqrt(1 / D) once the chain wave has the reciprocals (pivot order: z[j][k T + i] multiplies pivot i of system k)
-      df_wait(cgw + DFG_FAC, 1u, cw + DFC_BAD);
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int idx = wt + m * NWT;
-        if (idx < n) rz[(size_t)idx * 2 + 1] = rz[(size_t)idx * 2 + 1] * sqrt(Q[(size_t)idx * 4 + 3]);
-      }
-      df_signal(cgw + DFG_ZS);
-      if (vw >= VF_GROUP_WAVES) return;
-      df_wait(cgw + DFG_X, 1u, cw + DFC_BAD);
+      df_signal(cw + DFC_EIG);
     }
+    // the column sums: every streaming wave's partials are in (the slowest decides), fixed order over the waves
+    df_wait(cw + DFC_PART, (unsigned)NSW, cw + DFC_BAD);
+    if (stamps && pw == first_worker && lane == 0) stamps[1] = wall_clock64();      // (diagnostic builds: the slowest wave's stream has ended)
+    if (!live) return;
+    const int e = wk * WAVE + lane;                          // this thread's element of the column (n <= NWT: vf_df_fits)
+    const int ek = e < n ? e / T : 0, et = e < n ? e - ek * T : 0;
+    if (e < n) {
+      const double* p = lds + (size_t)ek * ACC_TILE + cg * T + et;
+      double s = 0.0;
+      for (int w = 0; w < NSW; ++w) s += p[(size_t)w * K * ACC_TILE];
+      mraw[et * K + ek] = 0.0 + s;
+    }
+    df_signal(cgw + DFG_IN);
+    df_wait(cgw + DFG_IN, (unsigned)NWK, cw + DFC_BAD);
+    df_wait(cw + DFC_EIG, 1u, cw + DFC_BAD);
+    // rotated right-hand sides, delivered where the chains will read them: r(t) of system k is r(i + S) of the ascending
+    // chain's pivot i = t - S (its first S values go to the head), of the descending chain's pivot i = T-1-t - S, and the
+    // separator's right-hand side at the depths nl .. nl + S - 1
+    if (e < n) {
+      const int k = ek, t = et;
+      double s = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) s = fma(Ush[kk * K + k], mraw[t * K + kk], s);
+      s *= a.s;
+      mt[k * Tp + t] = s;
+      const int m = T - 1 - t;
+      if (t < S) head[(size_t)k * 4 + t] = s; else if (t - S < nl) rz[(size_t)(k * T + t - S) * 2] = s;
+      if (nr > 0) { if (m < S) head[(size_t)(K + k) * 4 + m] = s; else if (m - S < nr) rz[(size_t)(k * T + nl + m - S) * 2] = s; }
+      if (ns > 0 && t >= nl && t < nl + S) rz[(size_t)(k * T + nl + nr + t - nl) * 2] = s;
+    }
+    df_signal(cgw + DFG_ROT);
+    if (vw >= VF_GROUP_WAVES) return;
+    df_wait<8>(cgw + DFG_X, 1u, cw + DFC_BAD);
   }
   // =========================== final stage: the column's four virtual waves ===========================
   // rotate back, write V[j] (depth-major), residual part, Gram share - v_spectral_kernel's geometry (tid = vw 64 + lane)

@@ -24,6 +24,9 @@ namespace btf {
 #ifndef BTF_ACC_WAVES
 #define BTF_ACC_WAVES 16
 #endif
+#ifndef BTF_DF_UNR
+#define BTF_DF_UNR 3
+#endif
 #ifndef BTF_ACC_UNR
 #define BTF_ACC_UNR 2
 #endif
@@ -420,7 +423,8 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES, FUSE)
   constexpr int KK = tri(K);
   constexpr int NV = MODE == 0 ? K : K + KK;
   constexpr int ACC_WAVES = WAVES;                       // shadows the namespace defaults inside this kernel
-  constexpr int ACC_UNR = UNRV > 0 ? UNRV : (MODE >= 1 ? BTF_ACC_UNR_WT : (K >= 9 ? BTF_ACC_UNR_K9 : BTF_ACC_UNR));
+  // (the dataflow instance: its chain waves do not stream - the others keep BTF_DF_UNR rows in flight each)
+  constexpr int ACC_UNR = FUSE == FUSE_VDF ? BTF_DF_UNR : (UNRV > 0 ? UNRV : (MODE >= 1 ? BTF_ACC_UNR_WT : (K >= 9 ? BTF_ACC_UNR_K9 : BTF_ACC_UNR)));
   // values per round of the cross-wave reduction: as many as the workgroup has 128-thread slots for and 96 KB of LDS hold
   // (16 waves: 6, 12 waves: 6, 8 waves: 4), never more than there are - K = 5 complete data (5 values) reduces in one round
   // instead of two, the weighted modes (20 values, 12 waves) in four instead of five; at least the old four (side-task scratch)
@@ -613,6 +617,11 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES, FUSE)
   DfEarly df_early{0ULL, 0ULL, 0.0};
   VDfPre dfpre;
   if constexpr (dataflow) v_df_begin<K, 3>(fz, tile, &red[0][0][0], dfpre);
+  // (dataflow tail: the columns' chain waves - waves 0 .. ncw-1 - do NOT stream: they wait for the eigenvalues and factor
+  //  while the other waves, which share the rows among themselves, stream; btf_fused.h)
+  int df_ncw = 0;
+  if constexpr (dataflow) df_ncw = fuse_chain_waves<FUSE>(fz);
+  const int nwr_rt = NWR - df_ncw;                              // waves along the rows (a constant unless dataflow)
   bool band_early = false;
   if constexpr (FUSE == FUSE_V) band_early = v_fused_band_early<K, 3>(fz, tile, &red[0][0][0], UNRV == 3);
   typename FusePre<FUSE>::type vpre;
@@ -667,7 +676,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES, FUSE)
     constexpr bool NT = decltype(ntc)::value;       // (the statistic by non-temporal loads: see ChunkMap.nt)
 #pragma unroll
     for (int u = 0; u < ACC_UNR; ++u) {
-      const int r = rb + u * NWR;  // wave-uniform
+      const int r = rb + u * (dataflow ? nwr_rt : NWR);  // wave-uniform
       if constexpr (ULDS) {
         const double* up = ush + (size_t)((FULL ? r : min(r, r1 - 1)) - ublk0) * K;         // wave-uniform: broadcast reads
 #pragma unroll
@@ -812,44 +821,30 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES, FUSE)
       v_fused_prefetch_loads<K, 3>(fz, tile, vpre, band_early);
     }
     if constexpr (dataflow) {
-      // dataflow tail (btf_fused.h): the band image the columns' copying waves asked for at kernel start came back with the
-      // first rows' loads (in order): into the LDS now, nothing parked through the stream ...
-      if (rb < full_end - STEP) {
+      // dataflow tail (btf_fused.h): WAVES - ncw waves share the rows; the band image the columns' copying waves asked for
+      // at kernel start came back with the first rows' loads (in order): into the LDS behind the first row group, nothing
+      // parked through the stream
+      const int step = nwr_rt * ACC_UNR, fend = r1 - (ACC_UNR - 1) * nwr_rt;
+      rb = r0 + wv - df_ncw;
+      if (rb < fend) {
         Rows A;
         load_rows(rb, A, std::true_type{}, ntc);
         compute(rb, A);
-        rb += STEP;
+        rb += step;
         v_df_band_store<K, 3>(fz, tile, &red[0][0][0], dfpre);
         df_band_done = true;
       }
-      for (; rb < full_end - STEP; rb += STEP) {
+      for (; rb < fend; rb += step) {
         Rows A;
         load_rows(rb, A, std::true_type{}, ntc);
         compute(rb, A);
       }
-      if (rb < full_end) {
-        // ... and the chain waves' speculative loads (the tagged eigenvalue granules of the lane's system, nu2) go out BEHIND
-        // the last whole row group's loads: back right after them, no wait of their own
+      if (rb < r1) {
         Rows A;
-        load_rows(rb, A, std::true_type{}, ntc);
-        asm volatile("" ::: "memory");
-        const int ncw = fuse_chain_waves<FUSE>(fz);
-        if (wave < ncw) {
-          const int kk = lane < K ? lane : (lane < 2 * K ? lane - K : 0);
-          const unsigned long long* gp = fuse_eig_gran<FUSE>(fz);
-          df_early.ghi = __hip_atomic_load(gp + 2 * kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          df_early.glo = __hip_atomic_load(gp + 2 * kk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const double* np = fuse_nu2_ptr<FUSE>(fz);
-          if (np) df_early.nu2 = *np;
-          // (the tail reads a few hundred bytes of kernel arguments the stream never touches, and the stream's own scalar
-          //  loads - the factor rows - have long pushed them out of the scalar cache: touch their lines now, one scalar load
-          //  each, so that the chain wave does not start its tail with a chain of scalar-cache misses)
-          fuse_touch_args<FUSE>(fz);
-        }
-        asm volatile("" ::: "memory");
+        load_rows(rb, A, std::false_type{}, ntc);
         compute(rb, A);
-        rb += STEP;
       }
+      rb = r1;                                                // (the generic loops below: nothing left)
     }
     for (; rb < full_end; rb += STEP) {
       Rows A;
@@ -866,7 +861,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES, FUSE)
   }
 
   };
-  if (nt) run_stream(std::true_type{}); else run_stream(std::false_type{});
+  if (!(dataflow && wave < df_ncw)) { if (nt) run_stream(std::true_type{}); else run_stream(std::false_type{}); }
   ACC_STAMP(2);
   if constexpr (dataflow) {
     if (!df_band_done) {                                    // (a row range too short for the in-stream store: fetched again, now)
