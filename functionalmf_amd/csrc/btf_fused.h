@@ -923,10 +923,13 @@ __host__ __device__ inline bool vf_df_fits(int T, int K, int TF, int nD, int wav
   const int nwt = ((waves - ng) / ng) * WAVE;                 // worker threads per column (v_fused_df: every streaming wave): one element each
   if (T * K > nwt || T * K > 768) return false;
   const int room = vf_red_doubles(false) - VF_MAILBOX - ng * df_layout(T, K, TF + 1).size;
-  return (waves - ng) * K * ACC_TILE + ng * df_work(T, K, TF + 1).stride <= room;      // partial sums [w][k][128], the working arrays behind them
+  return waves * K * ACC_TILE + ng * df_work(T, K, TF + 1).stride <= room;      // partial sums [w][k][128], the working arrays behind them
 }
 template <> __device__ __forceinline__ int fuse_chain_waves<FUSE_VDF>(const FuseV& fz) { return ACC_TILE / fz.a.T; }
 template <> __device__ __forceinline__ const unsigned long long* fuse_eig_gran<FUSE_VDF>(const FuseV& fz) { return fz.eig_gran; }
+template <> __device__ __forceinline__ const unsigned* fuse_eig_flag<FUSE_VDF>(const FuseV& fz) { return fz.eig_flag; }
+template <> __device__ __forceinline__ const double* fuse_eig_pub<FUSE_VDF>(const FuseV& fz) { return fz.eig_pub; }
+template <> __device__ __forceinline__ unsigned fuse_epoch<FUSE_VDF>(const FuseV& fz) { return fz.epoch; }
 template <> __device__ __forceinline__ const double* fuse_nu2_ptr<FUSE_VDF>(const FuseV& fz) { return (fz.a.hyp && fz.a.hyp_noise) ? fz.a.hyp + HYP_NU2 : nullptr; }
 template <> __device__ __forceinline__ void fuse_touch_args<FUSE_VDF>(const FuseV& fz) {
   // one field per 64-byte line of the argument block the tail reads (forced to be loaded HERE: inputs of an empty asm)
@@ -1024,8 +1027,8 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
   // The chain wave of a column (p < NG) does not stream (accum_kernel): it draws the column's normals, waits for the
   // eigenvalues and factors while the other 16 - NG waves stream.  Those are all workers of the sums afterwards: wave p
   // works for column p % NG, one element of the column per thread.
-  const int NSW = WAVES - NG;                              // streaming waves: their partial sums, [w][k][128] from the bottom of the LDS
-  const int NWK = NSW >> lgNG, NWT = NWK * WAVE;           // workers per column (15 / 7 / 3), their threads
+  const int NSW = WAVES;                                   // every wave has partial sums (the chain waves' share of the rows): [w][k][128] from the bottom of the LDS
+  const int NWK = (WAVES - NG) >> lgNG;                    // workers per column (15 / 7 / 3)
   const int wk = vw - 1;                                   // worker index of a non-chain wave: p = NG + wk NG + cg
   const int first_worker = NG;                             // it fetches the eigen-system for everybody
   const DfLayout D = df_layout(T, K, S);
@@ -1053,6 +1056,11 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
 
   if (vw == 0) {
     // =========================== the column's chain wave ===========================
+    // (its share of the stream has ended: the partial sums, one count - also for a dead column group: its rows count)
+#pragma unroll
+    for (int v = 0; v < K; ++v)
+      *reinterpret_cast<double2*>(&lds[((size_t)pw * K + v) * ACC_TILE + 2 * lane]) = make_double2(acc[v][0], acc[v][1]);
+    df_signal(cw + DFC_PART);
     if (!live) return;
     const int nchain = nr > 0 ? 2 * K : K;
     const bool chain = lane < nchain;
@@ -1096,8 +1104,9 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
     while (true) {
       bool good = true;
       gk = fma(g0, a.sR, shift);
-      if (chain) {
+      {
         // factor: window c[b][d] = A[i+b+d][i+b]; per pivot the new band row in, the quad [l1 l2 l3 1/D] out
+        // (the lanes outside the chains stay out of the pivots, not out of the eigen-system probe between them)
         double c[S + 1][S + 1];
 #pragma unroll
         for (int b = 0; b < S; ++b) {
@@ -1125,11 +1134,13 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
 #pragma unroll
             for (int d = 0; d <= S; ++d) c[b][d] = c[b + 1][d];
         };
+        if (chain) {
 #pragma unroll 4
-        for (int i = 0; i < n_common; ++i) pivot(i);
-        if (n_elim > n_common) pivot(n_common);
+          for (int i = 0; i < n_common; ++i) pivot(i);
+          if (n_elim > n_common) pivot(n_common);
+        }
         good = !bad;
-        if (ns > 0) {                                      // park the window for the separator system
+        if (chain && ns > 0) {                             // park the window for the separator system
           double* wp = win + (size_t)(side * K + k) * WN;
 #pragma unroll
           for (int b = 0; b < S; ++b)
@@ -1276,30 +1287,37 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
     // the wave's partial sums of the tile's 128 outputs (both lanes' pairs), then one count
 #pragma unroll
     for (int v = 0; v < K; ++v)
-      *reinterpret_cast<double2*>(&lds[((size_t)(pw - NG) * K + v) * ACC_TILE + 2 * lane]) = make_double2(acc[v][0], acc[v][1]);
+      *reinterpret_cast<double2*>(&lds[((size_t)pw * K + v) * ACC_TILE + 2 * lane]) = make_double2(acc[v][0], acc[v][1]);
     df_signal(cw + DFC_PART);
     if (pw == first_worker) {
-      // one wave of the workgroup fetches the eigen-system for the rotations (group 0 always exists)
+      // the eigen-system for the rotations (K + K K doubles, one per lane; group 0 always exists): this wave asked for it
+      // inside its stream - the flag's word behind one row group's loads, the payload behind a later one's once the flag
+      // had come back as this launch's (accum_kernel) - so it normally costs no round trip here
+      double epub = early.epub;
       bool okw = true;
-      if (lane == 0) okw = poll_flag(fv.eig_flag, fv.epoch);
-      okw = __builtin_amdgcn_readfirstlane(okw ? 1 : 0) != 0;
-      if (okw) {
-        for (int idx = lane; idx < K + K * K; idx += WAVE) mailbox[idx] = load_sc1(fv.eig_pub + idx);
-      } else if (lane == 0) {
-        __hip_atomic_store(cw + DFC_BAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (!early.have) {
+        if (lane == 0) okw = poll_flag(fv.eig_flag, fv.epoch);
+        okw = __builtin_amdgcn_readfirstlane(okw ? 1 : 0) != 0;
+        if (okw && lane < K + K * K) epub = load_sc1(fv.eig_pub + lane);
       }
+      if (okw) { if (lane < K + K * K) mailbox[lane] = epub; }
+      else if (lane == 0) __hip_atomic_store(cw + DFC_BAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       df_signal(cw + DFC_EIG);
     }
-    // the column sums: every streaming wave's partials are in (the slowest decides), fixed order over the waves
+    // this thread's element of the column (n <= NWK 64: vf_df_fits); T is 32, 64 or 128
+    const int lgT = 7 - lgNG;
+    const int e = wk * WAVE + lane;
+    const bool mine = live && e < n;
+    const int ek = mine ? e >> lgT : 0, et = mine ? e & (T - 1) : 0;
+    const double* psum = lds + (size_t)ek * ACC_TILE + cg * T + et;
+    // the column sums: every wave's partials are in (the slowest streaming wave decides), fixed order over the waves
     df_wait(cw + DFC_PART, (unsigned)NSW, cw + DFC_BAD);
     if (stamps && pw == first_worker && lane == 0) stamps[1] = wall_clock64();      // (diagnostic builds: the slowest wave's stream has ended)
     if (!live) return;
-    const int e = wk * WAVE + lane;                          // this thread's element of the column (n <= NWT: vf_df_fits)
-    const int ek = e < n ? e / T : 0, et = e < n ? e - ek * T : 0;
-    if (e < n) {
-      const double* p = lds + (size_t)ek * ACC_TILE + cg * T + et;
+    if (mine) {
       double s = 0.0;
-      for (int w = 0; w < NSW; ++w) s += p[(size_t)w * K * ACC_TILE];
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) s += psum[(size_t)w * K * ACC_TILE];
       mraw[et * K + ek] = 0.0 + s;
     }
     df_signal(cgw + DFG_IN);
@@ -1308,7 +1326,7 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
     // rotated right-hand sides, delivered where the chains will read them: r(t) of system k is r(i + S) of the ascending
     // chain's pivot i = t - S (its first S values go to the head), of the descending chain's pivot i = T-1-t - S, and the
     // separator's right-hand side at the depths nl .. nl + S - 1
-    if (e < n) {
+    if (mine) {
       const int k = ek, t = et;
       double s = 0.0;
 #pragma unroll

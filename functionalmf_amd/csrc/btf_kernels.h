@@ -27,6 +27,12 @@ namespace btf {
 #ifndef BTF_DF_UNR
 #define BTF_DF_UNR 3
 #endif
+#ifndef BTF_DF_PREFETCH
+#define BTF_DF_PREFETCH 1
+#endif
+#ifndef BTF_DF_SHARE
+#define BTF_DF_SHARE 0    // percent of a workgroup's rows the chain waves of the dataflow V tail stream too (0: none)
+#endif
 #ifndef BTF_ACC_UNR
 #define BTF_ACC_UNR 2
 #endif
@@ -364,8 +370,11 @@ template <int FUSE> __device__ __forceinline__ const double* fuse_nu2_ptr(const 
 template <int FUSE> __device__ __forceinline__ void fuse_touch_args(const typename FuseSel<FUSE>::type& fz) {}
 // what a chain wave fetched BEHIND its last rows' loads (in order: back right after them, no wait of its own): the tagged
 // eigenvalue granules of its lane's system, the device-resident nu2
-struct DfEarly { unsigned long long ghi, glo; double nu2; };
+struct DfEarly { double epub; bool have; };      // the eigen-system entry of this lane as the first worker wave prefetched it inside its stream
 template <int FUSE> __device__ __forceinline__ const unsigned long long* fuse_eig_gran(const typename FuseSel<FUSE>::type& fz) { return nullptr; }
+template <int FUSE> __device__ __forceinline__ const unsigned* fuse_eig_flag(const typename FuseSel<FUSE>::type& fz) { return nullptr; }
+template <int FUSE> __device__ __forceinline__ const double* fuse_eig_pub(const typename FuseSel<FUSE>::type& fz) { return nullptr; }
+template <int FUSE> __device__ __forceinline__ unsigned fuse_epoch(const typename FuseSel<FUSE>::type& fz) { return 0u; }
 template <int K, int S> __device__ __forceinline__ void v_df_begin(const FuseV& fv, int tile, double* lds, VDfPre& pre);
 template <int K, int S> __device__ __forceinline__ void v_df_band_load(const FuseV& fv, int tile, VDfPre& pre);
 template <int K, int S> __device__ __forceinline__ void v_df_band_store(const FuseV& fv, int tile, double* lds, const VDfPre& pre);
@@ -614,14 +623,14 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES, FUSE)
   constexpr bool dataflow = FUSE == FUSE_VDF;
   static_assert(!dataflow || (UNRV != 3 && NV <= ACC_RG && OPL == 2), "the dataflow tail: one reduction round, two rows in flight");
   bool df_band_done = false;
-  DfEarly df_early{0ULL, 0ULL, 0.0};
+  DfEarly df_early{0.0, false};
   VDfPre dfpre;
   if constexpr (dataflow) v_df_begin<K, 3>(fz, tile, &red[0][0][0], dfpre);
   // (dataflow tail: the columns' chain waves - waves 0 .. ncw-1 - do NOT stream: they wait for the eigenvalues and factor
   //  while the other waves, which share the rows among themselves, stream; btf_fused.h)
   int df_ncw = 0;
   if constexpr (dataflow) df_ncw = fuse_chain_waves<FUSE>(fz);
-  const int nwr_rt = NWR - df_ncw;                              // waves along the rows (a constant unless dataflow)
+  int nwr_rt = NWR;                                             // waves along the rows of the span being streamed (dataflow only)
   bool band_early = false;
   if constexpr (FUSE == FUSE_V) band_early = v_fused_band_early<K, 3>(fz, tile, &red[0][0][0], UNRV == 3);
   typename FusePre<FUSE>::type vpre;
@@ -821,28 +830,50 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES, FUSE)
       v_fused_prefetch_loads<K, 3>(fz, tile, vpre, band_early);
     }
     if constexpr (dataflow) {
-      // dataflow tail (btf_fused.h): WAVES - ncw waves share the rows; the band image the columns' copying waves asked for
-      // at kernel start came back with the first rows' loads (in order): into the LDS behind the first row group, nothing
-      // parked through the stream
-      const int step = nwr_rt * ACC_UNR, fend = r1 - (ACC_UNR - 1) * nwr_rt;
-      rb = r0 + wv - df_ncw;
-      if (rb < fend) {
+      // dataflow tail (btf_fused.h): the first BTF_DF_SHARE percent of the rows are dealt over all the waves - the chain
+      // waves have nothing else to do until the eigenvalues arrive - the rest over the WAVES - ncw streaming waves.  The band
+      // image the columns' copying waves asked for at kernel start came back with the first rows' loads (in order): into
+      // the LDS behind the first row group, nothing parked through the stream
+      const int g1 = NWR * ACC_UNR;
+      const int rsplit = r0 + ((r1 - r0) * BTF_DF_SHARE / 100) / g1 * g1;      // whole row groups of all the waves
+      nwr_rt = NWR;
+      for (rb = r0 + wv; rb < rsplit; rb += g1) {
         Rows A;
         load_rows(rb, A, std::true_type{}, ntc);
         compute(rb, A);
-        rb += step;
-        v_df_band_store<K, 3>(fz, tile, &red[0][0][0], dfpre);
-        df_band_done = true;
+        if (!df_band_done) { v_df_band_store<K, 3>(fz, tile, &red[0][0][0], dfpre); df_band_done = true; }
       }
-      for (; rb < fend; rb += step) {
-        Rows A;
-        load_rows(rb, A, std::true_type{}, ntc);
-        compute(rb, A);
-      }
-      if (rb < r1) {
-        Rows A;
-        load_rows(rb, A, std::false_type{}, ntc);
-        compute(rb, A);
+      if (wave >= df_ncw) {
+        nwr_rt = NWR - df_ncw;
+        const int step = nwr_rt * ACC_UNR, fend = r1 - (ACC_UNR - 1) * nwr_rt;
+        // (the first of them also prefetches the eigen-system the workers' rotations need - btf_fused.h: from 5/8 of its
+        //  rows on it looks at the side workgroup's flag behind a row group's loads, and once the word has come back as
+        //  this launch's it asks for the K + K K doubles, one per lane, behind the next group's: no round trip at stream end)
+        const bool eigw = BTF_DF_PREFETCH && wave == df_ncw;
+        const int rprobe = r0 + (r1 - r0) * 5 / 8;
+        unsigned eflag = 0u;
+        int estate = 0;
+        for (rb = rsplit + wv - df_ncw; rb < fend; rb += step) {
+          Rows A;
+          load_rows(rb, A, std::true_type{}, ntc);
+          if (eigw && estate < 2 && rb >= rprobe) {
+            if (estate == 1 && eflag == fuse_epoch<FUSE>(fz)) {
+              if (lane < K + K * K) df_early.epub = load_sc1(fuse_eig_pub<FUSE>(fz) + lane);
+              df_early.have = true;
+              estate = 2;
+            } else {
+              eflag = __hip_atomic_load(fuse_eig_flag<FUSE>(fz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              estate = 1;
+            }
+          }
+          compute(rb, A);
+          if (!df_band_done) { v_df_band_store<K, 3>(fz, tile, &red[0][0][0], dfpre); df_band_done = true; }
+        }
+        if (rb < r1) {
+          Rows A;
+          load_rows(rb, A, std::false_type{}, ntc);
+          compute(rb, A);
+        }
       }
       rb = r1;                                                // (the generic loops below: nothing left)
     }
@@ -861,7 +892,7 @@ __global__ __launch_bounds__(WAVES * WAVE) BTF_ACC_EU_ATTR(K, MODE, WAVES, FUSE)
   }
 
   };
-  if (!(dataflow && wave < df_ncw)) { if (nt) run_stream(std::true_type{}); else run_stream(std::false_type{}); }
+  if (nt) run_stream(std::true_type{}); else run_stream(std::false_type{});
   ACC_STAMP(2);
   if constexpr (dataflow) {
     if (!df_band_done) {                                    // (a row range too short for the in-stream store: fetched again, now)
