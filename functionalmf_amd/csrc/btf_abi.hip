@@ -168,6 +168,9 @@ struct btf_ctx {
   bool nu2_drawn_since_v = false;      // a device nu2 draw happened since the last V half-sweep: the caller runs full sweeps
   bool sc_pending = false; unsigned long long sc_seed = 0; int sc_which = 0; double sc_prior[4] = {0, 0, 0, 0};
   bool lam_pending = false; unsigned long long lam_seed = 0; int lam_exact = 0;            // btf_queue_lam2
+  bool band_in_wsolve = true;                                         // (A/B aid: BTF_BAND_IN_WSOLVE=0: the band's own launch)
+  bool v_wants_band = false, band_img = false; int band_PB = 0;       // the last fused V launch loaded the precomputed prior band (and its LDS image)
+  bool lam_in_wsolve = true;                                          // (A/B aid: BTF_LAM_IN_WSOLVE=0 leaves the draw to the V launch)
   unsigned long long sweep_w = 0, sweep_v = 0;
   // the two-launch W+V step (BTF_OPT_FUSED_STEP, btf_fused.h): tickets / flags (zeroed once; 32 words = one 128-byte line
   // per flag), the write-through copies the tails read, the epoch of the hand-offs (one per fused launch, never reused)
@@ -410,6 +413,7 @@ void launch_accum(btf_ctx* c, int kid, int mode, const double* X, const double* 
         constexpr int RG = K < 4 ? 4 : (K > 6 ? 6 : K);        // accum_kernel's ACC_RG of the 16-wave complete-data instance
         f2.dataflow = (df_on && f2.a.pband && f2.pimg && !f2.cnt && !f2.hp.flag && K <= 6 &&
                        vf_df_fits(f2.a.T, K, f2.a.TF, f2.a.nD, 16, RG)) ? 1 : 0;
+
         if constexpr (K <= 6) {
           if (f2.dataflow) { p.launch(accum_kernel<K, 0, 16, double, double, 0, 2, FUSE_VDF>, grid, dim3(16 * WAVE), 0, X, Cx, U, srcmap, c->part, Rdim, ld, rpb, side, sidec, tau, gram, cm, sw, f2); return; }
         }
@@ -491,7 +495,7 @@ template <int K>
 void launch_wsolve(btf_ctx* c, const WSolveArgs& a) {
   Prof p(c, BTF_K_W_SOLVE);
   const int rw = ws_rows_for(a.nl);
-  const dim3 grid((a.nl + rw - 1) / rw);
+  const dim3 grid((a.nl + rw - 1) / rw + (a.lam.hyp ? 1 : 0) + (a.band.pband ? a.band.ml : 0));      // (+ the lam2 workgroup and the band's of a full sweep)
 #define WS_LAUNCH(WT, RWV) p.launch(w_solve_kernel<K, WT, RWV>, grid, dim3(WS_ROWS * ws_split_of(K, WT)), 0, a)
 #define WS_PICK(WT) do { if (rw == 8) WS_LAUNCH(WT, 8); else if (rw == 16) WS_LAUNCH(WT, 16); else if (rw == 32) WS_LAUNCH(WT, 32); else WS_LAUNCH(WT, 64); } while (0)
   if (a.weighted) WS_PICK(true); else WS_PICK(false);
@@ -954,6 +958,8 @@ int btf_create(btf_ctx** out, int nrows, int ncols, int ndepth, int nembeds, int
   if (e != hipSuccess) { g_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete c; return BTF_EHIP; }
   { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->ncu = n; }
   { const char* e = std::getenv("BTF_FUSED_STEP"); if (e) c->fused_step = std::max(0, std::min(2, std::atoi(e))); }      // (A/B aid; BTF_OPT_FUSED_STEP is the interface)
+  { const char* e = std::getenv("BTF_LAM_IN_WSOLVE"); if (e) c->lam_in_wsolve = std::atoi(e) != 0; }
+  { const char* e = std::getenv("BTF_BAND_IN_WSOLVE"); if (e) c->band_in_wsolve = std::atoi(e) != 0; }
   { const char* e = std::getenv("BTF_VF_DATAFLOW"); if (e) c->fused_dataflow = std::atoi(e) != 0 ? 1 : 0; }             // (A/B aid; BTF_OPT_FUSED_DATAFLOW is the interface)
   if (stream) { c->stream = (hipStream_t)stream; }
   else {
@@ -1669,6 +1675,30 @@ int btf_resample_W(btf_ctx* c, const double* z, uint64_t seed, int compat) {
     a.z = dz; a.seed = seed; a.stream = 2 * c->sweep_w + 0x10000ULL;
     a.status = c->status;
     if (cv) { a.cv = CurveLists{c->cv_rptr, c->cv_rcol, c->cv_rdef}; a.cv_blocks = c->gpart_v; }
+    // a queued lam2 | rest draw (full sweeps) rides here, as one more workgroup: the Tau2 chain of this sweep - whose
+    // column sums it needs - ran in the accumulation launch in front, and a V half-sweep that finds lam2 already drawn
+    // uses the precomputed prior band and the dataflow tail (the draw used to be a side workgroup of the V launch itself,
+    // whose tails then had to form the band from Tau2: 25.4 us per V launch against 19 + 2 for the band's launch)
+    if (c->lam_in_wsolve && c->lam_pending && c->dev_scalars && c->lsum && c->have_chain) {
+      a.lam = LamSide{c->lsum, c->M, (double)c->nD * c->M * c->K + 1.0, c->lam_exact, c->lam_seed, c->hyp, nullptr, nullptr, 0u};
+      c->lam_pending = false;
+      ++c->prior_version;
+      // ... and, where the last V half-sweep loaded the precomputed prior band, that band - of the Tau2 the accumulation
+      // launch in front has just drawn and the lam2 the workgroup above draws - by one more workgroup per column (BandSide:
+      // they wait for the lam2 workgroup's flag), instead of a launch of its own in front of the V launch
+      const int TD1 = c->T * (c->TF + 2);
+      if (c->band_in_wsolve && c->v_wants_band && c->pband && (!c->band_img || c->pimg) && TD1 <= 2 * WS_ROWS * ws_split_of(K, wt) &&
+          c->nD <= 2 * WS_ROWS * ws_split_of(K, wt)) {
+        if ((rc = ensure_fused(c))) return rc;
+        ++c->fz_epoch;
+        a.lam.pub = c->fz_pub + FZ_PUB_HYP; a.lam.flag = c->fz_words + FZ_LAM; a.lam.epoch = c->fz_epoch;
+        a.band = BandSide{c->Tau2, c->nD, c->st_ptr, c->st_row, c->st_coef, TD1, c->col0, c->ml, c->pband,
+                          c->band_img ? c->pimg : nullptr, c->T, c->TF + 2, c->band_PB, nullptr, 0.0,
+                          c->fz_pub + FZ_PUB_HYP, c->fz_words + FZ_LAM, c->fz_epoch, c->status};
+        c->pband_version = c->prior_version;
+        c->pimg_version = c->band_img ? c->prior_version : 0;
+      }
+    }
     K_SWITCH(K, launch_wsolve<KT>(c, a));
     c->ngp_w = a.gout ? wblocks : 0;
     c->ngp_v = 0;   // V'V partials are consumed once; any other W/V change must recompute
@@ -1980,11 +2010,18 @@ int btf_resample_V(btf_ctx* c, const double* z, uint64_t seed, int compat, doubl
             HIPCHK(c, hipMemsetAsync(c->pimg, 0, (size_t)c->ml * 2 * PB * sizeof(double), c->stream));      // (the zero rows: once)
             c->pimg_version = 0;
           }
+          // (full sweeps: the w_solve launch in front has already rebuilt it beside the solves - BandSide, btf_kernels.h)
+          c->v_wants_band = true; c->band_img = img; c->band_PB = PB;
           if (c->pband_version != c->prior_version || (img && c->pimg_version != c->prior_version)) {
             Prof p(c, BTF_K_PRIOR);
-            p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
-                     (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
-                     (const double*)(c->dev_scalars ? c->hyp : nullptr), 1, img ? c->pimg : (double*)nullptr, T, c->TF + 2, PB);
+            if (TD1 <= 512 && c->nD <= 256)      // (T <= 128: one workgroup per column)
+              p.launch(prior_band_cols_kernel, dim3(c->ml), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
+                       (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->pband,
+                       (const double*)(c->dev_scalars ? c->hyp : nullptr), img ? c->pimg : (double*)nullptr, T, c->TF + 2, PB);
+            else
+              p.launch(prior_band_kernel, dim3((c->ml * TD1 + 255) / 256), dim3(256), 0, (const double*)c->Tau2, c->lam2, c->nD,
+                       (const int*)c->st_ptr, (const int*)c->st_row, (const double*)c->st_coef, TD1, c->col0, c->ml, c->pband,
+                       (const double*)(c->dev_scalars ? c->hyp : nullptr), 1, img ? c->pimg : (double*)nullptr, T, c->TF + 2, PB);
             c->pband_version = c->prior_version;
             c->pimg_version = img ? c->prior_version : 0;
           }

@@ -282,6 +282,21 @@ struct ScalarSide {
 // in the W accumulation launch; the V sampler - the next kernel - reads the draw.  hyp == nullptr: none.
 struct LamSide { const double* lsum; int M; double shape; int exact; unsigned long long seed; double* hyp; double* pub; unsigned* flag; unsigned epoch; };
 struct SweepSide { ScalarSide sc; LamSide lam; };
+// The prior band of every local column (P_j = Delta' diag(1 / (lam2 Tau2_j)) Delta, half-bandwidth tf_order + 1: what
+// prior_band_cols_kernel computes) as MORE workgroups of the w_solve launch of a full sweep, one per column: Tau2 was
+// redrawn by the accumulation launch in front, lam2 by the lam2 workgroup of this very launch (LamSide: the band
+// workgroups fetch their Tau2 row and stencil bounds, then wait for its flag) - and the V launch behind finds its band and
+// the band's LDS image ready without a launch of their own.  pband == nullptr: none.
+struct BandSide {
+  const double* Tau2; int nD;
+  const int* st_ptr; const int* st_row; const double* st_coef;
+  int TD1, col0, ml;
+  double* pband; double* pimg; int img_T, img_D1, img_PB;
+  const double* hyp; double lam2;                 // lam2 when no workgroup of this launch draws it: hyp[HYP_LAM2] or the host's value
+  const double* lam_pub; const unsigned* lam_flag; unsigned epoch;
+  int* status;
+};
+__device__ inline void band_side(const BandSide& bs, int j, double* itau, int nthreads);
 
 // MODE 0: X only (complete data)
 // MODE 1: X, C and the outer products UU
@@ -1124,6 +1139,11 @@ struct WSolveArgs {
   int hyp_noise;       // 1: the noise scale s comes from hyp[HYP_NU2] (scalar-nu2 models only)
   CurveLists cv;       // curve-structured counts: deficient columns of every row (global row index), or ptr == nullptr
   const double* cv_blocks;   // [M][KK] per-column Grams V_j'V_j
+  // full sweeps: lam2 | rest drawn by ONE MORE workgroup of this launch (the last block index; hyp == nullptr: none) - it
+  // needs the column sums the Tau2 chain left in the W accumulation launch in front of this one and nothing of the solve;
+  // the V half-sweep behind it then finds lam2 drawn and can use the precomputed prior band (btf_abi.hip)
+  LamSide lam;
+  BandSide band;       // ... and behind it one workgroup per local column for the prior band of the V half-sweep (pband == nullptr: none)
 #ifdef BTF_WS_STAMPS
   long long* dbg;      // diagnostic builds: [gridDim.x][6] shader-clock stamps of wave 0 (scripts/ws_stamps.py)
 #endif
@@ -1137,6 +1157,57 @@ struct WSolveArgs {
 // device-resident scalar hyper-parameters (rng="device": drawn by scalars_kernel / lam2_kernel,
 // read by the half-sweep kernels, so that a full sweep needs no host round trip)
 enum { HYP_NU2 = 0, HYP_SIGMA2 = 1, HYP_LAM2 = 2, HYP_LAM2A = 3, HYP_SSE = 4, HYP_WSQ = 5, HYP_COUNT = 8 };
+__device__ inline void band_side(const BandSide& bs, int j, double* itau, int nthreads) {
+  const double* tau = bs.Tau2 + (size_t)(bs.col0 + j) * bs.nD;
+  // independent of lam2: this thread's Tau2 values (two: nD <= 2 nthreads) and the CSR bounds of its entries (two)
+  double tv[2] = {1.0, 1.0};
+  int p0[2] = {0, 0}, p1[2] = {0, 0};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = threadIdx.x + u * nthreads, e0 = threadIdx.x + u * nthreads;
+    if (r < bs.nD) tv[u] = tau[r];
+    if (e0 < bs.TD1) { p0[u] = bs.st_ptr[e0]; p1[u] = bs.st_ptr[e0 + 1]; }
+  }
+  double lam2 = bs.hyp ? bs.hyp[HYP_LAM2] : bs.lam2;
+  if (bs.lam_flag) {
+    // (bounded: the lam2 workgroup has a lower block index - dispatched first - and publishes whatever happens)
+    __shared__ int okf;
+    if (threadIdx.x == 0) {
+      bool seen = false;
+      for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+        if (__hip_atomic_load((const gu32_t*)bs.lam_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == bs.epoch) { seen = true; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      okf = seen ? 1 : 0;
+      if (!seen && atomicCAS(&bs.status[0], 0, 2) == 0) bs.status[1] = -2;
+    }
+    __syncthreads();
+    if (!okf) return;
+    lam2 = load_sc1(bs.lam_pub + HYP_LAM2);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = threadIdx.x + u * nthreads;
+    if (r < bs.nD) itau[r] = 1.0 / __dmul_rn(lam2, tv[u]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e0 = threadIdx.x + u * nthreads;
+    if (e0 < bs.TD1) {
+      double s = 0.0;
+      for (int e = p0[u]; e < p1[u]; ++e) s = fma(bs.st_coef[e], itau[bs.st_row[e]], s);
+      bs.pband[(size_t)j * bs.TD1 + e0] = s;
+      if (bs.pimg) {
+        const int t = e0 / bs.img_D1, d = e0 - t * bs.img_D1;
+        double* im = bs.pimg + (size_t)j * 2 * bs.img_PB;
+        im[e0] = s;
+        if (t + d < bs.img_T) im[bs.img_PB + (bs.img_T - 1 - t - d) * bs.img_D1 + d] = s;
+      }
+    }
+  }
+}
+
 
 constexpr int WS_ROWS = 64;   // rows per workgroup (one per lane)
 // waves per workgroup: the chunk partials are summed WS_SPLIT-way in parallel (LDS-bounded)
@@ -1201,6 +1272,19 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
   __shared__ double zsh[K][WS_ROWS];
   __shared__ double cvq[WEIGHTED ? 1 : RW][WEIGHTED ? 1 : KK];   // curve counts: sum_{j in D(i)} (R - c_ij) V_j'V_j per row
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  {
+    // block indices behind the solves': the lam2 workgroup (if any), then the band's (if any) - all uniform per workgroup
+    const int nsolve = (a.nl + RW - 1) / RW;
+    if ((int)blockIdx.x >= nsolve) {
+      int b = (int)blockIdx.x - nsolve;
+      if (a.lam.hyp) {
+        if (b == 0) { sweep_lam_side<WS_ROWS * WS_SPLIT / WAVE>(a.lam, &red[0][0][0]); return; }
+        --b;
+      }
+      if (a.band.pband && b < a.band.ml) band_side(a.band, b, &red[0][0][0], WS_ROWS * WS_SPLIT);
+      return;
+    }
+  }
   if constexpr (!WEIGHTED) {
     if (a.cv.ptr) {
       // The rows of a workgroup are consecutive, so their lists are ONE range of the CSR arrays: thread (g, q) takes
@@ -1587,6 +1671,46 @@ static __global__ void prior_band_kernel(const double* __restrict__ Tau2, double
     double* im = pimg + (size_t)j * 2 * img_PB;
     im[e0] = s;
     if (t + d < img_T) im[img_PB + (img_T - 1 - t - d) * img_D1 + d] = s;
+  }
+}
+
+// The spectral form of the same band, one WORKGROUP per column (T <= 128: the fused V launch's shapes): the reciprocal
+// 1 / (lam2 Tau2[j][r]) once per penalty row into LDS - one round trip, beside the threads' CSR bounds - then every band
+// entry from its stencil's entries.  Two dependent round trips and nD divisions per column where the thread-per-entry
+// kernel above takes four and a division per term (4.4 us -> see profiles/README.md); the same bits (the reciprocal of the
+// rounded product, one fma per penalty row in row order).  Full sweeps rebuild the band every sweep.
+static __global__ __launch_bounds__(256) void prior_band_cols_kernel(const double* __restrict__ Tau2, double lam2, int nD,
+                                  const int* __restrict__ st_ptr, const int* __restrict__ st_row,
+                                  const double* __restrict__ st_coef, int TD1, int col0,
+                                  double* __restrict__ pband, const double* __restrict__ hyp,
+                                  double* __restrict__ pimg, int img_T, int img_D1, int img_PB) {
+  __shared__ double itau[256];
+  const int j = blockIdx.x;
+  if (hyp) lam2 = hyp[HYP_LAM2];
+  const double* tau = Tau2 + (size_t)(col0 + j) * nD;
+  int p0[2], p1[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e0 = threadIdx.x + u * 256;
+    p0[u] = e0 < TD1 ? st_ptr[e0] : 0;
+    p1[u] = e0 < TD1 ? st_ptr[e0 + 1] : 0;
+  }
+  for (int r = threadIdx.x; r < nD; r += 256) itau[r] = 1.0 / __dmul_rn(lam2, tau[r]);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e0 = threadIdx.x + u * 256;
+    if (e0 < TD1) {
+      double s = 0.0;
+      for (int e = p0[u]; e < p1[u]; ++e) s = fma(st_coef[e], itau[st_row[e]], s);
+      pband[(size_t)j * TD1 + e0] = s;
+      if (pimg) {
+        const int t = e0 / img_D1, d = e0 - t * img_D1;
+        double* im = pimg + (size_t)j * 2 * img_PB;
+        im[e0] = s;
+        if (t + d < img_T) im[img_PB + (img_T - 1 - t - d) * img_D1 + d] = s;
+      }
+    }
   }
 }
 
