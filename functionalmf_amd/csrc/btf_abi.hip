@@ -1023,6 +1023,7 @@ int btf_set_shard(btf_ctx* c, int row0, int nrows_local, int col0, int ncols_loc
   ++c->prior_version;
   if (c->pband) { (void)hipFree(c->pband); c->pband = nullptr; c->pband_version = 0; }      // (sized for the old column block)
   if (c->pimg) { (void)hipFree(c->pimg); c->pimg = nullptr; c->pimg_version = 0; }
+  c->v_wants_band = false;        // (until a V half-sweep of the new geometry has sized the band again)
   c->nb_bwt_written = false;      // (the skip of nb_bwt_target is only valid for the shard geometry B_wT was written under)
   return BTF_OK;
 }

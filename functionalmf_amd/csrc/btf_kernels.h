@@ -25,7 +25,7 @@ namespace btf {
 #define BTF_ACC_WAVES 16
 #endif
 #ifndef BTF_DF_UNR
-#define BTF_DF_UNR 3
+#define BTF_DF_UNR 4
 #endif
 #ifndef BTF_DF_PREFETCH
 #define BTF_DF_PREFETCH 1
