@@ -105,6 +105,40 @@ def test_two_launch_full_sweeps_walk_the_same_chain():
     assert np.array_equal(a.W, c.W) and np.array_equal(a.V, c.V)
 
 
+@pytest.mark.parametrize("dataflow", [0, 1])
+def test_full_sweeps_with_lam2_and_the_prior_band_inside_the_w_solve_launch(monkeypatch, dataflow):
+    """Full device sweeps: lam2 | rest as one more workgroup of the w_solve launch and the prior band (+ its LDS image) by one
+    workgroup per column behind it (BandSide, csrc/btf_kernels.h: they wait for the lam2 workgroup's flag), against the band
+    as a launch of its own in front of the V launch (BTF_BAND_IN_WSOLVE=0) and against lam2 drawn by a side workgroup of
+    the V launch whose tails form the band themselves (BTF_LAM_IN_WSOLVE=0): the same conditionals, the same Philox
+    streams, the same band bits - with the barrier tail all three chains coincide bit for bit (and with the four-launch
+    sweep: test_two_launch_full_sweeps_walk_the_same_chain); with the dataflow tail the first two do (the third runs the
+    barrier tail: equal to rounding).  No launch for the band in the first form."""
+    dims = (96, 8, 64, 2, 5)
+    Y = _synth(*dims)
+    outs, launches = [], []
+    for lam_in, band_in in ((1, 1), (1, 0), (0, 0)):
+        monkeypatch.setenv("BTF_LAM_IN_WSOLVE", str(lam_in))
+        monkeypatch.setenv("BTF_BAND_IN_WSOLVE", str(band_in))
+        m = _make(dims, 1, "device", "reference", dataflow=dataflow)
+        m.resample(Y)
+        m.resample(Y)
+        m._ctx.kernel_times()
+        m.resample_sweeps(Y, 6)
+        m.sync()
+        launches.append(_launches(m))
+        outs.append((m.W.copy(), m.V.copy(), np.asarray(m.Tau2).copy(), (m.nu2, m.sigma2, m.lam2)))
+    assert "prior_band" not in launches[0] and launches[1].get("prior_band") == 6 and "prior_band" not in launches[2], launches
+    a, b, c = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    if dataflow == 0:
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2]) and a[3] == c[3]
+    else:
+        # (eight sweeps: the differently grouped sums move V at its conditioning-limited 1e-6 - the tolerance of the V fixtures)
+        assert np.abs(a[1] - c[1]).max() < 1e-5 * np.abs(c[1]).max() and abs(a[3][2] - c[3][2]) < 1e-6 * c[3][2]
+    assert np.isfinite(a[1]).all()
+
+
 def test_two_launch_step_at_c3_size_matches_and_repeats():
     """BASELINE config 3 (512,256,64,4) nembeds 5: 128 + 1 workgroups per launch, every tail polling the eigen side
     workgroup's flag; 30 steps, fused against unfused, and the fused run twice (the tickets / epochs carry no state
