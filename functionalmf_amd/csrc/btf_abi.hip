@@ -492,10 +492,12 @@ void launch_gram(btf_ctx* c, const double* U, int Rdim) {
   p.launch(gram_kernel<K>, dim3(c->ngp_gram), dim3(GRAM_THREADS), 0, U, Rdim, c->gpart);
 }
 template <int K>
-void launch_wsolve(btf_ctx* c, const WSolveArgs& a) {
+void launch_wsolve(btf_ctx* c, const WSolveArgs& a0) {
   Prof p(c, BTF_K_W_SOLVE);
+  WSolveArgs a = a0;
   const int rw = ws_rows_for(a.nl);
-  const dim3 grid((a.nl + rw - 1) / rw + (a.lam.hyp ? 1 : 0) + (a.band.pband ? a.band.ml : 0));      // (+ the lam2 workgroup and the band's of a full sweep)
+  a.nside = (a.lam.hyp ? 1 : 0) + (a.band.pband ? a.band.ml : 0);      // (the lam2 workgroup and the band's of a full sweep)
+  const dim3 grid((a.nl + rw - 1) / rw + a.nside);
 #define WS_LAUNCH(WT, RWV) p.launch(w_solve_kernel<K, WT, RWV>, grid, dim3(WS_ROWS * ws_split_of(K, WT)), 0, a)
 #define WS_PICK(WT) do { if (rw == 8) WS_LAUNCH(WT, 8); else if (rw == 16) WS_LAUNCH(WT, 16); else if (rw == 32) WS_LAUNCH(WT, 32); else WS_LAUNCH(WT, 64); } while (0)
   if (a.weighted) WS_PICK(true); else WS_PICK(false);

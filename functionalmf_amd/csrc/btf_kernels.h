@@ -1142,6 +1142,7 @@ struct WSolveArgs {
   // full sweeps: lam2 | rest drawn by ONE MORE workgroup of this launch (the last block index; hyp == nullptr: none) - it
   // needs the column sums the Tau2 chain left in the W accumulation launch in front of this one and nothing of the solve;
   // the V half-sweep behind it then finds lam2 drawn and can use the precomputed prior band (btf_abi.hip)
+  int nside;           // workgroups behind the solves' (0: none): the two side tasks below
   LamSide lam;
   BandSide band;       // ... and behind it one workgroup per local column for the prior band of the V half-sweep (pband == nullptr: none)
 #ifdef BTF_WS_STAMPS
@@ -1272,9 +1273,9 @@ __global__ __launch_bounds__(WS_ROWS * ws_split_of(K, WEIGHTED)) void w_solve_ke
   __shared__ double zsh[K][WS_ROWS];
   __shared__ double cvq[WEIGHTED ? 1 : RW][WEIGHTED ? 1 : KK];   // curve counts: sum_{j in D(i)} (R - c_ij) V_j'V_j per row
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  {
+  if (a.nside) {
     // block indices behind the solves': the lam2 workgroup (if any), then the band's (if any) - all uniform per workgroup
-    const int nsolve = (a.nl + RW - 1) / RW;
+    const int nsolve = (int)gridDim.x - a.nside;
     if ((int)blockIdx.x >= nsolve) {
       int b = (int)blockIdx.x - nsolve;
       if (a.lam.hyp) {
