@@ -1369,15 +1369,18 @@ __device__ __forceinline__ void v_fused_df(const FuseV& fv, int tile, double* ld
   if (a.sse_out) {
     const double v = wave_sum(sse_acc);
     if (lane == 0) flag[2 + vw] = v;
-    df_signal(cgw + DFG_SSE);
-    if (vw == 0) {
-      df_wait(cgw + DFG_SSE, (unsigned)VF_GROUP_WAVES, cw + DFC_BAD);
-      if (ok && lane == 0) a.sse_out[j] = (flag[2] + flag[3]) + (flag[4] + flag[5]);
+    if (!a.gout) {                                           // (with a Gram share behind it, its first count covers the parts too)
+      df_signal(cgw + DFG_SSE);
+      if (vw == 0) {
+        df_wait(cgw + DFG_SSE, (unsigned)VF_GROUP_WAVES, cw + DFC_BAD);
+        if (ok && lane == 0) a.sse_out[j] = (flag[2] + flag[3]) + (flag[4] + flag[5]);
+      }
     }
   }
   if (a.gout) {
     df_signal(cgw + DFG_G1);
-    df_wait(cgw + DFG_G1, (unsigned)VF_GROUP_WAVES, cw + DFC_BAD);      // the fresh column stands in xout
+    df_wait(cgw + DFG_G1, (unsigned)VF_GROUP_WAVES, cw + DFC_BAD);      // the fresh column stands in xout (and the residual parts in flag[])
+    if (a.sse_out && vw == 0 && ok && lane == 0) a.sse_out[j] = (flag[2] + flag[3]) + (flag[4] + flag[5]);
     int ng = NT / KK;
     if (ng > 16) ng = 16;
     if (ng < 1) ng = 1;
