@@ -854,35 +854,36 @@ __device__ __forceinline__ void v_fused_tail(const FuseV& fv, int tile, double* 
 }
 
 // =================================================================================================================
-// V tail, dataflow form (FuseV.dataflow; BTF_VF_DATAFLOW=0 keeps the barrier form above)
+// V tail, dataflow form (FuseV.dataflow; BTF_OPT_FUSED_DATAFLOW 0 keeps the barrier form above)
 // =================================================================================================================
 // The barrier form serialises, behind the LAST wave's stream: reduction -> sums into the sampler's layout -> rotation ->
 // the 2K elimination chains (31 pivots of ~240 cycles on ONE wave per column) -> w -> back-substitution -> rotation back.
-// But the factorisation of A_k = g_k I + P_j needs only the eigenvalues (the side workgroup has them 8.3 us into the
-// launch) and the prior band (precomputed) - not the column sums.  Here the chain wave of a column writes its partial
-// sums to LDS when ITS stream ends and factors at once, while the other waves are still streaming, then reduce and
-// rotate; the right-hand sides meet the finished factors in a forward substitution of four fused multiply-adds per pivot.
+// But the factorisation of A_k = g_k I + P_j needs only the eigenvalues (the side workgroup has them ~7 us into the
+// launch) and the prior band (precomputed) - not the column sums.  Here the CHAIN wave of a column does not stream at
+// all (accum_kernel deals the rows over the other 16 - NG waves, BTF_DF_UNR in flight each): it draws the column's
+// normals, polls the eigenvalues' granules, factors, scales the normals by sqrt(1/D) - all while the others stream - and
+// then meets the right-hand sides in a forward substitution of four fused multiply-adds per pivot.
 // No workgroup barrier behind the stream: a wave at an s_barrier would wait for the chain waves.  The stages are ordered
 // by counters in LDS (one relaxed add per producing wave behind a workgroup-scope release; consumers poll with s_sleep):
 // every wait names producers that signal unconditionally and every wave's program is a straight line of stages, so the
 // grid drains whatever the data hold (a failed factorisation or a missed flag skips the arithmetic, not the signals).
-// Same values through the same operations as v_fused_tail / v_spectral_kernel: bit-identical draws
-// (tests/test_gpu_fused.py).
+// The same operations as v_fused_tail / v_spectral_kernel on column sums that are grouped over 16 - NG waves instead of
+// 16: equal to those forms to rounding, deterministic (tests/test_gpu_fused.py).
 //
-// What the measurements of this form taught (scripts/chain_probe.hip, scripts/stamps_df_ab.sh): a lone wave issues one
-// instruction per ~9 cycles WHATEVER it is (f64 arithmetic, an LDS read, a move) - the chains cost their instruction
-// count, so (1) the chain wave does nothing but chains: the band arrives as a ready LDS image copied by another wave, the
-// records are 32-byte quads [l1 l2 l3 | 1/D -> w -> x] and the right-hand sides come paired with the scaled normals
-// [r(i+S) z(i) sqrt(1/D(i))] - three reads, four fused multiply-adds and one write per forward pivot, two reads, three
-// and one per backward pivot; (2) the workers of a column are the waves on the SIMDs no chain wave runs on.
+// What the measurements taught (scripts/chain_probe.hip, scripts/stamps_df_ab.sh): a lone wave issues one instruction
+// per ~9 cycles WHATEVER it is (f64 arithmetic, an LDS read, a move) - the chains cost their instruction count, so the
+// band arrives as a ready LDS image copied by another wave, the records are 32-byte quads [l1 l2 l3 | 1/D -> w -> x] and
+// the right-hand sides come paired with the scaled normals [r(i+S) z(i) sqrt(1/D(i))] - three reads, four fused
+// multiply-adds and one write per forward pivot, two reads, three and one per backward pivot.
 //
-// Roles in a tile of NG = 128 / T columns (16 waves, wave p on SIMD p % 4): p < NG is the CHAIN wave of column p; the
-// workers of column c are the waves p % NG == c on the other SIMDs (T = 32: every other wave), four at T = 64; the four
+// Roles in a tile of NG = 128 / T columns (16 waves): p < NG is the CHAIN wave of column p; every other wave streams and
+// is afterwards a worker of column p % NG (one element of the column per thread): sums over the waves' partials,
+// rotation into the eigen-basis, delivery where the chains read.  The first worker (p = NG) asks for the eigen-system
+// inside its stream (accum_kernel: the flag's word behind one row group's loads, the payload behind the next).  The four
 // virtual waves of the final stage (rotation back, store, residual part, Gram share - v_spectral_kernel's thread
-// geometry, for its fixed-order sums) are p / NG = 0..3.  LDS (doubles): [0, 16 RG 128) the waves' partial sums,
-// overlaid - once every worker has read its sums - by the columns' working arrays (mraw, mt, the (r, z) pairs, heads,
-// Gram scratch); below the mailbox, per column: P | Pm, the record quads, the separator windows, flag words - the chain
-// waves' working set, disjoint from the partials so that they never wait for a reader.  Mailbox (top 128 doubles):
+// geometry) are p / NG = 0..3.  LDS (doubles): [0, 16 K 128) the waves' partial sums [wave][k][128]; behind them the
+// columns' working arrays (mraw, mt, the (r, z) pairs, heads, Gram scratch); below the mailbox, per column: P | Pm, the
+// record quads, the separator windows, flag words - the chain waves' working set.  Mailbox (top 128 doubles):
 // eigen-system [0, K + K K), 64 counter words from double 96.
 enum { DFC_PART = 0, DFC_READ = 1, DFC_EIG = 2, DFC_BAD = 3, DFC_GROUP0 = 8, DFC_PER_GROUP = 12 };
 enum { DFG_IN = 0, DFG_ROT, DFG_FAC, DFG_ZS, DFG_X, DFG_G1, DFG_G2, DFG_SSE, DFG_BAND, DFG_PROG, DFG_ZRAW };
