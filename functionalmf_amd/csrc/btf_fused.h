@@ -885,8 +885,8 @@ __device__ __forceinline__ void v_fused_tail(const FuseV& fv, int tile, double* 
 // columns' working arrays (mraw, mt, the (r, z) pairs, heads, Gram scratch); below the mailbox, per column: P | Pm, the
 // record quads, the separator windows, flag words - the chain waves' working set.  Mailbox (top 128 doubles):
 // eigen-system [0, K + K K), 64 counter words from double 96.
-enum { DFC_PART = 0, DFC_READ = 1, DFC_EIG = 2, DFC_BAD = 3, DFC_GROUP0 = 8, DFC_PER_GROUP = 12 };
-enum { DFG_IN = 0, DFG_ROT, DFG_FAC, DFG_ZS, DFG_X, DFG_G1, DFG_G2, DFG_SSE, DFG_BAND, DFG_PROG, DFG_ZRAW };
+enum { DFC_PART = 0, DFC_EIG = 2, DFC_BAD = 3, DFC_GROUP0 = 8, DFC_PER_GROUP = 12 };
+enum { DFG_IN = 0, DFG_ROT, DFG_X, DFG_G1, DFG_G2, DFG_SSE, DFG_BAND };
 struct DfLayout { int PB, P, Pm, Q, win, flag, size; };
 __host__ __device__ inline DfLayout df_layout(int T, int K, int S) {
   DfLayout D;
@@ -927,16 +927,9 @@ __host__ __device__ inline bool vf_df_fits(int T, int K, int TF, int nD, int wav
   return waves * K * ACC_TILE + ng * df_work(T, K, TF + 1).stride <= room;      // partial sums [w][k][128], the working arrays behind them
 }
 template <> __device__ __forceinline__ int fuse_chain_waves<FUSE_VDF>(const FuseV& fz) { return ACC_TILE / fz.a.T; }
-template <> __device__ __forceinline__ const unsigned long long* fuse_eig_gran<FUSE_VDF>(const FuseV& fz) { return fz.eig_gran; }
 template <> __device__ __forceinline__ const unsigned* fuse_eig_flag<FUSE_VDF>(const FuseV& fz) { return fz.eig_flag; }
 template <> __device__ __forceinline__ const double* fuse_eig_pub<FUSE_VDF>(const FuseV& fz) { return fz.eig_pub; }
 template <> __device__ __forceinline__ unsigned fuse_epoch<FUSE_VDF>(const FuseV& fz) { return fz.epoch; }
-template <> __device__ __forceinline__ const double* fuse_nu2_ptr<FUSE_VDF>(const FuseV& fz) { return (fz.a.hyp && fz.a.hyp_noise) ? fz.a.hyp + HYP_NU2 : nullptr; }
-template <> __device__ __forceinline__ void fuse_touch_args<FUSE_VDF>(const FuseV& fz) {
-  // one field per 64-byte line of the argument block the tail reads (forced to be loaded HERE: inputs of an empty asm)
-  asm volatile("" :: "s"(fz.a.nch), "s"(fz.a.nD), "s"(fz.a.st_drow), "s"(fz.a.ml), "s"(fz.a.attempts), "s"(fz.a.Rrep), "s"(fz.a.eig_cols),
-               "s"(fz.a.pband), "s"(fz.epoch), "s"(fz.eig_gran), "s"(fz.a.sse_out), "s"(fz.a.gout), "s"(fz.a.eps0), "s"(fz.a.seed));
-}
 template <> __device__ __forceinline__ unsigned* fuse_tickets<FUSE_VDF>(const FuseV& fz) { return nullptr; }
 template <> __device__ __forceinline__ int fuse_chunks<FUSE_VDF>(const FuseV& fz) { return 1; }
 template <> __device__ __forceinline__ int fuse_owners<FUSE_VDF>(const FuseV&) { return 0; }

@@ -381,12 +381,9 @@ constexpr int VF_MAILBOX_DOUBLES = 128;
 // factor while the other waves are still streaming / reducing; LDS counters order the stages
 struct VDfPre { double2 pv[8]; };
 template <int FUSE> __device__ __forceinline__ int fuse_chain_waves(const typename FuseSel<FUSE>::type& fz) { return 0; }
-template <int FUSE> __device__ __forceinline__ const double* fuse_nu2_ptr(const typename FuseSel<FUSE>::type& fz) { return nullptr; }
-template <int FUSE> __device__ __forceinline__ void fuse_touch_args(const typename FuseSel<FUSE>::type& fz) {}
 // what a chain wave fetched BEHIND its last rows' loads (in order: back right after them, no wait of its own): the tagged
 // eigenvalue granules of its lane's system, the device-resident nu2
 struct DfEarly { double epub; bool have; };      // the eigen-system entry of this lane as the first worker wave prefetched it inside its stream
-template <int FUSE> __device__ __forceinline__ const unsigned long long* fuse_eig_gran(const typename FuseSel<FUSE>::type& fz) { return nullptr; }
 template <int FUSE> __device__ __forceinline__ const unsigned* fuse_eig_flag(const typename FuseSel<FUSE>::type& fz) { return nullptr; }
 template <int FUSE> __device__ __forceinline__ const double* fuse_eig_pub(const typename FuseSel<FUSE>::type& fz) { return nullptr; }
 template <int FUSE> __device__ __forceinline__ unsigned fuse_epoch(const typename FuseSel<FUSE>::type& fz) { return 0u; }
