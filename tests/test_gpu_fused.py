@@ -105,16 +105,17 @@ def test_two_launch_full_sweeps_walk_the_same_chain():
     assert np.array_equal(a.W, c.W) and np.array_equal(a.V, c.V)
 
 
+@pytest.mark.parametrize("dims", [(96, 8, 64, 2, 5), (40, 3, 128, 1, 4), (70, 9, 32, 2, 3)])
 @pytest.mark.parametrize("dataflow", [0, 1])
-def test_full_sweeps_with_lam2_and_the_prior_band_inside_the_w_solve_launch(monkeypatch, dataflow):
+def test_full_sweeps_with_lam2_and_the_prior_band_inside_the_w_solve_launch(monkeypatch, dataflow, dims):
     """Full device sweeps: lam2 | rest as one more workgroup of the w_solve launch and the prior band (+ its LDS image) by one
     workgroup per column behind it (BandSide, csrc/btf_kernels.h: they wait for the lam2 workgroup's flag), against the band
     as a launch of its own in front of the V launch (BTF_BAND_IN_WSOLVE=0) and against lam2 drawn by a side workgroup of
     the V launch whose tails form the band themselves (BTF_LAM_IN_WSOLVE=0): the same conditionals, the same Philox
     streams, the same band bits - with the barrier tail all three chains coincide bit for bit (and with the four-launch
     sweep: test_two_launch_full_sweeps_walk_the_same_chain); with the dataflow tail the first two do (the third runs the
-    barrier tail: equal to rounding).  No launch for the band in the first form."""
-    dims = (96, 8, 64, 2, 5)
+    barrier tail: equal to rounding).  No launch for the band in the first form.  Depth axes of 64, 128 and 32 (two, one, four
+    columns per tile; 256 / 512 / 128 band entries and 191 / 383 / 95 penalty rows per column)."""
     Y = _synth(*dims)
     outs, launches = [], []
     for lam_in, band_in in ((1, 1), (1, 0), (0, 0)):
